@@ -1,0 +1,698 @@
+// amg_setup.h -- K3/K4/K5: smoothed-aggregation AMG setup entirely on the device.
+//
+// GPU counterpart of AlgebraicMultigrid.jl `smoothed_aggregation(matrix; ...)` as the reference calls it
+// (src/core.jl:164-167, src/raster/advanced.jl:308; algorithm restated in SURVEY.md section 2.3):
+//
+//   reference (sequential)                          here (parallel, deterministic, atomic-free floating point)
+//   ----------------------------------------------  -------------------------------------------------------------
+//   SymmetricStrength(theta)                        same predicate, evaluated on the fly (no S matrix stored)
+//   StandardAggregation: greedy 3-pass sweep        distance-2 maximal independent set with fixed priorities:
+//     (seeds a node whose neighbours are all free,    raster coordinates -> 3x3 tile centres first (the pattern the
+//     i.e. a lexicographic MIS(2))                    greedy sweep yields on rasters), hashed node id otherwise;
+//                                                     neighbours join their root, distance-2 nodes join their
+//                                                     most strongly coupled aggregated neighbour
+//   fit_candidates with B = 1                       T_i = sqrt(size_i / size_agg(i)), sizes tracked as exact integers
+//   JacobiProlongation(4/3), local weighting        P = T - (4/3) Dl^-1 A T, Dl_i = sum_j |a_ij|      (same formula)
+//   R = P'                                          explicit transpose (count / scan / fill / per-row rank sort)
+//   A_c = R*A*P                                     two row-wise multiway-merge SpGEMMs (sorted, deterministic)
+//   improve_candidates (4 Gauss-Seidel sweeps)      omitted: B = 1 already satisfies A*B ~ 0 for a Laplacian
+//   GaussSeidel pre/post smoother                   damped Jacobi, omega = omega_s / rho_Gershgorin(D^-1 A)
+//   Pinv coarse solver                              dense symmetric pseudo-inverse of the coarsest operator
+//
+// Parity with the reference is at the level of converged solutions (the reference pins nothing else).
+#pragma once
+#include <algorithm>
+#include <cmath>
+
+#include "prims.h"
+
+namespace csgpu {
+
+// ------------------------------------------------------------------------------------------------ row statistics
+// diag[i] = a_ii, labs[i] = sum_j |a_ij|, block partial max of labs/|diag| (Gershgorin bound on rho(D^-1 A)).
+template <class T>
+__global__ __launch_bounds__(256) void row_stats_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        const T* __restrict__ va, T* __restrict__ diag,
+                                                        T* __restrict__ labs, double* __restrict__ part_max) {
+  __shared__ double sm[4];
+  double mx = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    T d = T(0), l = T(0);
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const T v = va[k];
+      if (ci[k] == i) d += v;
+      l += v < T(0) ? -v : v;
+    }
+    diag[i] = d;
+    labs[i] = l;
+    const double ad = d < T(0) ? -(double)d : (double)d;
+    if (ad > 0.0) {
+      const double q = (double)l / ad;
+      mx = q > mx ? q : mx;
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = sm[0];
+    for (int w = 1; w < 4; ++w) m = sm[w] > m ? sm[w] : m;
+    part_max[blockIdx.x] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ aggregation
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+template <class T>
+__device__ __forceinline__ bool is_strong(int i, int j, T a, const T* diag, double theta2) {
+  if (j == i || a == T(0)) return false;
+  if (theta2 == 0.0) return true;
+  const double di = fabs((double)diag[i]), dj = fabs((double)diag[j]);
+  return (double)a * (double)a >= theta2 * di * dj;
+}
+
+static const unsigned long long kKeyIn = ~0ull;
+static const unsigned long long kKeyOut = 0ull;
+
+// Undecided nodes carry their priority: [class:8][hash:24][node id:32]; class 2 = raster 3x3 tile centre.
+__global__ __launch_bounds__(256) void mis_init_kernel(int n, unsigned long long* __restrict__ key,
+                                                       const int* __restrict__ nrow, const int* __restrict__ ncol) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    unsigned long long cls = 1;
+    if (nrow && (nrow[i] % 3 == 1) && (ncol[i] % 3 == 1)) cls = 2;
+    key[i] = (cls << 56) | ((unsigned long long)(hash32((unsigned)i) & 0xffffffu) << 32) | (unsigned)i;
+  }
+}
+
+// out[i] = max(in[i], max over strong neighbours in[j])
+template <class T>
+__global__ __launch_bounds__(256) void mis_prop_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                       const T* __restrict__ va, const T* __restrict__ diag,
+                                                       double theta2, const unsigned long long* __restrict__ in,
+                                                       unsigned long long* __restrict__ out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    unsigned long long m = in[i];
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int j = ci[k];
+      if (is_strong(i, j, va[k], diag, theta2)) {
+        const unsigned long long v = in[j];
+        m = v > m ? v : m;
+      }
+    }
+    out[i] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void mis_decide_kernel(int n, unsigned long long* __restrict__ key,
+                                                         const unsigned long long* __restrict__ k2,
+                                                         int* __restrict__ undecided) {
+  int cnt = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const unsigned long long me = key[i];
+    if (me == kKeyIn || me == kKeyOut) continue;
+    const unsigned long long m = k2[i];
+    if (m == me)
+      key[i] = kKeyIn;
+    else if (m == kKeyIn)
+      key[i] = kKeyOut;
+    else
+      ++cnt;
+  }
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(undecided, cnt);
+}
+
+__global__ __launch_bounds__(256) void mis_roots_kernel(int n, const unsigned long long* __restrict__ key,
+                                                        int* __restrict__ flag) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) flag[i] = key[i] == kKeyIn ? 1 : 0;
+}
+
+// pass 1: roots take their scanned id, direct strong neighbours of a root join it
+template <class T>
+__global__ __launch_bounds__(256) void agg_pass1_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        const T* __restrict__ va, const T* __restrict__ diag,
+                                                        double theta2, const unsigned long long* __restrict__ key,
+                                                        const int* __restrict__ root_id, int* __restrict__ agg1) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int a = -1;
+    if (key[i] == kKeyIn) {
+      a = root_id[i];
+    } else {
+      for (int k = rp[i]; k < rp[i + 1]; ++k) {
+        const int j = ci[k];
+        if (is_strong(i, j, va[k], diag, theta2) && key[j] == kKeyIn) {
+          a = root_id[j];
+          break;
+        }
+      }
+    }
+    agg1[i] = a;
+  }
+}
+
+// pass 2: the rest joins its most strongly coupled neighbour that was aggregated in pass 1
+template <class T>
+__global__ __launch_bounds__(256) void agg_pass2_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                        const T* __restrict__ va, const T* __restrict__ diag,
+                                                        double theta2, const int* __restrict__ agg1,
+                                                        int* __restrict__ agg, int* __restrict__ orphan_flag) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int a = agg1[i];
+    if (a < 0) {
+      double best = -1.0;
+      for (int k = rp[i]; k < rp[i + 1]; ++k) {
+        const int j = ci[k];
+        if (!is_strong(i, j, va[k], diag, theta2)) continue;
+        const int aj = agg1[j];
+        const double w = fabs((double)va[k]);
+        if (aj >= 0 && w > best) {
+          best = w;
+          a = aj;
+        }
+      }
+    }
+    agg[i] = a;
+    orphan_flag[i] = a < 0 ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void agg_orphans_kernel(int n, int* __restrict__ agg,
+                                                          const int* __restrict__ orphan_scan, int nagg) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (agg[i] < 0) agg[i] = nagg + orphan_scan[i];
+}
+
+// coarse sizes (exact integers) and coarse raster coordinates (root's tile index)
+__global__ __launch_bounds__(256) void agg_sizes_kernel(int n, const int* __restrict__ agg,
+                                                        const long long* __restrict__ size_f,
+                                                        unsigned long long* __restrict__ size_c) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    atomicAdd(&size_c[agg[i]], (unsigned long long)(size_f ? size_f[i] : 1));
+}
+
+__global__ __launch_bounds__(256) void agg_coords_kernel(int n, const int* __restrict__ agg,
+                                                         const unsigned long long* __restrict__ key,
+                                                         const int* __restrict__ orphan_flag,
+                                                         const int* __restrict__ nrow, const int* __restrict__ ncol,
+                                                         int* __restrict__ crow, int* __restrict__ ccol) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (key[i] == kKeyIn || orphan_flag[i]) {
+      crow[agg[i]] = nrow[i] / 3;
+      ccol[agg[i]] = ncol[i] / 3;
+    }
+}
+
+// tentative prolongator as CSR with exactly one entry per row
+template <class T>
+__global__ __launch_bounds__(256) void tentative_kernel(int n, const int* __restrict__ agg,
+                                                        const long long* __restrict__ size_f,
+                                                        const unsigned long long* __restrict__ size_c,
+                                                        int* __restrict__ trp, int* __restrict__ tci,
+                                                        T* __restrict__ tva) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) {
+    trp[i] = i;
+    if (i < n) {
+      const int a = agg[i];
+      tci[i] = a;
+      const double sf = size_f ? (double)size_f[i] : 1.0;
+      tva[i] = (T)sqrt(sf / (double)size_c[a]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SpGEMM
+// Row-wise multiway merge C = A*B with a group of G lanes per row (G = 2..64, power of two).
+// B's rows have sorted columns; every A entry keeps a cursor into its B row (global workspace `cursor`,
+// one int per nonzero of A). Each step takes the minimum column under the cursors (group min through
+// width-G shuffles), sums the matching products in a fixed order and advances those cursors, so C's rows
+// come out sorted and the floating-point result is deterministic. NUMERIC=false only counts.
+template <class T, int G, bool NUMERIC>
+__global__ __launch_bounds__(256) void spgemm_merge_kernel(int nrows, const int* __restrict__ Arp,
+                                                           const int* __restrict__ Aci, const T* __restrict__ Ava,
+                                                           const int* __restrict__ Brp, const int* __restrict__ Bci,
+                                                           const T* __restrict__ Bva, int* __restrict__ cursor,
+                                                           int* __restrict__ Ccount, const int* __restrict__ Crp,
+                                                           int* __restrict__ Cci, T* __restrict__ Cva) {
+  const int lg = threadIdx.x % G;
+  const int groups_per_block = 256 / G;
+  for (int row = blockIdx.x * groups_per_block + threadIdx.x / G; row < nrows; row += gridDim.x * groups_per_block) {
+    const int ab = Arp[row], ae = Arp[row + 1];
+    for (int ka = ab + lg; ka < ae; ka += G) cursor[ka] = Brp[Aci[ka]];
+    int count = 0;
+    const int out0 = NUMERIC ? Crp[row] : 0;
+    for (;;) {
+      int cmin = 0x7fffffff;
+      for (int ka = ab + lg; ka < ae; ka += G) {
+        const int k = Aci[ka];
+        const int cu = cursor[ka];
+        if (cu < Brp[k + 1]) {
+          const int cc = Bci[cu];
+          cmin = cc < cmin ? cc : cmin;
+        }
+      }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) {
+        const int t = __shfl_xor(cmin, o, G);
+        cmin = t < cmin ? t : cmin;
+      }
+      if (cmin == 0x7fffffff) break;
+      T s = T(0);
+      for (int ka = ab + lg; ka < ae; ka += G) {
+        const int k = Aci[ka];
+        const int cu = cursor[ka];
+        if (cu < Brp[k + 1] && Bci[cu] == cmin) {
+          if (NUMERIC) s += Ava[ka] * Bva[cu];
+          cursor[ka] = cu + 1;
+        }
+      }
+      if (NUMERIC) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
+        if (lg == 0) {
+          Cci[out0 + count] = cmin;
+          Cva[out0 + count] = s;
+        }
+      }
+      ++count;
+    }
+    if (!NUMERIC && lg == 0) Ccount[row] = count;
+  }
+}
+
+template <class T, int G>
+inline void spgemm_group(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st) {
+  const int n = A.nrows;
+  C.nrows = n;
+  C.ncols = B.ncols;
+  C.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+  DBuf cursor = dalloc<int>((size_t)std::max<int64_t>(A.nnz, 1));
+  const int groups_per_block = 256 / G;
+  int grid = ceil_div(n, groups_per_block);
+  if (grid > 65536) grid = 65536;
+  if (grid < 1) grid = 1;
+  CS_HIP(hipMemsetAsync(C.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL((spgemm_merge_kernel<T, G, false>), dim3(grid), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(),
+                     B.rp(), B.ci(), B.va(), dptr<int>(cursor), C.rp(), (const int*)nullptr, (int*)nullptr,
+                     (T*)nullptr);
+  check_launch("spgemm symbolic");
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(C.rp(), (int64_t)n + 1, st, dptr<int>(total));
+  C.nnz = read_int(dptr<int>(total), st);
+  CS_REQUIRE(C.nnz >= 0, CSGPU_BAD_ARGS, "SpGEMM result exceeds 2^31 nonzeros");
+  C.col.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(int));
+  C.val.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(T));
+  hipLaunchKernelGGL((spgemm_merge_kernel<T, G, true>), dim3(grid), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(),
+                     B.rp(), B.ci(), B.va(), dptr<int>(cursor), (int*)nullptr, C.rp(), C.ci(), C.va());
+  check_launch("spgemm numeric");
+  CS_HIP(hipStreamSynchronize(st));  // cursor freed on return
+}
+
+template <class T>
+inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st) {
+  const double avg = A.nrows > 0 ? (double)A.nnz / (double)A.nrows : 1.0;
+  if (avg <= 3.0)
+    spgemm_group<T, 2>(A, B, C, st);
+  else if (avg <= 6.0)
+    spgemm_group<T, 4>(A, B, C, st);
+  else if (avg <= 12.0)
+    spgemm_group<T, 8>(A, B, C, st);
+  else if (avg <= 24.0)
+    spgemm_group<T, 16>(A, B, C, st);
+  else if (avg <= 48.0)
+    spgemm_group<T, 32>(A, B, C, st);
+  else
+    spgemm_group<T, 64>(A, B, C, st);
+}
+
+// ------------------------------------------------------------------------------------------------ transpose
+__global__ __launch_bounds__(256) void col_count_kernel(int64_t nnz, const int* __restrict__ ci,
+                                                        int* __restrict__ counts) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256)
+    atomicAdd(&counts[ci[k]], 1);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void transpose_fill_kernel(int nrows, const int* __restrict__ rp,
+                                                             const int* __restrict__ ci, const T* __restrict__ va,
+                                                             int* __restrict__ fillpos, int* __restrict__ tci,
+                                                             T* __restrict__ tva) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nrows; i += gridDim.x * 256)
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int pos = atomicAdd(&fillpos[ci[k]], 1);
+      tci[pos] = i;
+      tva[pos] = va[k];
+    }
+}
+
+// Per-row rank sort (keys unique within a row): entry e goes to rowstart + #{keys in the row smaller than key_e}.
+template <class T, int G>
+__global__ __launch_bounds__(256) void row_rank_sort_kernel(int nrows, const int* __restrict__ rp,
+                                                            const int* __restrict__ ci_in, const T* __restrict__ va_in,
+                                                            int* __restrict__ ci_out, T* __restrict__ va_out) {
+  const int lg = threadIdx.x % G;
+  const int groups_per_block = 256 / G;
+  for (int row = blockIdx.x * groups_per_block + threadIdx.x / G; row < nrows; row += gridDim.x * groups_per_block) {
+    const int b = rp[row], e = rp[row + 1];
+    for (int k = b + lg; k < e; k += G) {
+      const int key = ci_in[k];
+      int rank = 0;
+      for (int m = b; m < e; ++m) rank += ci_in[m] < key ? 1 : 0;
+      ci_out[b + rank] = key;
+      va_out[b + rank] = va_in[k];
+    }
+  }
+}
+
+template <class T>
+inline void transpose(const Csr<T>& A, Csr<T>& At, hipStream_t st) {
+  At.nrows = A.ncols;
+  At.ncols = A.nrows;
+  At.nnz = A.nnz;
+  const int m = At.nrows;
+  At.rowptr.alloc((size_t)(m + 1) * sizeof(int));
+  At.col.alloc((size_t)std::max<int64_t>(A.nnz, 1) * sizeof(int));
+  At.val.alloc((size_t)std::max<int64_t>(A.nnz, 1) * sizeof(T));
+  CS_HIP(hipMemsetAsync(At.rp(), 0, (size_t)(m + 1) * sizeof(int), st));
+  if (A.nnz > 0)
+    hipLaunchKernelGGL(col_count_kernel, dim3(grid_for(A.nnz)), dim3(256), 0, st, A.nnz, A.ci(), At.rp());
+  exclusive_scan_i32(At.rp(), (int64_t)m + 1, st);
+  DBuf fillpos = dalloc<int>((size_t)m + 1);
+  CS_HIP(hipMemcpyAsync(fillpos.p, At.rp(), (size_t)(m + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+  DBuf tci = dalloc<int>((size_t)std::max<int64_t>(A.nnz, 1));
+  DBuf tva = dalloc<T>((size_t)std::max<int64_t>(A.nnz, 1));
+  hipLaunchKernelGGL((transpose_fill_kernel<T>), dim3(grid_for(A.nrows)), dim3(256), 0, st, A.nrows, A.rp(), A.ci(),
+                     A.va(), dptr<int>(fillpos), dptr<int>(tci), dptr<T>(tva));
+  int grid = ceil_div(m, 256 / 16);
+  if (grid > 65536) grid = 65536;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((row_rank_sort_kernel<T, 16>), dim3(grid), dim3(256), 0, st, m, At.rp(), dptr<int>(tci),
+                     dptr<T>(tva), At.ci(), At.va());
+  check_launch("transpose");
+  CS_HIP(hipStreamSynchronize(st));
+}
+
+// ------------------------------------------------------------------------------------------------ prolongator smoothing
+// In place on C = A*T:  P_ij = [j == agg(i)] t_i - (omega_p / labs_i) C_ij
+template <class T>
+__global__ __launch_bounds__(256) void smooth_prolongator_kernel(int n, const int* __restrict__ rp,
+                                                                 const int* __restrict__ ci, T* __restrict__ va,
+                                                                 const int* __restrict__ agg, const T* __restrict__ tva,
+                                                                 const T* __restrict__ labs, double omega_p,
+                                                                 int* __restrict__ missing) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double l = (double)labs[i];
+    const double w = l != 0.0 ? omega_p / l : 0.0;
+    const int a = agg[i];
+    bool found = false;
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      double v = -w * (double)va[k];
+      if (ci[k] == a) {
+        v += (double)tva[i];
+        found = true;
+      }
+      va[k] = (T)v;
+    }
+    if (!found) atomicAdd(missing, 1);
+  }
+}
+
+// dinv[i] = 1 / a_ii (0 where the diagonal is 0)
+template <class T>
+__global__ __launch_bounds__(256) void dinv_kernel(int n, const T* __restrict__ diag, T* __restrict__ dinv) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dinv[i] = diag[i] != T(0) ? T(1) / diag[i] : T(0);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// Dense symmetric pseudo-inverse (cyclic Jacobi eigen-solver); n is at most a few hundred.
+inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n) {
+  std::vector<double> V((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      const double s = 0.5 * (M[(size_t)i * n + j] + M[(size_t)j * n + i]);
+      M[(size_t)i * n + j] = M[(size_t)j * n + i] = s;
+    }
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, dg = 0;
+    for (int i = 0; i < n; ++i) {
+      dg += M[(size_t)i * n + i] * M[(size_t)i * n + i];
+      for (int j = i + 1; j < n; ++j) off += M[(size_t)i * n + j] * M[(size_t)i * n + j];
+    }
+    if (off <= 1e-30 * dg || off == 0) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = M[(size_t)p * n + q];
+        if (apq == 0) continue;
+        const double app = M[(size_t)p * n + p], aqq = M[(size_t)q * n + q];
+        const double tau = (aqq - app) / (2 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
+        const double c = 1 / std::sqrt(1 + t * t), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double mkp = M[(size_t)k * n + p], mkq = M[(size_t)k * n + q];
+          M[(size_t)k * n + p] = c * mkp - s * mkq;
+          M[(size_t)k * n + q] = s * mkp + c * mkq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double mpk = M[(size_t)p * n + k], mqk = M[(size_t)q * n + k];
+          M[(size_t)p * n + k] = c * mpk - s * mqk;
+          M[(size_t)q * n + k] = s * mpk + c * mqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double smax = 0;
+  for (int i = 0; i < n; ++i) smax = std::max(smax, std::fabs(M[(size_t)i * n + i]));
+  // eigenvalues below n*eps*lambda_max are treated as the null space (Julia pinv's default rtol)
+  const double cut = 2.220446049250313e-16 * (double)n * smax;
+  std::vector<double> Pinv((size_t)n * n, 0.0);
+  for (int e = 0; e < n; ++e) {
+    const double lam = M[(size_t)e * n + e];
+    if (!(std::fabs(lam) > cut)) continue;
+    const double inv = 1.0 / lam;
+    for (int i = 0; i < n; ++i) {
+      const double vi = V[(size_t)i * n + e] * inv;
+      for (int j = 0; j < n; ++j) Pinv[(size_t)i * n + j] += vi * V[(size_t)j * n + e];
+    }
+  }
+  return Pinv;
+}
+
+template <class T>
+struct Level {
+  Csr<T> A, P, R;       // P, R empty on the coarsest level
+  DBuf dinv;            // 1/a_ii
+  double omega = 0;     // damped-Jacobi weight
+  double rho = 0;       // Gershgorin bound on rho(D^-1 A)
+  int n = 0;
+  // solve-phase work vectors (allocated for a batch width K on demand)
+  DBuf xa, rb, b;
+};
+
+template <class T>
+struct Hierarchy {
+  std::vector<Level<T>> levels;
+  DBuf coarse_inv;      // dense pseudo-inverse of the last level's A (n_c x n_c), empty if too large
+  int coarse_n = 0;
+  bool coarse_dense = false;
+  double setup_ms = 0;
+  int work_k = 0;       // batch width the work vectors are allocated for
+};
+
+struct SetupParams {
+  int max_levels = 16;
+  int max_coarse = 100;
+  int aggregation = CSGPU_AGG_AUTO;
+  double theta = 0.0;
+  double omega_p = 4.0 / 3.0;
+  double omega_s = 4.0 / 3.0;
+};
+
+// Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
+template <class T>
+inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
+                     DBuf& crow, DBuf& ccol, hipStream_t st) {
+  const int n = A.nrows;
+  const double theta2 = theta * theta;
+  DBuf key = dalloc<unsigned long long>(n), k1 = dalloc<unsigned long long>(n), k2 = dalloc<unsigned long long>(n);
+  DBuf counter = dalloc<int>(1);
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(mis_init_kernel, dim3(g), dim3(256), 0, st, n, dptr<unsigned long long>(key), nrow, ncol);
+  for (int round = 0; round < 1000; ++round) {
+    CS_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL((mis_prop_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
+                       dptr<unsigned long long>(key), dptr<unsigned long long>(k1));
+    hipLaunchKernelGGL((mis_prop_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
+                       dptr<unsigned long long>(k1), dptr<unsigned long long>(k2));
+    hipLaunchKernelGGL(mis_decide_kernel, dim3(g), dim3(256), 0, st, n, dptr<unsigned long long>(key),
+                       dptr<unsigned long long>(k2), dptr<int>(counter));
+    check_launch("mis round");
+    if (read_int(dptr<int>(counter), st) == 0) break;
+    CS_REQUIRE(round < 999, CSGPU_INTERNAL, "MIS(2) aggregation did not terminate");
+  }
+  DBuf root_id = dalloc<int>((size_t)n + 1);
+  CS_HIP(hipMemsetAsync(root_id.p, 0, ((size_t)n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(mis_roots_kernel, dim3(g), dim3(256), 0, st, n, dptr<unsigned long long>(key), dptr<int>(root_id));
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(dptr<int>(root_id), (int64_t)n + 1, st, dptr<int>(total));
+  int nagg = read_int(dptr<int>(total), st);
+  DBuf agg1 = dalloc<int>(n);
+  agg.alloc((size_t)n * sizeof(int));
+  DBuf orphan = dalloc<int>((size_t)n + 1);
+  CS_HIP(hipMemsetAsync(orphan.p, 0, ((size_t)n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL((agg_pass1_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
+                     dptr<unsigned long long>(key), dptr<int>(root_id), dptr<int>(agg1));
+  hipLaunchKernelGGL((agg_pass2_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
+                     dptr<int>(agg1), dptr<int>(agg), dptr<int>(orphan));
+  // nodes that could not be attached (cannot happen for a symmetric strength graph; kept as a safety net)
+  DBuf orphan_flag = dalloc<int>((size_t)n + 1);
+  CS_HIP(hipMemcpyAsync(orphan_flag.p, orphan.p, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+  exclusive_scan_i32(dptr<int>(orphan), (int64_t)n + 1, st, dptr<int>(total));
+  const int norph = read_int(dptr<int>(total), st);
+  if (norph > 0) {
+    hipLaunchKernelGGL(agg_orphans_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(agg), dptr<int>(orphan), nagg);
+    nagg += norph;
+  }
+  if (nrow) {
+    crow.alloc((size_t)nagg * sizeof(int));
+    ccol.alloc((size_t)nagg * sizeof(int));
+    hipLaunchKernelGGL(agg_coords_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(agg), dptr<unsigned long long>(key),
+                       dptr<int>(orphan_flag), nrow, ncol, dptr<int>(crow), dptr<int>(ccol));
+  }
+  check_launch("aggregate");
+  CS_HIP(hipStreamSynchronize(st));
+  return nagg;
+}
+
+template <class T>
+inline void level_stats(Level<T>& L, DBuf& diag, DBuf& labs, double omega_s, hipStream_t st) {
+  const int n = L.A.nrows;
+  diag.alloc((size_t)n * sizeof(T));
+  labs.alloc((size_t)n * sizeof(T));
+  const int g = grid_for(n);
+  DBuf part = dalloc<double>(g);
+  hipLaunchKernelGGL((row_stats_kernel<T>), dim3(g), dim3(256), 0, st, n, L.A.rp(), L.A.ci(), L.A.va(), dptr<T>(diag),
+                     dptr<T>(labs), dptr<double>(part));
+  L.dinv.alloc((size_t)n * sizeof(T));
+  hipLaunchKernelGGL((dinv_kernel<T>), dim3(g), dim3(256), 0, st, n, dptr<T>(diag), dptr<T>(L.dinv));
+  std::vector<double> hp(g);
+  CS_HIP(hipMemcpyAsync(hp.data(), part.p, (size_t)g * sizeof(double), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  double rho = 0;
+  for (double v : hp) rho = std::max(rho, v);
+  if (!(rho > 0)) rho = 1.0;
+  L.rho = rho;
+  L.omega = omega_s / rho;
+  L.n = n;
+}
+
+// Build the hierarchy. A0 is moved into level 0. node_row/node_col (device, may be null) are raster coordinates.
+template <class T>
+inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const int* node_row, const int* node_col,
+                      hipStream_t st) {
+  hipEvent_t e0, e1;
+  CS_HIP(hipEventCreate(&e0));
+  CS_HIP(hipEventCreate(&e1));
+  CS_HIP(hipEventRecord(e0, st));
+  H.levels.clear();
+  H.levels.emplace_back();
+  H.levels.back().A = std::move(A0);
+  DBuf crow_prev, ccol_prev;  // coarse coordinates of the current level (owned here)
+  const int* cur_row = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_row;
+  const int* cur_col = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_col;
+  DBuf size_prev;  // long long fine sizes of the current level (null on level 0 => all ones)
+  for (;;) {
+    Level<T>& L = H.levels.back();
+    DBuf diag, labs;
+    level_stats(L, diag, labs, sp.omega_s, st);
+    const int n = L.A.nrows;
+    if (n <= sp.max_coarse || (int)H.levels.size() >= sp.max_levels) break;
+    DBuf agg, crow, ccol;
+    const int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st);
+    if (nagg >= n || nagg < 1 || (double)nagg > 0.8 * (double)n) break;  // coarsening stagnated
+    // sizes
+    DBuf size_c = dalloc<unsigned long long>(nagg);
+    CS_HIP(hipMemsetAsync(size_c.p, 0, (size_t)nagg * sizeof(unsigned long long), st));
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(agg_sizes_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(agg),
+                       (const long long*)size_prev.p, dptr<unsigned long long>(size_c));
+    // tentative prolongator
+    Csr<T> Tm;
+    Tm.nrows = n;
+    Tm.ncols = nagg;
+    Tm.nnz = n;
+    Tm.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+    Tm.col.alloc((size_t)n * sizeof(int));
+    Tm.val.alloc((size_t)n * sizeof(T));
+    hipLaunchKernelGGL((tentative_kernel<T>), dim3(g), dim3(256), 0, st, n, dptr<int>(agg),
+                       (const long long*)size_prev.p, dptr<unsigned long long>(size_c), Tm.rp(), Tm.ci(), Tm.va());
+    check_launch("tentative");
+    // P = T - omega_p Dl^-1 A T
+    spgemm(L.A, Tm, L.P, st);
+    DBuf missing = dalloc<int>(1);
+    CS_HIP(hipMemsetAsync(missing.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL((smooth_prolongator_kernel<T>), dim3(g), dim3(256), 0, st, n, L.P.rp(), L.P.ci(), L.P.va(),
+                       dptr<int>(agg), Tm.va(), dptr<T>(labs), sp.omega_p, dptr<int>(missing));
+    check_launch("smooth prolongator");
+    CS_REQUIRE(read_int(dptr<int>(missing), st) == 0, CSGPU_BAD_ARGS,
+               "matrix has rows without a stored diagonal entry (not a graph Laplacian)");
+    transpose(L.P, L.R, st);
+    Csr<T> AP, Ac;
+    spgemm(L.A, L.P, AP, st);
+    spgemm(L.R, AP, Ac, st);
+    // next level
+    size_prev = std::move(size_c);  // unsigned long long and long long share the representation for these counts
+    crow_prev = std::move(crow);
+    ccol_prev = std::move(ccol);
+    cur_row = crow_prev.p ? dptr<int>(crow_prev) : nullptr;
+    cur_col = ccol_prev.p ? dptr<int>(ccol_prev) : nullptr;
+    H.levels.emplace_back();
+    H.levels.back().A = std::move(Ac);
+  }
+  // coarsest level: dense pseudo-inverse when small enough
+  {
+    Level<T>& L = H.levels.back();
+    const int n = L.A.nrows;
+    H.coarse_n = n;
+    H.coarse_dense = n <= 1024;
+    if (H.coarse_dense) {
+      std::vector<int> rp(n + 1), ci((size_t)L.A.nnz);
+      std::vector<T> va((size_t)L.A.nnz);
+      CS_HIP(hipMemcpyAsync(rp.data(), L.A.rp(), (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (L.A.nnz > 0) {
+        CS_HIP(hipMemcpyAsync(ci.data(), L.A.ci(), (size_t)L.A.nnz * sizeof(int), hipMemcpyDeviceToHost, st));
+        CS_HIP(hipMemcpyAsync(va.data(), L.A.va(), (size_t)L.A.nnz * sizeof(T), hipMemcpyDeviceToHost, st));
+      }
+      CS_HIP(hipStreamSynchronize(st));
+      std::vector<double> M((size_t)n * n, 0.0);
+      for (int i = 0; i < n; ++i)
+        for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + ci[k]] += (double)va[k];
+      std::vector<double> Pi = dense_sym_pinv(std::move(M), n);
+      std::vector<T> Pt((size_t)n * n);
+      for (size_t i = 0; i < Pt.size(); ++i) Pt[i] = (T)Pi[i];
+      H.coarse_inv.alloc(std::max<size_t>(Pt.size(), 1) * sizeof(T));
+      CS_HIP(hipMemcpyAsync(H.coarse_inv.p, Pt.data(), Pt.size() * sizeof(T), hipMemcpyHostToDevice, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
+  }
+  CS_HIP(hipEventRecord(e1, st));
+  CS_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  H.setup_ms = ms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+}
+
+}  // namespace csgpu

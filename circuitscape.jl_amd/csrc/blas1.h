@@ -1,0 +1,223 @@
+// blas1.h -- K2: fused vector kernels of the PCG loop, with device-resident scalars (no host sync per iteration).
+//
+// GPU counterpart of the vector algebra inside Krylov.cg (reference call site src/core.jl:639):
+//   alpha = gamma / p'Ap ; x += alpha p ; r -= alpha Ap ; gamma' = r'z ; beta = gamma'/gamma ; p = z + beta p
+// and of its stopping rule  sqrt(r'z) <= atol + rtol*sqrt(r0'z0)   (or the true-residual variant).
+//
+// All vectors are interleaved [n][K] (see spmv.h). Reductions are two-stage and atomic-free: every workgroup
+// writes one partial per column (wave64 shuffle -> LDS), a single-workgroup "scalar" kernel sums the partials in
+// a fixed order and updates the per-column CG scalars in device memory. Results are bit-reproducible run to run.
+#pragma once
+#include "prims.h"
+
+namespace csgpu {
+
+// Per-batch CG scalars living in device memory (one struct per handle, arrays indexed by column c < K).
+static const int kMaxK = 16;
+struct CgScalars {
+  double gamma[kMaxK];   // r'z
+  double pAp[kMaxK];
+  double alpha[kMaxK];
+  double beta[kMaxK];
+  double rnorm[kMaxK];   // current value of the monitored norm
+  double rnorm0[kMaxK];
+  double eps[kMaxK];     // stopping threshold atol + rtol*rnorm0
+  double bnorm[kMaxK];   // ||b||_2 (for the final relative residual)
+  double relres[kMaxK];  // ||A x - b|| / ||b|| from the explicit post-check
+  int done[kMaxK];       // 1 converged, 2 breakdown (p'Ap <= 0 or non-finite)
+  int iters[kMaxK];
+  int all_done;
+  int pad;
+};
+
+// ---- dot products: partials[block][c] = sum_i a[i,c]*b[i,c]  (second pair optional: a2.b2 -> partials2)
+template <class T, int K, bool TWO>
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                  double* __restrict__ partials, const T* __restrict__ a2,
+                                                  const T* __restrict__ b2, double* __restrict__ partials2) {
+  __shared__ double s_red[4 * K];
+  __shared__ double s_red2[4 * K];
+  // each thread keeps a fixed column: stride over elements is a multiple of K because 256 % K == 0
+  double s = 0.0, s2 = 0.0;
+  const int64_t total = n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    s += (double)a[e] * (double)b[e];
+    if (TWO) s2 += (double)a2[e] * (double)b2[e];
+  }
+#pragma unroll
+  for (int o = 32; o >= K; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    if (TWO) s2 += __shfl_xor(s2, o, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane < K) {
+    s_red[w * K + lane] = s;
+    if (TWO) s_red2[w * K + lane] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int t = threadIdx.x;
+    partials[(size_t)blockIdx.x * K + t] = s_red[t] + s_red[K + t] + s_red[2 * K + t] + s_red[3 * K + t];
+    if (TWO) partials2[(size_t)blockIdx.x * K + t] = s_red2[t] + s_red2[K + t] + s_red2[2 * K + t] + s_red2[3 * K + t];
+  }
+}
+
+// Sum `nparts` partial rows for column c in a fixed order (called by one workgroup of 256 threads).
+template <int K>
+__device__ __forceinline__ double reduce_partials(const double* partials, int nparts, int c, double* sm) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partials[(size_t)i * K + c];
+  return block_sum_256(s, sm);
+}
+
+// ---- scalar kernel 1: pAp -> alpha
+template <int K>
+__global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const double* partials, int nparts) {
+  __shared__ double sm[4];
+  for (int c = 0; c < K; ++c) {
+    const double pAp = reduce_partials<K>(partials, nparts, c, sm);
+    if (threadIdx.x == 0) {
+      S->pAp[c] = pAp;
+      double alpha = 0.0;
+      if (!S->done[c]) {
+        if (pAp > 0.0 && pAp == pAp && S->gamma[c] == S->gamma[c]) {
+          alpha = S->gamma[c] / pAp;
+        } else {
+          S->done[c] = 2;  // breakdown (zero curvature / non-finite), Krylov.jl exits likewise
+        }
+      }
+      S->alpha[c] = alpha;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- x += alpha p ; r -= alpha Ap ; optional partials of r'r (true-residual criterion)
+template <class T, int K, bool RR>
+__global__ __launch_bounds__(256) void cg_update_xr_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
+                                                           T* __restrict__ r, const T* __restrict__ p,
+                                                           const T* __restrict__ Ap, double* __restrict__ partials) {
+  __shared__ double s_red[4 * K];
+  const int c = threadIdx.x % K;
+  const T alpha = (T)S->alpha[c];
+  double s = 0.0;
+  const int64_t total = n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    x[e] += alpha * p[e];
+    const T rn = r[e] - alpha * Ap[e];
+    r[e] = rn;
+    if (RR) s += (double)rn * (double)rn;
+  }
+  if (RR) {
+#pragma unroll
+    for (int o = 32; o >= K; o >>= 1) s += __shfl_xor(s, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < K) s_red[w * K + lane] = s;
+    __syncthreads();
+    if (threadIdx.x < K) {
+      const int t = threadIdx.x;
+      partials[(size_t)blockIdx.x * K + t] = s_red[t] + s_red[K + t] + s_red[2 * K + t] + s_red[3 * K + t];
+    }
+  }
+}
+
+// ---- scalar kernel 2: gamma' = r'z -> convergence test, beta.   criterion 0: monitored norm = sqrt(|r'z|),
+// criterion 1: sqrt(r'r) from `partials_rr`.   `init` != 0: first evaluation (sets rnorm0 / eps, no beta).
+template <int K>
+__global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double* partials_rz, int nparts_rz,
+                                                      const double* partials_rr, int nparts_rr, int criterion,
+                                                      double rtol, double atol, int init, int ncols_active) {
+  __shared__ double sm[4];
+  __shared__ int s_all;
+  if (threadIdx.x == 0) s_all = 1;
+  __syncthreads();
+  for (int c = 0; c < K; ++c) {
+    const double rz = reduce_partials<K>(partials_rz, nparts_rz, c, sm);
+    double rr = 0.0;
+    if (criterion == 1) rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
+    if (threadIdx.x == 0) {
+      const double mon = criterion == 1 ? sqrt(rr) : sqrt(fabs(rz));
+      if (init) {
+        S->rnorm0[c] = mon;
+        S->eps[c] = atol + rtol * mon;
+        S->rnorm[c] = mon;
+        S->gamma[c] = rz;
+        S->beta[c] = 0.0;
+        S->iters[c] = 0;
+        S->done[c] = (c >= ncols_active || mon <= S->eps[c] || !(rz == rz)) ? 1 : 0;
+      } else {
+        if (!S->done[c]) {
+          S->iters[c] += 1;
+          S->rnorm[c] = mon;
+          const double g = S->gamma[c];
+          if (mon <= S->eps[c] || mon + 1.0 <= 1.0) {
+            S->done[c] = 1;
+            S->beta[c] = 0.0;
+          } else if (!(rz == rz) || g == 0.0) {
+            S->done[c] = 2;
+            S->beta[c] = 0.0;
+          } else {
+            S->beta[c] = rz / g;
+          }
+          S->gamma[c] = rz;
+        } else {
+          S->beta[c] = 0.0;
+        }
+      }
+      if (!S->done[c]) s_all = 0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) S->all_done = s_all;
+}
+
+// ---- p = z + beta p
+template <class T, int K>
+__global__ __launch_bounds__(256) void cg_update_p_kernel(int64_t n, const CgScalars* S, T* __restrict__ p,
+                                                          const T* __restrict__ z) {
+  const int c = threadIdx.x % K;
+  const T beta = (T)S->beta[c];
+  const int64_t total = n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    p[e] = z[e] + beta * p[e];
+}
+
+// ---- y = s * dinv .* b   (first damped-Jacobi sweep from a zero initial guess)
+template <class T, int K>
+__global__ __launch_bounds__(256) void scale_dinv_kernel(int64_t n, T* __restrict__ y, const T* __restrict__ b,
+                                                         const T* __restrict__ dinv, T s) {
+  const int64_t total = n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    y[e] = s * dinv[e / K] * b[e];
+}
+
+// ---- dense coarse solve: y[i,c] = sum_j M[i,j] * b[j,c]   (M = pseudo-inverse of the coarsest operator)
+template <class T, int K>
+__global__ __launch_bounds__(256) void dense_apply_kernel(int n, const T* __restrict__ M, const T* __restrict__ b,
+                                                          T* __restrict__ y) {
+  const int64_t total = (int64_t)n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / K), c = (int)(e % K);
+    T s = T(0);
+    for (int j = 0; j < n; ++j) s += M[(size_t)i * n + j] * b[(size_t)j * K + c];
+    y[e] = s;
+  }
+}
+
+// ---- relative residual post-check: partials of ||b - A x||^2 come from a DOT-fused SpMV; this finishes it
+template <int K>
+__global__ __launch_bounds__(256) void relres_kernel(CgScalars* S, const double* partials_rr, int nparts_rr,
+                                                     const double* partials_bb, int nparts_bb) {
+  __shared__ double sm[4];
+  for (int c = 0; c < K; ++c) {
+    const double rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
+    const double bb = reduce_partials<K>(partials_bb, nparts_bb, c, sm);
+    if (threadIdx.x == 0) {
+      S->bnorm[c] = sqrt(bb);
+      S->relres[c] = bb > 0.0 ? sqrt(rr / bb) : sqrt(rr);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace csgpu

@@ -1,0 +1,128 @@
+// common.h -- error handling, device buffers, CSR container shared by all csrc/ headers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/csgpu.h"
+
+namespace csgpu {
+
+struct Error : public std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define CS_HIP(expr)                                                                                    \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) {                                                                             \
+      char _buf[512];                                                                                   \
+      snprintf(_buf, sizeof(_buf), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+               __LINE__);                                                                               \
+      throw ::csgpu::Error((int)_e == (int)hipErrorOutOfMemory ? CSGPU_OOM : CSGPU_HIP_ERROR, _buf);    \
+    }                                                                                                   \
+  } while (0)
+
+#define CS_REQUIRE(cond, code, msg)                  \
+  do {                                               \
+    if (!(cond)) throw ::csgpu::Error((code), (msg)); \
+  } while (0)
+
+// Checked after every kernel launch sequence in setup code paths (cheap: no sync).
+inline void check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw Error(CSGPU_HIP_ERROR, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static int64_t g_live_bytes = 0;  // bookkeeping for csgpu_info.device_bytes (single-threaded per process use)
+
+// Owning device allocation.
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DBuf() {}
+  explicit DBuf(size_t b) { alloc(b); }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DBuf() { release(); }
+  void alloc(size_t b) {
+    release();
+    if (b == 0) return;
+    CS_HIP(hipMalloc(&p, b));
+    bytes = b;
+    g_live_bytes += (int64_t)b;
+  }
+  void release() {
+    if (p) {
+      hipFree(p);
+      g_live_bytes -= (int64_t)bytes;
+    }
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class U>
+  U* as() const {
+    return (U*)p;
+  }
+};
+
+template <class U>
+inline U* dptr(const DBuf& b) {
+  return (U*)b.p;
+}
+
+template <class U>
+inline DBuf dalloc(size_t count) {
+  return DBuf(count * sizeof(U));
+}
+
+// Device CSR matrix, int32 / 0-based, columns sorted within a row.
+template <class T>
+struct Csr {
+  int nrows = 0, ncols = 0;
+  int64_t nnz = 0;
+  DBuf rowptr, col, val;
+  const int* rp() const { return rowptr.as<int>(); }
+  const int* ci() const { return col.as<int>(); }
+  const T* va() const { return val.as<T>(); }
+  int* rp() { return rowptr.as<int>(); }
+  int* ci() { return col.as<int>(); }
+  T* va() { return val.as<T>(); }
+  size_t device_bytes() const { return rowptr.bytes + col.bytes + val.bytes; }
+};
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Grid size for grid-stride elementwise / reduction kernels: fixed cap so partial-sum layouts (and hence
+// floating-point summation order) do not depend on the device.
+static const int kBlock = 256;
+static const int kMaxGrid = 2048;
+inline int grid_for(int64_t work_items, int per_block = kBlock) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+}  // namespace csgpu

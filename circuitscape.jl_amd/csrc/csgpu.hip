@@ -1,0 +1,630 @@
+// csgpu.hip -- C ABI of libcsgpu.so (see include/csgpu.h for the reference interfaces each entry point replaces).
+// Single translation unit: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csgpu.hip -o libcsgpu.so
+#include <chrono>
+#include <memory>
+#include <mutex>
+
+#include "pairs.h"
+#include "pcg.h"
+#include "raster.h"
+
+namespace csgpu {
+
+static thread_local std::string g_last_error;
+
+struct ISolver {
+  virtual ~ISolver() {}
+  virtual void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
+                           const int64_t* gather, int64_t ngather, void* gathered_out, void* resist_out,
+                           csgpu_stats* stats) = 0;
+  virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
+  virtual void get_info(csgpu_info* info) const = 0;
+  virtual double spmv_bench(int k, int reps) = 0;
+  virtual void spmv_host(const void* x, void* y, int k) = 0;
+  virtual void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz, int32_t* rowptr,
+                                int32_t* colidx, void* vals) const = 0;
+};
+
+// index conversion kernels (Julia hands Int64 / 1-based arrays by default: src/run.jl:34, src/config.jl:28)
+template <class I>
+__global__ __launch_bounds__(256) void convert_index_kernel(int64_t n, const I* __restrict__ in, int base,
+                                                            int* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = (int)(in[i] - (I)base);
+}
+
+template <class T>
+struct Solver : ISolver {
+  int device = 0;
+  hipStream_t st = nullptr;
+  csgpu_opts opts;
+  Hierarchy<T> H;
+  PcgWork<T> W;
+  double upload_ms = 0;
+  int64_t n = 0, nnz = 0;
+  std::mutex mu;
+
+  explicit Solver(const csgpu_opts& o) : opts(o) {
+    if (opts.device >= 0) {
+      CS_HIP(hipSetDevice(opts.device));
+      device = opts.device;
+    } else {
+      CS_HIP(hipGetDevice(&device));
+    }
+    CS_HIP(hipStreamCreate(&st));
+  }
+  ~Solver() override {
+    if (st) hipStreamDestroy(st);
+  }
+
+  SetupParams setup_params() const {
+    SetupParams sp;
+    sp.max_levels = opts.max_levels;
+    sp.max_coarse = opts.max_coarse;
+    sp.aggregation = opts.aggregation;
+    sp.theta = opts.theta;
+    sp.omega_p = opts.omega_p;
+    sp.omega_s = opts.omega_s;
+    return sp;
+  }
+  PcgParams pcg_params() const {
+    PcgParams pp;
+    pp.rtol = opts.rtol;
+    pp.atol = opts.atol;
+    pp.criterion = opts.criterion;
+    pp.itmax = opts.itmax;
+    pp.check_every = opts.check_every > 0 ? opts.check_every : 4;
+    pp.nu_pre = opts.nu_pre;
+    pp.nu_post = opts.nu_post;
+    return pp;
+  }
+
+  void setup_from_host(const void* rowptr, const void* colidx, const void* vals, int64_t n_, int64_t nnz_,
+                       int idx_bytes, int index_base) {
+    auto t0 = std::chrono::steady_clock::now();
+    n = n_;
+    nnz = nnz_;
+    Csr<T> A;
+    A.nrows = A.ncols = (int)n;
+    A.nnz = nnz;
+    A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+    A.col.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(int));
+    A.val.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(T));
+    if (idx_bytes == 4 && index_base == 0) {
+      CS_HIP(hipMemcpyAsync(A.rp(), rowptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(A.ci(), colidx, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    } else {
+      DBuf raw((size_t)std::max<int64_t>(std::max<int64_t>(nnz, n + 1), 1) * idx_bytes);
+      CS_HIP(hipMemcpyAsync(raw.p, rowptr, (size_t)(n + 1) * idx_bytes, hipMemcpyHostToDevice, st));
+      if (idx_bytes == 8)
+        hipLaunchKernelGGL((convert_index_kernel<int64_t>), dim3(grid_for(n + 1)), dim3(256), 0, st, n + 1,
+                           dptr<int64_t>(raw), index_base, A.rp());
+      else
+        hipLaunchKernelGGL((convert_index_kernel<int32_t>), dim3(grid_for(n + 1)), dim3(256), 0, st, n + 1,
+                           dptr<int32_t>(raw), index_base, A.rp());
+      CS_HIP(hipStreamSynchronize(st));
+      if (nnz > 0) {
+        CS_HIP(hipMemcpyAsync(raw.p, colidx, (size_t)nnz * idx_bytes, hipMemcpyHostToDevice, st));
+        if (idx_bytes == 8)
+          hipLaunchKernelGGL((convert_index_kernel<int64_t>), dim3(grid_for(nnz)), dim3(256), 0, st, nnz,
+                             dptr<int64_t>(raw), index_base, A.ci());
+        else
+          hipLaunchKernelGGL((convert_index_kernel<int32_t>), dim3(grid_for(nnz)), dim3(256), 0, st, nnz,
+                             dptr<int32_t>(raw), index_base, A.ci());
+      }
+      check_launch("index conversion");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (nnz > 0) CS_HIP(hipMemcpyAsync(A.va(), vals, (size_t)nnz * sizeof(T), hipMemcpyHostToDevice, st));
+    DBuf drow, dcol;
+    const int* prow = nullptr;
+    const int* pcol = nullptr;
+    if (opts.node_row && opts.node_col) {
+      drow.alloc((size_t)n * sizeof(int));
+      dcol.alloc((size_t)n * sizeof(int));
+      CS_HIP(hipMemcpyAsync(drow.p, opts.node_row, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dcol.p, opts.node_col, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+      prow = dptr<int>(drow);
+      pcol = dptr<int>(dcol);
+    }
+    CS_HIP(hipStreamSynchronize(st));
+    upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    opts.node_row = opts.node_col = nullptr;  // host pointers are never retained
+    amg_setup(H, std::move(A), setup_params(), prow, pcol, st);
+  }
+
+  void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg) {
+    auto t0 = std::chrono::steady_clock::now();
+    n = R * C;
+    DBuf dcond((size_t)n * sizeof(T));
+    CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+    Csr<T> A;
+    A.nrows = A.ncols = (int)n;
+    A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+    CS_HIP(hipMemsetAsync(A.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(raster_count_kernel, dim3(grid_for(n)), dim3(256), 0, st, (int)R, (int)C, four, A.rp());
+    DBuf total = dalloc<int>(1);
+    exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
+    nnz = read_int(dptr<int>(total), st);
+    A.nnz = nnz;
+    A.col.alloc((size_t)nnz * sizeof(int));
+    A.val.alloc((size_t)nnz * sizeof(T));
+    DBuf drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int));
+    hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       dptr<T>(dcond), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol));
+    if (reg) {
+      const int g = grid_for(nnz);
+      DBuf part = dalloc<double>(g);
+      hipLaunchKernelGGL((dot_kernel<T, 1, false>), dim3(g), dim3(256), 0, st, nnz, (const T*)A.va(), (const T*)A.va(),
+                         dptr<double>(part), (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+      hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(g), dim3(256), 0, st, nnz, A.va(), dptr<double>(part), g,
+                         (double)std::numeric_limits<T>::epsilon());
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    check_launch("raster build");
+    CS_HIP(hipStreamSynchronize(st));
+    dcond.release();
+    upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    amg_setup(H, std::move(A), setup_params(), dptr<int>(drow), dptr<int>(dcol), st);
+  }
+
+  int pick_k(int64_t ncols) const {
+    int kmax = opts.batch;
+    if (kmax < 1) kmax = 1;
+    if (kmax > kMaxK) kmax = kMaxK;
+    int k = 1;
+    while (k < kmax && k < ncols) k <<= 1;
+    return k;
+  }
+
+  template <int K>
+  PcgBatchResult run_batch(int ncols) {
+    return pcg_solve<T, K>(H, W, pcg_params(), ncols, st);
+  }
+  PcgBatchResult run_batch_k(int K, int ncols) {
+    switch (K) {
+      case 1: return run_batch<1>(ncols);
+      case 2: return run_batch<2>(ncols);
+      case 4: return run_batch<4>(ncols);
+      case 8: return run_batch<8>(ncols);
+      default: return run_batch<16>(ncols);
+    }
+  }
+
+  void accumulate(csgpu_stats* s, const PcgBatchResult& r, int ncols) {
+    if (!s) return;
+    for (int c = 0; c < ncols; ++c) {
+      s->total_iters += r.s.iters[c];
+      s->max_iters = std::max(s->max_iters, r.s.iters[c]);
+      s->max_relres = std::max(s->max_relres, r.s.relres[c]);
+      const bool bad = (r.s.done[c] != 1) || !(r.s.relres[c] < 1e-4);
+      if (bad) s->not_converged += 1;
+    }
+    s->device_ms += r.device_ms;
+    s->cg_spmv_ms += r.spmv_ms;
+    s->cg_spmv_calls += r.spmv_calls;
+  }
+
+#define CS_DISPATCH_K(K, ...)                               \
+  switch (K) {                                              \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; } break;   \
+    default: { constexpr int KK = 16; __VA_ARGS__; } break; \
+  }
+
+  void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out, const int64_t* gather,
+                   int64_t ngather, void* gathered_out, void* resist_out, csgpu_stats* stats) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (int64_t p = 0; p < npairs; ++p)
+      CS_REQUIRE(src[p] >= 0 && src[p] < n && dst[p] >= 0 && dst[p] < n, CSGPU_BAD_ARGS, "pair node id out of range");
+    for (int64_t g = 0; g < ngather; ++g)
+      CS_REQUIRE(gather[g] >= 0 && gather[g] < n, CSGPU_BAD_ARGS, "gather node id out of range");
+    const int K = pick_k(npairs);
+    W.ensure(n, K);
+    if (stats) {
+      stats->nrhs = (int)npairs;
+      stats->batch = K;
+    }
+    DBuf dsrc = dalloc<int>(K), ddst = dalloc<int>(K);
+    DBuf dgather = dalloc<int>((size_t)std::max<int64_t>(ngather, 1));
+    if (ngather > 0) {
+      std::vector<int> g32(ngather);
+      for (int64_t g = 0; g < ngather; ++g) g32[g] = (int)gather[g];
+      CS_HIP(hipMemcpyAsync(dgather.p, g32.data(), (size_t)ngather * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    DBuf dres = dalloc<T>(K), dgath = dalloc<T>((size_t)std::max<int64_t>(ngather, 1) * K);
+    DBuf dvolt;
+    if (volt_out) dvolt.alloc((size_t)n * K * sizeof(T));
+    std::vector<int> s32(K), d32(K);
+    for (int64_t p0 = 0; p0 < npairs; p0 += K) {
+      const int ncols = (int)std::min<int64_t>(K, npairs - p0);
+      for (int c = 0; c < K; ++c) {
+        s32[c] = (int)src[p0 + std::min(c, ncols - 1)];
+        d32[c] = (int)dst[p0 + std::min(c, ncols - 1)];
+      }
+      CS_HIP(hipMemcpyAsync(dsrc.p, s32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(ddst.p, d32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * K * sizeof(T), st));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, dptr<T>(W.b),
+                                           dptr<int>(dsrc), dptr<int>(ddst), ncols));
+      PcgBatchResult r = run_batch_k(K, ncols);
+      accumulate(stats, r, ncols);
+      const int ge = grid_for((int64_t)ncols * (ngather + 1));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_extract_kernel<T, KK>), dim3(ge), dim3(256), 0, st,
+                                           (const T*)dptr<T>(W.x), dptr<int>(dsrc), dptr<int>(ddst), ncols,
+                                           dptr<int>(dgather), (int)ngather, dptr<T>(dres), dptr<T>(dgath)));
+      if (resist_out)
+        CS_HIP(hipMemcpyAsync((T*)resist_out + p0, dres.p, (size_t)ncols * sizeof(T), hipMemcpyDeviceToHost, st));
+      if (gathered_out && ngather > 0)
+        CS_HIP(hipMemcpyAsync((T*)gathered_out + (size_t)p0 * ngather, dgath.p, (size_t)ncols * ngather * sizeof(T),
+                              hipMemcpyDeviceToHost, st));
+      if (volt_out) {
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_volt_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                             (const T*)dptr<T>(W.x), dptr<int>(dsrc), ncols, dptr<T>(dvolt)));
+        CS_HIP(hipMemcpyAsync((T*)volt_out + (size_t)p0 * n, dvolt.p, (size_t)n * ncols * sizeof(T),
+                              hipMemcpyDeviceToHost, st));
+      }
+      check_launch("solve_pairs batch");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
+  void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const int K = pick_k(nrhs);
+    W.ensure(n, K);
+    if (stats) {
+      stats->nrhs = (int)nrhs;
+      stats->batch = K;
+    }
+    DBuf stage((size_t)n * K * sizeof(T));
+    for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
+      const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
+      CS_HIP(hipMemcpyAsync(stage.p, (const T*)rhs + (size_t)p0 * n, (size_t)n * ncols * sizeof(T),
+                            hipMemcpyHostToDevice, st));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
+      PcgBatchResult r = run_batch_k(K, ncols);
+      accumulate(stats, r, ncols);
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
+      CS_HIP(hipMemcpyAsync((T*)x_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T), hipMemcpyDeviceToHost,
+                            st));
+      check_launch("solve_rhs batch");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
+  static int64_t spmv_bytes(const Csr<T>& A, int k) {
+    return A.nnz * (int64_t)(sizeof(T) + 4) + ((int64_t)A.nrows + 1) * 4 +
+           ((int64_t)A.nrows + (int64_t)A.ncols) * k * (int64_t)sizeof(T);
+  }
+
+  void get_info(csgpu_info* info) const override {
+    memset(info, 0, sizeof(*info));
+    info->n = n;
+    info->nnz = nnz;
+    info->levels = (int)H.levels.size();
+    info->val_bytes = (int)sizeof(T);
+    double nnz_sum = 0, n_sum = 0;
+    int64_t bytes = 0;
+    for (size_t l = 0; l < H.levels.size(); ++l) {
+      const Level<T>& L = H.levels[l];
+      nnz_sum += (double)L.A.nnz;
+      n_sum += (double)L.A.nrows;
+      if (l < 32) {
+        info->level_n[l] = L.A.nrows;
+        info->level_nnz[l] = L.A.nnz;
+      }
+      bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.dinv.bytes + L.xa.bytes +
+                         L.rb.bytes + L.b.bytes);
+    }
+    bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
+    info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
+    info->grid_complexity = n_sum / std::max(1.0, (double)H.levels[0].A.nrows);
+    info->setup_ms = H.setup_ms;
+    info->upload_ms = upload_ms;
+    info->device_bytes = bytes;
+    info->spmv_bytes_fine = spmv_bytes(H.levels[0].A, 1);
+    // B_iter = B_spmv(A0) + 10 n sizeof(T) + sum_l [(nu1+nu2+1) B_spmv(A_l) + B_spmv(P_l) + B_spmv(R_l) + 4 n_l sizeof(T)]
+    int64_t bi = spmv_bytes(H.levels[0].A, 1) + 10 * n * (int64_t)sizeof(T);
+    for (size_t l = 0; l + 1 < H.levels.size(); ++l) {
+      const Level<T>& L = H.levels[l];
+      // first pre-sweep from a zero guess needs no product: (nu_pre - 1) + nu_post Jacobi products + 1 residual
+      const int prods = std::max(opts.nu_pre - 1, 0) + opts.nu_post + 1;
+      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.P, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(T);
+    }
+    info->bytes_per_iteration = bi;
+  }
+
+  double spmv_bench(int k, int reps) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    const Csr<T>& A = H.levels[0].A;
+    DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
+    fill<T>(dptr<T>(x), n * k, T(1), st);
+    hipEvent_t e0, e1;
+    CS_HIP(hipEventCreate(&e0));
+    CS_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+      SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+      CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
+    };
+    launch();  // warm-up
+    CS_HIP(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) launch();
+    CS_HIP(hipEventRecord(e1, st));
+    CS_HIP(hipEventSynchronize(e1));
+    check_launch("spmv bench");
+    float ms = 0;
+    CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return (double)ms / std::max(reps, 1);
+  }
+
+  void spmv_host(const void* xh, void* yh, int k) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    const Csr<T>& A = H.levels[0].A;
+    DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
+    CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
+    SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+    CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
+    check_launch("spmv_host");
+    CS_HIP(hipMemcpyAsync(yh, y.p, y.bytes, hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+  }
+
+  void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
+                        int32_t* colidx, void* vals) const override {
+    CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
+    const Level<T>& L = H.levels[lvl];
+    const Csr<T>& M = which == 0 ? L.A : (which == 1 ? L.P : L.R);
+    if (nrows) *nrows = M.nrows;
+    if (ncols) *ncols = M.ncols;
+    if (nnz_out) *nnz_out = M.nnz;
+    if (rowptr && M.rowptr.p) CS_HIP(hipMemcpy(rowptr, M.rp(), (size_t)(M.nrows + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (colidx && M.nnz > 0) CS_HIP(hipMemcpy(colidx, M.ci(), (size_t)M.nnz * sizeof(int), hipMemcpyDeviceToHost));
+    if (vals && M.nnz > 0) CS_HIP(hipMemcpy(vals, M.va(), (size_t)M.nnz * sizeof(T), hipMemcpyDeviceToHost));
+  }
+};
+
+}  // namespace csgpu
+
+struct csgpu_handle {
+  std::unique_ptr<csgpu::ISolver> solver;
+};
+
+using csgpu::Error;
+using csgpu::g_last_error;
+
+#define CS_API_BEGIN try {
+#define CS_API_END                                   \
+  }                                                  \
+  catch (const Error& e) {                           \
+    g_last_error = e.what();                         \
+    return e.code;                                   \
+  }                                                  \
+  catch (const std::bad_alloc&) {                    \
+    g_last_error = "host allocation failed";         \
+    return CSGPU_OOM;                                \
+  }                                                  \
+  catch (const std::exception& e) {                  \
+    g_last_error = e.what();                         \
+    return CSGPU_INTERNAL;                           \
+  }
+
+extern "C" {
+
+const char* csgpu_version(void) { return "csgpu 0.1 (gfx950)"; }
+const char* csgpu_last_error(void) { return g_last_error.c_str(); }
+
+int csgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void csgpu_default_opts(csgpu_opts* o) {
+  memset(o, 0, sizeof(*o));
+  o->struct_size = (int32_t)sizeof(csgpu_opts);
+  o->device = -1;
+  o->max_levels = 16;
+  o->max_coarse = 100;
+  o->aggregation = CSGPU_AGG_AUTO;
+  o->nu_pre = 1;
+  o->nu_post = 1;
+  o->criterion = CSGPU_CRIT_KRYLOV;
+  o->itmax = 100000;
+  o->batch = 8;
+  o->check_every = 4;
+  o->theta = 0.0;
+  o->omega_p = 4.0 / 3.0;
+  o->omega_s = 4.0 / 3.0;
+  o->rtol = 1e-6;
+  o->atol = -1.0;
+  o->node_row = nullptr;
+  o->node_col = nullptr;
+}
+
+static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts* opts) {
+  if (n <= 0 || nnz < 0 || (val_bytes != 4 && val_bytes != 8)) {
+    g_last_error = "bad arguments: n, nnz or val_bytes";
+    return CSGPU_BAD_ARGS;
+  }
+  if (nnz >= ((int64_t)1 << 31) || n * 16 >= ((int64_t)1 << 31) * 1) {
+    if (nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) / 16) {
+      g_last_error = "matrix too large for int32 device indexing (need nnz < 2^31 and n < 2^27)";
+      return CSGPU_BAD_ARGS;
+    }
+  }
+  if (opts && opts->struct_size != (int32_t)sizeof(csgpu_opts)) {
+    g_last_error = "csgpu_opts.struct_size mismatch (call csgpu_default_opts first)";
+    return CSGPU_BAD_ARGS;
+  }
+  return CSGPU_OK;
+}
+
+int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
+                int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out) {
+  CS_API_BEGIN
+  if (!rowptr || !colidx || !vals || !out || (idx_bytes != 4 && idx_bytes != 8) || (index_base != 0 && index_base != 1)) {
+    g_last_error = "bad arguments: null pointer, idx_bytes or index_base";
+    return CSGPU_BAD_ARGS;
+  }
+  int rc = check_common(n, nnz, val_bytes, opts);
+  if (rc) return rc;
+  csgpu_opts o;
+  if (opts) o = *opts; else csgpu_default_opts(&o);
+  std::unique_ptr<csgpu_handle> h(new csgpu_handle());
+  if (val_bytes == 8) {
+    auto* s = new csgpu::Solver<double>(o);
+    h->solver.reset(s);
+    s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
+  } else {
+    auto* s = new csgpu::Solver<float>(o);
+    h->solver.reset(s);
+    s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
+  }
+  *out = h.release();
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
+                       int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out) {
+  CS_API_BEGIN
+  if (!cond || !out || nrows <= 0 || ncols <= 0) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  int rc = check_common(nrows * ncols, 0, val_bytes, opts);
+  if (rc) return rc;
+  if (nrows * ncols * 9 >= ((int64_t)1 << 31)) {
+    g_last_error = "raster too large for int32 device indexing";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_opts o;
+  if (opts) o = *opts; else csgpu_default_opts(&o);
+  o.node_row = o.node_col = nullptr;
+  std::unique_ptr<csgpu_handle> h(new csgpu_handle());
+  if (val_bytes == 8) {
+    auto* s = new csgpu::Solver<double>(o);
+    h->solver.reset(s);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+  } else {
+    auto* s = new csgpu::Solver<float>(o);
+    h->solver.reset(s);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+  }
+  *out = h.release();
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_get_info(const csgpu_handle* h, csgpu_info* info) {
+  CS_API_BEGIN
+  if (!h || !info) {
+    g_last_error = "null handle";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->get_info(info);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
+                      const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
+                      csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || npairs < 0 || (npairs > 0 && (!src || !dst)) || ngather < 0 || (ngather > 0 && !gather_idx)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  if (npairs == 0) return CSGPU_OK;
+  h->solver->solve_pairs(src, dst, npairs, volt_out, gather_idx, ngather, gathered_out, resist_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || nrhs < 0 || (nrhs > 0 && (!rhs || !x_out))) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  if (nrhs == 0) return CSGPU_OK;
+  h->solver->solve_rhs(rhs, nrhs, x_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms) {
+  CS_API_BEGIN
+  if (!h || !avg_ms || reps < 1 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  *avg_ms = h->solver->spmv_bench(k, reps);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k) {
+  CS_API_BEGIN
+  if (!h || !x || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->spmv_host(x, y, k);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                           int32_t* rowptr, int32_t* colidx, void* vals) {
+  CS_API_BEGIN
+  if (!h || which < 0 || which > 2) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->get_level_matrix(lvl, which, nrows, ncols, nnz, rowptr, colidx, vals);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+void csgpu_free(csgpu_handle* h) { delete h; }
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// pcg.h -- K6/K7/K8: AMG V-cycle application and the preconditioned-CG driver.
+//
+// GPU counterpart of
+//   aspreconditioner(ml) / ldiv!(z, P, r): one V(nu_pre, nu_post) cycle from a zero initial guess
+//       (AlgebraicMultigrid.jl __solve!, restated in SURVEY.md 2.3; reference call site src/core.jl:164,178)
+//   Krylov.cg(G, curr; M, ldiv=true, rtol, itmax): src/core.jl:639, and the residual check src/core.jl:640-641.
+// The smoother is damped Jacobi fused into the SpMV epilogue (symmetric, so CG theory holds); the first
+// pre-smoothing sweep from the zero guess needs no matrix product at all.
+#pragma once
+#include <limits>
+
+#include "amg_setup.h"
+#include "blas1.h"
+#include "spmv.h"
+
+namespace csgpu {
+
+template <class T>
+inline void ensure_level_work(Hierarchy<T>& H, int K) {
+  if (H.work_k == K) return;
+  for (size_t l = 0; l < H.levels.size(); ++l) {
+    Level<T>& L = H.levels[l];
+    const size_t elems = (size_t)std::max(L.A.nrows, 1) * K;
+    L.xa.alloc(elems * sizeof(T));
+    L.rb.alloc(elems * sizeof(T));
+    if (l > 0)
+      L.b.alloc(2 * elems * sizeof(T));  // [0, elems): restricted rhs, [elems, 2*elems): this level's solution
+    else
+      L.b.release();
+  }
+  H.work_k = K;
+}
+
+// out = V-cycle(b) on level l, zero initial guess. `out` must not alias b or the level's work vectors.
+template <class T, int K>
+inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre, int nu_post, hipStream_t st) {
+  Level<T>& L = H.levels[l];
+  const int n = L.A.nrows;
+  const bool last = (l + 1 == (int)H.levels.size());
+  const int gv = grid_for((int64_t)n * K);
+  if (last && H.coarse_dense) {
+    hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, dptr<T>(H.coarse_inv), b, out);
+    return;
+  }
+  T* cur = dptr<T>(L.xa);
+  T* oth = dptr<T>(L.rb);
+  const T omega = (T)L.omega;
+  auto jacobi_sweep = [&](const T* xin, T* xout) {
+    SpmvArgs<T> a = spmv_args(L.A, xin, xout);
+    a.b = b;
+    a.dinv = dptr<T>(L.dinv);
+    a.omega = omega;
+    spmv_launch<T, K>(a, EPI_JACOBI, false, st);
+  };
+  if (last) {
+    // coarsest level too large for a dense inverse: a fixed number of damped-Jacobi sweeps
+    hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
+    const int sweeps = 8;
+    for (int s = 0; s < sweeps; ++s) {
+      T* dst = (s + 1 == sweeps) ? out : oth;
+      jacobi_sweep(cur, dst);
+      std::swap(cur, oth);
+      if (s + 1 == sweeps) break;
+    }
+    return;
+  }
+  // pre-smoothing (first sweep from x = 0 is a scaling)
+  if (nu_pre >= 1) {
+    hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
+    for (int s = 1; s < nu_pre; ++s) {
+      jacobi_sweep(cur, oth);
+      std::swap(cur, oth);
+    }
+  } else {
+    CS_HIP(hipMemsetAsync(cur, 0, (size_t)n * K * sizeof(T), st));
+  }
+  // residual r = b - A x  -> oth
+  {
+    SpmvArgs<T> a = spmv_args(L.A, cur, oth);
+    a.b = b;
+    spmv_launch<T, K>(a, EPI_RESID, false, st);
+  }
+  // restrict: b_{l+1} = R r
+  Level<T>& Lc = H.levels[l + 1];
+  const size_t celems = (size_t)std::max(Lc.A.nrows, 1) * K;
+  T* bc = dptr<T>(Lc.b);
+  T* xc = dptr<T>(Lc.b) + celems;
+  {
+    SpmvArgs<T> a = spmv_args(L.R, oth, bc);
+    spmv_launch<T, K>(a, EPI_PLAIN, false, st);
+  }
+  vcycle<T, K>(H, l + 1, bc, xc, nu_pre, nu_post, st);
+  // prolongate and correct in place: x += P xc
+  {
+    SpmvArgs<T> a = spmv_args(L.P, xc, cur);
+    a.xadd = cur;
+    spmv_launch<T, K>(a, EPI_ADD, false, st);
+  }
+  // post-smoothing; the last sweep writes straight into `out`
+  if (nu_post >= 1) {
+    for (int s = 0; s < nu_post; ++s) {
+      T* dst = (s + 1 == nu_post) ? out : oth;
+      jacobi_sweep(cur, dst);
+      std::swap(cur, oth);
+    }
+  } else {
+    CS_HIP(hipMemcpyAsync(out, cur, (size_t)n * K * sizeof(T), hipMemcpyDeviceToDevice, st));
+  }
+}
+
+struct PcgParams {
+  double rtol = 1e-6;
+  double atol = -1.0;
+  int criterion = CSGPU_CRIT_KRYLOV;
+  int itmax = 100000;
+  int check_every = 4;
+  int nu_pre = 1, nu_post = 1;
+};
+
+template <class T>
+struct PcgWork {
+  int K = 0;
+  int64_t n = 0;
+  DBuf x, r, z, p, Ap, b;
+  DBuf scalars;               // CgScalars
+  DBuf part_a, part_b, part_c;
+  std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
+  void ensure(int64_t n_, int K_) {
+    if (n == n_ && K == K_) return;
+    n = n_;
+    K = K_;
+    const size_t bytes = (size_t)n * K * sizeof(T);
+    x.alloc(bytes);
+    r.alloc(bytes);
+    z.alloc(bytes);
+    p.alloc(bytes);
+    Ap.alloc(bytes);
+    b.alloc(bytes);
+    scalars.alloc(sizeof(CgScalars));
+    const size_t pb = (size_t)4096 * kMaxK * sizeof(double);
+    part_a.alloc(pb);
+    part_b.alloc(pb);
+    part_c.alloc(pb);
+  }
+  ~PcgWork() {
+    for (auto e : ev) hipEventDestroy(e);
+  }
+};
+
+struct PcgBatchResult {
+  CgScalars s;
+  double device_ms = 0;
+  double spmv_ms = 0;
+  int64_t spmv_calls = 0;
+};
+
+// Solve A X = B for the K interleaved columns held in W.b; solution left in W.x.
+template <class T, int K>
+inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams& pp, int ncols_active,
+                                hipStream_t st) {
+  Level<T>& L0 = H.levels[0];
+  const Csr<T>& A = L0.A;
+  const int64_t n = A.nrows;
+  ensure_level_work(H, K);
+  T* x = dptr<T>(W.x);
+  T* r = dptr<T>(W.r);
+  T* z = dptr<T>(W.z);
+  T* p = dptr<T>(W.p);
+  T* Ap = dptr<T>(W.Ap);
+  const T* b = dptr<T>(W.b);
+  CgScalars* S = dptr<CgScalars>(W.scalars);
+  double* pa = dptr<double>(W.part_a);
+  double* pb = dptr<double>(W.part_b);
+  const size_t vbytes = (size_t)n * K * sizeof(T);
+  const int gv = grid_for(n * K);
+  const double atol = pp.atol < 0 ? std::sqrt((double)std::numeric_limits<T>::epsilon()) : pp.atol;
+
+  hipEvent_t e0, e1;
+  CS_HIP(hipEventCreate(&e0));
+  CS_HIP(hipEventCreate(&e1));
+  CS_HIP(hipEventRecord(e0, st));
+
+  CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
+  CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
+  CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
+  vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, st);
+  hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)z, pa,
+                     (const T*)r, (const T*)r, pb);
+  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv,
+                     pp.criterion, pp.rtol, atol, 1, ncols_active);
+  CS_HIP(hipMemcpyAsync(p, z, vbytes, hipMemcpyDeviceToDevice, st));
+  check_launch("pcg init");
+
+  int host_done = 0;
+  CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+
+  const int max_timed = 512;
+  int timed = 0;
+  int it = 0;
+  const int spmv_g = spmv_grid((int)n);
+  while (!host_done && it < pp.itmax) {
+    // Ap = A p, fused partials of p'Ap
+    {
+      SpmvArgs<T> a = spmv_args(A, (const T*)p, Ap);
+      a.dotw = p;
+      a.partials = pa;
+      const bool time_it = timed < max_timed;
+      if (time_it) {
+        if ((int)W.ev.size() < 2 * (timed + 1)) {
+          hipEvent_t ea, eb;
+          CS_HIP(hipEventCreate(&ea));
+          CS_HIP(hipEventCreate(&eb));
+          W.ev.push_back(ea);
+          W.ev.push_back(eb);
+        }
+        CS_HIP(hipEventRecord(W.ev[2 * timed], st));
+      }
+      spmv_launch<T, K>(a, EPI_PLAIN, true, st);
+      if (time_it) {
+        CS_HIP(hipEventRecord(W.ev[2 * timed + 1], st));
+        ++timed;
+      }
+    }
+    hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g);
+    if (pp.criterion == CSGPU_CRIT_TRUE_RESIDUAL)
+      hipLaunchKernelGGL((cg_update_xr_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, r,
+                         (const T*)p, (const T*)Ap, pb);
+    else
+      hipLaunchKernelGGL((cg_update_xr_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, r,
+                         (const T*)p, (const T*)Ap, pb);
+    vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, st);
+    hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)z, pa,
+                       (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv,
+                       pp.criterion, pp.rtol, atol, 0, ncols_active);
+    hipLaunchKernelGGL((cg_update_p_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, p, (const T*)z);
+    ++it;
+    if (it % pp.check_every == 0 || it >= pp.itmax) {
+      check_launch("pcg iteration");
+      CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
+  }
+  // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
+  {
+    SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
+    a.b = b;
+    spmv_launch<T, K>(a, EPI_RESID, false, st);
+    hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
+    hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv);
+  }
+  CS_HIP(hipEventRecord(e1, st));
+  PcgBatchResult res;
+  CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  check_launch("pcg finish");
+  float ms = 0;
+  CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  res.device_ms = ms;
+  for (int t = 0; t < timed; ++t) {
+    float m2 = 0;
+    CS_HIP(hipEventElapsedTime(&m2, W.ev[2 * t], W.ev[2 * t + 1]));
+    res.spmv_ms += m2;
+  }
+  res.spmv_calls = timed;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return res;
+}
+
+}  // namespace csgpu

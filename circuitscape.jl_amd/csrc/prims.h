@@ -1,0 +1,128 @@
+// prims.h -- wave64 / workgroup primitives and a device-wide exclusive scan (hand-written, no rocPRIM).
+#pragma once
+#include "common.h"
+
+namespace csgpu {
+
+// ---- wave64 reductions through cross-lane shuffles (DPP/permute on gfx950)
+template <class V>
+__device__ __forceinline__ V wave_sum(V v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <class V>
+__device__ __forceinline__ V wave_max(V v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    V w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// Sum over the 256 threads of a workgroup; result valid in every thread. `sm` needs 4 slots.
+template <class V>
+__device__ __forceinline__ V block_sum_256(V v, V* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Inclusive scan across a wave.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------- device-wide exclusive scan (int32)
+static const int kScanItems = 8;
+static const int kScanTile = kBlock * kScanItems;  // 2048 elements per workgroup
+
+__global__ __launch_bounds__(256) void scan_tiles_kernel(int* __restrict__ data, int64_t n,
+                                                         int* __restrict__ tile_sums) {
+  __shared__ int s_wave[4];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int local = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = base + j;
+    v[j] = i < n ? data[i] : 0;
+    local += v[j];
+  }
+  const int incl = wave_inclusive_scan(local);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int k = 0; k < w; ++k) wave_off += s_wave[k];
+  int run = wave_off + incl - local;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = base + j;
+    if (i < n) data[i] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 255) tile_sums[blockIdx.x] = wave_off + incl;
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(int* __restrict__ data, int64_t n,
+                                                       const int* __restrict__ tile_offsets) {
+  const int off = tile_offsets[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  for (int j = threadIdx.x; j < kScanTile; j += kBlock) {
+    const int64_t i = base + j;
+    if (i < n) data[i] += off;
+  }
+}
+
+// In-place exclusive scan of data[0..n). If total_out != nullptr the grand total is written there (device int).
+inline void exclusive_scan_i32(int* data, int64_t n, hipStream_t st, int* total_out_dev = nullptr) {
+  if (n <= 0) {
+    if (total_out_dev) CS_HIP(hipMemsetAsync(total_out_dev, 0, sizeof(int), st));
+    return;
+  }
+  const int ntiles = ceil_div(n, kScanTile);
+  DBuf sums = dalloc<int>((size_t)ntiles + 1);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(ntiles), dim3(kBlock), 0, st, data, n, dptr<int>(sums));
+  if (ntiles > 1) {
+    exclusive_scan_i32(dptr<int>(sums), ntiles, st, total_out_dev);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(ntiles), dim3(kBlock), 0, st, data, n, dptr<int>(sums));
+  } else if (total_out_dev) {
+    CS_HIP(hipMemcpyAsync(total_out_dev, dptr<int>(sums), sizeof(int), hipMemcpyDeviceToDevice, st));
+  }
+  check_launch("exclusive_scan_i32");
+  CS_HIP(hipStreamSynchronize(st));  // `sums` is freed on return
+}
+
+// ---------------------------------------------------------------- small utility kernels
+template <class V>
+__global__ __launch_bounds__(256) void fill_kernel(V* __restrict__ p, int64_t n, V v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+template <class V>
+inline void fill(V* p, int64_t n, V v, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL((fill_kernel<V>), dim3(grid_for(n)), dim3(kBlock), 0, st, p, n, v);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int)i;
+}
+
+inline int read_int(const int* dev, hipStream_t st) {
+  int v = 0;
+  CS_HIP(hipMemcpyAsync(&v, dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  return v;
+}
+
+}  // namespace csgpu

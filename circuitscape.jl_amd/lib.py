@@ -1,0 +1,266 @@
+"""ctypes binding of the C ABI declared in include/csgpu.h.
+
+This is plumbing only: it loads ``libcsgpu.so`` (the hipcc-built gfx950 library that lives next to this file)
+and exposes its entry points 1:1. There is NO fallback: if the library is missing, cannot be loaded, or no HIP
+device is visible, every entry point raises -- the product path never silently computes on the CPU.
+
+A different shared object can only be substituted explicitly through ``load(path)``; the test-suite uses that to
+run the *same* kernel sources compiled against the CPU fiber emulator (tests/emu), which is test infrastructure.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libcsgpu.so")
+
+CSGPU_OK, CSGPU_NOT_CONVERGED, CSGPU_HIP_ERROR, CSGPU_OOM, CSGPU_BAD_ARGS, CSGPU_INTERNAL = range(6)
+CRIT_KRYLOV, CRIT_TRUE_RESIDUAL = 0, 1
+AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
+
+EXPORTS = [
+    "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
+    "csgpu_solve_pairs", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_get_level_matrix",
+    "csgpu_free", "csgpu_last_error", "csgpu_version",
+]
+
+
+class CsgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("max_levels", ctypes.c_int32),
+        ("max_coarse", ctypes.c_int32), ("aggregation", ctypes.c_int32), ("nu_pre", ctypes.c_int32),
+        ("nu_post", ctypes.c_int32), ("criterion", ctypes.c_int32), ("itmax", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("check_every", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("theta", ctypes.c_double), ("omega_p", ctypes.c_double), ("omega_s", ctypes.c_double),
+        ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
+        ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),
+    ]
+
+
+class Info(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int64), ("nnz", ctypes.c_int64), ("levels", ctypes.c_int32), ("val_bytes", ctypes.c_int32),
+        ("operator_complexity", ctypes.c_double), ("grid_complexity", ctypes.c_double),
+        ("setup_ms", ctypes.c_double), ("upload_ms", ctypes.c_double), ("device_bytes", ctypes.c_int64),
+        ("level_n", ctypes.c_int64 * 32), ("level_nnz", ctypes.c_int64 * 32),
+        ("spmv_bytes_fine", ctypes.c_int64), ("bytes_per_iteration", ctypes.c_int64),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("nrhs", ctypes.c_int32), ("max_iters", ctypes.c_int32), ("total_iters", ctypes.c_int64),
+        ("max_relres", ctypes.c_double), ("solve_ms", ctypes.c_double), ("device_ms", ctypes.c_double),
+        ("cg_spmv_ms", ctypes.c_double), ("cg_spmv_calls", ctypes.c_int64), ("batch", ctypes.c_int32),
+        ("not_converged", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_LIB = None
+_LIB_PATH = None
+
+
+def _bind(L):
+    vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    L.csgpu_device_count.restype = i32
+    L.csgpu_default_opts.argtypes = [ctypes.POINTER(Opts)]
+    L.csgpu_default_opts.restype = None
+    L.csgpu_setup.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.csgpu_raster_setup.argtypes = [vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.csgpu_get_info.argtypes = [vp, ctypes.POINTER(Info)]
+    L.csgpu_solve_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
+    L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
+    L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
+    L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                         vp, vp, vp]
+    L.csgpu_free.argtypes = [vp]
+    L.csgpu_free.restype = None
+    L.csgpu_last_error.restype = ctypes.c_char_p
+    L.csgpu_version.restype = ctypes.c_char_p
+    return L
+
+
+def load(path=None):
+    """Load the shared library (default: the in-tree hipcc build). Raises if it is missing -- no fallback."""
+    global _LIB, _LIB_PATH
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if _LIB is not None and _LIB_PATH == path:
+        return _LIB
+    if not os.path.exists(path):
+        raise CsgpuError(CSGPU_INTERNAL,
+                         "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; "
+                         "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise CsgpuError(CSGPU_INTERNAL, "%s does not export %s" % (path, name))
+    _LIB, _LIB_PATH = _bind(L), path
+    return _LIB
+
+
+def lib():
+    return _LIB if _LIB is not None else load()
+
+
+def loaded_path():
+    return _LIB_PATH
+
+
+def _check(rc):
+    if rc != 0:
+        raise CsgpuError(rc, (lib().csgpu_last_error() or b"").decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().csgpu_device_count()
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().csgpu_default_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+class Handle:
+    """Owns a csgpu_handle* (device-resident matrix + AMG hierarchy); freed on close()/GC like the reference's
+    factor objects (ext/CircuitscapePardisoExt.jl:8-13)."""
+
+    def __init__(self, ptr, dtype, keepalive=None):
+        self._p = ptr
+        self.dtype = np.dtype(dtype)
+        self._keep = keepalive
+
+    def close(self):
+        if self._p:
+            lib().csgpu_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def info(self):
+        i = Info()
+        _check(lib().csgpu_get_info(self._p, ctypes.byref(i)))
+        d = {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz")}
+        d["level_n"] = [i.level_n[l] for l in range(min(i.levels, 32))]
+        d["level_nnz"] = [i.level_nnz[l] for l in range(min(i.levels, 32))]
+        return d
+
+    def solve_pairs(self, src, dst, gather=None, want_voltages=False):
+        """0-based node ids. Returns (resistances[npairs], gathered[npairs, ngather] or None,
+        voltages[n, npairs] (Fortran order) or None, stats dict)."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        npairs = len(src)
+        n = self.info["n"]
+        res = np.zeros(npairs, dtype=self.dtype)
+        g = np.ascontiguousarray(gather, dtype=np.int64) if gather is not None and len(gather) else None
+        gathered = np.zeros((npairs, len(g)), dtype=self.dtype) if g is not None else None
+        volt = np.zeros((n, npairs), dtype=self.dtype, order="F") if want_voltages else None
+        st = Stats()
+        rc = lib().csgpu_solve_pairs(self._p, src.ctypes.data, dst.ctypes.data, npairs,
+                                     volt.ctypes.data if volt is not None else None,
+                                     g.ctypes.data if g is not None else None, len(g) if g is not None else 0,
+                                     gathered.ctypes.data if gathered is not None else None, res.ctypes.data,
+                                     ctypes.byref(st))
+        _check(rc)
+        return res, gathered, volt, st.as_dict()
+
+    def solve_rhs(self, rhs):
+        rhs = np.asarray(rhs, dtype=self.dtype)
+        one = rhs.ndim == 1
+        B = np.asfortranarray(rhs.reshape(rhs.shape[0], -1))
+        X = np.zeros_like(B, order="F")
+        st = Stats()
+        _check(lib().csgpu_solve_rhs(self._p, B.ctypes.data, B.shape[1], X.ctypes.data, ctypes.byref(st)))
+        return (X[:, 0] if one else X), st.as_dict()
+
+    def spmv_bench(self, k=1, reps=20):
+        ms = ctypes.c_double(0)
+        _check(lib().csgpu_spmv_bench(self._p, k, reps, ctypes.byref(ms)))
+        return ms.value
+
+    def spmv(self, x):
+        """y = A x for x of shape (n,) or (n, k) with k in {1,2,4,8,16} (host arrays; test helper)."""
+        x = np.asarray(x, dtype=self.dtype)
+        k = 1 if x.ndim == 1 else x.shape[1]
+        xi = np.ascontiguousarray(x.reshape(x.shape[0], k))  # C order == interleaved [n][k]
+        y = np.zeros_like(xi)
+        _check(lib().csgpu_spmv_host(self._p, xi.ctypes.data, y.ctypes.data, k))
+        return y[:, 0] if x.ndim == 1 else y
+
+    def level_matrix(self, lvl, which="A"):
+        import scipy.sparse as sp
+        w = {"A": 0, "P": 1, "R": 2}[which]
+        nr, nc, nz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().csgpu_get_level_matrix(self._p, lvl, w, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nz),
+                                            None, None, None))
+        rp = np.zeros(nr.value + 1, dtype=np.int32)
+        ci = np.zeros(max(nz.value, 1), dtype=np.int32)
+        va = np.zeros(max(nz.value, 1), dtype=self.dtype)
+        _check(lib().csgpu_get_level_matrix(self._p, lvl, w, None, None, None, rp.ctypes.data, ci.ctypes.data,
+                                            va.ctypes.data))
+        return sp.csr_matrix((va[:nz.value], ci[:nz.value], rp), shape=(nr.value, nc.value))
+
+
+def setup(matrix, opts=None, node_row=None, node_col=None, index_dtype=np.int64, index_base=1):
+    """csgpu_setup on a scipy sparse symmetric matrix. By default the arrays are handed over the way Julia's
+    SparseMatrixCSC{T,Int64} would hand them (Int64, 1-based) so the conversion path is the one production uses."""
+    m = matrix.tocsr()
+    m.sort_indices()
+    dtype = np.float32 if m.dtype == np.float32 else np.float64
+    n = m.shape[0]
+    rp = np.ascontiguousarray(m.indptr.astype(index_dtype) + index_base)
+    ci = np.ascontiguousarray(m.indices.astype(index_dtype) + index_base)
+    va = np.ascontiguousarray(m.data, dtype=dtype)
+    o = opts if opts is not None else default_opts()
+    keep = []
+    if node_row is not None:
+        nr = np.ascontiguousarray(node_row, dtype=np.int32)
+        nc = np.ascontiguousarray(node_col, dtype=np.int32)
+        o.node_row = nr.ctypes.data
+        o.node_col = nc.ctypes.data
+        keep = [nr, nc]
+    h = ctypes.c_void_p(0)
+    rc = lib().csgpu_setup(rp.ctypes.data, ci.ctypes.data, va.ctypes.data, n, m.nnz, np.dtype(index_dtype).itemsize,
+                           np.dtype(dtype).itemsize, index_base, ctypes.byref(o), ctypes.byref(h))
+    o.node_row = None
+    o.node_col = None
+    del keep
+    _check(rc)
+    return Handle(h, dtype)
+
+
+def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True):
+    """csgpu_raster_setup: Laplacian of an all-valid conductance raster built directly in HBM."""
+    cond = np.ascontiguousarray(cond)
+    dtype = np.float32 if cond.dtype == np.float32 else np.float64
+    cond = np.ascontiguousarray(cond, dtype=dtype)
+    o = opts if opts is not None else default_opts()
+    h = ctypes.c_void_p(0)
+    rc = lib().csgpu_raster_setup(cond.ctypes.data, cond.shape[0], cond.shape[1], np.dtype(dtype).itemsize,
+                                  int(four_neighbors), int(avg_resistances), int(reg), ctypes.byref(o),
+                                  ctypes.byref(h))
+    _check(rc)
+    return Handle(h, dtype)

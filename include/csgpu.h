@@ -1,0 +1,166 @@
+/* =============================================================================
+ * csgpu.h -- C ABI of libcsgpu.so: the MI355X (gfx950) Laplacian-solve backend for Circuitscape.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference (Circuitscape.jl v5.17.1):
+ * AMG-preconditioned CG on the SPD graph Laplacian for pairwise effective resistance.
+ * Plain C types only (pointers + sizes); no torch / HIP types appear in any signature.
+ *
+ * Reference interfaces each entry point replaces (paths relative to /root/reference):
+ *
+ *   csgpu_setup            <-> construct_cholesky_factor(matrix, ::XSolver) -> handle     src/core.jl:519-523,
+ *                              ext/CircuitscapePardisoExt.jl:31-32; and the AMG setup site
+ *                              aspreconditioner(smoothed_aggregation(matrix; ...))         src/core.jl:164-167
+ *   csgpu_solve_rhs        <-> solve_linear_system(factor, matrix, rhs::Matrix) -> lhs     src/core.jl:646-653,
+ *                              ext/CircuitscapePardisoExt.jl:34-45; iterative flavour
+ *                              solve_linear_system(G, curr::Vector, M)                     src/core.jl:636-643;
+ *                              multiple_solve(s, matrix, sources)                          src/raster/advanced.jl:307-312
+ *   csgpu_solve_pairs      <-> the per-pair body of solve(prob, ::AMGSolver, ...):
+ *                              RHS -1/+1 (core.jl:224-226), solve (:229), grounding shift and resistance
+ *                              (:231-232), focal-voltage gather for the shortcut (update_voltmatrix! :685-703);
+ *                              batched like the direct-solver driver (core.jl:448-493)
+ *   csgpu_free             <-> GC finalizer of the factor object (PardisoFactorize, Pardiso ext :8-13)
+ *   csgpu_last_error       <-> error(msg) strings (core.jl:641,650)
+ *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for an all-valid raster
+ *                              (src/raster/pairwise.jl:271-362, src/core.jl:608-634) -- "next" row N4, used by
+ *                              bench.py so the synthetic Laplacian is born in HBM
+ *
+ * Conventions
+ *   - The matrix is a symmetric SPD (or singular-consistent) graph Laplacian in compressed sparse
+ *     column/row form (identical by symmetry) exactly as Julia's SparseMatrixCSC stores it:
+ *     rowptr[n+1], colidx[nnz] (sorted within a row), vals[nnz]; idx_bytes in {4,8}, val_bytes in {4,8},
+ *     index_base in {0,1}. The library COPIES it to the device; host pointers are never retained.
+ *   - On device everything is int32 / 0-based; n < 2^31/16 and nnz < 2^31 are required (status 4 otherwise).
+ *   - All calls are blocking; a handle is serialised internally (one caller at a time per handle).
+ *   - Return value: 0 ok, 1 not converged (some right-hand side hit itmax or failed the reference's
+ *     1e-4 true-residual check), 2 HIP runtime error, 3 out of memory, 4 bad arguments, 5 internal error.
+ *     csgpu_last_error() returns a thread-local human-readable message for the last non-zero status.
+ * ============================================================================= */
+#ifndef CSGPU_H
+#define CSGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct csgpu_handle csgpu_handle;
+
+enum {
+  CSGPU_OK = 0,
+  CSGPU_NOT_CONVERGED = 1,
+  CSGPU_HIP_ERROR = 2,
+  CSGPU_OOM = 3,
+  CSGPU_BAD_ARGS = 4,
+  CSGPU_INTERNAL = 5
+};
+
+/* Convergence rules. 0 = Krylov.jl rule used by the reference (core.jl:639): stop when
+ * sqrt(r'M^-1 r) <= atol + rtol*sqrt(r0'M^-1 r0). 1 = true residual: ||r||_2 <= atol + rtol*||b||_2. */
+enum { CSGPU_CRIT_KRYLOV = 0, CSGPU_CRIT_TRUE_RESIDUAL = 1 };
+
+/* Aggregation strategy. AUTO = grid tiles when node coordinates are supplied, else MIS(2). */
+enum { CSGPU_AGG_AUTO = 0, CSGPU_AGG_MIS2 = 1, CSGPU_AGG_GRID = 2 };
+
+typedef struct csgpu_opts {
+  int32_t struct_size;    /* = sizeof(csgpu_opts); set by csgpu_default_opts */
+  int32_t device;         /* HIP device ordinal, -1 = current device */
+  int32_t max_levels;     /* default 16 */
+  int32_t max_coarse;     /* stop coarsening at <= this many unknowns (dense pseudo-inverse); default 100 */
+  int32_t aggregation;    /* CSGPU_AGG_* */
+  int32_t nu_pre;         /* damped-Jacobi pre-smoothing sweeps, default 1 */
+  int32_t nu_post;        /* damped-Jacobi post-smoothing sweeps, default 1 */
+  int32_t criterion;      /* CSGPU_CRIT_*, default KRYLOV (the reference's rule) */
+  int32_t itmax;          /* default 100000 (core.jl:639) */
+  int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
+  int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 4 */
+  int32_t reserved0;
+  double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
+  double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting, default 4/3 */
+  double omega_s;         /* Jacobi smoother weight numerator: omega = omega_s / rho_gershgorin, default 4/3 */
+  double rtol;            /* default 1e-6 (core.jl:639) */
+  double atol;            /* < 0 means sqrt(eps(T)) (Krylov.jl default); default -1 */
+  /* Optional raster coordinates of every node (length n, 0-based cell row / col of the node's first
+   * cell). When given, aggregation seeds 3x3 tiles (the shape the reference's greedy StandardAggregation
+   * produces on rasters). NULL for network graphs. */
+  const int32_t* node_row;
+  const int32_t* node_col;
+} csgpu_opts;
+
+typedef struct csgpu_info {
+  int64_t n;
+  int64_t nnz;
+  int32_t levels;               /* including the coarsest */
+  int32_t val_bytes;
+  double operator_complexity;   /* sum_l nnz(A_l) / nnz(A_0) */
+  double grid_complexity;       /* sum_l n_l / n_0 */
+  double setup_ms;              /* device time of the AMG setup (HIP events) */
+  double upload_ms;             /* host->device copy + index conversion */
+  int64_t device_bytes;         /* bytes held by the handle */
+  int64_t level_n[32];
+  int64_t level_nnz[32];
+  int64_t spmv_bytes_fine;      /* algorithmic bytes of one fine-level CSR SpMV (SURVEY.md 8d formula) */
+  int64_t bytes_per_iteration;  /* algorithmic bytes of one PCG iteration at batch 1 */
+} csgpu_info;
+
+typedef struct csgpu_stats {
+  int32_t nrhs;
+  int32_t max_iters;            /* max over right-hand sides */
+  int64_t total_iters;          /* sum over right-hand sides */
+  double max_relres;            /* max over rhs of ||A x - b|| / ||b|| (the reference's post-check, core.jl:640) */
+  double solve_ms;              /* wall time of the call, host clock */
+  double device_ms;             /* HIP-event time of the PCG loops only */
+  double cg_spmv_ms;            /* sum of HIP-event durations of the fine-level CG SpMV/SpMM launches */
+  int64_t cg_spmv_calls;        /* number of those launches */
+  int32_t batch;                /* batch width actually used */
+  int32_t not_converged;        /* number of rhs that hit itmax / broke down / failed the 1e-4 check */
+} csgpu_stats;
+
+int csgpu_device_count(void);
+void csgpu_default_opts(csgpu_opts* opts);
+
+/* Copy a host CSR/CSC symmetric matrix to the device and build the AMG hierarchy there. */
+int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
+                int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out);
+
+/* Build the 4/8-neighbour Laplacian of an all-valid conductance raster directly in HBM and set up AMG.
+ * cond: host pointer, nrows*ncols values (row-major, the orientation of the reference's cellmap[i,j]),
+ * all > 0; node numbering is column-major like construct_node_map (raster/pairwise.jl:273-275).
+ * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). */
+int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
+                       int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
+
+int csgpu_get_info(const csgpu_handle* h, csgpu_info* info);
+
+/* Solve A v = e_dst - e_src for every pair (0-based node ids), batched `opts.batch` at a time.
+ *   resist_out[p]              = v[dst_p] - v[src_p]                                  (core.jl:232), may be NULL
+ *   gathered_out[p*ngather+g]  = v[gather_idx[g]] - v[src_p]                         (may be NULL / ngather 0)
+ *   volt_out[p*n + i]          = v[i] - v[src_p]  (column-major n x npairs, core.jl:231), may be NULL
+ * All outputs are host pointers of the handle's value type (float or double). */
+int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
+                      const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
+                      csgpu_stats* stats);
+
+/* General right-hand sides: rhs and x_out are host column-major n x nrhs arrays of the handle's value type. */
+int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats);
+
+/* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
+ * library's stream; returns the average milliseconds per launch. Used by bench.py for the roofline line. */
+int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms);
+
+/* y = A x on the device for host vectors (tests: parity of the SpMV kernel itself). */
+int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k);
+
+/* Copy level `lvl`'s operator (which: 0 = A, 1 = P, 2 = R) back to the host for inspection by tests.
+ * Pass NULL arrays to query sizes only. */
+int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                           int32_t* rowptr, int32_t* colidx, void* vals);
+
+void csgpu_free(csgpu_handle* h);
+const char* csgpu_last_error(void);
+const char* csgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSGPU_H */
