@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-solves/sec + CG-SpMV GB/s vs the HBM roofline on the synthetic raster pairwise problem.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches
+it under torch.distributed.run with one rank per GPU. One JSON line is printed by rank 0.
+
+Workload (BASELINE.json configs[2]): R x R all-valid raster (default 10000 x 10000), 8-neighbour,
+average conductance, resistances r = exp(N(0,1)) (seed 12345), g = 1/r; the Laplacian is built directly in HBM
+(csgpu_raster_setup) and regularised like the reference (core.jl:161); 15 focal cells (seed 67890) -> the
+lexicographic pair list (105 pairs, the first 100 are the config's "100 focal pairs").
+
+A step = one batch of `--batch` pair solves (AMG-preconditioned CG, the reference's stopping rule: rtol 1e-6 /
+atol sqrt(eps) on sqrt(r'M^-1 r), core.jl:639) through csgpu_solve_pairs. AMG setup happens once per matrix (as in
+the reference, core.jl:164) before the timed region; its cost is reported separately AND amortised into `value`
+over the config's 100 pairs:  value = pairs / (t_steps + t_setup * pairs/100).
+
+N > 1 (weak scaling): every rank holds the full matrix + hierarchy (the path shards by independent pairs,
+SURVEY.md 8e), solves its own K batches, and the resistances are gathered with one RCCL all_gather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def make_raster(size, seed=12345, sigma=1.0, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    r = np.exp(sigma * rng.standard_normal((size, size)))
+    return (1.0 / r).astype(dtype)
+
+
+def focal_pairs(size, npts=15, seed=67890):
+    rng = np.random.default_rng(seed)
+    cells = rng.choice(size * size, size=npts, replace=False)
+    pairs = [(int(cells[i]), int(cells[j])) for i in range(npts) for j in range(i + 1, npts)]
+    return cells, pairs
+
+
+def cpu_baseline(sample_size, nsolve=2):
+    """Oracle (CPU restatement of the reference CG+AMG path, one thread) on a bounded sample of the same workload."""
+    from oracle import refgraph as rg, refsolve as rs
+    g = make_raster(sample_size)
+    G = rg.raster_laplacian_from_conductance(g)
+    A = rs.regularize(G)
+    t0 = time.time()
+    S = rs.OracleAMG(A)
+    t_setup = time.time() - t0
+    cells, pairs = focal_pairs(sample_size)
+    src = [p[0] for p in pairs[:nsolve]]
+    dst = [p[1] for p in pairs[:nsolve]]
+    t0 = time.time()
+    R, _, res = S.solve_pairs(src, dst)
+    t_solve = (time.time() - t0) / nsolve
+    return dict(setup_s=t_setup, solve_s=t_solve, iters=[r["iters"] for r in res], spmv_s=S.spmv_seconds(3),
+                n=sample_size * sample_size, nnz=int(A.nnz), R=R.tolist())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=13)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--precision", default="double", choices=["double", "single"])
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="raster edge of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--criterion", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    import circuitscape_jl_amd  # noqa: F401
+    from circuitscape_jl_amd import lib
+    lib.load()  # fails loudly if the HIP library is missing
+    if lib.device_count() < 1:
+        raise SystemExit("no HIP device visible")
+
+    dtype = np.float64 if args.precision == "double" else np.float32
+    size = args.size
+    g = make_raster(size, dtype=dtype)
+    cells, pairs = focal_pairs(size)
+    opts = lib.default_opts(device=local_rank, batch=args.batch, criterion=args.criterion)
+    t0 = time.time()
+    h = lib.raster_setup(g, opts)
+    t_setup_wall = time.time() - t0
+    del g
+    info = h.info
+    B = args.batch
+    K, Wm = args.steps, args.warmup
+
+    def batch_pairs(step_index):
+        # rank r takes batches r, r+world, ... of the (cyclic) lexicographic pair list
+        b = step_index * world + rank
+        idx = [(b * B + c) % len(pairs) for c in range(B)]
+        return [pairs[i][0] for i in idx], [pairs[i][1] for i in idx]
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for w in range(Wm):
+        s, d = batch_pairs(w)
+        h.solve_pairs(s, d)
+    sync()
+    t0 = time.perf_counter()
+    results = []
+    agg = dict(total_iters=0, max_iters=0, cg_spmv_ms=0.0, cg_spmv_calls=0, device_ms=0.0, max_relres=0.0)
+    for k in range(K):
+        s, d = batch_pairs(Wm + k)
+        R, _, _, st = h.solve_pairs(s, d)
+        results.append(R)
+        agg["total_iters"] += st["total_iters"]
+        agg["max_iters"] = max(agg["max_iters"], st["max_iters"])
+        agg["cg_spmv_ms"] += st["cg_spmv_ms"]
+        agg["cg_spmv_calls"] += st["cg_spmv_calls"]
+        agg["device_ms"] += st["device_ms"]
+        agg["max_relres"] = max(agg["max_relres"], st["max_relres"])
+    res_local = torch.from_numpy(np.concatenate(results).astype(np.float64)).to(dev)
+    if dist is not None:
+        gathered = [torch.empty_like(res_local) for _ in range(world)]
+        dist.all_gather(gathered, res_local)  # the path's only collective: final result gather over RCCL/xGMI
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        pairs_done = K * B * world
+        setup_s = (info["setup_ms"] + info["upload_ms"]) / 1e3
+        # setup is per GPU and amortised over the config's 100 pairs per matrix
+        value = pairs_done / (elapsed + setup_s * (K * B) / 100.0)
+        spmv_avg_ms = agg["cg_spmv_ms"] / max(agg["cg_spmv_calls"], 1)
+        vb = 8 if dtype == np.float64 else 4
+        spmm_bytes = info["nnz"] * (vb + 4) + (info["n"] + 1) * 4 + 2 * info["n"] * B * vb
+        achieved = spmm_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        spmv1_ms = h.spmv_bench(1, 10)
+        out = {
+            "metric": "pair-solves/sec (AMG-PCG, setup amortised over 100 pairs) on %dx%d raster pairwise" % (size, size),
+            "value": value,
+            "unit": "pair-solves/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if dtype == np.float64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic raster, 8-neighbour, %d pairs/GPU in batches of %d, %s"
+                                   % (size, size, K * B, B, "fp64" if vb == 8 else "fp32"),
+                       "n": info["n"], "nnz": info["nnz"], "batch": B, "levels": info["levels"],
+                       "operator_complexity": info["operator_complexity"], "criterion": args.criterion},
+            "solve_only_pairs_per_s": pairs_done / elapsed,
+            "setup_s": setup_s, "setup_device_s": info["setup_ms"] / 1e3, "setup_wall_s": t_setup_wall,
+            "iters_mean": agg["total_iters"] / float(K * B), "iters_max": agg["max_iters"],
+            "max_relres": agg["max_relres"],
+            "roofline": {"bound": "hbm", "kernel": "spmv_kernel<%s,%d,PLAIN,DOT> (fine-level CG SpMM)" % ("double" if vb == 8 else "float", B),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": spmm_bytes, "avg_ms": spmv_avg_ms,
+                         "launches_timed": agg["cg_spmv_calls"],
+                         "spmv_k1_avg_ms": spmv1_ms,
+                         "spmv_k1_GBs": info["spmv_bytes_fine"] / (spmv1_ms * 1e-3) / 1e9 if spmv1_ms > 0 else 0.0},
+        }
+        if args.cpu_sample > 0 and world == 1:
+            cb = cpu_baseline(args.cpu_sample)
+            scale = float(info["n"]) / cb["n"]
+            cpu_value = 1.0 / (cb["solve_s"] * scale + cb["setup_s"] * scale / 100.0)
+            out["cpu_baseline"] = {
+                "value": cpu_value, "unit": "pair-solves/s", "cores": 1, "kind": "port",
+                "sample": "oracle (C++ restatement of the reference CG+AMG path, 1 thread) on a %dx%d raster of the same "
+                          "generator: setup %.2fs + %d pair solves at %.2fs (%s iterations); time scaled linearly in n (x%.0f) "
+                          "to the %dx%d workload, setup amortised over 100 pairs"
+                          % (args.cpu_sample, args.cpu_sample, cb["setup_s"], len(cb["iters"]), cb["solve_s"], cb["iters"], scale, size, size),
+                "spmv_GBs": (cb["nnz"] * 12 + (cb["n"] + 1) * 4 + 2 * cb["n"] * 8) / cb["spmv_s"] / 1e9,
+            }
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

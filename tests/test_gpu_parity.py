@@ -1,0 +1,81 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _raster(oracle_mod, n, sigma=1.0):
+    from oracle import refgraph as rg
+    G, g = rg.synthetic_raster_problem(n, n, sigma=sigma)
+    return oracle_mod.regularize(G), g
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_spmv_matches_scipy(gpu_lib, oracle, k, dtype):
+    A, g = _raster(oracle, 150)
+    A = A.astype(dtype)
+    h = gpu_lib.setup(A, gpu_lib.default_opts(batch=k))
+    x = np.random.default_rng(k).standard_normal((A.shape[0], k)).astype(dtype)
+    y = h.spmv(x if k > 1 else x[:, 0])
+    ref = A.astype(np.float64) @ x.astype(np.float64)
+    ref = ref if k > 1 else ref[:, 0]
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.max(np.abs(y - ref)) <= tol * max(1.0, np.abs(ref).max())
+    h.close()
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_pairs_match_tight_oracle(gpu_lib, oracle, batch):
+    N = 300
+    A, g = _raster(oracle, N)
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=batch))
+    info = h.info
+    assert info["n"] == N * N and info["nnz"] == A.nnz
+    assert info["level_n"][1] == 100 * 100  # 3x3 tiles
+    cells = np.random.default_rng(67890).choice(N * N, size=5, replace=False)
+    src = [cells[i] for i in range(5) for j in range(i + 1, 5)]
+    dst = [cells[j] for i in range(5) for j in range(i + 1, 5)]
+    R, gath, V, st = h.solve_pairs(src, dst, gather=cells, want_voltages=True)
+    S = oracle.OracleAMG(A)
+    Ro, go, _ = S.solve_pairs(src, dst, gather=cells, rtol=1e-12, atol=0.0, criterion=1)
+    assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+    # north_star: resistances within 1e-6 relative of the reference path
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    assert np.max(np.abs(gath - go)) < 1e-5
+    for p in range(len(src)):
+        assert V[src[p], p] == 0.0 and abs(V[dst[p], p] - R[p]) < 1e-12
+    h.close()
+
+
+def test_general_rhs_and_host_csr_path(gpu_lib, oracle):
+    """csgpu_setup (Int64, 1-based arrays as Julia hands them) + csgpu_solve_rhs, MIS(2) aggregation (no coordinates)."""
+    A, g = _raster(oracle, 120)
+    h = gpu_lib.setup(A, gpu_lib.default_opts(batch=4, criterion=gpu_lib.CRIT_TRUE_RESIDUAL, rtol=1e-10, atol=0.0))
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, 5))
+    B -= B.mean(axis=0)  # consistent with the (near-)singular Laplacian
+    X, st = h.solve_rhs(B)
+    res = np.linalg.norm(A @ X - B, axis=0) / np.linalg.norm(B, axis=0)
+    assert st["not_converged"] == 0 and res.max() < 1e-8
+    h.close()
+
+
+def test_large_raster_properties(gpu_lib):
+    """Size-independent checks at a size the CPU oracle would not finish quickly: symmetry R(a,b) == R(b,a),
+    triangle inequality of the resistance metric, positivity, residual check."""
+    N = 1500
+    g = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((N, N)))
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=8))
+    cells = np.random.default_rng(1).choice(N * N, size=4, replace=False)
+    a, b, c, d = cells
+    src = [a, b, a, c, b, a, b, d]
+    dst = [b, a, c, a, c, d, d, c]
+    R, _, _, st = h.solve_pairs(src, dst)
+    assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+    assert np.all(R > 0)
+    assert abs(R[0] - R[1]) < 1e-6 * R[0] and abs(R[2] - R[3]) < 1e-6 * R[2]
+    assert R[2] <= R[0] + R[4] + 1e-9  # R(a,c) <= R(a,b) + R(b,c)
+    h.close()
