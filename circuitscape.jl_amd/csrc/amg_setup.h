@@ -23,6 +23,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <limits>
 
 #include "prims.h"
 
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void dinv_kernel(int n, const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------ host side
 // Dense symmetric pseudo-inverse (cyclic Jacobi eigen-solver); n is at most a few hundred.
-inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n) {
+inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double eps) {
   std::vector<double> V((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j) {
@@ -474,8 +475,8 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n) {
   }
   double smax = 0;
   for (int i = 0; i < n; ++i) smax = std::max(smax, std::fabs(M[(size_t)i * n + i]));
-  // eigenvalues below n*eps*lambda_max are treated as the null space (Julia pinv's default rtol)
-  const double cut = 2.220446049250313e-16 * (double)n * smax;
+  // eigenvalues below n*eps(T)*lambda_max are treated as the null space (Julia pinv's default rtol)
+  const double cut = eps * (double)n * smax;
   std::vector<double> Pinv((size_t)n * n, 0.0);
   for (int e = 0; e < n; ++e) {
     const double lam = M[(size_t)e * n + e];
@@ -678,7 +679,7 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       std::vector<double> M((size_t)n * n, 0.0);
       for (int i = 0; i < n; ++i)
         for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + ci[k]] += (double)va[k];
-      std::vector<double> Pi = dense_sym_pinv(std::move(M), n);
+      std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon());
       std::vector<T> Pt((size_t)n * n);
       for (size_t i = 0; i < Pt.size(); ++i) Pt[i] = (T)Pi[i];
       H.coarse_inv.alloc(std::max<size_t>(Pt.size(), 1) * sizeof(T));

