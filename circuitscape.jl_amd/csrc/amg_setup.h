@@ -26,6 +26,7 @@
 #include <limits>
 
 #include "prims.h"
+#include "spmv.h"
 
 namespace csgpu {
 
@@ -494,6 +495,7 @@ template <class T>
 struct Level {
   Csr<T> A, P, R;       // P, R empty on the coarsest level
   DBuf dinv;            // 1/a_ii
+  DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
   double omega = 0;     // damped-Jacobi weight
   double rho = 0;       // Gershgorin bound on rho(D^-1 A)
   int n = 0;
@@ -596,6 +598,7 @@ inline void level_stats(Level<T>& L, DBuf& diag, DBuf& labs, double omega_s, hip
   L.rho = rho;
   L.omega = omega_s / rho;
   L.n = n;
+  spmv_block_order(L.A, L.orderA, st);
 }
 
 // Build the hierarchy. A0 is moved into level 0. node_row/node_col (device, may be null) are raster coordinates.

@@ -92,20 +92,22 @@ __global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const doubl
   }
 }
 
-// ---- x += alpha p ; r -= alpha Ap ; optional partials of r'r (true-residual criterion)
+// ---- r -= alpha Ap, fused with the first damped-Jacobi sweep of the next preconditioner application from a zero
+//      guess (xa = omega * dinv .* r; skipped when xa == nullptr) and, optionally, the partials of r'r.
 template <class T, int K, bool RR>
-__global__ __launch_bounds__(256) void cg_update_xr_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
-                                                           T* __restrict__ r, const T* __restrict__ p,
-                                                           const T* __restrict__ Ap, double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgScalars* S, T* __restrict__ r,
+                                                          const T* __restrict__ Ap, T* __restrict__ xa,
+                                                          const T* __restrict__ dinv, T omega,
+                                                          double* __restrict__ partials) {
   __shared__ double s_red[4 * K];
   const int c = threadIdx.x % K;
   const T alpha = (T)S->alpha[c];
   double s = 0.0;
   const int64_t total = n * K;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    x[e] += alpha * p[e];
     const T rn = r[e] - alpha * Ap[e];
     r[e] = rn;
+    if (xa) xa[e] = omega * dinv[e / K] * rn;
     if (RR) s += (double)rn * (double)rn;
   }
   if (RR) {
@@ -118,6 +120,21 @@ __global__ __launch_bounds__(256) void cg_update_xr_kernel(int64_t n, const CgSc
       const int t = threadIdx.x;
       partials[(size_t)blockIdx.x * K + t] = s_red[t] + s_red[K + t] + s_red[2 * K + t] + s_red[3 * K + t];
     }
+  }
+}
+
+// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished)
+template <class T, int K>
+__global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
+                                                           T* __restrict__ p, const T* __restrict__ z) {
+  const int c = threadIdx.x % K;
+  const T alpha = (T)S->alpha[c];
+  const T beta = (T)S->beta[c];
+  const int64_t total = n * K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const T pe = p[e];
+    x[e] += alpha * pe;
+    p[e] = z[e] + beta * pe;
   }
 }
 
@@ -169,17 +186,6 @@ __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double
     __syncthreads();
   }
   if (threadIdx.x == 0) S->all_done = s_all;
-}
-
-// ---- p = z + beta p
-template <class T, int K>
-__global__ __launch_bounds__(256) void cg_update_p_kernel(int64_t n, const CgScalars* S, T* __restrict__ p,
-                                                          const T* __restrict__ z) {
-  const int c = threadIdx.x % K;
-  const T beta = (T)S->beta[c];
-  const int64_t total = n * K;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
-    p[e] = z[e] + beta * p[e];
 }
 
 // ---- y = s * dinv .* b   (first damped-Jacobi sweep from a zero initial guess)

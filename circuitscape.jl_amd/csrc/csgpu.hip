@@ -76,6 +76,7 @@ struct Solver : ISolver {
     pp.check_every = opts.check_every > 0 ? opts.check_every : 4;
     pp.nu_pre = opts.nu_pre;
     pp.nu_post = opts.nu_post;
+    pp.nu_coarse = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
     return pp;
   }
 
@@ -342,7 +343,8 @@ struct Solver : ISolver {
     for (size_t l = 0; l + 1 < H.levels.size(); ++l) {
       const Level<T>& L = H.levels[l];
       // first pre-sweep from a zero guess needs no product: (nu_pre - 1) + nu_post Jacobi products + 1 residual
-      const int prods = std::max(opts.nu_pre - 1, 0) + opts.nu_post + 1;
+      const int nup = l == 0 ? opts.nu_pre : opts.nu_coarse, nuq = l == 0 ? opts.nu_post : opts.nu_coarse;
+      const int prods = std::max(nup - 1, 0) + nuq + 1;
       bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.P, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(T);
     }
     info->bytes_per_iteration = bi;
@@ -358,7 +360,7 @@ struct Solver : ISolver {
     CS_HIP(hipEventCreate(&e0));
     CS_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
-      SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+      SpmvArgs<T> a = level_args(H.levels[0], (const T*)dptr<T>(x), dptr<T>(y));
       CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
     };
     launch();  // warm-up
@@ -380,7 +382,7 @@ struct Solver : ISolver {
     const Csr<T>& A = H.levels[0].A;
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
     CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
-    SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+    SpmvArgs<T> a = level_args(H.levels[0], (const T*)dptr<T>(x), dptr<T>(y));
     CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
     check_launch("spmv_host");
     CS_HIP(hipMemcpyAsync(yh, y.p, y.bytes, hipMemcpyDeviceToHost, st));
@@ -450,6 +452,7 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->itmax = 100000;
   o->batch = 8;
   o->check_every = 4;
+  o->nu_coarse = 2;
   o->theta = 0.0;
   o->omega_p = 4.0 / 3.0;
   o->omega_s = 4.0 / 3.0;

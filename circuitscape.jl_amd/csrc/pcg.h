@@ -31,44 +31,71 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
   H.work_k = K;
 }
 
+// Optional fusions at level 0 of the V-cycle.
+template <class T>
+struct VcycleFuse {
+  bool xa_ready = false;       // level-0 first pre-smoothing sweep already written to L.xa by the caller
+  const T* dotw = nullptr;     // fuse partials of dotw . out into the final post-smoothing product
+  double* partials = nullptr;  // [spmv_grid][K]
+};
+
+template <class T>
+inline SpmvArgs<T> level_args(const Level<T>& L, const T* x, T* y) {
+  SpmvArgs<T> a = spmv_args(L.A, x, y);
+  a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
+  return a;
+}
+
 // out = V-cycle(b) on level l, zero initial guess. `out` must not alias b or the level's work vectors.
+// Smoothing: nu_pre / nu_post damped-Jacobi sweeps on level 0, nu_coarse on every coarser level (they hold ~1/9 of
+// the work each, so extra sweeps there are nearly free and cut the iteration count).
 template <class T, int K>
-inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre, int nu_post, hipStream_t st) {
+inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int nu_post0, int nu_coarse,
+                   hipStream_t st, const VcycleFuse<T>* fuse = nullptr) {
   Level<T>& L = H.levels[l];
   const int n = L.A.nrows;
   const bool last = (l + 1 == (int)H.levels.size());
   const int gv = grid_for((int64_t)n * K);
+  const int nu_pre = l == 0 ? nu_pre0 : nu_coarse, nu_post = l == 0 ? nu_post0 : nu_coarse;
+  const bool want_dot = fuse && fuse->dotw && l == 0;
   if (last && H.coarse_dense) {
     hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, dptr<T>(H.coarse_inv), b, out);
+    if (want_dot)
+      hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
+                         (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
     return;
   }
   T* cur = dptr<T>(L.xa);
   T* oth = dptr<T>(L.rb);
   const T omega = (T)L.omega;
-  auto jacobi_sweep = [&](const T* xin, T* xout) {
-    SpmvArgs<T> a = spmv_args(L.A, xin, xout);
+  auto jacobi_sweep = [&](const T* xin, T* xout, bool dot) {
+    SpmvArgs<T> a = level_args(L, xin, xout);
     a.b = b;
     a.dinv = dptr<T>(L.dinv);
     a.omega = omega;
-    spmv_launch<T, K>(a, EPI_JACOBI, false, st);
+    if (dot) {
+      a.dotw = fuse->dotw;
+      a.partials = fuse->partials;
+    }
+    spmv_launch<T, K>(a, EPI_JACOBI, dot, st);
   };
   if (last) {
     // coarsest level too large for a dense inverse: a fixed number of damped-Jacobi sweeps
     hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
     const int sweeps = 8;
     for (int s = 0; s < sweeps; ++s) {
-      T* dst = (s + 1 == sweeps) ? out : oth;
-      jacobi_sweep(cur, dst);
+      const bool fin = (s + 1 == sweeps);
+      jacobi_sweep(cur, fin ? out : oth, fin && want_dot);
       std::swap(cur, oth);
-      if (s + 1 == sweeps) break;
     }
     return;
   }
   // pre-smoothing (first sweep from x = 0 is a scaling)
   if (nu_pre >= 1) {
-    hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
+    if (!(fuse && fuse->xa_ready && l == 0))
+      hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
     for (int s = 1; s < nu_pre; ++s) {
-      jacobi_sweep(cur, oth);
+      jacobi_sweep(cur, oth, false);
       std::swap(cur, oth);
     }
   } else {
@@ -76,7 +103,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre, int n
   }
   // residual r = b - A x  -> oth
   {
-    SpmvArgs<T> a = spmv_args(L.A, cur, oth);
+    SpmvArgs<T> a = level_args(L, (const T*)cur, oth);
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);
   }
@@ -86,25 +113,28 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre, int n
   T* bc = dptr<T>(Lc.b);
   T* xc = dptr<T>(Lc.b) + celems;
   {
-    SpmvArgs<T> a = spmv_args(L.R, oth, bc);
+    SpmvArgs<T> a = spmv_args(L.R, (const T*)oth, bc);
     spmv_launch<T, K>(a, EPI_PLAIN, false, st);
   }
-  vcycle<T, K>(H, l + 1, bc, xc, nu_pre, nu_post, st);
+  vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st);
   // prolongate and correct in place: x += P xc
   {
-    SpmvArgs<T> a = spmv_args(L.P, xc, cur);
+    SpmvArgs<T> a = spmv_args(L.P, (const T*)xc, cur);
     a.xadd = cur;
     spmv_launch<T, K>(a, EPI_ADD, false, st);
   }
-  // post-smoothing; the last sweep writes straight into `out`
+  // post-smoothing; the last sweep writes straight into `out` (with the fused dot partials on level 0)
   if (nu_post >= 1) {
     for (int s = 0; s < nu_post; ++s) {
-      T* dst = (s + 1 == nu_post) ? out : oth;
-      jacobi_sweep(cur, dst);
+      const bool fin = (s + 1 == nu_post);
+      jacobi_sweep(cur, fin ? out : oth, fin && want_dot);
       std::swap(cur, oth);
     }
   } else {
     CS_HIP(hipMemcpyAsync(out, cur, (size_t)n * K * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (want_dot)
+      hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
+                         (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
   }
 }
 
@@ -114,7 +144,7 @@ struct PcgParams {
   int criterion = CSGPU_CRIT_KRYLOV;
   int itmax = 100000;
   int check_every = 4;
-  int nu_pre = 1, nu_post = 1;
+  int nu_pre = 1, nu_post = 1, nu_coarse = 2;
 };
 
 template <class T>
@@ -180,13 +210,23 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   CS_HIP(hipEventCreate(&e1));
   CS_HIP(hipEventRecord(e0, st));
 
+  const int spmv_g = spmv_grid<T, K>((int)n);
+  double* pc = dptr<double>(W.part_c);
+  T* xa0 = dptr<T>(L0.xa);
+  const T omega0 = (T)L0.omega;
+  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1;
+  VcycleFuse<T> fuse;
+  fuse.dotw = r;
+  fuse.partials = pa;
+
   CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
   CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
-  vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, st);
-  hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)z, pa,
-                     (const T*)r, (const T*)r, pb);
-  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv,
+  // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
+  vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+  hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
+                     (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g, (const double*)pb, gv,
                      pp.criterion, pp.rtol, atol, 1, ncols_active);
   CS_HIP(hipMemcpyAsync(p, z, vbytes, hipMemcpyDeviceToDevice, st));
   check_launch("pcg init");
@@ -198,13 +238,13 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   const int max_timed = 512;
   int timed = 0;
   int it = 0;
-  const int spmv_g = spmv_grid((int)n);
+  fuse.xa_ready = fuse_xa;
   while (!host_done && it < pp.itmax) {
     // Ap = A p, fused partials of p'Ap
     {
-      SpmvArgs<T> a = spmv_args(A, (const T*)p, Ap);
+      SpmvArgs<T> a = level_args(L0, (const T*)p, Ap);
       a.dotw = p;
-      a.partials = pa;
+      a.partials = pc;
       const bool time_it = timed < max_timed;
       if (time_it) {
         if ((int)W.ev.size() < 2 * (timed + 1)) {
@@ -222,19 +262,19 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
         ++timed;
       }
     }
-    hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g);
+    hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pc, spmv_g);
+    // r -= alpha Ap, fused with the level-0 first pre-smoothing sweep xa = omega D^-1 r (and r'r when monitored)
     if (pp.criterion == CSGPU_CRIT_TRUE_RESIDUAL)
-      hipLaunchKernelGGL((cg_update_xr_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, r,
-                         (const T*)p, (const T*)Ap, pb);
+      hipLaunchKernelGGL((cg_update_r_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
+                         (const T*)Ap, fuse_xa ? xa0 : (T*)nullptr, (const T*)dptr<T>(L0.dinv), omega0, pb);
     else
-      hipLaunchKernelGGL((cg_update_xr_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, r,
-                         (const T*)p, (const T*)Ap, pb);
-    vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, st);
-    hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)z, pa,
-                       (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv,
+      hipLaunchKernelGGL((cg_update_r_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
+                         (const T*)Ap, fuse_xa ? xa0 : (T*)nullptr, (const T*)dptr<T>(L0.dinv), omega0, pb);
+    vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g, (const double*)pb, gv,
                        pp.criterion, pp.rtol, atol, 0, ncols_active);
-    hipLaunchKernelGGL((cg_update_p_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, p, (const T*)z);
+    // x += alpha p ; p = z + beta p   (one pass over p)
+    hipLaunchKernelGGL((cg_update_xp_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p, (const T*)z);
     ++it;
     if (it % pp.check_every == 0 || it >= pp.itmax) {
       check_launch("pcg iteration");
@@ -244,7 +284,7 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   }
   // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
   {
-    SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
+    SpmvArgs<T> a = level_args(L0, (const T*)x, Ap);
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);
     hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);

@@ -21,6 +21,11 @@
 //
 // Algorithmic bytes per launch: nnz*(sizeof(T)+4) + (n+1)*4 + 2*n*K*sizeof(T).
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+#include <vector>
+
 #include "prims.h"
 
 namespace csgpu {
@@ -49,10 +54,12 @@ struct SpmvArgs {
   T omega;          // EPI_JACOBI
   const T* dotw;    // DOT: partial[c] += dotw[row*K+c] * y[row*K+c]
   double* partials; // DOT: [gridDim.x][K]
+  const int* order; // optional traversal order of the row blocks (band-aware, see spmv_block_order); may be null
 };
 
 template <class T, int K, int EPI, bool DOT>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
+  // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
   __shared__ int s_rp[kSpmvRows + 1];
   __shared__ T s_val[kSpmvTile];
   __shared__ int s_col[K > 1 ? kSpmvTile : 1];
@@ -63,8 +70,20 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
   const int c = K > 1 ? tid % K : 0;
   double dot_acc = 0.0;
 
+  // Row-block -> workgroup mapping. Workgroup b is dispatched to XCD b % 8 (observed, used for speed only): give each
+  // XCD one CONTIGUOUS eighth of the row blocks and let its workgroups march through it in order, so the x rows a
+  // raster row block shares with its neighbours +-nrows_of_raster away are re-used out of that XCD's private 4 MiB L2
+  // instead of being fetched by three different XCDs.
   const int nblocks = (a.nrows + kSpmvRows - 1) / kSpmvRows;
-  for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+  int rb_first = blockIdx.x, rb_last = nblocks, rb_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, chunk = (nblocks + 7) >> 3;
+    rb_first = xcd * chunk + (blockIdx.x >> 3);
+    rb_last = min(nblocks, (xcd + 1) * chunk);
+    rb_step = gridDim.x >> 3;
+  }
+  for (int pos = rb_first; pos < rb_last; pos += rb_step) {
+    const int rb = a.order ? a.order[pos] : pos;
     const int row0 = rb * kSpmvRows;
     const int nr = min(kSpmvRows, a.nrows - row0);
     __syncthreads();  // previous pass finished with s_rp / tiles
@@ -80,12 +99,30 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
       const int te = min(kend, ts + kSpmvTile);
       if (ts != kbeg) __syncthreads();
       // ---- phase 2: coalesced stream of the tile
-      for (int k = ts + tid; k < te; k += 256) {
+      {
+        constexpr int U = kSpmvTile / 256;  // all of a lane's loads are issued before the first dependent use
+        T vv[U];
+        int cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = ts + tid + u * 256;
+          vv[u] = k < te ? a.val[k] : T(0);
+          cc[u] = k < te ? a.col[k] : 0;
+        }
         if (K == 1) {
-          s_val[k - ts] = a.val[k] * a.x[a.col[k]];
+          T xx[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) xx[u] = (ts + tid + u * 256 < te) ? a.x[cc[u]] : T(0);
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (ts + tid + u * 256 < te) s_val[tid + u * 256] = vv[u] * xx[u];
         } else {
-          s_val[k - ts] = a.val[k];
-          s_col[k - ts] = a.col[k];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (ts + tid + u * 256 < te) {
+              s_val[tid + u * 256] = vv[u];
+              s_col[tid + u * 256] = cc[u];
+            }
         }
       }
       __syncthreads();
@@ -98,15 +135,34 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
           acc[0] += s;
         }
       } else {
+        // the lane owns column c of K rows (r = tid/K + p*RPP); walk them in lock-step so K independent gathers are in
+        // flight per step. Per-row summation order (ascending k) is unchanged.
+        int lo[K], len[K];
+        int maxlen = 0;
 #pragma unroll
         for (int p = 0; p < K; ++p) {
           const int r = tid / K + p * RPP;
+          lo[p] = 0;
+          len[p] = 0;
           if (r < nr) {
-            const int lo = max(s_rp[r], ts), hi = min(s_rp[r + 1], te);
-            T s = T(0);
-            for (int k = lo; k < hi; ++k) s += s_val[k - ts] * a.x[(size_t)s_col[k - ts] * K + c];
-            acc[p] += s;
+            const int l = max(s_rp[r], ts), h = min(s_rp[r + 1], te);
+            lo[p] = l - ts;
+            len[p] = h - l;
           }
+          maxlen = max(maxlen, len[p]);
+        }
+        for (int j = 0; j < maxlen; ++j) {
+          T xv[K], vv[K];
+#pragma unroll
+          for (int p = 0; p < K; ++p) {
+            const bool on = j < len[p];
+            const int i = on ? lo[p] + j : 0;
+            vv[p] = on ? s_val[i] : T(0);
+            xv[p] = on ? a.x[(size_t)s_col[i] * K + c] : T(0);
+          }
+#pragma unroll
+          for (int p = 0; p < K; ++p)
+            if (j < len[p]) acc[p] += vv[p] * xv[p];
         }
       }
     }
@@ -142,15 +198,20 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
 }
 
 // Number of workgroups launched for an nrows-row product (also the number of dot partials per column).
+// grid (= number of dot partials per column) for an nrows-row product; a multiple of 8 once there is enough
+// work, so that the kernel's XCD-aware row-block mapping applies.
+template <class T, int K>
 inline int spmv_grid(int nrows) {
   int nb = ceil_div(nrows, kSpmvRows);
   if (nb < 1) nb = 1;
-  return nb < 4096 ? nb : 4096;
+  if (nb > 4096) nb = 4096;
+  if (nb >= 64) nb &= ~7;
+  return nb;
 }
 
 template <class T, int K, int EPI, bool DOT>
 inline void spmv_launch_t(const SpmvArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL((spmv_kernel<T, K, EPI, DOT>), dim3(spmv_grid(a.nrows)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((spmv_kernel<T, K, EPI, DOT>), dim3(spmv_grid<T, K>(a.nrows)), dim3(256), 0, st, a);
 }
 
 template <class T, int K>
@@ -172,6 +233,55 @@ inline void spmv_launch(const SpmvArgs<T>& a, int epi, bool dot, hipStream_t st)
   }
 }
 
+// ---- band-aware traversal order ------------------------------------------------------------------------------
+// A raster Laplacian in column-major numbering couples row i with rows i +- 1 and i +- R (R = raster height), so a
+// block of 256 consecutive rows reads three bands of x that lie R rows apart. Walking the row blocks in natural
+// order re-reads every x row three times (once per band) because the re-use distance (R rows of x) outlives the
+// 4 MiB L2. `spmv_block_order` detects the dominant band offset from the matrix itself and orders the row blocks
+// "across raster columns": blocks whose first row has the same offset inside the period are consecutive, so blocks
+// that share x rows run next to each other (same XCD, same time) and the re-use is served from L2.
+// Matrices without a wide band (network graphs, tiny levels) keep the natural order (empty buffer).
+__global__ __launch_bounds__(256) void block_mincol_kernel(int nrows, const int* __restrict__ rp,
+                                                           const int* __restrict__ ci, int* __restrict__ mincol) {
+  const int nblocks = (nrows + kSpmvRows - 1) / kSpmvRows;
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < nblocks; b += gridDim.x * 256) {
+    const int r0 = b * kSpmvRows, r1 = min(nrows, r0 + kSpmvRows);
+    int m = 0x7fffffff;
+    for (int r = r0; r < r1; ++r)
+      if (rp[r] < rp[r + 1]) m = min(m, ci[rp[r]]);  // columns are sorted: first entry is the row minimum
+    mincol[b] = m;
+  }
+}
+
+template <class T>
+inline void spmv_block_order(const Csr<T>& A, DBuf& order, hipStream_t st) {
+  order.release();
+  if (A.nrows != A.ncols) return;
+  const int nblocks = ceil_div(A.nrows, kSpmvRows);
+  if (nblocks < 64) return;
+  DBuf dmin = dalloc<int>(nblocks);
+  hipLaunchKernelGGL(block_mincol_kernel, dim3(grid_for(nblocks)), dim3(256), 0, st, A.nrows, A.rp(), A.ci(), dptr<int>(dmin));
+  std::vector<int> mc(nblocks);
+  CS_HIP(hipMemcpyAsync(mc.data(), dmin.p, (size_t)nblocks * sizeof(int), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  std::vector<long long> off;
+  off.reserve(nblocks);
+  for (int b = 0; b < nblocks; ++b)
+    if (mc[b] != 0x7fffffff) off.push_back((long long)b * kSpmvRows - mc[b]);
+  if (off.empty()) return;
+  std::nth_element(off.begin(), off.begin() + off.size() / 2, off.end());
+  const long long period = off[off.size() / 2];  // ~ R (+1): distance to the far band
+  if (period < 4 * kSpmvRows || period > A.nrows / 4) return;
+  std::vector<std::pair<int, int>> key(nblocks);
+  for (int b = 0; b < nblocks; ++b) key[b] = std::make_pair((int)((((long long)b * kSpmvRows) % period) / kSpmvRows), b);
+  std::sort(key.begin(), key.end());
+  std::vector<int> ord(nblocks);
+  for (int b = 0; b < nblocks; ++b) ord[b] = key[b].second;
+  order.alloc((size_t)nblocks * sizeof(int));
+  CS_HIP(hipMemcpyAsync(order.p, ord.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice, st));
+  CS_HIP(hipStreamSynchronize(st));
+}
+
 // Convenience: y = A x (+ epilogue) for a Csr<T>.
 template <class T>
 inline SpmvArgs<T> spmv_args(const Csr<T>& A, const T* x, T* y) {
@@ -188,6 +298,7 @@ inline SpmvArgs<T> spmv_args(const Csr<T>& A, const T* x, T* y) {
   a.omega = T(0);
   a.dotw = nullptr;
   a.partials = nullptr;
+  a.order = nullptr;
   return a;
 }
 

@@ -37,7 +37,7 @@ class Opts(ctypes.Structure):
         ("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("max_levels", ctypes.c_int32),
         ("max_coarse", ctypes.c_int32), ("aggregation", ctypes.c_int32), ("nu_pre", ctypes.c_int32),
         ("nu_post", ctypes.c_int32), ("criterion", ctypes.c_int32), ("itmax", ctypes.c_int32),
-        ("batch", ctypes.c_int32), ("check_every", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("check_every", ctypes.c_int32), ("nu_coarse", ctypes.c_int32),
         ("theta", ctypes.c_double), ("omega_p", ctypes.c_double), ("omega_s", ctypes.c_double),
         ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
         ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),

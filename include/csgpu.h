@@ -74,7 +74,7 @@ typedef struct csgpu_opts {
   int32_t itmax;          /* default 100000 (core.jl:639) */
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 4 */
-  int32_t reserved0;
+  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 2 */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
   double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting, default 4/3 */
   double omega_s;         /* Jacobi smoother weight numerator: omega = omega_s / rho_gershgorin, default 4/3 */

@@ -145,3 +145,24 @@ def test_error_paths(emu_lib):
     o.struct_size = 4
     with pytest.raises(emu_lib.CsgpuError):
         emu_lib.setup(A, o)
+
+
+def test_band_aware_traversal_order_tall_raster(emu_lib, oracle):
+    """A raster tall enough (height >= 4 row blocks) to switch on the band-aware row-block order in the SpMV kernel;
+    results must not depend on the traversal order."""
+    from oracle import refgraph as rg
+    R, C = 1100, 30
+    rng = np.random.default_rng(5)
+    g = 1.0 / np.exp(rng.standard_normal((R, C)))
+    A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=4))
+    assert h.info["n"] == R * C and h.info["nnz"] == A.nnz
+    A0 = h.level_matrix(0, "A")
+    assert abs(A0 - A).max() < 1e-12
+    x = rng.standard_normal((R * C, 4))
+    assert np.max(np.abs(h.spmv(x) - A @ x)) < 1e-11
+    src, dst = [5, 900, 20000], [30000, 12345, 777]
+    Rg, _, _, st = h.solve_pairs(src, dst)
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    assert st["not_converged"] == 0 and np.max(np.abs(Rg - Ro) / Ro) < 1e-6
+    h.close()
