@@ -37,7 +37,7 @@ enum SpmvEpi {
   EPI_ADD = 3      // y = xadd + A x          (prolongation: xadd may alias y)
 };
 
-static const int kSpmvRows = 256;   // rows per workgroup pass
+static const int kSpmvRows = 256;   // rows per workgroup pass (row-block granularity of the traversal order)
 static const int kSpmvTile = 2560;  // nonzeros staged in LDS per tile
 
 template <class T>
@@ -57,6 +57,12 @@ struct SpmvArgs {
   const int* order; // optional traversal order of the row blocks (band-aware, see spmv_block_order); may be null
 };
 
+// N adjacent values moved with one (up to 16-byte) memory instruction
+template <class T, int N>
+struct alignas(sizeof(T) * N) SpmvVec {
+  T e[N];
+};
+
 template <class T, int K, int EPI, bool DOT>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
   // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
@@ -66,9 +72,17 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
   __shared__ double s_red[4 * (K > 1 ? K : 1)];
 
   const int tid = threadIdx.x;
-  constexpr int RPP = kSpmvRows / K;  // rows handled per pass when K lanes share a row
-  const int c = K > 1 ? tid % K : 0;
-  double dot_acc = 0.0;
+  // K > 1: a row's K-wide x segment is gathered as 16-byte vectors: CPL adjacent columns per lane, LPR lanes per row.
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CPL = K < VEC ? K : VEC;   // columns per lane
+  constexpr int LPR = K / CPL;             // lanes per row
+  constexpr int RPP = 256 / LPR;           // rows per pass (256 lanes / LPR)
+  constexpr int NPASS = kSpmvRows / RPP;   // rows owned by one lane
+  typedef SpmvVec<T, CPL> XV;
+  const int c0 = K > 1 ? (tid % LPR) * CPL : 0;  // first column owned by the lane
+  double dot_acc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
 
   // Row-block -> workgroup mapping. Workgroup b is dispatched to XCD b % 8 (observed, used for speed only): give each
   // XCD one CONTIGUOUS eighth of the row blocks and let its workgroups march through it in order, so the x rows a
@@ -91,9 +105,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
     __syncthreads();
     const int kbeg = s_rp[0], kend = s_rp[nr];
 
-    T acc[K];
+    T acc[NPASS][CPL];
 #pragma unroll
-    for (int p = 0; p < K; ++p) acc[p] = T(0);
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) acc[p][q] = T(0);
 
     for (int ts = kbeg; ts < kend; ts += kSpmvTile) {
       const int te = min(kend, ts + kSpmvTile);
@@ -132,16 +148,16 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
           const int lo = max(s_rp[tid], ts), hi = min(s_rp[tid + 1], te);
           T s = T(0);
           for (int k = lo; k < hi; ++k) s += s_val[k - ts];
-          acc[0] += s;
+          acc[0][0] += s;
         }
       } else {
-        // the lane owns column c of K rows (r = tid/K + p*RPP); walk them in lock-step so K independent gathers are in
-        // flight per step. Per-row summation order (ascending k) is unchanged.
-        int lo[K], len[K];
+        // the lane owns CPL columns of NPASS rows (r = tid/LPR + p*RPP); walk the rows in lock-step, JU nonzeros at a
+        // time, so NPASS*JU independent 16-byte gathers are in flight. Per-row summation order (ascending k) is unchanged.
+        int lo[NPASS], len[NPASS];
         int maxlen = 0;
 #pragma unroll
-        for (int p = 0; p < K; ++p) {
-          const int r = tid / K + p * RPP;
+        for (int p = 0; p < NPASS; ++p) {
+          const int r = tid / LPR + p * RPP;
           lo[p] = 0;
           len[p] = 0;
           if (r < nr) {
@@ -151,53 +167,80 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
           }
           maxlen = max(maxlen, len[p]);
         }
-        for (int j = 0; j < maxlen; ++j) {
-          T xv[K], vv[K];
+        constexpr int JU = NPASS >= 8 ? 1 : (8 / NPASS);
+        for (int j = 0; j < maxlen; j += JU) {
+          XV xv[JU][NPASS];
+          T vv[JU][NPASS];
 #pragma unroll
-          for (int p = 0; p < K; ++p) {
-            const bool on = j < len[p];
-            const int i = on ? lo[p] + j : 0;
-            vv[p] = on ? s_val[i] : T(0);
-            xv[p] = on ? a.x[(size_t)s_col[i] * K + c] : T(0);
+          for (int u = 0; u < JU; ++u) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+              const bool on = j + u < len[p];
+              const int i = on ? lo[p] + j + u : 0;
+              vv[u][p] = on ? s_val[i] : T(0);
+              if (on) {
+                xv[u][p] = *reinterpret_cast<const XV*>(a.x + (size_t)s_col[i] * K + c0);
+              } else {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = T(0);
+              }
+            }
           }
 #pragma unroll
-          for (int p = 0; p < K; ++p)
-            if (j < len[p]) acc[p] += vv[p] * xv[p];
+          for (int u = 0; u < JU; ++u) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+              if (j + u < len[p]) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) acc[p][q] += vv[u][p] * xv[u][p].e[q];
+              }
+          }
         }
       }
     }
-    // ---- phase 4: epilogue
+    // ---- phase 4: epilogue (vectorised: CPL adjacent columns per lane)
 #pragma unroll
-    for (int p = 0; p < K; ++p) {
-      const int r = K == 1 ? tid : tid / K + p * RPP;
+    for (int p = 0; p < NPASS; ++p) {
+      const int r = K == 1 ? tid : tid / LPR + p * RPP;
       if (K == 1 && p > 0) break;
       if (r < nr) {
         const size_t row = (size_t)(row0 + r);
-        const size_t e = row * K + c;
-        T v = acc[p];
-        if (EPI == EPI_RESID) v = a.b[e] - v;
-        if (EPI == EPI_JACOBI) v = a.x[e] + a.omega * a.dinv[row] * (a.b[e] - v);
-        if (EPI == EPI_ADD) v = a.xadd[e] + v;
-        a.y[e] = v;
-        if (DOT) dot_acc += (double)a.dotw[e] * (double)v;
+        const size_t e0 = row * K + c0;
+        XV bv, xo, out, dw;
+        if (EPI == EPI_RESID || EPI == EPI_JACOBI) bv = *reinterpret_cast<const XV*>(a.b + e0);
+        if (EPI == EPI_JACOBI) xo = *reinterpret_cast<const XV*>(a.x + e0);
+        if (EPI == EPI_ADD) xo = *reinterpret_cast<const XV*>(a.xadd + e0);
+        if (DOT) dw = *reinterpret_cast<const XV*>(a.dotw + e0);
+        const T sc = EPI == EPI_JACOBI ? a.omega * a.dinv[row] : T(0);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          T v = acc[p][q];
+          if (EPI == EPI_RESID) v = bv.e[q] - v;
+          if (EPI == EPI_JACOBI) v = xo.e[q] + sc * (bv.e[q] - v);
+          if (EPI == EPI_ADD) v = xo.e[q] + v;
+          out.e[q] = v;
+          if (DOT) dot_acc[q] += (double)dw.e[q] * (double)v;
+        }
+        *reinterpret_cast<XV*>(a.y + e0) = out;
       }
     }
   }
 
   if (DOT) {
-    // lanes with equal c sit K apart: reduce over lane bits >= log2(K), then across the 4 waves via LDS.
-    double v = dot_acc;
-#pragma unroll
-    for (int o = 32; o >= (K > 1 ? K : 1); o >>= 1) v += __shfl_xor(v, o, 64);
+    // lanes owning the same columns sit LPR apart: reduce over lane bits >= log2(LPR), then across the 4 waves via LDS
     const int lane = tid & 63, w = tid >> 6;
     __syncthreads();
-    if (lane < K) s_red[w * K + lane] = v;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      double v = dot_acc[q];
+#pragma unroll
+      for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LPR) s_red[w * K + lane * CPL + q] = v;
+    }
     __syncthreads();
     if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
   }
 }
-
-// Number of workgroups launched for an nrows-row product (also the number of dot partials per column).
 // grid (= number of dot partials per column) for an nrows-row product; a multiple of 8 once there is enough
 // work, so that the kernel's XCD-aware row-block mapping applies.
 template <class T, int K>
