@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-sample", type=int, default=1000, help="raster edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
+    ap.add_argument("--precond", default="same", choices=["same", "fp32"],
+                    help="precision of the AMG preconditioner: same as --precision, or fp32 under an fp64 CG")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,7 +98,8 @@ def main():
     size = args.size
     g = make_raster(size, dtype=dtype)
     cells, pairs = focal_pairs(size)
-    opts = lib.default_opts(device=local_rank, batch=args.batch, criterion=args.criterion)
+    opts = lib.default_opts(device=local_rank, batch=args.batch, criterion=args.criterion,
+                            precond_bytes=4 if args.precond == "fp32" else 0)
     t0 = time.time()
     h = lib.raster_setup(g, opts)
     t_setup_wall = time.time() - t0
@@ -171,7 +174,8 @@ def main():
             "config": {"workload": "%dx%d synthetic raster, 8-neighbour, %d pairs/GPU in batches of %d, %s"
                                    % (size, size, K * B, B, "fp64" if vb == 8 else "fp32"),
                        "n": info["n"], "nnz": info["nnz"], "batch": B, "levels": info["levels"],
-                       "operator_complexity": info["operator_complexity"], "criterion": args.criterion},
+                       "operator_complexity": info["operator_complexity"], "criterion": args.criterion,
+                       "preconditioner_precision": "fp32" if info["precond_bytes"] == 4 else "fp64"},
             "solve_only_pairs_per_s": pairs_done / elapsed,
             "setup_s": setup_s, "setup_device_s": info["setup_ms"] / 1e3, "setup_wall_s": t_setup_wall,
             "iters_mean": agg["total_iters"] / float(K * B), "iters_max": agg["max_iters"],

@@ -92,12 +92,19 @@ __global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const doubl
   }
 }
 
-// ---- r -= alpha Ap, fused with the first damped-Jacobi sweep of the next preconditioner application from a zero
-//      guess (xa = omega * dinv .* r; skipped when xa == nullptr) and, optionally, the partials of r'r.
-template <class T, int K, bool RR>
+// ---- y = (V) x   (precision conversion between the CG vectors and the preconditioner's vectors)
+template <class U, class V>
+__global__ __launch_bounds__(256) void convert_kernel(int64_t total, const U* __restrict__ x, V* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) y[e] = (V)x[e];
+}
+
+// ---- r -= alpha Ap, fused with: the preconditioner-precision copy of r (rp, when TP != T), the first damped-Jacobi
+//      sweep of the next preconditioner application from a zero guess (xa = omega * dinv .* r; skipped when xa is
+//      null) and, optionally, the partials of r'r.
+template <class T, class TP, int K, bool RR>
 __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgScalars* S, T* __restrict__ r,
-                                                          const T* __restrict__ Ap, T* __restrict__ xa,
-                                                          const T* __restrict__ dinv, T omega,
+                                                          const T* __restrict__ Ap, TP* __restrict__ rp,
+                                                          TP* __restrict__ xa, const TP* __restrict__ dinv, TP omega,
                                                           double* __restrict__ partials) {
   __shared__ double s_red[4 * K];
   const int c = threadIdx.x % K;
@@ -107,7 +114,8 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const T rn = r[e] - alpha * Ap[e];
     r[e] = rn;
-    if (xa) xa[e] = omega * dinv[e / K] * rn;
+    if (rp) rp[e] = (TP)rn;
+    if (xa) xa[e] = omega * dinv[e / K] * (TP)rn;
     if (RR) s += (double)rn * (double)rn;
   }
   if (RR) {
@@ -123,10 +131,10 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
   }
 }
 
-// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished)
-template <class T, int K>
+// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished; z in preconditioner precision)
+template <class T, class TP, int K>
 __global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
-                                                           T* __restrict__ p, const T* __restrict__ z) {
+                                                           T* __restrict__ p, const TP* __restrict__ z) {
   const int c = threadIdx.x % K;
   const T alpha = (T)S->alpha[c];
   const T beta = (T)S->beta[c];
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgSc
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const T pe = p[e];
     x[e] += alpha * pe;
-    p[e] = z[e] + beta * pe;
+    p[e] = (T)z[e] + beta * pe;
   }
 }
 

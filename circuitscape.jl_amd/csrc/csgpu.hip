@@ -33,13 +33,32 @@ __global__ __launch_bounds__(256) void convert_index_kernel(int64_t n, const I* 
     out[i] = (int)(in[i] - (I)base);
 }
 
-template <class T>
+// element-wise precision conversion of a CSR matrix (pattern copied)
+template <class T, class TP>
+inline void convert_csr(const Csr<T>& A, Csr<TP>& B, hipStream_t st) {
+  B.nrows = A.nrows;
+  B.ncols = A.ncols;
+  B.nnz = A.nnz;
+  B.rowptr.alloc(A.rowptr.bytes);
+  B.col.alloc(A.col.bytes);
+  B.val.alloc((size_t)std::max<int64_t>(A.nnz, 1) * sizeof(TP));
+  CS_HIP(hipMemcpyAsync(B.rowptr.p, A.rowptr.p, A.rowptr.bytes, hipMemcpyDeviceToDevice, st));
+  CS_HIP(hipMemcpyAsync(B.col.p, A.col.p, A.col.bytes, hipMemcpyDeviceToDevice, st));
+  if (A.nnz > 0)
+    hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(grid_for(A.nnz)), dim3(256), 0, st, A.nnz, A.va(), B.va());
+  CS_HIP(hipStreamSynchronize(st));
+}
+
+// T: precision of the CG iteration and of the C-ABI's vectors; TP: precision of the AMG preconditioner.
+template <class T, class TP>
 struct Solver : ISolver {
+  static constexpr bool MIXED = !std::is_same<T, TP>::value;
   int device = 0;
   hipStream_t st = nullptr;
   csgpu_opts opts;
-  Hierarchy<T> H;
-  PcgWork<T> W;
+  Csr<T> Aouter;      // the matrix CG sees when MIXED (otherwise level 0 of the hierarchy is used)
+  Hierarchy<TP> H;
+  PcgWork<T, TP> W;
   double upload_ms = 0;
   int64_t n = 0, nnz = 0;
   std::mutex mu;
@@ -131,7 +150,26 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     opts.node_row = opts.node_col = nullptr;  // host pointers are never retained
-    amg_setup(H, std::move(A), setup_params(), prow, pcol, st);
+    finish_setup(std::move(A), prow, pcol);
+  }
+
+  const Csr<T>& cg_matrix() const {
+    if constexpr (MIXED) {
+      return Aouter;
+    } else {
+      return H.levels[0].A;
+    }
+  }
+
+  void finish_setup(Csr<T>&& A, const int* prow, const int* pcol) {
+    if constexpr (MIXED) {
+      Csr<TP> Ap;
+      convert_csr(A, Ap, st);
+      Aouter = std::move(A);
+      amg_setup(H, std::move(Ap), setup_params(), prow, pcol, st);
+    } else {
+      amg_setup(H, std::move(A), setup_params(), prow, pcol, st);
+    }
   }
 
   void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg) {
@@ -166,7 +204,7 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
     dcond.release();
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    amg_setup(H, std::move(A), setup_params(), dptr<int>(drow), dptr<int>(dcol), st);
+    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol));
   }
 
   int pick_k(int64_t ncols) const {
@@ -180,7 +218,7 @@ struct Solver : ISolver {
 
   template <int K>
   PcgBatchResult run_batch(int ncols) {
-    return pcg_solve<T, K>(H, W, pcg_params(), ncols, st);
+    return pcg_solve<T, TP, K>(cg_matrix(), H, W, pcg_params(), ncols, st);
   }
   PcgBatchResult run_batch_k(int K, int ncols) {
     switch (K) {
@@ -307,9 +345,10 @@ struct Solver : ISolver {
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
-  static int64_t spmv_bytes(const Csr<T>& A, int k) {
-    return A.nnz * (int64_t)(sizeof(T) + 4) + ((int64_t)A.nrows + 1) * 4 +
-           ((int64_t)A.nrows + (int64_t)A.ncols) * k * (int64_t)sizeof(T);
+  template <class U>
+  static int64_t spmv_bytes(const Csr<U>& A, int k) {
+    return A.nnz * (int64_t)(sizeof(U) + 4) + ((int64_t)A.nrows + 1) * 4 +
+           ((int64_t)A.nrows + (int64_t)A.ncols) * k * (int64_t)sizeof(U);
   }
 
   void get_info(csgpu_info* info) const override {
@@ -318,10 +357,11 @@ struct Solver : ISolver {
     info->nnz = nnz;
     info->levels = (int)H.levels.size();
     info->val_bytes = (int)sizeof(T);
+    info->precond_bytes = (int)sizeof(TP);
     double nnz_sum = 0, n_sum = 0;
-    int64_t bytes = 0;
+    int64_t bytes = (int64_t)Aouter.device_bytes();
     for (size_t l = 0; l < H.levels.size(); ++l) {
-      const Level<T>& L = H.levels[l];
+      const Level<TP>& L = H.levels[l];
       nnz_sum += (double)L.A.nnz;
       n_sum += (double)L.A.nrows;
       if (l < 32) {
@@ -329,23 +369,23 @@ struct Solver : ISolver {
         info->level_nnz[l] = L.A.nnz;
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.dinv.bytes + L.xa.bytes +
-                         L.rb.bytes + L.b.bytes);
+                         L.rb.bytes + L.b.bytes + L.orderA.bytes);
     }
-    bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
+    bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
     info->grid_complexity = n_sum / std::max(1.0, (double)H.levels[0].A.nrows);
     info->setup_ms = H.setup_ms;
     info->upload_ms = upload_ms;
     info->device_bytes = bytes;
-    info->spmv_bytes_fine = spmv_bytes(H.levels[0].A, 1);
-    // B_iter = B_spmv(A0) + 10 n sizeof(T) + sum_l [(nu1+nu2+1) B_spmv(A_l) + B_spmv(P_l) + B_spmv(R_l) + 4 n_l sizeof(T)]
-    int64_t bi = spmv_bytes(H.levels[0].A, 1) + 10 * n * (int64_t)sizeof(T);
+    info->spmv_bytes_fine = spmv_bytes(cg_matrix(), 1);
+    // B_iter = B_spmv(A0) + 10 n sizeof(T) + sum_l [(nu1+nu2+1) B_spmv(A_l) + B_spmv(P_l) + B_spmv(R_l) + 4 n_l sizeof(TP)]
+    int64_t bi = spmv_bytes(cg_matrix(), 1) + 10 * n * (int64_t)sizeof(T);
     for (size_t l = 0; l + 1 < H.levels.size(); ++l) {
-      const Level<T>& L = H.levels[l];
+      const Level<TP>& L = H.levels[l];
       // first pre-sweep from a zero guess needs no product: (nu_pre - 1) + nu_post Jacobi products + 1 residual
       const int nup = l == 0 ? opts.nu_pre : opts.nu_coarse, nuq = l == 0 ? opts.nu_post : opts.nu_coarse;
       const int prods = std::max(nup - 1, 0) + nuq + 1;
-      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.P, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(T);
+      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.P, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(TP);
     }
     info->bytes_per_iteration = bi;
   }
@@ -353,14 +393,15 @@ struct Solver : ISolver {
   double spmv_bench(int k, int reps) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
-    const Csr<T>& A = H.levels[0].A;
+    const Csr<T>& A = cg_matrix();
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
     fill<T>(dptr<T>(x), n * k, T(1), st);
     hipEvent_t e0, e1;
     CS_HIP(hipEventCreate(&e0));
     CS_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
-      SpmvArgs<T> a = level_args(H.levels[0], (const T*)dptr<T>(x), dptr<T>(y));
+      SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+      a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
       CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
     };
     launch();  // warm-up
@@ -379,10 +420,11 @@ struct Solver : ISolver {
   void spmv_host(const void* xh, void* yh, int k) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
-    const Csr<T>& A = H.levels[0].A;
+    const Csr<T>& A = cg_matrix();
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
     CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
-    SpmvArgs<T> a = level_args(H.levels[0], (const T*)dptr<T>(x), dptr<T>(y));
+    SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+    a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
     CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
     check_launch("spmv_host");
     CS_HIP(hipMemcpyAsync(yh, y.p, y.bytes, hipMemcpyDeviceToHost, st));
@@ -392,14 +434,23 @@ struct Solver : ISolver {
   void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
-    const Level<T>& L = H.levels[lvl];
-    const Csr<T>& M = which == 0 ? L.A : (which == 1 ? L.P : L.R);
+    const Level<TP>& L = H.levels[lvl];
+    const Csr<TP>& M = which == 0 ? L.A : (which == 1 ? L.P : L.R);
     if (nrows) *nrows = M.nrows;
     if (ncols) *ncols = M.ncols;
     if (nnz_out) *nnz_out = M.nnz;
     if (rowptr && M.rowptr.p) CS_HIP(hipMemcpy(rowptr, M.rp(), (size_t)(M.nrows + 1) * sizeof(int), hipMemcpyDeviceToHost));
     if (colidx && M.nnz > 0) CS_HIP(hipMemcpy(colidx, M.ci(), (size_t)M.nnz * sizeof(int), hipMemcpyDeviceToHost));
-    if (vals && M.nnz > 0) CS_HIP(hipMemcpy(vals, M.va(), (size_t)M.nnz * sizeof(T), hipMemcpyDeviceToHost));
+    if (vals && M.nnz > 0) {
+      if (MIXED && lvl == 0 && which == 0) {
+        CS_HIP(hipMemcpy(vals, Aouter.va(), (size_t)M.nnz * sizeof(T), hipMemcpyDeviceToHost));
+      } else {
+        std::vector<TP> tmp((size_t)M.nnz);
+        CS_HIP(hipMemcpy(tmp.data(), M.va(), (size_t)M.nnz * sizeof(TP), hipMemcpyDeviceToHost));
+        T* out = (T*)vals;
+        for (size_t i = 0; i < tmp.size(); ++i) out[i] = (T)tmp[i];
+      }
+    }
   }
 };
 
@@ -460,6 +511,8 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->atol = -1.0;
   o->node_row = nullptr;
   o->node_col = nullptr;
+  o->precond_bytes = 0;
+  o->reserved1 = 0;
 }
 
 static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts* opts) {
@@ -472,6 +525,10 @@ static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts*
       g_last_error = "matrix too large for int32 device indexing (need nnz < 2^31 and n < 2^27)";
       return CSGPU_BAD_ARGS;
     }
+  }
+  if (opts && (opts->precond_bytes != 0 && opts->precond_bytes != 4 && opts->precond_bytes != 8)) {
+    g_last_error = "csgpu_opts.precond_bytes must be 0, 4 or 8";
+    return CSGPU_BAD_ARGS;
   }
   if (opts && opts->struct_size != (int32_t)sizeof(csgpu_opts)) {
     g_last_error = "csgpu_opts.struct_size mismatch (call csgpu_default_opts first)";
@@ -492,12 +549,16 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
-  if (val_bytes == 8) {
-    auto* s = new csgpu::Solver<double>(o);
+  if (val_bytes == 8 && o.precond_bytes == 4) {
+    auto* s = new csgpu::Solver<double, float>(o);
+    h->solver.reset(s);
+    s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
+  } else if (val_bytes == 8) {
+    auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);
     s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
   } else {
-    auto* s = new csgpu::Solver<float>(o);
+    auto* s = new csgpu::Solver<float, float>(o);
     h->solver.reset(s);
     s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
   }
@@ -523,12 +584,16 @@ int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_b
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
-  if (val_bytes == 8) {
-    auto* s = new csgpu::Solver<double>(o);
+  if (val_bytes == 8 && o.precond_bytes == 4) {
+    auto* s = new csgpu::Solver<double, float>(o);
+    h->solver.reset(s);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+  } else if (val_bytes == 8) {
+    auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);
     s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
   } else {
-    auto* s = new csgpu::Solver<float>(o);
+    auto* s = new csgpu::Solver<float, float>(o);
     h->solver.reset(s);
     s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
   }

@@ -8,6 +8,7 @@
 // pre-smoothing sweep from the zero guess needs no matrix product at all.
 #pragma once
 #include <limits>
+#include <type_traits>
 
 #include "amg_setup.h"
 #include "blas1.h"
@@ -147,11 +148,14 @@ struct PcgParams {
   int nu_pre = 1, nu_post = 1, nu_coarse = 2;
 };
 
-template <class T>
+// T = precision of the CG iteration (matrix seen by CG, x, r, p, Ap); TP = precision of the AMG hierarchy and of
+// everything inside the V-cycle (TP == T, or TP = float under T = double: "fp32 preconditioner").
+template <class T, class TP>
 struct PcgWork {
   int K = 0;
   int64_t n = 0;
-  DBuf x, r, z, p, Ap, b;
+  DBuf x, r, p, Ap, b;        // T
+  DBuf z, rp;                 // TP: preconditioned residual; TP copy of r (aliases r when TP == T)
   DBuf scalars;               // CgScalars
   DBuf part_a, part_b, part_c;
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
@@ -162,10 +166,11 @@ struct PcgWork {
     const size_t bytes = (size_t)n * K * sizeof(T);
     x.alloc(bytes);
     r.alloc(bytes);
-    z.alloc(bytes);
     p.alloc(bytes);
     Ap.alloc(bytes);
     b.alloc(bytes);
+    z.alloc((size_t)n * K * sizeof(TP));
+    if (!std::is_same<T, TP>::value) rp.alloc((size_t)n * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
     const size_t pb = (size_t)4096 * kMaxK * sizeof(double);
     part_a.alloc(pb);
@@ -185,25 +190,29 @@ struct PcgBatchResult {
 };
 
 // Solve A X = B for the K interleaved columns held in W.b; solution left in W.x.
-template <class T, int K>
-inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams& pp, int ncols_active,
-                                hipStream_t st) {
-  Level<T>& L0 = H.levels[0];
-  const Csr<T>& A = L0.A;
+// A is the matrix CG sees (precision T); H is the hierarchy (precision TP) whose level 0 has A's sparsity pattern.
+template <class T, class TP, int K>
+inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP>& W, const PcgParams& pp,
+                                int ncols_active, hipStream_t st) {
+  constexpr bool MIXED = !std::is_same<T, TP>::value;
+  Level<TP>& L0 = H.levels[0];
   const int64_t n = A.nrows;
   ensure_level_work(H, K);
   T* x = dptr<T>(W.x);
   T* r = dptr<T>(W.r);
-  T* z = dptr<T>(W.z);
   T* p = dptr<T>(W.p);
   T* Ap = dptr<T>(W.Ap);
   const T* b = dptr<T>(W.b);
+  TP* z = dptr<TP>(W.z);
+  TP* rp = MIXED ? dptr<TP>(W.rp) : (TP*)r;
   CgScalars* S = dptr<CgScalars>(W.scalars);
   double* pa = dptr<double>(W.part_a);
   double* pb = dptr<double>(W.part_b);
+  double* pc = dptr<double>(W.part_c);
   const size_t vbytes = (size_t)n * K * sizeof(T);
   const int gv = grid_for(n * K);
   const double atol = pp.atol < 0 ? std::sqrt((double)std::numeric_limits<T>::epsilon()) : pp.atol;
+  const int* orderA = L0.orderA.p ? dptr<int>(L0.orderA) : nullptr;
 
   hipEvent_t e0, e1;
   CS_HIP(hipEventCreate(&e0));
@@ -211,24 +220,26 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   CS_HIP(hipEventRecord(e0, st));
 
   const int spmv_g = spmv_grid<T, K>((int)n);
-  double* pc = dptr<double>(W.part_c);
-  T* xa0 = dptr<T>(L0.xa);
-  const T omega0 = (T)L0.omega;
+  const int spmv_gp = spmv_grid<TP, K>((int)n);
+  TP* xa0 = dptr<TP>(L0.xa);
+  const TP omega0 = (TP)L0.omega;
   const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1;
-  VcycleFuse<T> fuse;
-  fuse.dotw = r;
+  VcycleFuse<TP> fuse;
+  fuse.dotw = rp;
   fuse.partials = pa;
 
   CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
   CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
+  if (MIXED)
+    hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
-  vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+  vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
   hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
                      (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
-  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g, (const double*)pb, gv,
+  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
                      pp.criterion, pp.rtol, atol, 1, ncols_active);
-  CS_HIP(hipMemcpyAsync(p, z, vbytes, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL((convert_kernel<TP, T>), dim3(gv), dim3(256), 0, st, n * K, (const TP*)z, p);
   check_launch("pcg init");
 
   int host_done = 0;
@@ -242,7 +253,8 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   while (!host_done && it < pp.itmax) {
     // Ap = A p, fused partials of p'Ap
     {
-      SpmvArgs<T> a = level_args(L0, (const T*)p, Ap);
+      SpmvArgs<T> a = spmv_args(A, (const T*)p, Ap);
+      a.order = orderA;
       a.dotw = p;
       a.partials = pc;
       const bool time_it = timed < max_timed;
@@ -263,18 +275,22 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
       }
     }
     hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pc, spmv_g);
-    // r -= alpha Ap, fused with the level-0 first pre-smoothing sweep xa = omega D^-1 r (and r'r when monitored)
+    // r -= alpha Ap, fused with the TP copy of r, the level-0 first pre-smoothing sweep xa = omega D^-1 r and
+    // (when the true residual is monitored) the partials of r'r
     if (pp.criterion == CSGPU_CRIT_TRUE_RESIDUAL)
-      hipLaunchKernelGGL((cg_update_r_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
-                         (const T*)Ap, fuse_xa ? xa0 : (T*)nullptr, (const T*)dptr<T>(L0.dinv), omega0, pb);
+      hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
+                         (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
+                         (const TP*)dptr<TP>(L0.dinv), omega0, pb);
     else
-      hipLaunchKernelGGL((cg_update_r_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
-                         (const T*)Ap, fuse_xa ? xa0 : (T*)nullptr, (const T*)dptr<T>(L0.dinv), omega0, pb);
-    vcycle<T, K>(H, 0, r, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
-    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_g, (const double*)pb, gv,
+      hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
+                         (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
+                         (const TP*)dptr<TP>(L0.dinv), omega0, pb);
+    vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
                        pp.criterion, pp.rtol, atol, 0, ncols_active);
     // x += alpha p ; p = z + beta p   (one pass over p)
-    hipLaunchKernelGGL((cg_update_xp_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p, (const T*)z);
+    hipLaunchKernelGGL((cg_update_xp_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p,
+                       (const TP*)z);
     ++it;
     if (it % pp.check_every == 0 || it >= pp.itmax) {
       check_launch("pcg iteration");
@@ -284,7 +300,8 @@ inline PcgBatchResult pcg_solve(Hierarchy<T>& H, PcgWork<T>& W, const PcgParams&
   }
   // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
   {
-    SpmvArgs<T> a = level_args(L0, (const T*)x, Ap);
+    SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
+    a.order = orderA;
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);
     hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);

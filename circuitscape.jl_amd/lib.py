@@ -41,12 +41,14 @@ class Opts(ctypes.Structure):
         ("theta", ctypes.c_double), ("omega_p", ctypes.c_double), ("omega_s", ctypes.c_double),
         ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
         ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),
+        ("precond_bytes", ctypes.c_int32), ("reserved1", ctypes.c_int32),
     ]
 
 
 class Info(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int64), ("nnz", ctypes.c_int64), ("levels", ctypes.c_int32), ("val_bytes", ctypes.c_int32),
+        ("precond_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("operator_complexity", ctypes.c_double), ("grid_complexity", ctypes.c_double),
         ("setup_ms", ctypes.c_double), ("upload_ms", ctypes.c_double), ("device_bytes", ctypes.c_int64),
         ("level_n", ctypes.c_int64 * 32), ("level_nnz", ctypes.c_int64 * 32),

@@ -85,6 +85,11 @@ typedef struct csgpu_opts {
    * produces on rasters). NULL for network graphs. */
   const int32_t* node_row;
   const int32_t* node_col;
+  /* Storage / arithmetic precision of the AMG preconditioner (hierarchy + V-cycle): 0 = same as val_bytes,
+   * 4 = fp32 preconditioner under an fp64 CG iteration (residuals, search directions, dot products and the
+   * reference's residual check stay in val_bytes precision). Default 0. */
+  int32_t precond_bytes;
+  int32_t reserved1;
 } csgpu_opts;
 
 typedef struct csgpu_info {
@@ -92,6 +97,8 @@ typedef struct csgpu_info {
   int64_t nnz;
   int32_t levels;               /* including the coarsest */
   int32_t val_bytes;
+  int32_t precond_bytes;
+  int32_t reserved;
   double operator_complexity;   /* sum_l nnz(A_l) / nnz(A_0) */
   double grid_complexity;       /* sum_l n_l / n_0 */
   double setup_ms;              /* device time of the AMG setup (HIP events) */

@@ -166,3 +166,33 @@ def test_band_aware_traversal_order_tall_raster(emu_lib, oracle):
     Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
     assert st["not_converged"] == 0 and np.max(np.abs(Rg - Ro) / Ro) < 1e-6
     h.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_fp32_preconditioner_under_fp64_cg(emu_lib, oracle, batch):
+    """precond_bytes = 4: the AMG hierarchy and the V-cycle run in fp32, CG (residual, directions, dots, the
+    reference's residual check) stays fp64; resistances must still match the tight oracle to 1e-6."""
+    from oracle import refgraph as rg
+    N = 60
+    G, g = rg.synthetic_raster_problem(N, N)
+    A = oracle.regularize(G)
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=batch, precond_bytes=4))
+    assert h.info["precond_bytes"] == 4 and h.info["val_bytes"] == 8
+    cells = np.random.default_rng(4).choice(N * N, size=4, replace=False)
+    src = [cells[0], cells[0], cells[1], cells[2], cells[3]]
+    dst = [cells[1], cells[2], cells[3], cells[3], cells[0]]
+    R, gath, V, st = h.solve_pairs(src, dst, gather=cells, want_voltages=True)
+    Ro, go, _ = oracle.OracleAMG(A).solve_pairs(src, dst, gather=cells, rtol=1e-12, atol=0.0, criterion=1)
+    assert st["not_converged"] == 0
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    P = h.level_matrix(0, "P")
+    A0 = h.level_matrix(0, "A")
+    assert abs(A0 - A).max() < 1e-12 and P.dtype == np.float64
+    h.close()
+    # tight tolerance is still reachable with the fp32 preconditioner (outer iteration is fp64)
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=batch, precond_bytes=4, criterion=emu_lib.CRIT_TRUE_RESIDUAL,
+                                                     rtol=1e-11, atol=0.0))
+    R2, _, _, st2 = h.solve_pairs(src, dst)
+    assert st2["not_converged"] == 0 and st2["max_relres"] < 1e-10
+    assert np.max(np.abs(R2 - Ro) / Ro) < 1e-10
+    h.close()
