@@ -31,6 +31,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def pmc_traffic(size, batch, vb):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh -> profiles/),
+    collected with rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md prescribes. None when no
+    profile matches the current workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        key = "%d_k%d_f%d" % (size, batch, vb * 8)
+        return d.get(key, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def make_raster(size, seed=12345, sigma=1.0, dtype=np.float64):
     rng = np.random.default_rng(seed)
     r = np.exp(sigma * rng.standard_normal((size, size)))
@@ -73,8 +87,11 @@ def main():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-sample", type=int, default=1000, help="raster edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
-    ap.add_argument("--precond", default="same", choices=["same", "fp32"],
-                    help="precision of the AMG preconditioner: same as --precision, or fp32 under an fp64 CG")
+    ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
+                    help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "
+                         "precision as the CG iteration")
+    ap.add_argument("--compare-steps", type=int, default=3,
+                    help="N=1 only: also time this many steps with an fp64 preconditioner and report them (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +187,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64" if dtype == np.float64 else "f32",
+            "dtype_note": ("CG iteration, residuals, dot products and the residual check in f64; AMG preconditioner "
+                           "(hierarchy + V-cycle) in f32" if (vb == 8 and info["precond_bytes"] == 4) else "uniform precision"),
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic raster, 8-neighbour, %d pairs/GPU in batches of %d, %s"
                                    % (size, size, K * B, B, "fp64" if vb == 8 else "fp32"),
@@ -182,11 +201,33 @@ def main():
             "max_relres": agg["max_relres"],
             "roofline": {"bound": "hbm", "kernel": "spmv_kernel<%s,%d,PLAIN,DOT> (fine-level CG SpMM)" % ("double" if vb == 8 else "float", B),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": spmm_bytes, "avg_ms": spmv_avg_ms,
+                         "traffic": pmc_traffic(size, B, vb), "algorithmic_bytes_per_launch": spmm_bytes, "avg_ms": spmv_avg_ms,
                          "launches_timed": agg["cg_spmv_calls"],
                          "spmv_k1_avg_ms": spmv1_ms,
                          "spmv_k1_GBs": info["spmv_bytes_fine"] / (spmv1_ms * 1e-3) / 1e9 if spmv1_ms > 0 else 0.0},
         }
+        if world == 1 and args.compare_steps > 0 and args.precond == "fp32" and dtype == np.float64:
+            # same workload with the preconditioner in fp64 as well (pure-fp64 path), for comparison
+            h.close()
+            h2 = lib.raster_setup(make_raster(size, dtype=dtype), lib.default_opts(device=local_rank, batch=B,
+                                                                                  criterion=args.criterion))
+            s, d = batch_pairs(0)
+            h2.solve_pairs(s, d)
+            t1 = time.perf_counter()
+            its = 0
+            for k in range(args.compare_steps):
+                s, d = batch_pairs(Wm + k)
+                R2, _, _, st2 = h2.solve_pairs(s, d)
+                its += st2["total_iters"]
+            el2 = time.perf_counter() - t1
+            i2 = h2.info
+            out["fp64_preconditioner"] = {
+                "solve_only_pairs_per_s": args.compare_steps * B / el2,
+                "value": args.compare_steps * B / (el2 + (i2["setup_ms"] + i2["upload_ms"]) / 1e3 * args.compare_steps * B / 100.0),
+                "steps": args.compare_steps, "iters_mean": its / float(args.compare_steps * B),
+                "max_abs_diff_R_vs_fp32_preconditioner": float(np.max(np.abs(R2 - results[args.compare_steps - 1])))
+                if args.compare_steps <= K else None}
+            h2.close()
         if args.cpu_sample > 0 and world == 1:
             cb = cpu_baseline(args.cpu_sample)
             scale = float(info["n"]) / cb["n"]
@@ -200,7 +241,10 @@ def main():
                 "spmv_GBs": (cb["nnz"] * 12 + (cb["n"] + 1) * 4 + 2 * cb["n"] * 8) / cb["spmv_s"] / 1e9,
             }
         print(json.dumps(out), flush=True)
-    h.close()
+    try:
+        h.close()
+    except Exception:
+        pass
     if dist is not None:
         dist.destroy_process_group()
 
