@@ -74,6 +74,12 @@ __device__ __forceinline__ double reduce_partials(const double* partials, int np
 template <int K>
 __global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const double* partials, int nparts) {
   __shared__ double sm[4];
+  if (S->all_done) {
+    // a surplus iteration enqueued before the host saw the flag: neutralise it (the final x update is already in)
+    if (threadIdx.x < K) S->alpha[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) S->all_done = 2;
+    return;
+  }
   for (int c = 0; c < K; ++c) {
     const double pAp = reduce_partials<K>(partials, nparts, c, sm);
     if (threadIdx.x == 0) {
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
                                                           TP* __restrict__ xa, const TP* __restrict__ dinv, TP omega,
                                                           double* __restrict__ partials) {
   __shared__ double s_red[4 * K];
+  if (S->all_done) return;
   const int c = threadIdx.x % K;
   const T alpha = (T)S->alpha[c];
   double s = 0.0;
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
 template <class T, class TP, int K>
 __global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
                                                            T* __restrict__ p, const TP* __restrict__ z) {
+  if (S->all_done == 2) return;  // 2 = the final x update has already been applied
   const int c = threadIdx.x % K;
   const T alpha = (T)S->alpha[c];
   const T beta = (T)S->beta[c];
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double
                                                       double rtol, double atol, int init, int ncols_active) {
   __shared__ double sm[4];
   __shared__ int s_all;
+  if (!init && S->all_done) return;
   if (threadIdx.x == 0) s_all = 1;
   __syncthreads();
   for (int c = 0; c < K; ++c) {
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double
 // ---- y = s * dinv .* b   (first damped-Jacobi sweep from a zero initial guess)
 template <class T, int K>
 __global__ __launch_bounds__(256) void scale_dinv_kernel(int64_t n, T* __restrict__ y, const T* __restrict__ b,
-                                                         const T* __restrict__ dinv, T s) {
+                                                         const T* __restrict__ dinv, T s, const int* skip) {
+  if (skip && *skip) return;
   const int64_t total = n * K;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
     y[e] = s * dinv[e / K] * b[e];
@@ -208,7 +218,8 @@ __global__ __launch_bounds__(256) void scale_dinv_kernel(int64_t n, T* __restric
 // ---- dense coarse solve: y[i,c] = sum_j M[i,j] * b[j,c]   (M = pseudo-inverse of the coarsest operator)
 template <class T, int K>
 __global__ __launch_bounds__(256) void dense_apply_kernel(int n, const T* __restrict__ M, const T* __restrict__ b,
-                                                          T* __restrict__ y) {
+                                                          T* __restrict__ y, const int* skip) {
+  if (skip && *skip) return;
   const int64_t total = (int64_t)n * K;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e / K), c = (int)(e % K);

@@ -37,13 +37,15 @@ template <class T>
 struct VcycleFuse {
   bool xa_ready = false;       // level-0 first pre-smoothing sweep already written to L.xa by the caller
   const T* dotw = nullptr;     // fuse partials of dotw . out into the final post-smoothing product
+  const int* skip = nullptr;   // device flag: non-zero turns every launch of the cycle into a no-op
   double* partials = nullptr;  // [spmv_grid][K]
 };
 
 template <class T>
-inline SpmvArgs<T> level_args(const Level<T>& L, const T* x, T* y) {
+inline SpmvArgs<T> level_args(const Level<T>& L, const T* x, T* y, const int* skip = nullptr) {
   SpmvArgs<T> a = spmv_args(L.A, x, y);
   a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
+  a.skip = skip;
   return a;
 }
 
@@ -59,8 +61,9 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   const int gv = grid_for((int64_t)n * K);
   const int nu_pre = l == 0 ? nu_pre0 : nu_coarse, nu_post = l == 0 ? nu_post0 : nu_coarse;
   const bool want_dot = fuse && fuse->dotw && l == 0;
+  const int* skip = fuse ? fuse->skip : nullptr;
   if (last && H.coarse_dense) {
-    hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, dptr<T>(H.coarse_inv), b, out);
+    hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, dptr<T>(H.coarse_inv), b, out, skip);
     if (want_dot)
       hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
                          (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
@@ -70,7 +73,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   T* oth = dptr<T>(L.rb);
   const T omega = (T)L.omega;
   auto jacobi_sweep = [&](const T* xin, T* xout, bool dot) {
-    SpmvArgs<T> a = level_args(L, xin, xout);
+    SpmvArgs<T> a = level_args(L, xin, xout, skip);
     a.b = b;
     a.dinv = dptr<T>(L.dinv);
     a.omega = omega;
@@ -82,7 +85,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   };
   if (last) {
     // coarsest level too large for a dense inverse: a fixed number of damped-Jacobi sweeps
-    hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
+    hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega, skip);
     const int sweeps = 8;
     for (int s = 0; s < sweeps; ++s) {
       const bool fin = (s + 1 == sweeps);
@@ -94,7 +97,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   // pre-smoothing (first sweep from x = 0 is a scaling)
   if (nu_pre >= 1) {
     if (!(fuse && fuse->xa_ready && l == 0))
-      hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega);
+      hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega, skip);
     for (int s = 1; s < nu_pre; ++s) {
       jacobi_sweep(cur, oth, false);
       std::swap(cur, oth);
@@ -104,7 +107,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   }
   // residual r = b - A x  -> oth
   {
-    SpmvArgs<T> a = level_args(L, (const T*)cur, oth);
+    SpmvArgs<T> a = level_args(L, (const T*)cur, oth, skip);
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);
   }
@@ -115,12 +118,16 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   T* xc = dptr<T>(Lc.b) + celems;
   {
     SpmvArgs<T> a = spmv_args(L.R, (const T*)oth, bc);
+    a.skip = skip;
     spmv_launch<T, K>(a, EPI_PLAIN, false, st);
   }
-  vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st);
+  VcycleFuse<T> cf;
+  cf.skip = skip;
+  vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
   // prolongate and correct in place: x += P xc
   {
     SpmvArgs<T> a = spmv_args(L.P, (const T*)xc, cur);
+    a.skip = skip;
     a.xadd = cur;
     spmv_launch<T, K>(a, EPI_ADD, false, st);
   }
@@ -250,11 +257,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int timed = 0;
   int it = 0;
   fuse.xa_ready = fuse_xa;
+  fuse.skip = &S->all_done;
   while (!host_done && it < pp.itmax) {
     // Ap = A p, fused partials of p'Ap
     {
       SpmvArgs<T> a = spmv_args(A, (const T*)p, Ap);
       a.order = orderA;
+      a.skip = &S->all_done;
       a.dotw = p;
       a.partials = pc;
       const bool time_it = timed < max_timed;

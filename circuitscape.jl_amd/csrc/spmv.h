@@ -55,6 +55,7 @@ struct SpmvArgs {
   const T* dotw;    // DOT: partial[c] += dotw[row*K+c] * y[row*K+c]
   double* partials; // DOT: [gridDim.x][K]
   const int* order; // optional traversal order of the row blocks (band-aware, see spmv_block_order); may be null
+  const int* skip;  // optional device flag: when *skip != 0 the launch returns immediately (all columns converged)
 };
 
 // N adjacent values moved with one (up to 16-byte) memory instruction
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
   __shared__ int s_col[K > 1 ? kSpmvTile : 1];
   __shared__ double s_red[4 * (K > 1 ? K : 1)];
 
+  if (a.skip && *a.skip) return;  // wave-uniform: the PCG loop already converged, this launch is a no-op
   const int tid = threadIdx.x;
   // K > 1: a row's K-wide x segment is gathered as 16-byte vectors: CPL adjacent columns per lane, LPR lanes per row.
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -106,10 +108,19 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
     const int kbeg = s_rp[0], kend = s_rp[nr];
 
     T acc[NPASS][CPL];
+    // the row's own x values, captured when the diagonal entry is gathered (saves re-reading x in the epilogue)
+    XV xself[NPASS];
+    bool have_self[NPASS];
+    constexpr bool WANT_SELF = (K > 1) && (EPI == EPI_JACOBI || DOT);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p)
+    for (int p = 0; p < NPASS; ++p) {
+      have_self[p] = false;
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) acc[p][q] = T(0);
+      for (int q = 0; q < CPL; ++q) {
+        acc[p][q] = T(0);
+        xself[p].e[q] = T(0);
+      }
+    }
 
     for (int ts = kbeg; ts < kend; ts += kSpmvTile) {
       const int te = min(kend, ts + kSpmvTile);
@@ -179,7 +190,12 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
               const int i = on ? lo[p] + j + u : 0;
               vv[u][p] = on ? s_val[i] : T(0);
               if (on) {
-                xv[u][p] = *reinterpret_cast<const XV*>(a.x + (size_t)s_col[i] * K + c0);
+                const int col = s_col[i];
+                xv[u][p] = *reinterpret_cast<const XV*>(a.x + (size_t)col * K + c0);
+                if (WANT_SELF && col == row0 + tid / LPR + p * RPP) {
+                  xself[p] = xv[u][p];
+                  have_self[p] = true;
+                }
               } else {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = T(0);
@@ -208,9 +224,19 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
         const size_t e0 = row * K + c0;
         XV bv, xo, out, dw;
         if (EPI == EPI_RESID || EPI == EPI_JACOBI) bv = *reinterpret_cast<const XV*>(a.b + e0);
-        if (EPI == EPI_JACOBI) xo = *reinterpret_cast<const XV*>(a.x + e0);
+        if (EPI == EPI_JACOBI) {
+          if (WANT_SELF && have_self[p])
+            xo = xself[p];
+          else
+            xo = *reinterpret_cast<const XV*>(a.x + e0);
+        }
         if (EPI == EPI_ADD) xo = *reinterpret_cast<const XV*>(a.xadd + e0);
-        if (DOT) dw = *reinterpret_cast<const XV*>(a.dotw + e0);
+        if (DOT) {
+          if (WANT_SELF && a.dotw == a.x && have_self[p])
+            dw = xself[p];
+          else
+            dw = *reinterpret_cast<const XV*>(a.dotw + e0);
+        }
         const T sc = EPI == EPI_JACOBI ? a.omega * a.dinv[row] : T(0);
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
@@ -342,6 +368,7 @@ inline SpmvArgs<T> spmv_args(const Csr<T>& A, const T* x, T* y) {
   a.dotw = nullptr;
   a.partials = nullptr;
   a.order = nullptr;
+  a.skip = nullptr;
   return a;
 }
 
