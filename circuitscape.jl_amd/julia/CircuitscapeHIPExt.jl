@@ -1,0 +1,112 @@
+# CircuitscapeHIPExt.jl -- reference-side binding of libcsgpu.so (NOT executed in the build image: no Julia there).
+#
+# Pattern: ext/CircuitscapePardisoExt.jl / ext/CircuitscapeAppleAccelerateExt.jl of Circuitscape.jl v5.17.1.
+# Because libcsgpu is a plain shared library (not a Julia package) this file is `include`d from
+# src/Circuitscape.jl after core.jl; together with the ~15-line patch in INTEGRATION.md it adds the solver
+# alias `solver = hip` to the INI surface. Every ccall below maps 1:1 onto include/csgpu.h.
+#
+# Set ENV["CSGPU_LIB"] to the path of libcsgpu.so (built with hipcc --offload-arch=gfx950).
+
+const LIBCSGPU = get(ENV, "CSGPU_LIB", "libcsgpu.so")
+
+struct HIPAMGSolver <: Solver
+    bs::Int
+end
+
+# mirror of csgpu_opts (include/csgpu.h); filled by csgpu_default_opts
+mutable struct CsgpuOpts
+    struct_size::Int32; device::Int32; max_levels::Int32; max_coarse::Int32; aggregation::Int32
+    nu_pre::Int32; nu_post::Int32; criterion::Int32; itmax::Int32; batch::Int32; check_every::Int32; nu_coarse::Int32
+    theta::Float64; omega_p::Float64; omega_s::Float64; rtol::Float64; atol::Float64
+    node_row::Ptr{Int32}; node_col::Ptr{Int32}
+    precond_bytes::Int32; reserved1::Int32
+    CsgpuOpts() = new()
+end
+
+mutable struct CsgpuStats
+    nrhs::Int32; max_iters::Int32; total_iters::Int64; max_relres::Float64; solve_ms::Float64; device_ms::Float64
+    cg_spmv_ms::Float64; cg_spmv_calls::Int64; batch::Int32; not_converged::Int32
+    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0)
+end
+
+mutable struct HIPFactor          # cf. PardisoFactorize (Pardiso ext :8-13): owns the device-resident hierarchy
+    ptr::Ptr{Cvoid}
+    function HIPFactor(ptr)
+        f = new(ptr)
+        finalizer(x -> (x.ptr != C_NULL && ccall((:csgpu_free, LIBCSGPU), Cvoid, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), f)
+        f
+    end
+end
+
+csgpu_error() = unsafe_string(ccall((:csgpu_last_error, LIBCSGPU), Cstring, ()))
+
+function default_opts(bs::Int)
+    o = CsgpuOpts()
+    ccall((:csgpu_default_opts, LIBCSGPU), Cvoid, (Ref{CsgpuOpts},), o)
+    o.batch = Int32(clamp(nextpow(2, bs), 1, 16))
+    o
+end
+
+"""
+construct_cholesky_factor(matrix, ::HIPAMGSolver) -- same hook the Pardiso / Accelerate extensions implement
+(src/core.jl:519-523). SparseMatrixCSC of a symmetric Laplacian == CSR; Int64 / 1-based arrays are converted on
+the device. `coords` (optional) = (rows, cols)::Tuple{Vector{Int32},Vector{Int32}} of each node's first cell.
+"""
+function construct_cholesky_factor(matrix::SparseMatrixCSC{T,V}, s::HIPAMGSolver; coords = nothing) where {T,V}
+    o = default_opts(s.bs)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    n = size(matrix, 1)
+    rc = GC.@preserve matrix coords begin
+        if coords !== nothing
+            o.node_row = pointer(coords[1]); o.node_col = pointer(coords[2])
+        end
+        ccall((:csgpu_setup, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Ref{CsgpuOpts}, Ref{Ptr{Cvoid}}),
+              matrix.colptr, matrix.rowval, matrix.nzval, n, nnz(matrix), sizeof(V), sizeof(T), 1, o, h)
+    end
+    rc == 0 || error("csgpu_setup failed: $(csgpu_error())")
+    HIPFactor(h[])
+end
+
+"solve_linear_system(factor, matrix, rhs) -- batched multi-RHS flavour (src/core.jl:646-653)."
+function solve_linear_system(factor::HIPFactor, matrix::SparseMatrixCSC{T,V}, rhs::VecOrMat{T}) where {T,V}
+    lhs = similar(rhs)
+    st = CsgpuStats()
+    rc = GC.@preserve rhs lhs ccall((:csgpu_solve_rhs, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{CsgpuStats}), factor.ptr, rhs, size(rhs, 2), lhs, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_rhs failed: $(csgpu_error())")
+    lhs
+end
+
+function multiple_solve(s::HIPAMGSolver, matrix::SparseMatrixCSC{T,V}, sources::Vector{T}) where {T,V}
+    factor = construct_cholesky_factor(matrix, s)
+    volt = solve_linear_system(factor, matrix, sources)
+    finalize(factor)
+    volt
+end
+
+"""
+Pair batch on the device: resistances (core.jl:232), focal voltages for the shortcut (core.jl:685-703) and, when
+maps are written, full grounded voltage vectors (core.jl:231). `src`, `dst`, `gather` are 0-based local node ids.
+"""
+function solve_pairs(factor::HIPFactor, ::Type{T}, n::Int, src::Vector{Int64}, dst::Vector{Int64};
+                     gather::Vector{Int64} = Int64[], want_voltages::Bool = false) where {T}
+    np = length(src)
+    res = Vector{T}(undef, np)
+    gat = Matrix{T}(undef, length(gather), np)
+    volt = want_voltages ? Matrix{T}(undef, n, np) : Matrix{T}(undef, 0, 0)
+    st = CsgpuStats()
+    rc = GC.@preserve src dst gather res gat volt ccall((:csgpu_solve_pairs, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, src, dst, np, want_voltages ? pointer(volt) : C_NULL, gather, length(gather),
+              isempty(gather) ? C_NULL : pointer(gat), res, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_pairs failed: $(csgpu_error())")
+    res, gat, volt, st
+end
+
+# solve(prob, ::HIPAMGSolver, flags, cfg, log): identical bookkeeping to solve(prob, ::AMGSolver, ...) (core.jl:96-305)
+# except that per connected component the pair list is handed to `solve_pairs` in ONE call (no Threads.@spawn fan-out
+# over blocking ccalls) -- the Python mirror of exactly this method is circuitscape.jl_amd/solver.py::solve and is what
+# the parity tests exercise against the reference's golden files.
