@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
                     help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "
                          "precision as the CG iteration")
+    ap.add_argument("--opt", action="append", default=[], help="extra csgpu_opts override key=value (tuning)")
     ap.add_argument("--compare-steps", type=int, default=3,
                     help="N=1 only: also time this many steps with an fp64 preconditioner and report them (0 = skip)")
     args = ap.parse_args()
@@ -115,8 +116,12 @@ def main():
     size = args.size
     g = make_raster(size, dtype=dtype)
     cells, pairs = focal_pairs(size)
+    extra = {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        extra[k] = float(v) if k in ("theta", "omega_p", "omega_s", "rtol", "atol") else int(v)
     opts = lib.default_opts(device=local_rank, batch=args.batch, criterion=args.criterion,
-                            precond_bytes=4 if args.precond == "fp32" else 0)
+                            precond_bytes=4 if args.precond == "fp32" else 0, **extra)
     t0 = time.time()
     h = lib.raster_setup(g, opts)
     t_setup_wall = time.time() - t0

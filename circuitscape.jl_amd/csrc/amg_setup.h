@@ -518,8 +518,8 @@ struct SetupParams {
   int max_coarse = 100;
   int aggregation = CSGPU_AGG_AUTO;
   double theta = 0.0;
-  double omega_p = 4.0 / 3.0;
-  double omega_s = 4.0 / 3.0;
+  double omega_p = 1.6;
+  double omega_s = 1.5;
 };
 
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.

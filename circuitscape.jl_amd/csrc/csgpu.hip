@@ -503,10 +503,10 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->itmax = 100000;
   o->batch = 8;
   o->check_every = 4;
-  o->nu_coarse = 2;
+  o->nu_coarse = 3;
   o->theta = 0.0;
-  o->omega_p = 4.0 / 3.0;
-  o->omega_s = 4.0 / 3.0;
+  o->omega_p = 1.6;
+  o->omega_s = 1.5;
   o->rtol = 1e-6;
   o->atol = -1.0;
   o->node_row = nullptr;

@@ -152,7 +152,7 @@ struct PcgParams {
   int criterion = CSGPU_CRIT_KRYLOV;
   int itmax = 100000;
   int check_every = 4;
-  int nu_pre = 1, nu_post = 1, nu_coarse = 2;
+  int nu_pre = 1, nu_post = 1, nu_coarse = 3;
 };
 
 // T = precision of the CG iteration (matrix seen by CG, x, r, p, Ap); TP = precision of the AMG hierarchy and of

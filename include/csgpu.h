@@ -74,10 +74,13 @@ typedef struct csgpu_opts {
   int32_t itmax;          /* default 100000 (core.jl:639) */
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 4 */
-  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 2 */
+  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 3 */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
-  double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting, default 4/3 */
-  double omega_s;         /* Jacobi smoother weight numerator: omega = omega_s / rho_gershgorin, default 4/3 */
+  double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting: P = T - omega_p Dl^-1 A T.
+                             The reference's JacobiProlongation uses 4/3; 1.6 (default) measured 35 % fewer PCG
+                             iterations on the 10000^2 raster (tools/sweep.sh) */
+  double omega_s;         /* Jacobi smoother weight numerator: omega = omega_s / rho_gershgorin (< 2/rho: always
+                             convergent), default 1.5 */
   double rtol;            /* default 1e-6 (core.jl:639) */
   double atol;            /* < 0 means sqrt(eps(T)) (Krylov.jl default); default -1 */
   /* Optional raster coordinates of every node (length n, 0-based cell row / col of the node's first
