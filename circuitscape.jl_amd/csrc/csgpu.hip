@@ -368,8 +368,8 @@ struct Solver : ISolver {
         info->level_n[l] = L.A.nrows;
         info->level_nnz[l] = L.A.nnz;
       }
-      bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.dinv.bytes + L.xa.bytes +
-                         L.rb.bytes + L.b.bytes + L.orderA.bytes);
+      bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
+                         L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes);
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
@@ -384,8 +384,10 @@ struct Solver : ISolver {
       const Level<TP>& L = H.levels[l];
       // first pre-sweep from a zero guess needs no product: (nu_pre - 1) + nu_post Jacobi products + 1 residual
       const int nup = l == 0 ? opts.nu_pre : opts.nu_coarse, nuq = l == 0 ? opts.nu_post : opts.nu_coarse;
-      const int prods = std::max(nup - 1, 0) + nuq + 1;
-      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.P, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(TP);
+      // products with A: (nu_pre - 1) pre-sweeps after the free first one, 1 residual, (nu_post - 1) post-sweeps after
+      // the first one, which is fused with the prolongation into one product with Q = P - omega D^-1 A P
+      const int prods = std::max(nup - 1, 0) + 1 + std::max(nuq - 1, 0);
+      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.Q, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(TP);
     }
     info->bytes_per_iteration = bi;
   }

@@ -24,6 +24,7 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
     const size_t elems = (size_t)std::max(L.A.nrows, 1) * K;
     L.xa.alloc(elems * sizeof(T));
     L.rb.alloc(elems * sizeof(T));
+    L.qs.release();  // third buffer, allocated on demand by levels that run more than one post-smoothing sweep
     if (l > 0)
       L.b.alloc(2 * elems * sizeof(T));  // [0, elems): restricted rhs, [elems, 2*elems): this level's solution
     else
@@ -124,6 +125,40 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   VcycleFuse<T> cf;
   cf.skip = skip;
   vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
+  if (nu_post >= 1 && L.Q.nnz > 0) {
+    // fused prolongation + first post-smoothing sweep: x' = x + omega D^-1 r + Q xc   (r = b - A x is still in `oth`)
+    const bool fin = (nu_post == 1);
+    SpmvArgs<T> a = spmv_args(L.Q, (const T*)xc, out);
+    a.skip = skip;
+    a.xadd = cur;
+    a.b = oth;
+    a.dinv = dptr<T>(L.dinv);
+    a.omega = omega;
+    if (fin && want_dot) {
+      a.dotw = fuse->dotw;
+      a.partials = fuse->partials;
+    }
+    if (fin) {
+      spmv_launch<T, K>(a, EPI_QADD, want_dot, st);
+    } else {
+      // result must not overwrite `cur` or `oth` while they are read: use the level's third buffer
+      if (L.qs.bytes < (size_t)n * K * sizeof(T)) L.qs.alloc((size_t)n * K * sizeof(T));
+      a.y = dptr<T>(L.qs);
+      spmv_launch<T, K>(a, EPI_QADD, false, st);
+      T* x2 = dptr<T>(L.qs);
+      // remaining sweeps ping-pong between x2/cur (oth is free now)
+      T* src = x2;
+      T* spare = cur;
+      for (int s2 = 1; s2 < nu_post; ++s2) {
+        const bool last_sweep = (s2 + 1 == nu_post);
+        T* d2 = last_sweep ? out : spare;
+        jacobi_sweep(src, d2, last_sweep && want_dot);
+        spare = src;
+        src = d2;
+      }
+    }
+    return;
+  }
   // prolongate and correct in place: x += P xc
   {
     SpmvArgs<T> a = spmv_args(L.P, (const T*)xc, cur);
@@ -324,12 +359,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   float ms = 0;
   CS_HIP(hipEventElapsedTime(&ms, e0, e1));
   res.device_ms = ms;
-  for (int t = 0; t < timed; ++t) {
+  // launches enqueued after every column had converged return immediately (device flag): leave them out of the average
+  int real_its = 0;
+  for (int c = 0; c < ncols_active && c < kMaxK; ++c) real_its = std::max(real_its, res.s.iters[c]);
+  const int counted = std::min(timed, real_its);
+  for (int t = 0; t < counted; ++t) {
     float m2 = 0;
     CS_HIP(hipEventElapsedTime(&m2, W.ev[2 * t], W.ev[2 * t + 1]));
     res.spmv_ms += m2;
   }
-  res.spmv_calls = timed;
+  res.spmv_calls = counted;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return res;

@@ -34,7 +34,8 @@ enum SpmvEpi {
   EPI_PLAIN = 0,   // y = A x
   EPI_RESID = 1,   // y = b - A x
   EPI_JACOBI = 2,  // y = x + omega * dinv .* (b - A x)
-  EPI_ADD = 3      // y = xadd + A x          (prolongation: xadd may alias y)
+  EPI_ADD = 3,     // y = xadd + A x          (prolongation: xadd may alias y)
+  EPI_QADD = 4     // y = xadd + omega * dinv .* b + A x   (fused prolongation + first post-smoothing sweep, A = Q)
 };
 
 static const int kSpmvRows = 256;   // rows per workgroup pass (row-block granularity of the traversal order)
@@ -223,27 +224,28 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
         const size_t row = (size_t)(row0 + r);
         const size_t e0 = row * K + c0;
         XV bv, xo, out, dw;
-        if (EPI == EPI_RESID || EPI == EPI_JACOBI) bv = *reinterpret_cast<const XV*>(a.b + e0);
+        if (EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_QADD) bv = *reinterpret_cast<const XV*>(a.b + e0);
         if (EPI == EPI_JACOBI) {
           if (WANT_SELF && have_self[p])
             xo = xself[p];
           else
             xo = *reinterpret_cast<const XV*>(a.x + e0);
         }
-        if (EPI == EPI_ADD) xo = *reinterpret_cast<const XV*>(a.xadd + e0);
+        if (EPI == EPI_ADD || EPI == EPI_QADD) xo = *reinterpret_cast<const XV*>(a.xadd + e0);
         if (DOT) {
           if (WANT_SELF && a.dotw == a.x && have_self[p])
             dw = xself[p];
           else
             dw = *reinterpret_cast<const XV*>(a.dotw + e0);
         }
-        const T sc = EPI == EPI_JACOBI ? a.omega * a.dinv[row] : T(0);
+        const T sc = (EPI == EPI_JACOBI || EPI == EPI_QADD) ? a.omega * a.dinv[row] : T(0);
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
           T v = acc[p][q];
           if (EPI == EPI_RESID) v = bv.e[q] - v;
           if (EPI == EPI_JACOBI) v = xo.e[q] + sc * (bv.e[q] - v);
           if (EPI == EPI_ADD) v = xo.e[q] + v;
+          if (EPI == EPI_QADD) v = xo.e[q] + sc * bv.e[q] + v;
           out.e[q] = v;
           if (DOT) dot_acc[q] += (double)dw.e[q] * (double)v;
         }
@@ -298,6 +300,9 @@ inline void spmv_launch(const SpmvArgs<T>& a, int epi, bool dot, hipStream_t st)
       break;
     case EPI_ADD:
       spmv_launch_t<T, K, EPI_ADD, false>(a, st);
+      break;
+    case EPI_QADD:
+      dot ? spmv_launch_t<T, K, EPI_QADD, true>(a, st) : spmv_launch_t<T, K, EPI_QADD, false>(a, st);
       break;
   }
 }
