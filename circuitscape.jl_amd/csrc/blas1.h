@@ -138,19 +138,20 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
   }
 }
 
-// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished; z in preconditioner precision)
+// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished). p and z live in the
+//      preconditioner's precision TP; x is updated with exactly the stored p, like r was (r -= alpha A p).
 template <class T, class TP, int K>
 __global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
-                                                           T* __restrict__ p, const TP* __restrict__ z) {
+                                                           TP* __restrict__ p, const TP* __restrict__ z) {
   if (S->all_done == 2) return;  // 2 = the final x update has already been applied
   const int c = threadIdx.x % K;
   const T alpha = (T)S->alpha[c];
   const T beta = (T)S->beta[c];
   const int64_t total = n * K;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const T pe = p[e];
+    const T pe = (T)p[e];
     x[e] += alpha * pe;
-    p[e] = (T)z[e] + beta * pe;
+    p[e] = (TP)((T)z[e] + beta * pe);
   }
 }
 

@@ -196,7 +196,9 @@ template <class T, class TP>
 struct PcgWork {
   int K = 0;
   int64_t n = 0;
-  DBuf x, r, p, Ap, b;        // T
+  DBuf x, r, Ap, b;           // T
+  DBuf p;                     // TP: search direction (x and r are updated with exactly these stored values, so the
+                              // invariant r = b - A x holds in T precision whatever p's storage precision)
   DBuf z, rp;                 // TP: preconditioned residual; TP copy of r (aliases r when TP == T)
   DBuf scalars;               // CgScalars
   DBuf part_a, part_b, part_c;
@@ -208,13 +210,13 @@ struct PcgWork {
     const size_t bytes = (size_t)n * K * sizeof(T);
     x.alloc(bytes);
     r.alloc(bytes);
-    p.alloc(bytes);
+    p.alloc((size_t)n * K * sizeof(TP));
     Ap.alloc(bytes);
     b.alloc(bytes);
     z.alloc((size_t)n * K * sizeof(TP));
     if (!std::is_same<T, TP>::value) rp.alloc((size_t)n * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
-    const size_t pb = (size_t)4096 * kMaxK * sizeof(double);
+    const size_t pb = (size_t)16384 * kMaxK * sizeof(double);  // >= spmv_grid() and kMaxGrid partial rows
     part_a.alloc(pb);
     part_b.alloc(pb);
     part_c.alloc(pb);
@@ -242,7 +244,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   ensure_level_work(H, K);
   T* x = dptr<T>(W.x);
   T* r = dptr<T>(W.r);
-  T* p = dptr<T>(W.p);
+  TP* p = dptr<TP>(W.p);
   T* Ap = dptr<T>(W.Ap);
   const T* b = dptr<T>(W.b);
   TP* z = dptr<TP>(W.z);
@@ -281,7 +283,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
                      (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
                      pp.criterion, pp.rtol, atol, 1, ncols_active);
-  hipLaunchKernelGGL((convert_kernel<TP, T>), dim3(gv), dim3(256), 0, st, n * K, (const TP*)z, p);
+  CS_HIP(hipMemcpyAsync(p, z, (size_t)n * K * sizeof(TP), hipMemcpyDeviceToDevice, st));
   check_launch("pcg init");
 
   int host_done = 0;
@@ -296,10 +298,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   while (!host_done && it < pp.itmax) {
     // Ap = A p, fused partials of p'Ap
     {
-      SpmvArgs<T> a = spmv_args(A, (const T*)p, Ap);
+      SpmvArgs<T, TP> a = spmv_args<T, TP>(A, (const TP*)p, Ap);
       a.order = orderA;
       a.skip = &S->all_done;
-      a.dotw = p;
+      a.dotw = nullptr;  // dot with x itself: p'Ap
       a.partials = pc;
       const bool time_it = timed < max_timed;
       if (time_it) {
@@ -312,7 +314,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
         }
         CS_HIP(hipEventRecord(W.ev[2 * timed], st));
       }
-      spmv_launch<T, K>(a, EPI_PLAIN, true, st);
+      spmv_launch_cg<T, K, TP>(a, st);
       if (time_it) {
         CS_HIP(hipEventRecord(W.ev[2 * timed + 1], st));
         ++timed;

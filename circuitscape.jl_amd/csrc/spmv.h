@@ -41,19 +41,21 @@ enum SpmvEpi {
 static const int kSpmvRows = 256;   // rows per workgroup pass (row-block granularity of the traversal order)
 static const int kSpmvTile = 2560;  // nonzeros staged in LDS per tile
 
-template <class T>
+// T: matrix values, accumulation and output; XT: type of the gathered input vector (XT == T except for the CG
+// product of the mixed-precision path, where the search direction p is stored in the preconditioner's precision).
+template <class T, class XT = T>
 struct SpmvArgs {
   int nrows;
   const int* rowptr;
   const int* col;
   const T* val;
-  const T* x;       // input, interleaved [ncols][K]
+  const XT* x;      // input, interleaved [ncols][K]
   T* y;             // output, interleaved [nrows][K]
   const T* b;       // EPI_RESID / EPI_JACOBI
   const T* xadd;    // EPI_ADD (may alias y); EPI_JACOBI reads x itself for the row's own value
   const T* dinv;    // EPI_JACOBI: 1 / a_ii
   T omega;          // EPI_JACOBI
-  const T* dotw;    // DOT: partial[c] += dotw[row*K+c] * y[row*K+c]
+  const T* dotw;    // DOT: partial[c] += dotw[row*K+c] * y[row*K+c]; null => dot with x itself (square A)
   double* partials; // DOT: [gridDim.x][K]
   const int* order; // optional traversal order of the row blocks (band-aware, see spmv_block_order); may be null
   const int* skip;  // optional device flag: when *skip != 0 the launch returns immediately (all columns converged)
@@ -65,8 +67,8 @@ struct alignas(sizeof(T) * N) SpmvVec {
   T e[N];
 };
 
-template <class T, int K, int EPI, bool DOT>
-__global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
+template <class T, int K, int EPI, bool DOT, class XT>
+__global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
   __shared__ int s_rp[kSpmvRows + 1];
   __shared__ T s_val[kSpmvTile];
@@ -76,12 +78,13 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
   if (a.skip && *a.skip) return;  // wave-uniform: the PCG loop already converged, this launch is a no-op
   const int tid = threadIdx.x;
   // K > 1: a row's K-wide x segment is gathered as 16-byte vectors: CPL adjacent columns per lane, LPR lanes per row.
-  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int VEC = 16 / (int)sizeof(XT);
   constexpr int CPL = K < VEC ? K : VEC;   // columns per lane
   constexpr int LPR = K / CPL;             // lanes per row
   constexpr int RPP = 256 / LPR;           // rows per pass (256 lanes / LPR)
   constexpr int NPASS = kSpmvRows / RPP;   // rows owned by one lane
-  typedef SpmvVec<T, CPL> XV;
+  typedef SpmvVec<XT, CPL> XV;  // gathered x segment
+  typedef SpmvVec<T, CPL> YV;   // epilogue vectors (b, xadd, dotw, y)
   const int c0 = K > 1 ? (tid % LPR) * CPL : 0;  // first column owned by the lane
   double dot_acc[CPL];
 #pragma unroll
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         acc[p][q] = T(0);
-        xself[p].e[q] = T(0);
+        xself[p].e[q] = XT(0);
       }
     }
 
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
         if (K == 1) {
           T xx[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) xx[u] = (ts + tid + u * 256 < te) ? a.x[cc[u]] : T(0);
+          for (int u = 0; u < U; ++u) xx[u] = (ts + tid + u * 256 < te) ? (T)a.x[cc[u]] : T(0);
 #pragma unroll
           for (int u = 0; u < U; ++u)
             if (ts + tid + u * 256 < te) s_val[tid + u * 256] = vv[u] * xx[u];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
                 }
               } else {
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = T(0);
+                for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = XT(0);
               }
             }
           }
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
             for (int p = 0; p < NPASS; ++p)
               if (j + u < len[p]) {
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) acc[p][q] += vv[u][p] * xv[u][p].e[q];
+                for (int q = 0; q < CPL; ++q) acc[p][q] += vv[u][p] * (T)xv[u][p].e[q];
               }
           }
         }
@@ -223,20 +226,30 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
       if (r < nr) {
         const size_t row = (size_t)(row0 + r);
         const size_t e0 = row * K + c0;
-        XV bv, xo, out, dw;
-        if (EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_QADD) bv = *reinterpret_cast<const XV*>(a.b + e0);
+        YV bv, xo, out, dw;
+        if (EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_QADD) bv = *reinterpret_cast<const YV*>(a.b + e0);
         if (EPI == EPI_JACOBI) {
+          XV xs;
           if (WANT_SELF && have_self[p])
-            xo = xself[p];
+            xs = xself[p];
           else
-            xo = *reinterpret_cast<const XV*>(a.x + e0);
+            xs = *reinterpret_cast<const XV*>(a.x + e0);
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) xo.e[q] = (T)xs.e[q];
         }
-        if (EPI == EPI_ADD || EPI == EPI_QADD) xo = *reinterpret_cast<const XV*>(a.xadd + e0);
+        if (EPI == EPI_ADD || EPI == EPI_QADD) xo = *reinterpret_cast<const YV*>(a.xadd + e0);
         if (DOT) {
-          if (WANT_SELF && a.dotw == a.x && have_self[p])
-            dw = xself[p];
-          else
-            dw = *reinterpret_cast<const XV*>(a.dotw + e0);
+          if (a.dotw) {
+            dw = *reinterpret_cast<const YV*>(a.dotw + e0);
+          } else {  // dot with x itself
+            XV xs;
+            if (WANT_SELF && have_self[p])
+              xs = xself[p];
+            else
+              xs = *reinterpret_cast<const XV*>(a.x + e0);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) dw.e[q] = (T)xs.e[q];
+          }
         }
         const T sc = (EPI == EPI_JACOBI || EPI == EPI_QADD) ? a.omega * a.dinv[row] : T(0);
 #pragma unroll
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
           out.e[q] = v;
           if (DOT) dot_acc[q] += (double)dw.e[q] * (double)v;
         }
-        *reinterpret_cast<XV*>(a.y + e0) = out;
+        *reinterpret_cast<YV*>(a.y + e0) = out;
       }
     }
   }
@@ -271,18 +284,41 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T> a) {
 }
 // grid (= number of dot partials per column) for an nrows-row product; a multiple of 8 once there is enough
 // work, so that the kernel's XCD-aware row-block mapping applies.
+// Workgroups per product: enough (64 per CU) that the hardware dispatcher, which starts workgroups in blockIdx
+// order as slots free up, keeps every XCD's resident set on a contiguous window of its row-block range (that is what
+// makes the band re-use hit in L2); capped so the dot-partial arrays stay small. Measured on MI355X, 10000^2 fp64:
+// 4096 -> 16384 workgroups: K=1 3.22 -> 2.84 ms, K=8 5.74 -> 5.52 ms.
+inline int spmv_grid_cap() {  // tuning knob (CSGPU_SPMV_GRID_CAP): 0 = one workgroup per row block
+  static int cap = [] {
+    const char* e = getenv("CSGPU_SPMV_GRID_CAP");
+    return e ? atoi(e) : 16384;
+  }();
+  return cap;
+}
+
 template <class T, int K>
 inline int spmv_grid(int nrows) {
   int nb = ceil_div(nrows, kSpmvRows);
   if (nb < 1) nb = 1;
-  if (nb > 4096) nb = 4096;
-  if (nb >= 64) nb &= ~7;
+  const int cap = spmv_grid_cap();
+  if (cap > 0) {
+    if (nb > cap) nb = cap;
+    if (nb >= 64) nb &= ~7;
+  } else if (nb >= 64) {
+    nb = (nb + 7) & ~7;
+  }
   return nb;
 }
 
-template <class T, int K, int EPI, bool DOT>
-inline void spmv_launch_t(const SpmvArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL((spmv_kernel<T, K, EPI, DOT>), dim3(spmv_grid<T, K>(a.nrows)), dim3(256), 0, st, a);
+template <class T, int K, int EPI, bool DOT, class XT = T>
+inline void spmv_launch_t(const SpmvArgs<T, XT>& a, hipStream_t st) {
+  hipLaunchKernelGGL((spmv_kernel<T, K, EPI, DOT, XT>), dim3(spmv_grid<T, K>(a.nrows)), dim3(256), 0, st, a);
+}
+
+// CG product of the mixed-precision path: y (T) = A (T) * p (XT), partials of p'Ap
+template <class T, int K, class XT>
+inline void spmv_launch_cg(const SpmvArgs<T, XT>& a, hipStream_t st) {
+  if (a.nrows > 0) spmv_launch_t<T, K, EPI_PLAIN, true, XT>(a, st);
 }
 
 template <class T, int K>
@@ -357,9 +393,9 @@ inline void spmv_block_order(const Csr<T>& A, DBuf& order, hipStream_t st) {
 }
 
 // Convenience: y = A x (+ epilogue) for a Csr<T>.
-template <class T>
-inline SpmvArgs<T> spmv_args(const Csr<T>& A, const T* x, T* y) {
-  SpmvArgs<T> a;
+template <class T, class XT = T>
+inline SpmvArgs<T, XT> spmv_args(const Csr<T>& A, const XT* x, T* y) {
+  SpmvArgs<T, XT> a;
   a.nrows = A.nrows;
   a.rowptr = A.rp();
   a.col = A.ci();
