@@ -177,7 +177,10 @@ def main():
         value = pairs_done / (elapsed + setup_s * (K * B) / 100.0)
         spmv_avg_ms = agg["cg_spmv_ms"] / max(agg["cg_spmv_calls"], 1)
         vb = 8 if dtype == np.float64 else 4
-        spmm_bytes = info["nnz"] * (vb + 4) + (info["n"] + 1) * 4 + 2 * info["n"] * B * vb
+        # CG product y = A p: matrix (values + int32 columns + row pointers) + read p once + write y once; p is stored in
+        # the preconditioner's precision (fp32 under the default mixed path), y in the CG precision
+        xb = info["precond_bytes"]
+        spmm_bytes = info["nnz"] * (vb + 4) + (info["n"] + 1) * 4 + info["n"] * B * (xb + vb)
         achieved = spmm_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         spmv1_ms = h.spmv_bench(1, 10)
         out = {
@@ -204,7 +207,7 @@ def main():
             "setup_s": setup_s, "setup_device_s": info["setup_ms"] / 1e3, "setup_wall_s": t_setup_wall,
             "iters_mean": agg["total_iters"] / float(K * B), "iters_max": agg["max_iters"],
             "max_relres": agg["max_relres"],
-            "roofline": {"bound": "hbm", "kernel": "spmv_kernel<%s,%d,PLAIN,DOT> (fine-level CG SpMM)" % ("double" if vb == 8 else "float", B),
+            "roofline": {"bound": "hbm", "kernel": "spmv_kernel<%s,%d,PLAIN,DOT,x=%s> (fine-level CG SpMM)" % ("double" if vb == 8 else "float", B, "float" if xb == 4 else "double"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(size, B, vb), "algorithmic_bytes_per_launch": spmm_bytes, "avg_ms": spmv_avg_ms,
                          "launches_timed": agg["cg_spmv_calls"],
