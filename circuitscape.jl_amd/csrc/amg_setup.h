@@ -649,7 +649,11 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     const int n = L.A.nrows;
     if (n <= sp.max_coarse || (int)H.levels.size() >= sp.max_levels) break;
     DBuf agg, crow, ccol;
-    const int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st);
+    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st);
+    if (sp.theta > 0.0 && (double)nagg > 0.5 * (double)n) {
+      // the strength filter left too few strong couplings to coarsen this level: aggregate on the full pattern
+      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st);
+    }
     if (nagg >= n || nagg < 1 || (double)nagg > 0.8 * (double)n) break;  // coarsening stagnated
     // sizes
     DBuf size_c = dalloc<unsigned long long>(nagg);

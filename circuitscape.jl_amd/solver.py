@@ -117,6 +117,61 @@ def multiple_solve(solver, matrix, sources):
     return volt
 
 
+def resolve_conflicts(sources, grounds, policy):
+    """src/raster/advanced.jl:118-149: finite grounds vector (or [-9999]), source/ground conflicts by policy,
+    sources on infinite grounds win over the ground."""
+    sources = np.array(sources, dtype=np.float64)
+    grounds = np.array(grounds, dtype=np.float64)
+    finitegrounds = np.where(grounds < np.inf, grounds, 0.0)
+    if np.count_nonzero(finitegrounds) == 0:
+        finitegrounds = np.array([-9999.0])
+    conflicts = (sources != 0) & (grounds != 0)
+    if conflicts.any():
+        if policy in ("rmvsrc", "rmvall"):
+            sources[conflicts] = 0
+        elif policy == "rmvgnd":
+            grounds[conflicts] = 0
+    infconflicts = (grounds == np.inf) & (sources > 0)
+    grounds[infconflicts] = 0
+    return sources, grounds, finitegrounds
+
+
+def multiple_solver(cfg, solver, a, sources, grounds, finitegrounds):
+    """src/raster/advanced.jl:274-305: finite grounds go on the diagonal, rows/columns of infinite grounds are deleted,
+    the reduced SPD system is handed to multiple_solve, zeros are re-inserted at the grounded nodes."""
+    a = sp.csr_matrix(a)
+    T = np.float32 if a.dtype == np.float32 else np.float64
+    asolve = a
+    if not (len(finitegrounds) == 1 and finitegrounds[0] == -9999):
+        asolve = (a + sp.diags(np.asarray(finitegrounds, dtype=T))).tocsr()
+    inf = np.flatnonzero(np.asarray(grounds) == np.inf)
+    keep = np.setdiff1d(np.arange(a.shape[0]), inf)
+    asolve = asolve[keep][:, keep]
+    volt = multiple_solve(solver, asolve.astype(T), np.asarray(sources, dtype=T)[keep])
+    voltages = np.zeros(a.shape[0], dtype=T)
+    voltages[keep] = volt
+    return voltages
+
+
+def advanced_kernel(G, cc, sources, grounds, finitegrounds, solver, cfg=None, check_node=-1):
+    """Solver-layer part of advanced_kernel (src/raster/advanced.jl:151-271) without map output: per connected component
+    with both a source and a ground, one grounded solve. Returns the node voltages (1-based node order)."""
+    G = sp.csr_matrix(G)
+    voltages = np.zeros(G.shape[0], dtype=np.float64)
+    for c in cc:
+        c = np.asarray(c, dtype=np.int64)
+        if check_node != -1 and check_node not in c:
+            continue
+        idx = c - 1
+        s_local, g_local = np.asarray(sources)[idx], np.asarray(grounds)[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        no_finite = len(finitegrounds) == 1 and finitegrounds[0] == -9999
+        f_local = finitegrounds if no_finite else np.asarray(finitegrounds)[idx]
+        voltages[idx] += multiple_solver(cfg, solver, G[idx][:, idx], s_local, g_local, f_local)
+    return voltages
+
+
 def _node_coords(nodemap, comp):
     """(row, col) of the first cell (column-major order) of every node of `comp` (1-based ids) in `nodemap`."""
     nm = np.asarray(nodemap)

@@ -357,3 +357,81 @@ def network_pairwise_from_fixture(case, mode="reference", precision="double", st
     prob = rg.compute_graph_data_network(case["edges_i"], case["edges_j"], case["edges_v"], case["focal"])
     flags = dict(write_volt_maps=False, write_cur_maps=False, write_cum_cur_map_only=False, write_max_cur_maps=False)
     return single_ground_all_pairs(prob, flags, mode, precision, stats)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# advanced mode, network flavour (scope row N2): restates
+#   _get_sources_and_grounds / resolve_conflicts   src/raster/advanced.jl:84-149
+#   advanced_kernel (network branch, no maps)      src/raster/advanced.jl:151-271
+#   multiple_solver / multiple_solve(::AMGSolver)  src/raster/advanced.jl:274-312
+def resolve_conflicts(sources, grounds, policy):
+    sources = np.array(sources, dtype=np.float64)
+    grounds = np.array(grounds, dtype=np.float64)
+    finitegrounds = np.where(grounds < np.inf, grounds, 0.0)
+    if np.count_nonzero(finitegrounds) == 0:
+        finitegrounds = np.array([-9999.0])
+    conflicts = (sources != 0) & (grounds != 0)
+    if conflicts.any():
+        if policy in ("rmvsrc", "rmvall"):
+            sources[conflicts] = 0
+        elif policy == "rmvgnd":
+            grounds[conflicts] = 0
+    infgrounds = grounds == np.inf
+    infconflicts = infgrounds & (sources > 0)
+    grounds[infconflicts] = 0
+    return sources, grounds, finitegrounds
+
+
+def multiple_solver(a, sources, grounds, finitegrounds, solve):
+    """advanced.jl:274-305. `solve(matrix, rhs) -> x` is the multiple_solve hook."""
+    asolve = sp.csr_matrix(a, dtype=np.float64)
+    if not (len(finitegrounds) == 1 and finitegrounds[0] == -9999):
+        asolve = (asolve + sp.diags(finitegrounds)).tocsr()
+    inf = np.flatnonzero(grounds == np.inf)
+    keep = np.setdiff1d(np.arange(a.shape[0]), inf)
+    asolve = asolve[keep][:, keep]
+    volt = solve(asolve, np.asarray(sources, dtype=np.float64)[keep])
+    voltages = np.zeros(a.shape[0])
+    voltages[keep] = volt
+    return voltages
+
+
+def _oracle_multiple_solve(mode):
+    def solve(matrix, rhs):
+        if mode == "direct":
+            return spla.spsolve(matrix.tocsc(), rhs)
+        S = OracleAMG(matrix)  # smoothed_aggregation(matrix) with all defaults == the pairwise setup (advanced.jl:308)
+        v = solve_linear_system(S, matrix, rhs, "tight" if mode == "tight" else "reference")
+        return v
+    return solve
+
+
+def network_advanced_from_fixture(case, mode="reference", solve=None):
+    """network_advanced (network/advanced.jl:1-17) on a tests/golden fixture: returns [node id (1-based), voltage]."""
+    from . import refgraph as rg
+    ei = np.asarray(case["edges_i"]); ej = np.asarray(case["edges_j"])
+    m = int(max(ei.max(), ej.max()))
+    A = sp.coo_matrix((np.asarray(case["edges_v"], dtype=np.float64), (ei - 1, ej - 1)), shape=(m, m)).tocsr()
+    A = (A + A.T).tocsr()
+    cc = rg.connected_components(A)
+    G = rg.laplacian(A)
+    sources = np.zeros(m); grounds = np.zeros(m)
+    gl = np.array(case["grounds"], dtype=np.float64)
+    if case["ground_file_is_resistances"]:
+        with np.errstate(divide="ignore"):
+            gl[:, 1] = 1.0 / gl[:, 1]
+    for node, val in case["sources"]:
+        sources[int(node) - 1] = val
+    for node, val in gl:
+        grounds[int(node) - 1] = val
+    sources, grounds, finitegrounds = resolve_conflicts(sources, grounds, case["remove_src_or_gnd"])
+    solve = solve or _oracle_multiple_solve(mode)
+    voltages = np.zeros(m)
+    for c in cc:
+        idx = np.asarray(c) - 1
+        s_local, g_local = sources[idx], grounds[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        f_local = finitegrounds[idx] if not (len(finitegrounds) == 1 and finitegrounds[0] == -9999) else finitegrounds
+        voltages[idx] += multiple_solver(G[idx][:, idx], s_local, g_local, f_local, solve)
+    return np.column_stack([np.arange(1, m + 1), voltages])

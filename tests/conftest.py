@@ -17,8 +17,13 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    names = sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json"))
-    return names
+    """pairwise cases (raster + network) of the reference's regression suite"""
+    return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("sg"))
+
+
+def advanced_cases():
+    """network advanced-mode cases (multiple_solve path)"""
+    return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgNetwork"))
 
 
 def load_case(name):

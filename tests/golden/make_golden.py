@@ -242,10 +242,47 @@ def network_case(idx):
     }
 
 
+def network_advanced_case(idx):
+    """mgNetworkVerify<idx>: network advanced mode (test/test_utils.jl:91-99) -- inputs after get_network_data
+    (io.jl:387-418: load_graph + read_point_strengths) and the golden node voltages."""
+    name = "mgNetworkVerify%d" % idx
+    d = parse_ini(os.path.join(REF, "input/network/%s.ini" % name))
+    with open(resolve(d["habitat_file"])) as f:
+        e = np.array([ln.split() for ln in f if ln.strip()], dtype=np.float64)
+    i = e[:, 0].astype(int)
+    j = e[:, 1].astype(int)
+    v = e[:, 2].copy()
+    zero_based = min(i.min(), j.min()) == 0
+    if zero_based:
+        i = i + 1
+        j = j + 1
+    if truthy(d, "habitat_map_is_resistances"):
+        v = 1.0 / v
+
+    def strengths(path):  # read_point_strengths, io.jl:84-89
+        with open(path) as f:
+            a = np.array([ln.split() for ln in f if ln.strip()], dtype=np.float64)
+        if a[:, 0].min() == 0 or zero_based:
+            a[:, 0] += 1
+        return a.tolist()
+
+    with open(os.path.join(REF, "output_verify", name + "_voltages.txt")) as f:
+        exp = [[float(x) for x in ln.split()] for ln in f if ln.strip()]
+    return {
+        "name": name, "kind": "network_advanced", "ini_solver": d.get("solver", "cg+amg"),
+        "edges_i": i.tolist(), "edges_j": j.tolist(), "edges_v": v.tolist(),
+        "sources": strengths(resolve(d["source_file"])), "grounds": strengths(resolve(d["ground_file"])),
+        "ground_file_is_resistances": truthy(d, "ground_file_is_resistances"),
+        "remove_src_or_gnd": d.get("remove_src_or_gnd", "keepall"),
+        "expected_voltages": exp,  # [node (0-based in the golden file), voltage]
+    }
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
-    cases = [raster_case(k) for k in range(1, 18)] + [network_case(k) for k in range(1, 4)]
+    cases = ([raster_case(k) for k in range(1, 18)] + [network_case(k) for k in range(1, 4)] +
+             [network_advanced_case(k) for k in range(1, 4)])
     for c in cases:
         with open(os.path.join(OUT, c["name"] + ".json"), "w") as f:
             json.dump(c, f, separators=(",", ":"))

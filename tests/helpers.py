@@ -65,3 +65,27 @@ def run_fixture(case, solver, stats=None):
 def expected_ids(case):
     exp = np.array(case["expected"])
     return exp[1:, 0] + (1 if case["kind"] == "network" else 0)
+
+
+def run_network_advanced_fixture(case, solver):
+    """network_advanced (src/network/advanced.jl:1-17) through the product's host mirror."""
+    import scipy.sparse as sp
+    from circuitscape_jl_amd import solver as ps
+    ei = np.asarray(case["edges_i"]); ej = np.asarray(case["edges_j"])
+    m = int(max(ei.max(), ej.max()))
+    A = sp.coo_matrix((np.asarray(case["edges_v"], dtype=np.float64), (ei - 1, ej - 1)), shape=(m, m)).tocsr()
+    A = (A + A.T).tocsr()
+    cc = rg.connected_components(A)
+    G = rg.laplacian(A)
+    sources = np.zeros(m); grounds = np.zeros(m)
+    gl = np.array(case["grounds"], dtype=np.float64)
+    if case["ground_file_is_resistances"]:
+        with np.errstate(divide="ignore"):
+            gl[:, 1] = 1.0 / gl[:, 1]
+    for node, val in case["sources"]:
+        sources[int(node) - 1] = val
+    for node, val in gl:
+        grounds[int(node) - 1] = val
+    sources, grounds, finite = ps.resolve_conflicts(sources, grounds, case["remove_src_or_gnd"])
+    v = ps.advanced_kernel(G, cc, sources, grounds, finite, solver)
+    return np.column_stack([np.arange(1, m + 1), v])

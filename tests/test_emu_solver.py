@@ -196,3 +196,34 @@ def test_fp32_preconditioner_under_fp64_cg(emu_lib, oracle, batch):
     assert st2["not_converged"] == 0 and st2["max_relres"] < 1e-10
     assert np.max(np.abs(R2 - Ro) / Ro) < 1e-10
     h.close()
+
+
+@pytest.mark.parametrize("theta", [0.1, 0.5])
+def test_strength_threshold_does_not_stall_coarsening(emu_lib, oracle, theta):
+    """theta > 0 on a strongly heterogeneous raster: levels that the strength filter cannot coarsen fall back to the
+    full pattern, so the hierarchy still reaches a small coarsest level and CG converges in a few iterations."""
+    from oracle import refgraph as rg
+    N = 72
+    G, g = rg.synthetic_raster_problem(N, N, sigma=2.0)
+    A = oracle.regularize(G)
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, theta=theta, itmax=200))
+    info = h.info
+    assert info["level_n"][-1] <= 100, info["level_n"]
+    src, dst = [3, 700], [5000, 4321]
+    R, _, _, st = h.solve_pairs(src, dst)
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    assert st["not_converged"] == 0 and st["max_iters"] < 60
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    h.close()
+
+
+@pytest.mark.parametrize("name", __import__("conftest").advanced_cases())
+def test_network_advanced_through_product_path(emu_lib, name):
+    """scope row N2: multiple_solver + multiple_solve(::HIPAMGSolver) on the reference's network advanced fixtures."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import run_network_advanced_fixture
+    case = load_case(name)
+    got = run_network_advanced_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
+    exp = np.array(case["expected_voltages"])
+    assert np.array_equal(exp[:, 0] + 1, got[:, 0])
+    assert np.max(np.abs(exp[:, 1] - got[:, 1])) <= 1e-6 * max(1.0, np.abs(exp[:, 1]).max())

@@ -74,3 +74,14 @@ def test_not_converged_is_reported_like_the_reference(gpu_lib, oracle):
         h.solve_pairs([0], [9999])
     assert e.value.code == gpu_lib.CSGPU_NOT_CONVERGED and "did not converge" in str(e.value)
     h.close()
+
+
+@pytest.mark.parametrize("name", __import__("conftest").advanced_cases())
+def test_network_advanced_on_gpu(gpu_lib, name):
+    from circuitscape_jl_amd import solver as ps
+    from helpers import run_network_advanced_fixture
+    case = load_case(name)
+    got = run_network_advanced_fixture(case, ps.HIPAMGSolver(bs=1))
+    exp = np.array(case["expected_voltages"])
+    assert np.array_equal(exp[:, 0] + 1, got[:, 0])
+    assert np.max(np.abs(exp[:, 1] - got[:, 1])) <= 1e-5 * max(1.0, np.abs(exp[:, 1]).max())

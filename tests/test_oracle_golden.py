@@ -41,3 +41,15 @@ def test_oracle_single_precision_behaviour(oracle):
     assert np.max(np.abs(exp[1:, 1:] - got[1:, 1:])) < 1e-2
     with pytest.raises(RuntimeError, match="did not converge"):
         oracle.raster_pairwise_from_fixture(load_case("sgVerify4"), mode="reference", precision="single")
+
+
+@pytest.mark.parametrize("name", __import__("conftest").advanced_cases())
+@pytest.mark.parametrize("mode", ["reference", "tight", "direct"])
+def test_oracle_network_advanced_matches_golden(oracle, name, mode):
+    """multiple_solver / multiple_solve(::AMGSolver) restatement vs mgNetworkVerify*_voltages.txt
+    (reference test: test/test_utils.jl:91-99, node ids +1)."""
+    case = load_case(name)
+    got = oracle.network_advanced_from_fixture(case, mode=mode)
+    exp = np.array(case["expected_voltages"])
+    assert np.array_equal(exp[:, 0] + 1, got[:, 0])
+    assert np.max(np.abs(exp[:, 1] - got[:, 1])) <= 1e-6 * max(1.0, np.abs(exp[:, 1]).max())
