@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
                     help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "
                          "precision as the CG iteration")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
+                         "multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--opt", action="append", default=[], help="extra csgpu_opts override key=value (tuning)")
     ap.add_argument("--compare-steps", type=int, default=3,
                     help="N=1 only: also time this many steps with an fp64 preconditioner and report them (0 = skip)")
@@ -100,11 +103,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev  # one rank per GPU under the driver; ranks share a GPU only in the gloo self-test
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+    dev = torch.device("cuda", dev_index)
 
     import circuitscape_jl_amd  # noqa: F401
     from circuitscape_jl_amd import lib
@@ -120,7 +128,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         extra[k] = float(v) if k in ("theta", "omega_p", "omega_s", "rtol", "atol") else int(v)
-    opts = lib.default_opts(device=local_rank, batch=args.batch, criterion=args.criterion,
+    opts = lib.default_opts(device=dev_index, batch=args.batch, criterion=args.criterion,
                             precond_bytes=4 if args.precond == "fp32" else 0, **extra)
     t0 = time.time()
     h = lib.raster_setup(g, opts)
@@ -159,14 +167,15 @@ def main():
         agg["cg_spmv_calls"] += st["cg_spmv_calls"]
         agg["device_ms"] += st["device_ms"]
         agg["max_relres"] = max(agg["max_relres"], st["max_relres"])
-    res_local = torch.from_numpy(np.concatenate(results).astype(np.float64)).to(dev)
+    res_local = torch.from_numpy(np.concatenate(results).astype(np.float64))
+    res_local = res_local.to(dev) if (dist is None or args.backend == "nccl") else res_local
     if dist is not None:
         gathered = [torch.empty_like(res_local) for _ in range(world)]
         dist.all_gather(gathered, res_local)  # the path's only collective: final result gather over RCCL/xGMI
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -217,7 +226,7 @@ def main():
         if world == 1 and args.compare_steps > 0 and args.precond == "fp32" and dtype == np.float64:
             # same workload with the preconditioner in fp64 as well (pure-fp64 path), for comparison
             h.close()
-            h2 = lib.raster_setup(make_raster(size, dtype=dtype), lib.default_opts(device=local_rank, batch=B,
+            h2 = lib.raster_setup(make_raster(size, dtype=dtype), lib.default_opts(device=dev_index, batch=B,
                                                                                   criterion=args.criterion))
             s, d = batch_pairs(0)
             h2.solve_pairs(s, d)
