@@ -4,6 +4,7 @@
 #include <memory>
 #include <mutex>
 
+#include "currents.h"
 #include "pairs.h"
 #include "pcg.h"
 #include "raster.h"
@@ -16,7 +17,8 @@ struct ISolver {
   virtual ~ISolver() {}
   virtual void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
                            const int64_t* gather, int64_t ngather, void* gathered_out, void* resist_out,
-                           csgpu_stats* stats) = 0;
+                           csgpu_stats* stats, const int32_t* weights = nullptr, void* curr_out = nullptr,
+                           void* cum_inout = nullptr, void* max_inout = nullptr) = 0;
   virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
@@ -254,7 +256,8 @@ struct Solver : ISolver {
   }
 
   void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out, const int64_t* gather,
-                   int64_t ngather, void* gathered_out, void* resist_out, csgpu_stats* stats) override {
+                   int64_t ngather, void* gathered_out, void* resist_out, csgpu_stats* stats, const int32_t* weights,
+                   void* curr_out, void* cum_inout, void* max_inout) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -279,8 +282,25 @@ struct Solver : ISolver {
     }
     DBuf dres = dalloc<T>(K), dgath = dalloc<T>((size_t)std::max<int64_t>(ngather, 1) * K);
     DBuf dvolt;
-    if (volt_out) dvolt.alloc((size_t)n * K * sizeof(T));
-    std::vector<int> s32(K), d32(K);
+    if (volt_out || curr_out) dvolt.alloc((size_t)n * K * sizeof(T));
+    // N1: node currents of every pair, optional cumulative / maximum accumulation over the pairs of this call
+    const bool want_curr = curr_out || cum_inout || max_inout;
+    DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax;
+    if (want_curr) {
+      dcurr.alloc((size_t)n * K * sizeof(T));
+      dweight.alloc((size_t)K * sizeof(int));
+      dbpart.alloc((size_t)kMaxGrid * K * 2 * sizeof(double));
+      dbmax.alloc((size_t)K * 2 * sizeof(double));
+      if (cum_inout) {
+        dcum.alloc((size_t)n * sizeof(T));
+        CS_HIP(hipMemsetAsync(dcum.p, 0, dcum.bytes, st));
+      }
+      if (max_inout) {
+        dmax.alloc((size_t)n * sizeof(T));
+        CS_HIP(hipMemsetAsync(dmax.p, 0, dmax.bytes, st));
+      }
+    }
+    std::vector<int> s32(K), d32(K), w32(K);
     for (int64_t p0 = 0; p0 < npairs; p0 += K) {
       const int ncols = (int)std::min<int64_t>(K, npairs - p0);
       for (int c = 0; c < K; ++c) {
@@ -309,8 +329,45 @@ struct Solver : ISolver {
         CS_HIP(hipMemcpyAsync((T*)volt_out + (size_t)p0 * n, dvolt.p, (size_t)n * ncols * sizeof(T),
                               hipMemcpyDeviceToHost, st));
       }
+      if (want_curr) {
+        const Csr<T>& A = cg_matrix();
+        const int gc = grid_for(n * K);
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_max_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
+                                            A.va(), (const T*)dptr<T>(W.x), dptr<double>(dbpart)));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_max_final_kernel<KK>), dim3(1), dim3(256), 0, st,
+                                            (const double*)dptr<double>(dbpart), gc, dptr<double>(dbmax)));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((node_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
+                                            A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
+                                            dptr<T>(dcurr)));
+        if (curr_out) {
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                              (const T*)dptr<T>(dcurr), ncols, dptr<T>(dvolt)));
+          CS_HIP(hipMemcpyAsync((T*)curr_out + (size_t)p0 * n, dvolt.p, (size_t)n * ncols * sizeof(T),
+                                hipMemcpyDeviceToHost, st));
+        }
+        if (cum_inout || max_inout) {
+          for (int c = 0; c < K; ++c) w32[c] = c < ncols ? (weights ? weights[p0 + c] : 1) : 0;
+          CS_HIP(hipMemcpyAsync(dweight.p, w32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((current_accumulate_kernel<T, KK>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                                              (const T*)dptr<T>(dcurr), ncols, (const int*)dptr<int>(dweight),
+                                              cum_inout ? dptr<T>(dcum) : (T*)nullptr, max_inout ? dptr<T>(dmax) : (T*)nullptr));
+        }
+      }
       check_launch("solve_pairs batch");
       CS_HIP(hipStreamSynchronize(st));
+    }
+    if (cum_inout || max_inout) {
+      std::vector<T> tmp((size_t)n);
+      if (cum_inout) {
+        CS_HIP(hipMemcpy(tmp.data(), dcum.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+        T* h = (T*)cum_inout;
+        for (int64_t i = 0; i < n; ++i) h[i] += tmp[i];
+      }
+      if (max_inout) {
+        CS_HIP(hipMemcpy(tmp.data(), dmax.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+        T* h = (T*)max_inout;
+        for (int64_t i = 0; i < n; ++i) h[i] = tmp[i] > h[i] ? tmp[i] : h[i];
+      }
     }
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -628,6 +685,31 @@ int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, i
   memset(s, 0, sizeof(*s));
   if (npairs == 0) return CSGPU_OK;
   h->solver->solve_pairs(src, dst, npairs, volt_out, gather_idx, ngather, gathered_out, resist_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs,
+                               const int32_t* weights, void* volt_out, void* curr_out, void* cum_curr_inout,
+                               void* max_curr_inout, void* resist_out, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || npairs < 0 || (npairs > 0 && (!src || !dst))) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  if (npairs == 0) return CSGPU_OK;
+  h->solver->solve_pairs(src, dst, npairs, volt_out, nullptr, 0, nullptr, resist_out, s, weights, curr_out, cum_curr_inout,
+                         max_curr_inout);
   if (s->not_converged > 0) {
     char buf[256];
     snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",

@@ -21,7 +21,7 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
-    "csgpu_solve_pairs", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_get_level_matrix",
+    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_get_level_matrix",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -81,6 +81,7 @@ def _bind(L):
     L.csgpu_raster_setup.argtypes = [vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
     L.csgpu_get_info.argtypes = [vp, ctypes.POINTER(Info)]
     L.csgpu_solve_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
@@ -188,6 +189,30 @@ class Handle:
                                      ctypes.byref(st))
         _check(rc)
         return res, gathered, volt, st.as_dict()
+
+    def solve_pairs_currents(self, src, dst, weights=None, want_voltages=False, want_currents=True, cum=None, mx=None):
+        """Pair solves + node currents (scope row N1). cum / mx: optional length-n arrays updated in place
+        (cum += sum_p w_p * curr_p, mx = max(mx, curr_p)). Returns (R, voltages or None, currents or None, stats)."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        npairs = len(src)
+        n = self.info["n"]
+        res = np.zeros(npairs, dtype=self.dtype)
+        volt = np.zeros((n, npairs), dtype=self.dtype, order="F") if want_voltages else None
+        curr = np.zeros((n, npairs), dtype=self.dtype, order="F") if want_currents else None
+        w = np.ascontiguousarray(weights, dtype=np.int32) if weights is not None else None
+        for a in (cum, mx):
+            assert a is None or (a.dtype == self.dtype and a.flags["C_CONTIGUOUS"] and a.shape == (n,))
+        st = Stats()
+        rc = lib().csgpu_solve_pairs_currents(self._p, src.ctypes.data, dst.ctypes.data, npairs,
+                                              w.ctypes.data if w is not None else None,
+                                              volt.ctypes.data if volt is not None else None,
+                                              curr.ctypes.data if curr is not None else None,
+                                              cum.ctypes.data if cum is not None else None,
+                                              mx.ctypes.data if mx is not None else None, res.ctypes.data,
+                                              ctypes.byref(st))
+        _check(rc)
+        return res, volt, curr, st.as_dict()
 
     def solve_rhs(self, rhs):
         rhs = np.asarray(rhs, dtype=self.dtype)

@@ -44,6 +44,22 @@ class OutputFlags:  # src/out.jl:1-10
     write_cur_maps: bool = False
     write_cum_cur_map_only: bool = False
     write_max_cur_maps: bool = False
+    set_null_currents_to_nodata: bool = False
+    set_null_voltages_to_nodata: bool = False
+    log_transform_maps: bool = False
+
+
+@dataclass
+class Cumulative:
+    """src/core.jl:1-8 (raster part): cumulative and maximum current maps shared by all pairs of a job."""
+    cum_curr: np.ndarray
+    max_curr: Optional[np.ndarray] = None
+
+
+def initialize_cum_maps(cellmap, write_max=False):
+    """src/utils.jl:122-131."""
+    cellmap = np.asarray(cellmap)
+    return Cumulative(np.zeros(cellmap.shape), np.full(cellmap.shape, -9999.0) if write_max else None)
 
 
 @dataclass
@@ -63,6 +79,8 @@ class GraphProblem:
     nodemap: Optional[np.ndarray] = None
     polymap: Optional[np.ndarray] = None
     solver: HIPAMGSolver = field(default_factory=HIPAMGSolver)
+    cellmap: Optional[np.ndarray] = None     # conductance raster (for the set_null_*_to_nodata options)
+    cum: Optional[Cumulative] = None         # cumulative / maximum current maps (scope row N1)
 
 
 def get_solver(cfg):
@@ -172,6 +190,74 @@ def advanced_kernel(G, cc, sources, grounds, finitegrounds, solver, cfg=None, ch
     return voltages
 
 
+def _colmajor_nonzero(mask):
+    jj, ii = np.nonzero(np.asarray(mask).T)
+    return ii, jj
+
+
+def _construct_node_map(gmap, polymap):
+    """src/raster/pairwise.jl:271-314 (needed by construct_local_node_map when polygons are present)."""
+    gmap = np.asarray(gmap, dtype=np.float64)
+    nodemap = np.zeros(gmap.shape, dtype=np.int64)
+    ii, jj = _colmajor_nonzero(gmap > 0)
+    nodemap[ii, jj] = np.arange(1, len(ii) + 1)
+    if polymap is None or np.size(polymap) == 0:
+        return nodemap
+    polymap = np.asarray(polymap, dtype=np.int64)
+    pruned = np.where(gmap > 0, polymap, 0)
+    for polynum in np.unique(polymap):
+        if polynum == 0:
+            continue
+        i1, j1 = _colmajor_nonzero(pruned == polynum)
+        if len(i1) > 0:
+            nodemap[polymap == polynum] = nodemap[i1[0], j1[0]]
+    ii, jj = _colmajor_nonzero(nodemap != 0)
+    _, inv = np.unique(nodemap[ii, jj], return_inverse=True)
+    nodemap[ii, jj] = inv + 1
+    return nodemap
+
+
+def construct_local_node_map(nodemap, component, polymap):
+    """src/utils.jl:10-30: node map restricted to one connected component, renumbered 1..n_component."""
+    nodemap = np.asarray(nodemap)
+    local = np.where(np.isin(nodemap, component), nodemap, 0)
+    if np.array_equal(local, nodemap):
+        return local
+    if polymap is None or np.size(polymap) == 0:
+        ii, jj = _colmajor_nonzero(local != 0)
+        local = local.copy()
+        local[ii, jj] = np.arange(1, len(ii) + 1)
+        return local
+    return _construct_node_map((local != 0).astype(float), np.where(local != 0, polymap, 0))
+
+
+def _scatter(values, local_nodemap):
+    """_create_current_maps (raster branch, out.jl:150-176) / _create_voltage_map (out.jl:418-432)."""
+    out = np.zeros(local_nodemap.shape)
+    m = local_nodemap > 0
+    out[m] = np.asarray(values, dtype=np.float64)[local_nodemap[m] - 1]
+    return out
+
+
+def _process_grid(cmap, cellmap, log_transform, set_null_to_nodata):
+    """process_grid! (out.jl:305-319)."""
+    if log_transform:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cmap = np.where(cmap > 0, np.log10(np.where(cmap > 0, cmap, 1.0)), -9999.0)
+    if set_null_to_nodata and cellmap is not None:
+        cmap = cmap.copy()
+        cmap[np.asarray(cellmap) == 0] = -9999.0
+    return cmap
+
+
+def write_cum_maps(cum):
+    """postprocess_cum_curmap! (utils.jl:114-120) applied like write_cum_maps does (out.jl:467-481)."""
+    cum.cum_curr[cum.cum_curr < -9999] = -9999
+    if cum.max_curr is not None:
+        cum.max_curr[cum.max_curr < -9999] = -9999
+    return cum
+
+
 def _node_coords(nodemap, comp):
     """(row, col) of the first cell (column-major order) of every node of `comp` (1-based ids) in `nodemap`."""
     nm = np.asarray(nodemap)
@@ -210,6 +296,15 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
     get_shortcut = (flags.is_raster and not of.write_volt_maps and not of.write_cur_maps and
                     not of.write_cum_cur_map_only and not of.write_max_cur_maps and len(exclude) == 0)  # core.jl:137-146
     want_volt = postprocess is not None and not get_shortcut
+    # scope row N1: current / voltage maps (raster). Node currents, their cumulative sum and maximum are computed on
+    # the device; only the per-pair maps the flags ask for come back to the host.
+    maps = None
+    raster_maps = (flags.is_raster and not get_shortcut and prob.nodemap is not None and np.size(prob.nodemap) and
+                   (of.write_cur_maps or of.write_cum_cur_map_only or of.write_max_cur_maps or of.write_volt_maps))
+    if raster_maps:
+        maps = stats.setdefault("maps", {"cur": {}, "volt": {}}) if stats is not None else {"cur": {}, "volt": {}}
+        if prob.cum is None:
+            prob.cum = initialize_cum_maps(prob.nodemap, of.write_max_cur_maps)
     nsolves = 0
     for comp in prob.cc:
         comp = np.asarray(comp, dtype=np.int64)
@@ -257,8 +352,12 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
                 gather = np.array([int(np.searchsorted(comp, points[i])) for i in focal_in_comp], dtype=np.int64)
             with construct_cholesky_factor(matrix, solver, node_row, node_col) as factor:   # core.jl:164 (once per CC)
                 try:
-                    R, gathered, V, st = factor.solve_pairs(src_nodes, dst_nodes, gather=gather,
-                                                            want_voltages=want_volt)
+                    if raster_maps:
+                        R, gathered, V, st = _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts,
+                                                                   of, maps, want_volt)
+                    else:
+                        R, gathered, V, st = factor.solve_pairs(src_nodes, dst_nodes, gather=gather,
+                                                                want_voltages=want_volt)
                 except lib.CsgpuError as e:
                     if e.code == lib.CSGPU_NOT_CONVERGED:
                         _raise_not_converged(e)                       # core.jl:641
@@ -294,6 +393,49 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
     if cfg is not None and cfg.get("output_file"):
         save_resistances(r, cfg["output_file"])
     return r
+
+
+def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts, of, maps, want_volt):
+    """postprocess() with maps on (core.jl:655-683 -> out.jl:29-115): voltage maps, per-pair current maps, cumulative and
+    maximum current maps. Node currents come from the device (csgpu_solve_pairs_currents)."""
+    n = len(comp)
+    local_nodemap = construct_local_node_map(prob.nodemap, comp, prob.polymap)       # core.jl:170
+    per_pair_cur = (of.write_cur_maps and not of.write_cum_cur_map_only) or of.log_transform_maps
+    need_volt = of.write_volt_maps or want_volt
+    weights = np.array([len(c) for c in fan], dtype=np.int32)   # the reference post-processes once per id combination
+    linear = not of.log_transform_maps
+    node_cum = np.zeros(n) if linear else None
+    node_max = np.zeros(n) if (linear and prob.cum.max_curr is not None) else None
+    R, V, C, st = factor.solve_pairs_currents(src_nodes, dst_nodes, weights=weights, want_voltages=need_volt,
+                                              want_currents=per_pair_cur, cum=node_cum, mx=node_max)
+    cum = prob.cum
+    if linear:
+        cmap = _scatter(node_cum, local_nodemap)
+        if of.set_null_currents_to_nodata and prob.cellmap is not None:
+            cmap[np.asarray(prob.cellmap) == 0] = -9999.0 * weights.sum()
+        cum.cum_curr += cmap
+        if cum.max_curr is not None:
+            mmap = _process_grid(_scatter(node_max, local_nodemap), prob.cellmap, False, of.set_null_currents_to_nodata)
+            np.maximum(cum.max_curr, mmap, out=cum.max_curr)
+    for p, combos in enumerate(fan):
+        cm = vm = None
+        if per_pair_cur:
+            cm = _process_grid(_scatter(C[:, p], local_nodemap), prob.cellmap, of.log_transform_maps,
+                               of.set_null_currents_to_nodata)
+        if of.write_volt_maps:
+            vm = _process_grid(_scatter(V[:, p], local_nodemap), prob.cellmap, False, of.set_null_voltages_to_nodata)
+        for (ci, cj) in combos:
+            key = (int(orig_pts[ci]), int(orig_pts[cj]))
+            if cm is not None:
+                if of.write_cur_maps and not of.write_cum_cur_map_only:
+                    maps["cur"][key] = cm
+                if not linear:
+                    cum.cum_curr += cm
+                    if cum.max_curr is not None:
+                        np.maximum(cum.max_curr, cm, out=cum.max_curr)
+            if vm is not None:
+                maps["volt"][key] = vm
+    return R, None, V, st
 
 
 def _update_shortcut_resistances(anchor, voltmatrix, shortcut, resistances, check):

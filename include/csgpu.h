@@ -18,6 +18,8 @@
  *                              RHS -1/+1 (core.jl:224-226), solve (:229), grounding shift and resistance
  *                              (:231-232), focal-voltage gather for the shortcut (update_voltmatrix! :685-703);
  *                              batched like the direct-solver driver (core.jl:448-493)
+ *   csgpu_solve_pairs_currents <-> the same plus postprocess() -> write_cur_maps -> _create_current_maps
+ *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
  *   csgpu_free             <-> GC finalizer of the factor object (PardisoFactorize, Pardiso ext :8-13)
  *   csgpu_last_error       <-> error(msg) strings (core.jl:641,650)
  *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for an all-valid raster
@@ -150,6 +152,17 @@ int csgpu_get_info(const csgpu_handle* h, csgpu_info* info);
 int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
                       const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
                       csgpu_stats* stats);
+
+/* Scope row N1 -- pair solves plus the reference's per-pair current post-processing on the device
+ * (get_node_currents src/out.jl:178-207, branch currents :250-290, cumulative / maximum maps :96-107):
+ *   curr_out[p*n + i]      = node current of node i for pair p  (max of the current entering and leaving the node,
+ *                            branch currents below 1e-8 of the largest one dropped)          may be NULL
+ *   cum_curr_inout[i]     += sum_p weights[p] * curr_p[i]       (weights NULL => 1)            may be NULL
+ *   max_curr_inout[i]      = max(max_curr_inout[i], max_p curr_p[i])                          may be NULL
+ *   volt_out, resist_out as in csgpu_solve_pairs. All arrays are host pointers of the handle's value type. */
+int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs,
+                               const int32_t* weights, void* volt_out, void* curr_out, void* cum_curr_inout,
+                               void* max_curr_inout, void* resist_out, csgpu_stats* stats);
 
 /* General right-hand sides: rhs and x_out are host column-major n x nrhs arrays of the handle's value type. */
 int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats);

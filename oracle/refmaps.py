@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE ONLY -- restatement of the reference's per-pair map post-processing (scope row N1).
+
+Restates (Circuitscape.jl, paths relative to /root/reference):
+  _get_branch_currents_posneg / _get_branch_currents   src/out.jl:209-290
+  _get_node_currents_posneg / get_node_currents        src/out.jl:178-207
+  _create_current_maps (raster branch)                 src/out.jl:150-176
+  _create_voltage_map                                  src/out.jl:418-432
+  construct_local_node_map                             src/utils.jl:10-30
+  write_cur_maps accumulation (cum / max)              src/out.jl:86-115, src/utils.jl:114-142
+  raster_pairwise drivers with maps on                 src/raster/pairwise.jl:55-135, src/core.jl:655-683
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import refgraph as rg
+from . import refsolve as rs
+
+
+def get_node_currents(G, voltages):
+    """out.jl:178-207 for finitegrounds == [-9999] (pairwise mode)."""
+    G = sp.csr_matrix(G)
+    coo = sp.triu(G, k=1).tocoo()  # entries (row < col): the reference's `i > row` orientation
+    g = np.abs(coo.data)
+    v = np.asarray(voltages, dtype=np.float64)
+    n = G.shape[0]
+    out = []
+    for pos in (True, False):
+        b = g * (v[coo.row] - v[coo.col]) if pos else g * (v[coo.col] - v[coo.row])
+        maxcur = b.max() if len(b) else 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = np.where(np.abs(b / maxcur) < 1e-8, 0.0, b)
+        B = sp.coo_matrix((b, (coo.row, coo.col)), shape=(n, n)).tocsr()
+        C = (B - B.T).tocsr()
+        C.data[C.data < 0] = 0.0
+        out.append(np.asarray(C.sum(axis=0)).ravel())
+    return np.maximum(out[0], out[1])
+
+
+def construct_local_node_map(nodemap, component, polymap):
+    """utils.jl:10-30 (component: 1-based node ids)."""
+    nodemap = np.asarray(nodemap)
+    local = np.where(np.isin(nodemap, component), nodemap, 0)
+    if np.array_equal(local, nodemap):
+        return local
+    if polymap is None or np.size(polymap) == 0:
+        ii, jj = rg._colmajor_nonzero(local != 0)
+        local = local.copy()
+        local[ii, jj] = np.arange(1, len(ii) + 1)
+        return local
+    local_poly = np.where(local != 0, polymap, 0)
+    return rg.construct_node_map((local != 0).astype(float), local_poly)
+
+
+def scatter(values, local_nodemap):
+    """_create_current_maps raster branch / _create_voltage_map: map[i,j] = values[nodemap[i,j]] (0 where no node)."""
+    out = np.zeros(local_nodemap.shape)
+    m = local_nodemap > 0
+    out[m] = np.asarray(values)[local_nodemap[m] - 1]
+    return out
+
+
+def process_grid(cmap, cellmap, log_transform, set_null_to_nodata):
+    """process_grid! / write_grid options, out.jl:305-319,355-365."""
+    cmap = np.array(cmap, dtype=np.float64)
+    if log_transform:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cmap = np.where(cmap > 0, np.log10(np.where(cmap > 0, cmap, 1.0)), -9999.0)
+    if set_null_to_nodata:
+        cmap[np.asarray(cellmap) == 0] = -9999.0
+    return cmap
+
+
+def raster_pairwise_maps_from_fixture(case, mode="direct"):
+    """Runs the pairwise driver with maps on (as the fixture's INI asks) and returns
+    {'cum': cum_curmap, 'max': max_curmap or None, 'cur': {(a,b): map}, 'volt': {(a,b): map}, 'R': padded matrix}."""
+    o = case["options"]
+    gmap = np.array(case["cellmap"], dtype=np.float64)
+    polymap = np.array(case["polymap"], dtype=np.int64) if case["polymap"] is not None else None
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    avg_res, four = o["connect_using_avg_resistances"], o["connect_four_neighbors_only"]
+    cum = np.zeros(gmap.shape)
+    mx = np.full(gmap.shape, -9999.0) if o["write_max_cur_maps"] else None
+    cur, volt = {}, {}
+
+    def process(prob):
+        a = prob.G.tocsr()
+        points = [int(p) for p in prob.points]
+        orig = [int(p) for p in prob.user_points]
+        exclude = set((int(x), int(y)) for x, y in prob.exclude_pairs)
+        for comp in prob.cc:
+            compset = {int(x): k for k, x in enumerate(comp)}
+            csub = []
+            for p in points:
+                if p in compset and p not in csub:
+                    csub.append(p)
+            if not csub:
+                continue
+            idx0 = np.asarray(comp, dtype=np.int64) - 1
+            matrix = rs.regularize(a[idx0][:, idx0])
+            solver = rs.DirectSolver(matrix) if mode == "direct" else rs.OracleAMG(matrix)
+            local_nodemap = construct_local_node_map(prob.nodemap, np.asarray(comp), prob.polymap)
+            for ai in range(len(csub)):
+                src_idx = [k for k, p in enumerate(points) if p == csub[ai]]
+                for bi in range(ai + 1, len(csub)):
+                    dst_idx = [k for k, p in enumerate(points) if p == csub[bi]]
+                    combos = [(ci, cj) for ci in src_idx for cj in dst_idx if (orig[ci], orig[cj]) not in exclude]
+                    if not combos:
+                        continue
+                    b = np.zeros(matrix.shape[0])
+                    b[compset[csub[ai]]] = -1.0
+                    b[compset[csub[bi]]] = 1.0
+                    v = rs.solve_linear_system(solver, matrix, b, mode)
+                    v = v - v[compset[csub[ai]]]
+                    nc = get_node_currents(matrix, v)
+                    cmap = process_grid(scatter(nc, local_nodemap), gmap, o.get("log_transform_maps", False),
+                                        o.get("set_null_currents_to_nodata", False))
+                    vmap = process_grid(scatter(v, local_nodemap), gmap, False, o.get("set_null_voltages_to_nodata", False))
+                    for (ci, cj) in combos:
+                        nonlocal_cum_add(cmap)
+                        cur[(orig[ci], orig[cj])] = cmap
+                        volt[(orig[ci], orig[cj])] = vmap
+
+    def nonlocal_cum_add(cmap):
+        cum[...] = cum + cmap
+        if mx is not None:
+            mx[...] = np.maximum(mx, cmap)
+
+    if len(points_rc[0]) == len(set(points_rc[2])):
+        prob = rg.compute_graph_data_no_polygons(gmap, polymap, points_rc, case["included_pairs"], avg_res, four)
+        process(prob)
+    else:
+        exclude = set()
+        if case["included_pairs"] is not None:
+            ex, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+            exclude = set(ex)
+        pts = []
+        for v in points_rc[2]:
+            if v not in pts:
+                pts.append(v)
+        for i in range(len(pts)):
+            for j in range(i + 1, len(pts)):
+                if (pts[i], pts[j]) in exclude or (pts[j], pts[i]) in exclude:
+                    continue
+                process(rg.compute_graph_data_polygons(gmap, polymap, points_rc, pts[i], pts[j], avg_res, four))
+    cum[cum < -9999] = -9999  # postprocess_cum_curmap!, utils.jl:114-120
+    if mx is not None:
+        mx[mx < -9999] = -9999
+    return {"cum": cum, "max": mx, "cur": cur, "volt": volt}

@@ -208,6 +208,25 @@ def raster_case(idx):
         read_included_pairs(resolve(d["included_pairs_file"])) if out["options"]["use_included_pairs"] else None
     )
     out["expected"] = read_expected(name)
+    # scope row N1: golden maps (cumulative / maximum current map, per-pair current and voltage maps of up to 4 pairs)
+    ov = os.path.join(REF, "output_verify")
+    maps = {}
+    for key, fn in (("cum_curmap", name + "_cum_curmap.asc"), ("max_curmap", name + "_max_curmap.asc")):
+        if os.path.exists(os.path.join(ov, fn)):
+            maps[key] = read_aagrid(os.path.join(ov, fn))[0].tolist()
+    pairs = sorted(f[len(name) + 8:-4] for f in os.listdir(ov) if f.startswith(name + "_curmap_") and f.endswith(".asc"))
+    maps["pairs"] = []
+    for pr in pairs[:4]:
+        entry = {"pair": [int(x) for x in pr.split("_")],
+                 "curmap": read_aagrid(os.path.join(ov, "%s_curmap_%s.asc" % (name, pr)))[0].tolist()}
+        vf = os.path.join(ov, "%s_voltmap_%s.asc" % (name, pr))
+        if os.path.exists(vf):
+            entry["voltmap"] = read_aagrid(vf)[0].tolist()
+        maps["pairs"].append(entry)
+    out["options"]["log_transform_maps"] = truthy(d, "log_transform_maps")
+    out["options"]["set_null_currents_to_nodata"] = truthy(d, "set_null_currents_to_nodata")
+    out["options"]["set_null_voltages_to_nodata"] = truthy(d, "set_null_voltages_to_nodata")
+    out["maps"] = maps
     return out
 
 

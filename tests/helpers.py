@@ -7,10 +7,11 @@ import numpy as np
 from oracle import refgraph as rg
 
 
-def to_product_problem(ref, solver):
+def to_product_problem(ref, solver, cellmap=None, cum=None):
     from circuitscape_jl_amd import solver as ps
     return ps.GraphProblem(G=ref.G, cc=ref.cc, points=ref.points, user_points=ref.user_points,
-                           exclude_pairs=ref.exclude_pairs, nodemap=ref.nodemap, polymap=ref.polymap, solver=solver)
+                           exclude_pairs=ref.exclude_pairs, nodemap=ref.nodemap, polymap=ref.polymap, solver=solver,
+                           cellmap=cellmap, cum=cum)
 
 
 def flags_from_case(case, is_raster):
@@ -18,7 +19,10 @@ def flags_from_case(case, is_raster):
     o = case.get("options", {})
     of = ps.OutputFlags(write_volt_maps=o.get("write_volt_maps", False), write_cur_maps=o.get("write_cur_maps", False),
                         write_cum_cur_map_only=o.get("write_cum_cur_map_only", False),
-                        write_max_cur_maps=o.get("write_max_cur_maps", False))
+                        write_max_cur_maps=o.get("write_max_cur_maps", False),
+                        set_null_currents_to_nodata=o.get("set_null_currents_to_nodata", False),
+                        set_null_voltages_to_nodata=o.get("set_null_voltages_to_nodata", False),
+                        log_transform_maps=o.get("log_transform_maps", False))
     return ps.Flags(is_raster=is_raster, outputflags=of)
 
 
@@ -34,9 +38,12 @@ def run_fixture(case, solver, stats=None):
     points_rc = tuple(list(x) for x in case["points_rc"])
     flags = flags_from_case(case, True)
     avg_res, four = o["connect_using_avg_resistances"], o["connect_four_neighbors_only"]
+    cum = ps.initialize_cum_maps(gmap, o.get("write_max_cur_maps", False))   # raster/pairwise.jl:231,86
+    if stats is not None:
+        stats["cum"] = cum
     if len(points_rc[0]) == len(set(points_rc[2])):          # _pt_file_no_polygons_path
         ref = rg.compute_graph_data_no_polygons(gmap, polymap, points_rc, case["included_pairs"], avg_res, four)
-        return ps.single_ground_all_pairs(to_product_problem(ref, solver), flags, stats=stats)
+        return ps.single_ground_all_pairs(to_product_problem(ref, solver, gmap, cum), flags, stats=stats)
     # _pt_file_polygons_path (raster/pairwise.jl:72-135): a fresh graph (and AMG setup) per pair of focal regions
     exclude = set()
     if case["included_pairs"] is not None:
@@ -52,7 +59,7 @@ def run_fixture(case, solver, stats=None):
             if (pts[i], pts[j]) in exclude or (pts[j], pts[i]) in exclude:
                 continue
             ref = rg.compute_graph_data_polygons(gmap, polymap, points_rc, pts[i], pts[j], avg_res, four)
-            pr = ps.single_ground_all_pairs(to_product_problem(ref, solver), flags, stats=stats)
+            pr = ps.single_ground_all_pairs(to_product_problem(ref, solver, gmap, cum), flags, stats=stats)
             res[i, j] = res[j, i] = pr[1, 2]
     np.fill_diagonal(res, 0)
     r = np.zeros((len(pts) + 1, len(pts) + 1))

@@ -227,3 +227,40 @@ def test_network_advanced_through_product_path(emu_lib, name):
     exp = np.array(case["expected_voltages"])
     assert np.array_equal(exp[:, 0] + 1, got[:, 0])
     assert np.max(np.abs(exp[:, 1] - got[:, 1])) <= 1e-6 * max(1.0, np.abs(exp[:, 1]).max())
+
+
+def _check_maps(case, st):
+    """scope row N1: cumulative / maximum / per-pair current maps and voltage maps vs the reference's golden .asc files
+    (reference criterion: sum(abs2, x - r) < 1e-6, test/test_utils.jl:196)."""
+    from circuitscape_jl_amd import solver as ps
+    m = case["maps"]
+    cum = ps.write_cum_maps(st["cum"])
+    o = case["options"]
+    if "cum_curmap" in m and (o["write_cur_maps"] or o["write_cum_cur_map_only"]):
+        assert np.sum((np.array(m["cum_curmap"]) - cum.cum_curr) ** 2) < 1e-6
+    if "max_curmap" in m and o["write_max_cur_maps"]:
+        assert np.sum((np.array(m["max_curmap"]) - cum.max_curr) ** 2) < 1e-6
+    ncmp = 0
+    for pe in m["pairs"]:
+        k = tuple(pe["pair"])
+        if k in st.get("maps", {}).get("cur", {}):
+            assert np.sum((np.array(pe["curmap"]) - st["maps"]["cur"][k]) ** 2) < 1e-6
+            ncmp += 1
+        if "voltmap" in pe and k in st.get("maps", {}).get("volt", {}):
+            assert np.sum((np.array(pe["voltmap"]) - st["maps"]["volt"][k]) ** 2) < 1e-6
+            ncmp += 1
+    return ncmp
+
+
+MAP_CASES = ["sgVerify1", "sgVerify3", "sgVerify4", "sgVerify5", "sgVerify9", "sgVerify11", "sgVerify13", "sgVerify14"]
+
+
+@pytest.mark.parametrize("name", MAP_CASES)
+def test_current_and_voltage_maps_through_product_path(emu_lib, name):
+    from circuitscape_jl_amd import solver as ps
+    case = load_case(name)
+    st = {}
+    run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
+    ncmp = _check_maps(case, st)
+    if name != "sgVerify3":  # write_cum_cur_map_only: no per-pair current maps
+        assert ncmp > 0
