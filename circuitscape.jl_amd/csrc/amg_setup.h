@@ -317,8 +317,131 @@ inline void spgemm_group(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_
   CS_HIP(hipStreamSynchronize(st));  // cursor freed on return
 }
 
+// ---- fast path: short rows on both sides (every product of the raster hierarchy) -------------------------------
+// Same multiway merge, but the B rows a lane needs are staged ONCE into LDS and the cursors live in registers, so the
+// merge loop touches no global memory: lane lg of the row's G-lane group owns A entries ab + lg + G*e (e < EPL) and
+// keeps the (at most MAXB) entries of B row A.col[...] in its LDS slot. Output order and summation order are identical
+// to spgemm_merge_kernel (ascending A entry within a lane, fixed shuffle tree across lanes).
+template <class T, int G, int EPL, int MAXB, bool NUMERIC>
+__global__ __launch_bounds__(256) void spgemm_lds_kernel(int nrows, const int* __restrict__ Arp,
+                                                         const int* __restrict__ Aci, const T* __restrict__ Ava,
+                                                         const int* __restrict__ Brp, const int* __restrict__ Bci,
+                                                         const T* __restrict__ Bva, int* __restrict__ Ccount,
+                                                         const int* __restrict__ Crp, int* __restrict__ Cci,
+                                                         T* __restrict__ Cva) {
+  __shared__ int s_col[256 * EPL * MAXB];
+  __shared__ T s_val[NUMERIC ? 256 * EPL * MAXB : 1];
+  const int lg = threadIdx.x % G;
+  const int groups_per_block = 256 / G;
+  int* mycol = s_col + (size_t)threadIdx.x * EPL * MAXB;
+  T* myval = s_val + (NUMERIC ? (size_t)threadIdx.x * EPL * MAXB : 0);
+  for (int row = blockIdx.x * groups_per_block + threadIdx.x / G; row < nrows; row += gridDim.x * groups_per_block) {
+    const int ab = Arp[row], ae = Arp[row + 1];
+    int blen[EPL], bpos[EPL];
+    T aval[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int ka = ab + lg + G * e;
+      blen[e] = 0;
+      bpos[e] = 0;
+      aval[e] = T(0);
+      if (ka < ae) {
+        const int k = Aci[ka];
+        const int b0 = Brp[k];
+        blen[e] = Brp[k + 1] - b0;
+        if (NUMERIC) aval[e] = Ava[ka];
+        for (int j = 0; j < blen[e]; ++j) {
+          mycol[e * MAXB + j] = Bci[b0 + j];
+          if (NUMERIC) myval[e * MAXB + j] = Bva[b0 + j];
+        }
+      }
+    }
+    int count = 0;
+    const int out0 = NUMERIC ? Crp[row] : 0;
+    for (;;) {
+      int cmin = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        if (bpos[e] < blen[e]) {
+          const int cc = mycol[e * MAXB + bpos[e]];
+          cmin = cc < cmin ? cc : cmin;
+        }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) {
+        const int t = __shfl_xor(cmin, o, G);
+        cmin = t < cmin ? t : cmin;
+      }
+      if (cmin == 0x7fffffff) break;
+      T sacc = T(0);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        if (bpos[e] < blen[e] && mycol[e * MAXB + bpos[e]] == cmin) {
+          if (NUMERIC) sacc += aval[e] * myval[e * MAXB + bpos[e]];
+          ++bpos[e];
+        }
+      if (NUMERIC) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, G);
+        if (lg == 0) {
+          Cci[out0 + count] = cmin;
+          Cva[out0 + count] = sacc;
+        }
+      }
+      ++count;
+    }
+    if (!NUMERIC && lg == 0) Ccount[row] = count;
+  }
+}
+
+// max row length of a CSR matrix (block partial maxima; finished on the host)
+__global__ __launch_bounds__(256) void max_row_len_kernel(int nrows, const int* __restrict__ rp, int* __restrict__ out) {
+  int m = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nrows; i += gridDim.x * 256) m = max(m, rp[i + 1] - rp[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+template <class T>
+inline int max_row_len(const Csr<T>& A, hipStream_t st) {
+  DBuf d = dalloc<int>(1);
+  CS_HIP(hipMemsetAsync(d.p, 0, sizeof(int), st));
+  if (A.nrows > 0) hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(A.nrows)), dim3(256), 0, st, A.nrows, A.rp(), dptr<int>(d));
+  return read_int(dptr<int>(d), st);
+}
+
+template <class T, int G, int EPL, int MAXB>
+inline void spgemm_lds(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st) {
+  const int n = A.nrows;
+  C.nrows = n;
+  C.ncols = B.ncols;
+  C.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+  const int groups_per_block = 256 / G;
+  int grid = ceil_div(n, groups_per_block);
+  if (grid > 65536) grid = 65536;
+  if (grid < 1) grid = 1;
+  CS_HIP(hipMemsetAsync(C.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL((spgemm_lds_kernel<T, G, EPL, MAXB, false>), dim3(grid), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(),
+                     B.rp(), B.ci(), B.va(), C.rp(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+  check_launch("spgemm (lds) symbolic");
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(C.rp(), (int64_t)n + 1, st, dptr<int>(total));
+  C.nnz = read_int(dptr<int>(total), st);
+  CS_REQUIRE(C.nnz >= 0, CSGPU_BAD_ARGS, "SpGEMM result exceeds 2^31 nonzeros");
+  C.col.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(int));
+  C.val.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(T));
+  hipLaunchKernelGGL((spgemm_lds_kernel<T, G, EPL, MAXB, true>), dim3(grid), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(),
+                     B.rp(), B.ci(), B.va(), (int*)nullptr, C.rp(), C.ci(), C.va());
+  check_launch("spgemm (lds) numeric");
+  CS_HIP(hipStreamSynchronize(st));
+}
+
 template <class T>
 inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st) {
+  // fast path when every row of A fits a lane group and every row of B fits its LDS slot
+  const int ma = max_row_len(A, st), mb = max_row_len(B, st);
+  if (mb <= 4 && ma <= 16) return spgemm_lds<T, 8, 2, 4>(A, B, C, st);
+  if (mb <= 12 && ma <= 16) return spgemm_lds<T, 8, 2, 12>(A, B, C, st);
+  if (mb <= 12 && ma <= 64) return spgemm_lds<T, 32, 2, 12>(A, B, C, st);
   const double avg = A.nrows > 0 ? (double)A.nnz / (double)A.nrows : 1.0;
   if (avg <= 3.0)
     spgemm_group<T, 2>(A, B, C, st);
