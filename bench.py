@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--size", type=int, default=10000)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--precision", default="double", choices=["double", "single"])
-    ap.add_argument("--cpu-sample", type=int, default=1000, help="raster edge of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1500, help="raster edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
     ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
                     help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "

@@ -153,7 +153,11 @@ class Handle:
             lib().csgpu_free(self._p)
             self._p = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def __enter__(self):
         return self
