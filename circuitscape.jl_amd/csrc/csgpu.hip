@@ -18,7 +18,7 @@ struct ISolver {
   virtual void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
                            const int64_t* gather, int64_t ngather, void* gathered_out, void* resist_out,
                            csgpu_stats* stats, const int32_t* weights = nullptr, void* curr_out = nullptr,
-                           void* cum_inout = nullptr, void* max_inout = nullptr) = 0;
+                           void* cum_inout = nullptr, void* max_inout = nullptr, void* branch_out = nullptr) = 0;
   virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
@@ -257,7 +257,7 @@ struct Solver : ISolver {
 
   void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out, const int64_t* gather,
                    int64_t ngather, void* gathered_out, void* resist_out, csgpu_stats* stats, const int32_t* weights,
-                   void* curr_out, void* cum_inout, void* max_inout) override {
+                   void* curr_out, void* cum_inout, void* max_inout, void* branch_out) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -284,8 +284,12 @@ struct Solver : ISolver {
     DBuf dvolt;
     if (volt_out || curr_out) dvolt.alloc((size_t)n * K * sizeof(T));
     // N1: node currents of every pair, optional cumulative / maximum accumulation over the pairs of this call
-    const bool want_curr = curr_out || cum_inout || max_inout;
-    DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax;
+    const bool want_curr = curr_out || cum_inout || max_inout || branch_out;
+    DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax, dbranch, dbranch2;
+    if (branch_out) {
+      dbranch.alloc((size_t)std::max<int64_t>(nnz, 1) * K * sizeof(T));
+      dbranch2.alloc((size_t)std::max<int64_t>(nnz, 1) * K * sizeof(T));
+    }
     if (want_curr) {
       dcurr.alloc((size_t)n * K * sizeof(T));
       dweight.alloc((size_t)K * sizeof(int));
@@ -339,6 +343,15 @@ struct Solver : ISolver {
         CS_DISPATCH_K(K, hipLaunchKernelGGL((node_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
                                             A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
                                             dptr<T>(dcurr)));
+        if (branch_out) {
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
+                                              A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
+                                              dptr<T>(dbranch)));
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(nnz * ncols)), dim3(256), 0, st, nnz,
+                                              (const T*)dptr<T>(dbranch), ncols, dptr<T>(dbranch2)));
+          CS_HIP(hipMemcpyAsync((T*)branch_out + (size_t)p0 * nnz, dbranch2.p, (size_t)nnz * ncols * sizeof(T),
+                                hipMemcpyDeviceToHost, st));
+        }
         if (curr_out) {
           CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                               (const T*)dptr<T>(dcurr), ncols, dptr<T>(dvolt)));
@@ -698,7 +711,7 @@ int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, i
 
 int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs,
                                const int32_t* weights, void* volt_out, void* curr_out, void* cum_curr_inout,
-                               void* max_curr_inout, void* resist_out, csgpu_stats* stats) {
+                               void* max_curr_inout, void* branch_out, void* resist_out, csgpu_stats* stats) {
   CS_API_BEGIN
   if (!h || npairs < 0 || (npairs > 0 && (!src || !dst))) {
     g_last_error = "bad arguments";
@@ -709,7 +722,7 @@ int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_
   memset(s, 0, sizeof(*s));
   if (npairs == 0) return CSGPU_OK;
   h->solver->solve_pairs(src, dst, npairs, volt_out, nullptr, 0, nullptr, resist_out, s, weights, curr_out, cum_curr_inout,
-                         max_curr_inout);
+                         max_curr_inout, branch_out);
   if (s->not_converged > 0) {
     char buf[256];
     snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",

@@ -111,6 +111,30 @@ __global__ __launch_bounds__(256) void node_current_kernel(int n, const int* __r
   }
 }
 
+// branch currents (network mode, out.jl:209-248 with pos = true, then abs): for every stored entry (row < col) the value
+// |g (v_row - v_col)| with the 1e-8 * maxcur_pos drop threshold, 0 at every other position; layout [nnz][K]
+template <class T, int K>
+__global__ __launch_bounds__(256) void branch_current_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                             const T* __restrict__ va, const T* __restrict__ x,
+                                                             const double* __restrict__ maxcur, T* __restrict__ out) {
+  const int c = threadIdx.x % K;
+  const double mp = maxcur[2 * c];
+  const int64_t total = (int64_t)n * K;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int row = (int)(it / K);
+    const double vr = (double)x[(size_t)row * K + c];
+    for (int k = rp[row]; k < rp[row + 1]; ++k) {
+      const int col = ci[k];
+      double b = 0.0;
+      if (col > row) {
+        b = fabs((double)va[k]) * (vr - (double)x[(size_t)col * K + c]);
+        if (fabs(b / mp) < 1e-8) b = 0.0;
+      }
+      out[(size_t)k * K + c] = (T)fabs(b);
+    }
+  }
+}
+
 // cum[row] += sum_c weight[c] * curr[row, c];  mx[row] = max(mx[row], max_c curr[row, c])   (columns c < ncols)
 template <class T, int K>
 __global__ __launch_bounds__(256) void current_accumulate_kernel(int n, const T* __restrict__ curr, int ncols,

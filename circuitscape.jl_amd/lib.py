@@ -81,7 +81,7 @@ def _bind(L):
     L.csgpu_raster_setup.argtypes = [vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
     L.csgpu_get_info.argtypes = [vp, ctypes.POINTER(Info)]
     L.csgpu_solve_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, vp, ctypes.POINTER(Stats)]
-    L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
@@ -194,7 +194,8 @@ class Handle:
         _check(rc)
         return res, gathered, volt, st.as_dict()
 
-    def solve_pairs_currents(self, src, dst, weights=None, want_voltages=False, want_currents=True, cum=None, mx=None):
+    def solve_pairs_currents(self, src, dst, weights=None, want_voltages=False, want_currents=True, cum=None, mx=None,
+                             want_branch=False):
         """Pair solves + node currents (scope row N1). cum / mx: optional length-n arrays updated in place
         (cum += sum_p w_p * curr_p, mx = max(mx, curr_p)). Returns (R, voltages or None, currents or None, stats)."""
         src = np.ascontiguousarray(src, dtype=np.int64)
@@ -204,6 +205,7 @@ class Handle:
         res = np.zeros(npairs, dtype=self.dtype)
         volt = np.zeros((n, npairs), dtype=self.dtype, order="F") if want_voltages else None
         curr = np.zeros((n, npairs), dtype=self.dtype, order="F") if want_currents else None
+        branch = np.zeros((self.info["nnz"], npairs), dtype=self.dtype, order="F") if want_branch else None
         w = np.ascontiguousarray(weights, dtype=np.int32) if weights is not None else None
         for a in (cum, mx):
             assert a is None or (a.dtype == self.dtype and a.flags["C_CONTIGUOUS"] and a.shape == (n,))
@@ -213,9 +215,12 @@ class Handle:
                                               volt.ctypes.data if volt is not None else None,
                                               curr.ctypes.data if curr is not None else None,
                                               cum.ctypes.data if cum is not None else None,
-                                              mx.ctypes.data if mx is not None else None, res.ctypes.data,
+                                              mx.ctypes.data if mx is not None else None,
+                                              branch.ctypes.data if branch is not None else None, res.ctypes.data,
                                               ctypes.byref(st))
         _check(rc)
+        if want_branch:
+            return res, volt, curr, st.as_dict(), branch
         return res, volt, curr, st.as_dict()
 
     def solve_rhs(self, rhs):

@@ -81,6 +81,8 @@ class GraphProblem:
     solver: HIPAMGSolver = field(default_factory=HIPAMGSolver)
     cellmap: Optional[np.ndarray] = None     # conductance raster (for the set_null_*_to_nodata options)
     cum: Optional[Cumulative] = None         # cumulative / maximum current maps (scope row N1)
+    net_coords: Optional[Sequence[Tuple[int, int]]] = None   # network mode: edge list (i, j) of the input file, for the
+                                                             # cumulative branch currents (utils.jl:133-142)
 
 
 def get_solver(cfg):
@@ -305,6 +307,17 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
         maps = stats.setdefault("maps", {"cur": {}, "volt": {}}) if stats is not None else {"cur": {}, "volt": {}}
         if prob.cum is None:
             prob.cum = initialize_cum_maps(prob.nodemap, of.write_max_cur_maps)
+    # network mode: per-pair node / branch current tables and voltages, cumulative vectors (out.jl:46-84)
+    network_tables = (not flags.is_raster) and (of.write_cur_maps or of.write_volt_maps)
+    if network_tables:
+        tables = stats.setdefault("tables", {}) if stats is not None else {}
+        ncoords = len(prob.net_coords) if prob.net_coords is not None else 0
+        net_cum = stats.setdefault("net_cum", {"branch": np.zeros(ncoords), "node": np.zeros(a.shape[0])}) \
+            if stats is not None else {"branch": np.zeros(ncoords), "node": np.zeros(a.shape[0])}
+        coord_index = {}
+        if prob.net_coords is not None:
+            for k, (ci_, cj_) in enumerate(prob.net_coords):
+                coord_index.setdefault((int(ci_), int(cj_)), k)
     nsolves = 0
     for comp in prob.cc:
         comp = np.asarray(comp, dtype=np.int64)
@@ -355,6 +368,27 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
                     if raster_maps:
                         R, gathered, V, st = _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts,
                                                                    of, maps, want_volt)
+                    elif network_tables:
+                        R, V, C, st, Bc = factor.solve_pairs_currents(src_nodes, dst_nodes, want_voltages=True,
+                                                                      want_currents=True, want_branch=True)
+                        gathered = None
+                        mcsr = matrix.tocsr()
+                        mcsr.sort_indices()
+                        rows_of = np.repeat(np.arange(mcsr.shape[0]), np.diff(mcsr.indptr))
+                        upper = mcsr.indices > rows_of                      # stored entries (row < col), CSR order
+                        for p, combos in enumerate(fan):
+                            br = np.column_stack([comp[rows_of[upper]], comp[mcsr.indices[upper]], Bc[upper, p]])
+                            node = np.column_stack([comp, C[:, p]])
+                            volt = np.column_stack([comp, V[:, p]])
+                            for (ci, cj) in combos:
+                                for row in br:                                   # cumulative branch currents by edge
+                                    k = coord_index.get((int(row[0]), int(row[1])), coord_index.get((int(row[1]), int(row[0]))))
+                                    if k is not None:
+                                        net_cum["branch"][k] += row[2]
+                                net_cum["node"][comp - 1] += C[:, p]
+                                tables[(int(orig_pts[ci]), int(orig_pts[cj]))] = {
+                                    "branch": br[~np.isclose(br[:, 2], 0.0, atol=1e-6)],   # write_currents, out.jl:117-124
+                                    "node": node, "voltages": volt}
                     else:
                         R, gathered, V, st = factor.solve_pairs(src_nodes, dst_nodes, gather=gather,
                                                                 want_voltages=want_volt)

@@ -159,10 +159,12 @@ int csgpu_solve_pairs(csgpu_handle* h, const int64_t* src, const int64_t* dst, i
  *                            branch currents below 1e-8 of the largest one dropped)          may be NULL
  *   cum_curr_inout[i]     += sum_p weights[p] * curr_p[i]       (weights NULL => 1)            may be NULL
  *   max_curr_inout[i]      = max(max_curr_inout[i], max_p curr_p[i])                          may be NULL
+ *   branch_out[p*nnz + k]  = |g_k (v_row - v_col)| for stored entry k with row < col (network branch currents,
+ *                            out.jl:209-290), 0 at all other positions of the CSR arrays          may be NULL
  *   volt_out, resist_out as in csgpu_solve_pairs. All arrays are host pointers of the handle's value type. */
 int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_t* dst, int64_t npairs,
                                const int32_t* weights, void* volt_out, void* curr_out, void* cum_curr_inout,
-                               void* max_curr_inout, void* resist_out, csgpu_stats* stats);
+                               void* max_curr_inout, void* branch_out, void* resist_out, csgpu_stats* stats);
 
 /* General right-hand sides: rhs and x_out are host column-major n x nrhs arrays of the handle's value type. */
 int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats);

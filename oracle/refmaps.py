@@ -146,3 +146,63 @@ def raster_pairwise_maps_from_fixture(case, mode="direct"):
     if mx is not None:
         mx[mx < -9999] = -9999
     return {"cum": cum, "max": mx, "cur": cur, "volt": volt}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# network pairwise with current output: restates write_cur_maps (network branch, out.jl:46-84), _convert_to_3col
+# (out.jl:128-148), write_currents (out.jl:117-124), write_voltages (out.jl:410-416), the cumulative vectors
+# (utils.jl:133-142) and network_pairwise's cum output (network/pairwise.jl:18-27).
+def branch_currents_3col(G, voltages, cc):
+    """|B| with B the pos-orientation branch currents (upper triangle, 1e-8*max threshold); rows (cc[row], cc[col], val)."""
+    G = sp.csr_matrix(G)
+    coo = sp.triu(G, k=1).tocoo()
+    v = np.asarray(voltages, dtype=np.float64)
+    b = np.abs(coo.data) * (v[coo.row] - v[coo.col])
+    maxcur = b.max() if len(b) else 1.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b = np.where(np.abs(b / maxcur) < 1e-8, 0.0, b)
+    cc = np.asarray(cc)
+    return np.column_stack([cc[coo.row], cc[coo.col], np.abs(b)])
+
+
+def network_pairwise_tables_from_fixture(case, mode="direct"):
+    """Returns {'pairs': {(a,b): {'branch','node','voltages'}}, 'branch_cum', 'node_cum'} with 1-based node ids."""
+    prob = rg.compute_graph_data_network(case["edges_i"], case["edges_j"], case["edges_v"], case["focal"])
+    a = prob.G.tocsr()
+    m = a.shape[0]
+    coords = list(zip(case["edges_i"], case["edges_j"]))
+    cum_branch = np.zeros(len(coords))
+    cum_node = np.zeros(m)
+    points = [int(p) for p in prob.points]
+    out = {}
+    for comp in prob.cc:
+        compset = {int(x): k for k, x in enumerate(comp)}
+        csub = []
+        for p in points:
+            if p in compset and p not in csub:
+                csub.append(p)
+        if not csub:
+            continue
+        idx0 = np.asarray(comp, dtype=np.int64) - 1
+        matrix = rs.regularize(a[idx0][:, idx0])
+        solver = rs.DirectSolver(matrix) if mode == "direct" else rs.OracleAMG(matrix)
+        for ai in range(len(csub)):
+            for bi in range(ai + 1, len(csub)):
+                b = np.zeros(matrix.shape[0])
+                b[compset[csub[ai]]] = -1.0
+                b[compset[csub[bi]]] = 1.0
+                v = rs.solve_linear_system(solver, matrix, b, mode)
+                v = v - v[compset[csub[ai]]]
+                node = get_node_currents(matrix, v)
+                br = branch_currents_3col(matrix, v, comp)
+                for row in br:
+                    key = (int(row[0]), int(row[1]))
+                    k = coords.index(key) if key in coords else coords.index((key[1], key[0]))
+                    cum_branch[k] += row[2]
+                cum_node[idx0] += node
+                out[(csub[ai], csub[bi])] = {"branch": br[~np.isclose(br[:, 2], 0.0, atol=1e-6)],
+                                              "node": np.column_stack([np.asarray(comp), node]),
+                                              "voltages": np.column_stack([np.asarray(comp), v])}
+    bc = np.column_stack([np.array(case["edges_i"]), np.array(case["edges_j"]), cum_branch])
+    return {"pairs": out, "branch_cum": bc[~np.isclose(bc[:, 2], 0.0, atol=1e-6)],
+            "node_cum": np.column_stack([np.arange(1, m + 1), cum_node])}

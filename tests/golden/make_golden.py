@@ -249,7 +249,24 @@ def network_case(idx):
         fp = np.array([float(x) for x in f.read().split()]).astype(int)
     if fp.min() == 0:
         fp = fp + 1
+    ov = os.path.join(REF, "output_verify")
+
+    def table(fn):
+        with open(os.path.join(ov, fn)) as f:
+            return [[float(x) for x in ln.split()] for ln in f if ln.strip()]
+
+    pairs = sorted(f[len(name) + 17:-4] for f in os.listdir(ov)
+                   if f.startswith(name + "_branch_currents_") and f.endswith(".txt") and not f.endswith("_cum.txt"))
+    tables = {"pairs": []}
+    for pr in pairs[:4]:
+        tables["pairs"].append({"pair": [int(x) for x in pr.split("_")],           # 0-based ids, as in the golden files
+                                "branch": table("%s_branch_currents_%s.txt" % (name, pr)),
+                                "node": table("%s_node_currents_%s.txt" % (name, pr)),
+                                "voltages": table("%s_voltages_%s.txt" % (name, pr))})
+    tables["branch_cum"] = table(name + "_branch_currents_cum.txt")
+    tables["node_cum"] = table(name + "_node_currents_cum.txt")
     return {
+        "tables": tables,
         "name": name,
         "kind": "network",
         "ini_solver": d.get("solver", "cg+amg"),

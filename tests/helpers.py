@@ -31,7 +31,13 @@ def run_fixture(case, solver, stats=None):
     from circuitscape_jl_amd import solver as ps
     if case["kind"] == "network":
         ref = rg.compute_graph_data_network(case["edges_i"], case["edges_j"], case["edges_v"], case["focal"])
-        return ps.single_ground_all_pairs(to_product_problem(ref, solver), flags_from_case(case, False), stats=stats)
+        prob = to_product_problem(ref, solver)
+        prob.net_coords = list(zip(case["edges_i"], case["edges_j"]))
+        flags = flags_from_case(case, False)
+        if stats is not None and stats.get("want_tables"):
+            flags.outputflags.write_cur_maps = True      # network jobs always post-process currents (core.jl:681)
+            flags.outputflags.write_volt_maps = True
+        return ps.single_ground_all_pairs(prob, flags, stats=stats)
     o = case["options"]
     gmap = np.array(case["cellmap"], dtype=np.float64)
     polymap = np.array(case["polymap"], dtype=np.int64) if case["polymap"] is not None else None

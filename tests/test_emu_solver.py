@@ -264,3 +264,46 @@ def test_current_and_voltage_maps_through_product_path(emu_lib, name):
     ncmp = _check_maps(case, st)
     if name != "sgVerify3":  # write_cum_cur_map_only: no per-pair current maps
         assert ncmp > 0
+
+
+def _sorted_rows(a):
+    a = np.asarray(a, dtype=float)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def _check_network_tables(case, st):
+    """scope row N1, network flavour: per-pair branch / node current tables, voltages and the cumulative tables vs the
+    reference's golden files (0-based ids there; reference criterion sum(abs2, sorted x - sorted r) < 1e-6,
+    test/test_utils.jl:217-226)."""
+    t = case["tables"]
+    n = 0
+    for pe in t["pairs"]:
+        k = (pe["pair"][0] + 1, pe["pair"][1] + 1)
+        got = st["tables"][k]
+        for key in ("branch", "node", "voltages"):
+            e = np.array(pe[key], dtype=float)
+            e[:, 0] += 1
+            if key == "branch":
+                e[:, 1] += 1
+            assert e.shape == np.asarray(got[key]).shape, (key, e.shape, np.asarray(got[key]).shape)
+            assert np.sum((_sorted_rows(e) - _sorted_rows(got[key])) ** 2) < 1e-6
+            n += 1
+    eb = np.array(t["branch_cum"], dtype=float)
+    eb[:, :2] += 1
+    cb = np.column_stack([np.array(case["edges_i"]), np.array(case["edges_j"]), st["net_cum"]["branch"]])
+    cb = cb[~np.isclose(cb[:, 2], 0.0, atol=1e-6)]
+    assert np.sum((_sorted_rows(eb) - _sorted_rows(cb)) ** 2) < 1e-6
+    en = np.array(t["node_cum"], dtype=float)
+    en[:, 0] += 1
+    cn = np.column_stack([np.arange(1, len(st["net_cum"]["node"]) + 1), st["net_cum"]["node"]])
+    assert np.sum((_sorted_rows(en) - _sorted_rows(cn)) ** 2) < 1e-6
+    return n
+
+
+@pytest.mark.parametrize("name", ["sgNetworkVerify1", "sgNetworkVerify2", "sgNetworkVerify3"])
+def test_network_current_tables_through_product_path(emu_lib, name):
+    from circuitscape_jl_amd import solver as ps
+    case = load_case(name)
+    st = {"want_tables": True}
+    run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
+    assert _check_network_tables(case, st) > 0

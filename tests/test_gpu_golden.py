@@ -117,3 +117,13 @@ def test_node_currents_conserve_charge_large(gpu_lib):
         assert C[:, p].min() >= 0.0
     assert np.max(np.abs(cum - C.sum(axis=1))) < 1e-9
     h.close()
+
+
+@pytest.mark.parametrize("name", ["sgNetworkVerify1", "sgNetworkVerify2", "sgNetworkVerify3"])
+def test_network_current_tables_on_gpu(gpu_lib, name):
+    from circuitscape_jl_amd import solver as ps
+    from test_emu_solver import _check_network_tables
+    case = load_case(name)
+    st = {"want_tables": True}
+    run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
+    assert _check_network_tables(case, st) > 0
