@@ -106,6 +106,30 @@ function solve_pairs(factor::HIPFactor, ::Type{T}, n::Int, src::Vector{Int64}, d
     res, gat, volt, st
 end
 
+"""
+Pair batch with the reference's current post-processing on the device (postprocess -> write_cur_maps, core.jl:655-683,
+out.jl:46-115,178-290): node currents per pair, cumulative (`cum`) and maximum (`mx`) node currents accumulated over the
+pairs (weights = number of id combinations of a node pair), optional branch currents for network mode.
+"""
+function solve_pairs_currents(factor::HIPFactor, ::Type{T}, n::Int, nnzA::Int, src::Vector{Int64}, dst::Vector{Int64};
+                              weights::Vector{Int32} = Int32[], want_voltages = false, want_currents = true,
+                              cum::Vector{T} = T[], mx::Vector{T} = T[], want_branch = false) where {T}
+    np = length(src)
+    res = Vector{T}(undef, np)
+    volt = want_voltages ? Matrix{T}(undef, n, np) : Matrix{T}(undef, 0, 0)
+    curr = want_currents ? Matrix{T}(undef, n, np) : Matrix{T}(undef, 0, 0)
+    br = want_branch ? Matrix{T}(undef, nnzA, np) : Matrix{T}(undef, 0, 0)
+    st = CsgpuStats()
+    p(x) = isempty(x) ? C_NULL : pointer(x)
+    rc = GC.@preserve src dst weights res volt curr cum mx br ccall((:csgpu_solve_pairs_currents, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+               Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, src, dst, np, p(weights), p(volt), p(curr), p(cum), p(mx), p(br), res, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_pairs_currents failed: $(csgpu_error())")
+    res, volt, curr, br, st
+end
+
 # solve(prob, ::HIPAMGSolver, flags, cfg, log): identical bookkeeping to solve(prob, ::AMGSolver, ...) (core.jl:96-305)
 # except that per connected component the pair list is handed to `solve_pairs` in ONE call (no Threads.@spawn fan-out
 # over blocking ccalls) -- the Python mirror of exactly this method is circuitscape.jl_amd/solver.py::solve and is what
