@@ -307,3 +307,33 @@ def test_network_current_tables_through_product_path(emu_lib, name):
     st = {"want_tables": True}
     run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
     assert _check_network_tables(case, st) > 0
+
+
+@pytest.mark.parametrize("index_dtype,index_base", [(np.int64, 1), (np.int64, 0), (np.int32, 1), (np.int32, 0)])
+def test_setup_accepts_every_index_layout(emu_lib, oracle, index_dtype, index_base):
+    """csgpu_setup: Int64 / Int32 arrays, 1- or 0-based (SparseMatrixCSC{T,V}, src/run.jl:34) give the same operator."""
+    from oracle import refgraph as rg
+    G, g = rg.synthetic_raster_problem(30, 30)
+    A = oracle.regularize(G)
+    h = emu_lib.setup(A, emu_lib.default_opts(batch=1), index_dtype=index_dtype, index_base=index_base)
+    assert abs(h.level_matrix(0, "A") - A).max() == 0
+    x = np.random.default_rng(0).standard_normal(A.shape[0])
+    assert np.max(np.abs(h.spmv(x) - A @ x)) < 1e-12
+    h.close()
+
+
+def test_two_handles_interleaved(emu_lib, oracle):
+    """Two live handles (e.g. two connected components) used alternately keep independent device state."""
+    from oracle import refgraph as rg
+    G1, g1 = rg.synthetic_raster_problem(40, 40, seed=1)
+    G2, g2 = rg.synthetic_raster_problem(33, 47, seed=2)
+    h1 = emu_lib.raster_setup(g1, emu_lib.default_opts(batch=2))
+    h2 = emu_lib.raster_setup(g2, emu_lib.default_opts(batch=4))
+    Ra, _, _, _ = h1.solve_pairs([0, 5], [1599, 700])
+    Rb, _, _, _ = h2.solve_pairs([3], [1500])
+    Ra2, _, _, _ = h1.solve_pairs([0, 5], [1599, 700])
+    assert np.array_equal(Ra, Ra2)  # bit-reproducible, unaffected by the other handle
+    Ro, _, _ = oracle.OracleAMG(oracle.regularize(G2)).solve_pairs([3], [1500], rtol=1e-12, atol=0.0, criterion=1)
+    assert abs(Rb[0] - Ro[0]) < 1e-6 * Ro[0]
+    h1.close()
+    h2.close()

@@ -79,3 +79,45 @@ def test_large_raster_properties(gpu_lib):
     assert abs(R[0] - R[1]) < 1e-6 * R[0] and abs(R[2] - R[3]) < 1e-6 * R[2]
     assert R[2] <= R[0] + R[4] + 1e-9  # R(a,c) <= R(a,b) + R(b,c)
     h.close()
+
+
+def test_full_size_baseline_raster_properties(gpu_lib):
+    """BASELINE.json configs[2] size (10000 x 10000, fp64, default mixed path): size-independent properties where the
+    oracle cannot be run in seconds -- symmetry R(a,b) = R(b,a) (independent solves of the reversed pair), positivity,
+    triangle inequality of the resistance metric, the reference's residual check, and agreement of the fp32-
+    preconditioned path with the all-fp64 path."""
+    N = 10000
+    g = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((N, N)))
+    cells = np.random.default_rng(67890).choice(N * N, size=3, replace=False)
+    a, b, c = [int(x) for x in cells]
+    src = [a, b, a, c, b, c, a, b]
+    dst = [b, a, c, a, c, b, b, c]
+    res = {}
+    for pb in (4, 0):
+        h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=8, precond_bytes=pb))
+        assert h.info["n"] == N * N and h.info["nnz"] == 899880004  # SURVEY.md section 8
+        R, _, _, st = h.solve_pairs(src, dst)
+        assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+        assert np.all(R > 0)
+        for i, j in ((0, 1), (2, 3), (4, 5)):
+            assert abs(R[i] - R[j]) < 1e-6 * R[i]
+        assert R[2] <= R[0] + R[4] + 1e-9
+        res[pb] = R
+        h.close()
+    assert np.max(np.abs(res[4] - res[0]) / res[0]) < 1e-6
+
+
+def test_linearity_of_general_rhs(gpu_lib):
+    """Superposition: x(b1 + b2) = x(b1) + x(b2) for the grounded (SPD) system used by multiple_solve."""
+    import scipy.sparse as sp
+    from oracle import refgraph as rg
+    N = 500
+    G, g = rg.synthetic_raster_problem(N, N)
+    A = (G + sp.diags(np.where(np.arange(N * N) % 977 == 0, 1.0, 0.0))).tocsr()  # a few finite grounds -> SPD
+    h = gpu_lib.setup(A, gpu_lib.default_opts(batch=4, criterion=gpu_lib.CRIT_TRUE_RESIDUAL, rtol=1e-11, atol=0.0))
+    rng = np.random.default_rng(9)
+    b1, b2 = rng.standard_normal(N * N), rng.standard_normal(N * N)
+    X, st = h.solve_rhs(np.column_stack([b1, b2, b1 + b2]))
+    assert st["not_converged"] == 0
+    assert np.max(np.abs(X[:, 0] + X[:, 1] - X[:, 2])) < 1e-7 * np.max(np.abs(X[:, 2]))
+    h.close()
