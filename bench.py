@@ -116,7 +116,7 @@ def main():
 
     import circuitscape_jl_amd  # noqa: F401
     from circuitscape_jl_amd import lib
-    lib.load()  # fails loudly if the HIP library is missing
+    lib.load(os.environ.get("CSGPU_LIB"))  # default: the in-tree hipcc build; fails loudly if it is missing
     if lib.device_count() < 1:
         raise SystemExit("no HIP device visible")
 

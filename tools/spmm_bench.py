@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import circuitscape_jl_amd  # noqa
 from circuitscape_jl_amd import lib
+if os.environ.get('CSGPU_LIB'):
+    lib.load(os.environ['CSGPU_LIB'])
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 prec = sys.argv[2] if len(sys.argv) > 2 else "double"
 dt = np.float64 if prec == "double" else np.float32
