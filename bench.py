@@ -9,7 +9,7 @@ average conductance, resistances r = exp(N(0,1)) (seed 12345), g = 1/r; the Lapl
 (csgpu_raster_setup) and regularised like the reference (core.jl:161); 15 focal cells (seed 67890) -> the
 lexicographic pair list (105 pairs, the first 100 are the config's "100 focal pairs").
 
-A step = one batch of `--batch` pair solves (AMG-preconditioned CG, the reference's stopping rule: rtol 1e-6 /
+A step = one batch of `--batch` (default 16) pair solves (AMG-preconditioned CG, the reference's stopping rule: rtol 1e-6 /
 atol sqrt(eps) on sqrt(r'M^-1 r), core.jl:639) through csgpu_solve_pairs. AMG setup happens once per matrix (as in
 the reference, core.jl:164) before the timed region; its cost is reported separately AND amortised into `value`
 over the config's 100 pairs:  value = pairs / (t_steps + t_setup * pairs/100).
@@ -80,10 +80,10 @@ def cpu_baseline(sample_size, nsolve=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=13)
+    ap.add_argument("--steps", type=int, default=7)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=10000)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-sample", type=int, default=1500, help="raster edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)

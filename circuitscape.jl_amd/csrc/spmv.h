@@ -70,9 +70,15 @@ struct alignas(sizeof(T) * N) SpmvVec {
 template <class T, int K, int EPI, bool DOT, class XT>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
-  __shared__ int s_rp[kSpmvRows + 1];
-  __shared__ T s_val[kSpmvTile];
-  __shared__ int s_col[K > 1 ? kSpmvTile : 1];
+  // K = 16: half-size row blocks (128 rows / 1280 nonzeros per tile) keep the per-lane state (rows owned by a lane) the
+  // same as at K = 8, so the kernel stays at 4 waves/SIMD; the traversal order (built for 256-row blocks) is followed
+  // at half-block granularity.
+  constexpr int SPLIT = K >= 16 ? 2 : 1;
+  constexpr int ROWS = kSpmvRows / SPLIT;
+  constexpr int TILE = kSpmvTile / SPLIT;
+  __shared__ int s_rp[ROWS + 1];
+  __shared__ T s_val[TILE];
+  __shared__ int s_col[K > 1 ? TILE : 1];
   __shared__ double s_red[4 * (K > 1 ? K : 1)];
 
   if (a.skip && *a.skip) return;  // wave-uniform: the PCG loop already converged, this launch is a no-op
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   constexpr int CPL = K < VEC ? K : VEC;   // columns per lane
   constexpr int LPR = K / CPL;             // lanes per row
   constexpr int RPP = 256 / LPR;           // rows per pass (256 lanes / LPR)
-  constexpr int NPASS = kSpmvRows / RPP;   // rows owned by one lane
+  constexpr int NPASS = ROWS / RPP;        // rows owned by one lane
   typedef SpmvVec<XT, CPL> XV;  // gathered x segment
   typedef SpmvVec<T, CPL> YV;   // epilogue vectors (b, xadd, dotw, y)
   const int c0 = K > 1 ? (tid % LPR) * CPL : 0;  // first column owned by the lane
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // XCD one CONTIGUOUS eighth of the row blocks and let its workgroups march through it in order, so the x rows a
   // raster row block shares with its neighbours +-nrows_of_raster away are re-used out of that XCD's private 4 MiB L2
   // instead of being fetched by three different XCDs.
-  const int nblocks = (a.nrows + kSpmvRows - 1) / kSpmvRows;
+  const int nblocks = SPLIT * ((a.nrows + kSpmvRows - 1) / kSpmvRows);  // halves of a partial last block may be empty
   int rb_first = blockIdx.x, rb_last = nblocks, rb_step = gridDim.x;
   if ((gridDim.x & 7) == 0) {
     const int xcd = blockIdx.x & 7, chunk = (nblocks + 7) >> 3;
@@ -103,9 +109,10 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
     rb_step = gridDim.x >> 3;
   }
   for (int pos = rb_first; pos < rb_last; pos += rb_step) {
-    const int rb = a.order ? a.order[pos] : pos;
-    const int row0 = rb * kSpmvRows;
-    const int nr = min(kSpmvRows, a.nrows - row0);
+    const int rb = a.order ? a.order[pos / SPLIT] * SPLIT + (pos % SPLIT) : pos;
+    const int row0 = rb * ROWS;
+    if (row0 >= a.nrows) continue;  // second half of a final, partial 256-row block
+    const int nr = min(ROWS, a.nrows - row0);
     __syncthreads();  // previous pass finished with s_rp / tiles
     for (int t = tid; t <= nr; t += 256) s_rp[t] = a.rowptr[row0 + t];
     __syncthreads();
@@ -126,12 +133,12 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
       }
     }
 
-    for (int ts = kbeg; ts < kend; ts += kSpmvTile) {
-      const int te = min(kend, ts + kSpmvTile);
+    for (int ts = kbeg; ts < kend; ts += TILE) {
+      const int te = min(kend, ts + TILE);
       if (ts != kbeg) __syncthreads();
       // ---- phase 2: coalesced stream of the tile
       {
-        constexpr int U = kSpmvTile / 256;  // all of a lane's loads are issued before the first dependent use
+        constexpr int U = TILE / 256;  // all of a lane's loads are issued before the first dependent use
         T vv[U];
         int cc[U];
 #pragma unroll
@@ -298,7 +305,7 @@ inline int spmv_grid_cap() {  // tuning knob (CSGPU_SPMV_GRID_CAP): 0 = one work
 
 template <class T, int K>
 inline int spmv_grid(int nrows) {
-  int nb = ceil_div(nrows, kSpmvRows);
+  int nb = ceil_div(nrows, kSpmvRows) * (K >= 16 ? 2 : 1);
   if (nb < 1) nb = 1;
   const int cap = spmv_grid_cap();
   if (cap > 0) {
