@@ -592,11 +592,9 @@ static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts*
     g_last_error = "bad arguments: n, nnz or val_bytes";
     return CSGPU_BAD_ARGS;
   }
-  if (nnz >= ((int64_t)1 << 31) || n * 16 >= ((int64_t)1 << 31) * 1) {
-    if (nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) / 16) {
-      g_last_error = "matrix too large for int32 device indexing (need nnz < 2^31 and n < 2^27)";
-      return CSGPU_BAD_ARGS;
-    }
+  if (nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) - 1) {
+    g_last_error = "matrix too large for int32 device indexing (need nnz < 2^31 and n < 2^31 - 1)";
+    return CSGPU_BAD_ARGS;
   }
   if (opts && (opts->precond_bytes != 0 && opts->precond_bytes != 4 && opts->precond_bytes != 8)) {
     g_last_error = "csgpu_opts.precond_bytes must be 0, 4 or 8";

@@ -31,7 +31,8 @@
  *     column/row form (identical by symmetry) exactly as Julia's SparseMatrixCSC stores it:
  *     rowptr[n+1], colidx[nnz] (sorted within a row), vals[nnz]; idx_bytes in {4,8}, val_bytes in {4,8},
  *     index_base in {0,1}. The library COPIES it to the device; host pointers are never retained.
- *   - On device everything is int32 / 0-based; n < 2^31/16 and nnz < 2^31 are required (status 4 otherwise).
+ *   - On device everything is int32 / 0-based; nnz < 2^31 (and n < 2^31 - 1) are required (status 4 otherwise);
+ *     vector element indices (node * batch + column) are 64-bit.
  *   - All calls are blocking; a handle is serialised internally (one caller at a time per handle).
  *   - Return value: 0 ok, 1 not converged (some right-hand side hit itmax or failed the reference's
  *     1e-4 true-residual check), 2 HIP runtime error, 3 out of memory, 4 bad arguments, 5 internal error.
