@@ -98,6 +98,7 @@ struct Solver : ISolver {
     pp.nu_pre = opts.nu_pre;
     pp.nu_post = opts.nu_post;
     pp.nu_coarse = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
+    pp.use_graph = opts.use_graph;
     return pp;
   }
 
@@ -244,6 +245,7 @@ struct Solver : ISolver {
     s->device_ms += r.device_ms;
     s->cg_spmv_ms += r.spmv_ms;
     s->cg_spmv_calls += r.spmv_calls;
+    s->graph_launches += r.graph_launches;
   }
 
 #define CS_DISPATCH_K(K, ...)                               \
@@ -584,7 +586,7 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->node_row = nullptr;
   o->node_col = nullptr;
   o->precond_bytes = 0;
-  o->reserved1 = 0;
+  o->use_graph = 0;
 }
 
 static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts* opts) {

@@ -188,6 +188,22 @@ struct PcgParams {
   int itmax = 100000;
   int check_every = 4;
   int nu_pre = 1, nu_post = 1, nu_coarse = 3;
+  int use_graph = 0;  // 0 = auto (small problems, where launch latency dominates), 1 = always, -1 = never
+};
+
+// One captured chunk of `check_every` PCG iterations. Kernel arguments are baked in at capture time, so a graph is
+// only valid for the buffers and parameters it was captured with: the key holds every value that reaches a kernel
+// argument and is not a pointer owned by PcgWork / the hierarchy (those invalidate the cache when they are
+// reallocated).
+struct PcgGraphKey {
+  int K = 0, ncols_active = 0, criterion = 0, nu_pre = 0, nu_post = 0, nu_coarse = 0, iters = 0;
+  double rtol = 0, atol = 0;
+  const void* matrix = nullptr;
+  bool operator==(const PcgGraphKey& o) const {
+    return K == o.K && ncols_active == o.ncols_active && criterion == o.criterion && nu_pre == o.nu_pre &&
+           nu_post == o.nu_post && nu_coarse == o.nu_coarse && iters == o.iters && rtol == o.rtol && atol == o.atol &&
+           matrix == o.matrix;
+  }
 };
 
 // T = precision of the CG iteration (matrix seen by CG, x, r, p, Ap); TP = precision of the AMG hierarchy and of
@@ -203,8 +219,15 @@ struct PcgWork {
   DBuf scalars;               // CgScalars
   DBuf part_a, part_b, part_c;
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
+  std::vector<std::pair<PcgGraphKey, hipGraphExec_t>> graphs;  // captured iteration chunks
+  bool graph_broken = false;                                   // capture failed once: stay on direct launches
+  void drop_graphs() {
+    for (auto& g : graphs) hipGraphExecDestroy(g.second);
+    graphs.clear();
+  }
   void ensure(int64_t n_, int K_) {
     if (n == n_ && K == K_) return;
+    drop_graphs();
     n = n_;
     K = K_;
     const size_t bytes = (size_t)n * K * sizeof(T);
@@ -222,6 +245,7 @@ struct PcgWork {
     part_c.alloc(pb);
   }
   ~PcgWork() {
+    drop_graphs();
     for (auto e : ev) hipEventDestroy(e);
   }
 };
@@ -231,6 +255,7 @@ struct PcgBatchResult {
   double device_ms = 0;
   double spmv_ms = 0;
   int64_t spmv_calls = 0;
+  int64_t graph_launches = 0;
 };
 
 // Solve A X = B for the K interleaved columns held in W.b; solution left in W.x.
@@ -293,9 +318,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   const int max_timed = 512;
   int timed = 0;
   int it = 0;
+  int graph_launches = 0;
   fuse.xa_ready = fuse_xa;
   fuse.skip = &S->all_done;
-  while (!host_done && it < pp.itmax) {
+  // one PCG iteration as a sequence of launches on `st` (no host interaction: this is what gets captured)
+  auto iteration = [&](bool time_it) {
     // Ap = A p, fused partials of p'Ap
     {
       SpmvArgs<T, TP> a = spmv_args<T, TP>(A, (const TP*)p, Ap);
@@ -303,7 +330,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       a.skip = &S->all_done;
       a.dotw = nullptr;  // dot with x itself: p'Ap
       a.partials = pc;
-      const bool time_it = timed < max_timed;
+      time_it = time_it && timed < max_timed;
       if (time_it) {
         if ((int)W.ev.size() < 2 * (timed + 1)) {
           hipEvent_t ea, eb;
@@ -337,12 +364,69 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     // x += alpha p ; p = z + beta p   (one pass over p)
     hipLaunchKernelGGL((cg_update_xp_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p,
                        (const TP*)z);
-    ++it;
-    if (it % pp.check_every == 0 || it >= pp.itmax) {
-      check_launch("pcg iteration");
-      CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
-      CS_HIP(hipStreamSynchronize(st));
+  };
+
+  // Launch-bound regime (small rasters: ~75 launches of a few microseconds each per iteration): replay a captured
+  // hipGraph of `check_every` iterations instead of issuing the launches one by one. The first chunk always runs
+  // directly (it is the one the SpMV timing events sit in); every device-side early-out (skip flag) works unchanged
+  // inside the graph because it lives in device memory.
+  const int chunk = std::max(1, pp.check_every);
+  const bool want_graph =
+      !W.graph_broken && (pp.use_graph > 0 || (pp.use_graph == 0 && (int64_t)n * K <= ((int64_t)1 << 25)));
+  PcgGraphKey gkey;
+  gkey.K = K;
+  gkey.ncols_active = ncols_active;
+  gkey.criterion = pp.criterion;
+  gkey.nu_pre = pp.nu_pre;
+  gkey.nu_post = pp.nu_post;
+  gkey.nu_coarse = pp.nu_coarse;
+  gkey.iters = chunk;
+  gkey.rtol = pp.rtol;
+  gkey.atol = atol;
+  gkey.matrix = (const void*)A.val.p;
+  auto chunk_graph = [&]() -> hipGraphExec_t {
+    for (auto& g : W.graphs)
+      if (g.first == gkey) return g.second;
+    check_launch("pcg before capture");
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      W.graph_broken = true;
+      return nullptr;
     }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    bool ok = true;
+    try {
+      for (int c = 0; c < chunk; ++c) iteration(false);
+    } catch (...) {
+      ok = false;
+    }
+    if (hipStreamEndCapture(st, &g) != hipSuccess || !g) ok = false;
+    if (ok && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ok = false;
+    if (g) hipGraphDestroy(g);
+    if (!ok || !ge) {
+      (void)hipGetLastError();
+      W.graph_broken = true;
+      return nullptr;
+    }
+    if (W.graphs.size() >= 8) W.drop_graphs();
+    W.graphs.emplace_back(gkey, ge);
+    return ge;
+  };
+
+  while (!host_done && it < pp.itmax) {
+    const int todo = (int)std::min<int64_t>(chunk, (int64_t)pp.itmax - it);
+    hipGraphExec_t ge = (want_graph && it > 0 && todo == chunk) ? chunk_graph() : nullptr;
+    if (ge) {
+      CS_HIP(hipGraphLaunch(ge, st));
+      ++graph_launches;
+    } else {
+      for (int c = 0; c < todo; ++c) iteration(true);
+    }
+    it += todo;
+    check_launch("pcg iteration");
+    CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
   }
   // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
   {
@@ -371,6 +455,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     res.spmv_ms += m2;
   }
   res.spmv_calls = counted;
+  res.graph_launches = graph_launches;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return res;

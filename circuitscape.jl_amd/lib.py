@@ -41,7 +41,7 @@ class Opts(ctypes.Structure):
         ("theta", ctypes.c_double), ("omega_p", ctypes.c_double), ("omega_s", ctypes.c_double),
         ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
         ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),
-        ("precond_bytes", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+        ("precond_bytes", ctypes.c_int32), ("use_graph", ctypes.c_int32),
     ]
 
 
@@ -61,7 +61,7 @@ class Stats(ctypes.Structure):
         ("nrhs", ctypes.c_int32), ("max_iters", ctypes.c_int32), ("total_iters", ctypes.c_int64),
         ("max_relres", ctypes.c_double), ("solve_ms", ctypes.c_double), ("device_ms", ctypes.c_double),
         ("cg_spmv_ms", ctypes.c_double), ("cg_spmv_calls", ctypes.c_int64), ("batch", ctypes.c_int32),
-        ("not_converged", ctypes.c_int32),
+        ("not_converged", ctypes.c_int32), ("graph_launches", ctypes.c_int64),
     ]
 
     def as_dict(self):

@@ -95,7 +95,9 @@ typedef struct csgpu_opts {
    * 4 = fp32 preconditioner under an fp64 CG iteration (residuals, search directions, dot products and the
    * reference's residual check stay in val_bytes precision). Default 0. */
   int32_t precond_bytes;
-  int32_t reserved1;
+  /* Replay the PCG iteration as a captured hipGraph of check_every iterations between two host polls:
+   * 0 = auto (on when n*batch <= 2^25, the launch-latency-bound regime), 1 = always, -1 = never. Default 0. */
+  int32_t use_graph;
 } csgpu_opts;
 
 typedef struct csgpu_info {
@@ -127,6 +129,7 @@ typedef struct csgpu_stats {
   int64_t cg_spmv_calls;        /* number of those launches */
   int32_t batch;                /* batch width actually used */
   int32_t not_converged;        /* number of rhs that hit itmax / broke down / failed the 1e-4 check */
+  int64_t graph_launches;       /* hipGraph replays issued (each = check_every PCG iterations) */
 } csgpu_stats;
 
 int csgpu_device_count(void);

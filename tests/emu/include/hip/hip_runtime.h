@@ -57,6 +57,14 @@ struct hipEmuEvent {
   std::chrono::steady_clock::time_point t;
 };
 typedef hipEmuEvent* hipEvent_t;
+// stream capture / graphs: a captured graph is the recorded list of launches, replayed in order
+struct hipEmuGraph { std::vector<std::function<void()>> nodes; };
+typedef hipEmuGraph* hipGraph_t;
+typedef hipEmuGraph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+namespace hipemu {
+inline hipEmuGraph*& capturing() { static thread_local hipEmuGraph* g = nullptr; return g; }
+}
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventDefault = 0 };
@@ -481,8 +489,14 @@ inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAX
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                         \
   do {                                                                                                     \
     auto _hipemu_args = std::make_tuple(__VA_ARGS__);                                                      \
-    ::hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem),                                             \
-                     std::function<void()>([=]() { std::apply(kernel, _hipemu_args); }));                 \
+    std::function<void()> _hipemu_fn([=]() { std::apply(kernel, _hipemu_args); });                        \
+    const dim3 _hipemu_g = dim3(grid), _hipemu_b = dim3(block);                                            \
+    const size_t _hipemu_s = (size_t)(shmem);                                                              \
+    if (::hipemu::capturing())                                                                             \
+      ::hipemu::capturing()->nodes.push_back(                                                              \
+          [=]() { ::hipemu::launch(_hipemu_g, _hipemu_b, _hipemu_s, _hipemu_fn); });                       \
+    else                                                                                                   \
+      ::hipemu::launch(_hipemu_g, _hipemu_b, _hipemu_s, _hipemu_fn);                                       \
   } while (0)
 
 // HIP exposes min/max in the global namespace for device code
@@ -527,9 +541,29 @@ template <class T>
 inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) {
+  if (hipemu::capturing()) { hipemu::capturing()->nodes.push_back([=]() { hipMemcpy(d, s, n, k); }); return hipSuccess; }
+  return hipMemcpy(d, s, n, k);
+}
 inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) {
+  if (hipemu::capturing()) { hipemu::capturing()->nodes.push_back([=]() { hipMemset(d, v, n); }); return hipSuccess; }
+  return hipMemset(d, v, n);
+}
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+  if (hipemu::capturing()) return hipErrorInvalidValue;
+  hipemu::capturing() = new hipEmuGraph();
+  return hipSuccess;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+  *g = hipemu::capturing();
+  hipemu::capturing() = nullptr;
+  return *g ? hipSuccess : hipErrorInvalidValue;
+}
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new hipEmuGraph(*g); return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto& f : e->nodes) f(); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)0x1; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

@@ -337,3 +337,47 @@ def test_two_handles_interleaved(emu_lib, oracle):
     assert abs(Rb[0] - Ro[0]) < 1e-6 * Ro[0]
     h1.close()
     h2.close()
+
+
+@pytest.mark.parametrize("precond_bytes,criterion", [(0, 0), (4, 0), (0, 1)])
+def test_graph_replay_is_bitwise_identical(emu_lib, precond_bytes, criterion):
+    """use_graph = 1 replays captured chunks of check_every PCG iterations; the launches are the same kernels with
+    the same arguments, so voltages and iteration counts must be bit-identical to direct launches (use_graph = -1).
+    Two consecutive calls (full batch, then a ragged tail batch) cover the graph cache and its key."""
+    from oracle import refgraph as rg
+    N = 48
+    _, g = rg.synthetic_raster_problem(N, N, seed=11)
+    cells = np.random.default_rng(5).choice(N * N, size=7, replace=False)
+    src, dst = cells[:-1], cells[1:]
+    out = {}
+    for ug in (-1, 1):
+        h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=4, precond_bytes=precond_bytes, criterion=criterion,
+                                                         use_graph=ug, check_every=2))
+        R, _, V, st = h.solve_pairs(src, dst, want_voltages=True)
+        R2, _, V2, st2 = h.solve_pairs(src[:3], dst[:3], want_voltages=True)
+        out[ug] = (R, V, st, R2, V2, st2)
+        h.close()
+    (Ra, Va, sa, Ra2, Va2, sa2), (Rb, Vb, sb, Rb2, Vb2, sb2) = out[-1], out[1]
+    assert sa["graph_launches"] == 0 and sa2["graph_launches"] == 0
+    assert sb["graph_launches"] > 0 and sb2["graph_launches"] > 0
+    assert sa["total_iters"] == sb["total_iters"] and sa2["total_iters"] == sb2["total_iters"]
+    assert sb["not_converged"] == 0 and sb2["not_converged"] == 0
+    assert np.array_equal(Ra, Rb) and np.array_equal(Va, Vb)
+    assert np.array_equal(Ra2, Rb2) and np.array_equal(Va2, Vb2)
+
+
+def test_graph_auto_mode_and_itmax_tail(emu_lib):
+    """Auto mode turns the graph on for small problems; an itmax that is not a multiple of check_every finishes
+    with direct launches and reports exactly itmax iterations for unconverged columns."""
+    from oracle import refgraph as rg
+    N = 40
+    _, g = rg.synthetic_raster_problem(N, N, seed=3)
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, check_every=4))
+    _, _, _, st = h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
+    assert st["graph_launches"] > 0 and st["not_converged"] == 0
+    h.close()
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, check_every=4, itmax=6, rtol=1e-14, atol=0.0,
+                                                     use_graph=1))
+    with pytest.raises(emu_lib.CsgpuError):
+        h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
+    h.close()

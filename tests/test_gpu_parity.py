@@ -121,3 +121,24 @@ def test_linearity_of_general_rhs(gpu_lib):
     assert st["not_converged"] == 0
     assert np.max(np.abs(X[:, 0] + X[:, 1] - X[:, 2])) < 1e-7 * np.max(np.abs(X[:, 2]))
     h.close()
+
+
+@pytest.mark.parametrize("precond_bytes", [0, 4])
+def test_graph_replay_matches_direct_launches(gpu_lib, precond_bytes):
+    """hipGraph replay of the PCG iteration (use_graph = 1) issues the same kernels with the same arguments as the
+    direct launches (use_graph = -1): voltages, resistances and iteration counts are bit-identical."""
+    from oracle import refgraph as rg
+    N = 400
+    _, g = rg.synthetic_raster_problem(N, N, seed=11)
+    cells = np.random.default_rng(5).choice(N * N, size=12, replace=False)
+    src, dst = cells[:-1], cells[1:]
+    out = {}
+    for ug in (-1, 1):
+        h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=8, precond_bytes=precond_bytes, use_graph=ug))
+        R, _, V, st = h.solve_pairs(src, dst, want_voltages=True)
+        out[ug] = (R, V, st)
+        h.close()
+    (Ra, Va, sa), (Rb, Vb, sb) = out[-1], out[1]
+    assert sa["graph_launches"] == 0 and sb["graph_launches"] > 0
+    assert sa["total_iters"] == sb["total_iters"] and sb["not_converged"] == 0
+    assert np.array_equal(Ra, Rb) and np.array_equal(Va, Vb)
