@@ -574,6 +574,44 @@ __global__ __launch_bounds__(256) void build_q_kernel(int n, const int* __restri
   }
 }
 
+// Two-product form of a V(1,1) level (zero initial guess, damped Jacobi with weight omega):
+//   x1 = omega D^-1 b                                   pre-smoothing
+//   b_c = R (b - A x1) = (P - omega D^-1 A P)^T b = Q^T b          (A, D symmetric)
+//   x_c = coarse solve(b_c)
+//   out = (x1 + P x_c) + omega D^-1 (b - A (x1 + P x_c)) = S b + Q x_c,   S = 2 omega D^-1 - omega D^-1 A omega D^-1
+// i.e. the whole level is  b_c = Q^T b  and  out = [S Q] [b; x_c]: two products instead of residual + restriction +
+// fused prolongation, and no x1 / residual vectors at all. M = [S Q] is stored as one CSR with n + n_c columns
+// (Q's columns shifted by n) acting on the vector [b; x_c] (x_c is written right behind b).
+template <class T>
+__global__ __launch_bounds__(256) void sq_rowptr_kernel(int n, const int* __restrict__ arp, const int* __restrict__ qrp,
+                                                        int* __restrict__ mrp) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) mrp[i] = arp[i] + qrp[i];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void build_sq_kernel(int n, const int* __restrict__ arp, const int* __restrict__ aci,
+                                                       const T* __restrict__ ava, const int* __restrict__ qrp,
+                                                       const int* __restrict__ qci, const T* __restrict__ qva,
+                                                       const T* __restrict__ dinv, double omega,
+                                                       const int* __restrict__ mrp, int* __restrict__ mci,
+                                                       T* __restrict__ mva) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int o = mrp[i];
+    const double wi = omega * (double)dinv[i];
+    for (int k = arp[i]; k < arp[i + 1]; ++k, ++o) {
+      const int j = aci[k];
+      double v = -wi * (double)ava[k] * omega * (double)dinv[j];
+      if (j == i) v += 2.0 * wi;
+      mci[o] = j;
+      mva[o] = (T)v;
+    }
+    for (int k = qrp[i]; k < qrp[i + 1]; ++k, ++o) {
+      mci[o] = n + qci[k];
+      mva[o] = qva[k];
+    }
+  }
+}
+
 // dinv[i] = 1 / a_ii (0 where the diagonal is 0)
 template <class T>
 __global__ __launch_bounds__(256) void dinv_kernel(int n, const T* __restrict__ diag, T* __restrict__ dinv) {
@@ -643,6 +681,7 @@ template <class T>
 struct Level {
   Csr<T> A, P, R;       // P, R empty on the coarsest level
   Csr<T> Q;             // Q = P - omega D^-1 A P: prolongation fused with the first post-smoothing sweep
+  Csr<T> QT, M;         // level 0 with V(1,1) smoothing only: Q^T and [S Q] of the two-product form (see build_sq_kernel)
   DBuf dinv;            // 1/a_ii
   DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
   double omega = 0;     // damped-Jacobi weight
@@ -669,6 +708,7 @@ struct SetupParams {
   double theta = 0.0;
   double omega_p = 1.6;
   double omega_s = 1.5;
+  bool two_product = false;  // build Q^T and [S Q] on level 0 (the solve phase runs V(1,1) there)
 };
 
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
@@ -816,6 +856,22 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       check_launch("build Q");
       CS_REQUIRE(read_int(dptr<int>(missing), st) == 0, CSGPU_INTERNAL, "pattern(P) is not contained in pattern(A*P)");
       L.Q = std::move(AP);
+    }
+    if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
+        (int64_t)n + nagg < 0x7fffffffLL) {
+      transpose(L.Q, L.QT, st);
+      Csr<T>& M = L.M;
+      M.nrows = n;
+      M.ncols = n + nagg;
+      M.nnz = L.A.nnz + L.Q.nnz;
+      M.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+      M.col.alloc((size_t)M.nnz * sizeof(int));
+      M.val.alloc((size_t)M.nnz * sizeof(T));
+      hipLaunchKernelGGL((sq_rowptr_kernel<T>), dim3(grid_for((int64_t)n + 1)), dim3(256), 0, st, n, L.A.rp(), L.Q.rp(),
+                         M.rp());
+      hipLaunchKernelGGL((build_sq_kernel<T>), dim3(g), dim3(256), 0, st, n, L.A.rp(), L.A.ci(), L.A.va(), L.Q.rp(),
+                         L.Q.ci(), L.Q.va(), dptr<T>(L.dinv), L.omega, M.rp(), M.ci(), M.va());
+      check_launch("build [S Q]");
     }
     // next level
     size_prev = std::move(size_c);  // unsigned long long and long long share the representation for these counts

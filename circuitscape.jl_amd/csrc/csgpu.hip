@@ -23,6 +23,7 @@ struct ISolver {
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
   virtual void spmv_host(const void* x, void* y, int k) = 0;
+  virtual void level_spmv_host(int lvl, int which, const void* x, void* y, int k, double* dots) = 0;
   virtual void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz, int32_t* rowptr,
                                 int32_t* colidx, void* vals) const = 0;
 };
@@ -86,6 +87,8 @@ struct Solver : ISolver {
     sp.theta = opts.theta;
     sp.omega_p = opts.omega_p;
     sp.omega_s = opts.omega_s;
+    static const bool no_two_product = getenv("CSGPU_NO_TWO_PRODUCT") != nullptr;  // tuning / A-B knob
+    sp.two_product = opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0 && !no_two_product;
     return sp;
   }
   PcgParams pcg_params() const {
@@ -269,7 +272,7 @@ struct Solver : ISolver {
     for (int64_t g = 0; g < ngather; ++g)
       CS_REQUIRE(gather[g] >= 0 && gather[g] < n, CSGPU_BAD_ARGS, "gather node id out of range");
     const int K = pick_k(npairs);
-    W.ensure(n, K);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = (int)npairs;
       stats->batch = K;
@@ -393,7 +396,7 @@ struct Solver : ISolver {
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
     const int K = pick_k(nrhs);
-    W.ensure(n, K);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = (int)nrhs;
       stats->batch = K;
@@ -505,11 +508,48 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
   }
 
+  // y = (level matrix) x through the launcher the V-cycle uses for that operator (test hook). Host arrays in the
+  // hierarchy's precision; for which == 5 ([S Q]) the fused dot x[0:n] . y is returned too.
+  void level_spmv_host(int lvl, int which, const void* xh, void* yh, int k, double* dots) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
+    Level<TP>& L = H.levels[lvl];
+    const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
+    CS_REQUIRE(M.nnz > 0, CSGPU_BAD_ARGS, "level has no such operator");
+    DBuf x((size_t)M.ncols * k * sizeof(TP)), y((size_t)M.nrows * k * sizeof(TP));
+    DBuf part = dalloc<double>((size_t)16384 * kMaxK);
+    CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
+    SpmvArgs<TP> a = spmv_args(M, (const TP*)dptr<TP>(x), dptr<TP>(y));
+    const bool sq = which == 5;
+    if (which == 0 || sq) a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
+    if (sq) a.partials = dptr<double>(part);
+    if (sq) {
+      CS_DISPATCH_K(k, spmv_launch_wide<TP, KK>(a, true, st));
+    } else {
+      CS_DISPATCH_K(k, spmv_launch<TP, KK>(a, EPI_PLAIN, false, st));
+    }
+    check_launch("level_spmv_host");
+    CS_HIP(hipMemcpyAsync(yh, y.p, y.bytes, hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    if (sq && dots) {
+      int g = 1;
+      CS_DISPATCH_K(k, g = spmv_grid<TP, KK>(M.nrows));
+      std::vector<double> ph((size_t)g * k);
+      CS_HIP(hipMemcpy(ph.data(), part.p, ph.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int c = 0; c < k; ++c) {
+        double s = 0;
+        for (int b = 0; b < g; ++b) s += ph[(size_t)b * k + c];
+        dots[c] = s;
+      }
+    }
+  }
+
   void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     const Level<TP>& L = H.levels[lvl];
-    const Csr<TP>& M = which == 0 ? L.A : (which == 1 ? L.P : L.R);
+    const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
     if (nrows) *nrows = M.nrows;
     if (ncols) *ncols = M.ncols;
     if (nnz_out) *nnz_out = M.nnz;
@@ -587,6 +627,8 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->node_col = nullptr;
   o->precond_bytes = 0;
   o->use_graph = 0;
+  o->two_product = 0;
+  o->reserved2 = 0;
 }
 
 static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts* opts) {
@@ -778,10 +820,21 @@ int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k) {
   CS_API_END
 }
 
+int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, void* y, int k, double* dots) {
+  CS_API_BEGIN
+  if (!h || !x || !y || which < 0 || which > 5 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->level_spmv_host(lvl, which, x, y, k, dots);
+  return CSGPU_OK;
+  CS_API_END
+}
+
 int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz,
                            int32_t* rowptr, int32_t* colidx, void* vals) {
   CS_API_BEGIN
-  if (!h || which < 0 || which > 2) {
+  if (!h || which < 0 || which > 5) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }

@@ -40,6 +40,8 @@ struct VcycleFuse {
   const T* dotw = nullptr;     // fuse partials of dotw . out into the final post-smoothing product
   const int* skip = nullptr;   // device flag: non-zero turns every launch of the cycle into a no-op
   double* partials = nullptr;  // [spmv_grid][K]
+  bool b_has_tail = false;     // level 0: the input vector b is followed by room for the level-1 solution, so the
+                               // two-product form out = [S Q][b; x_c] can be used (needs L.M and V(1,1))
 };
 
 template <class T>
@@ -93,6 +95,30 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
       jacobi_sweep(cur, fin ? out : oth, fin && want_dot);
       std::swap(cur, oth);
     }
+    return;
+  }
+  if (l == 0 && fuse && fuse->b_has_tail && nu_pre == 1 && nu_post == 1 && L.M.nnz > 0) {
+    // two-product form of the level (build_sq_kernel): b_c = Q^T b ; x_c = coarse(b_c) ; out = [S Q][b; x_c]
+    Level<T>& Lc = H.levels[l + 1];
+    T* bc = dptr<T>(Lc.b);
+    T* xc = const_cast<T*>(b) + (size_t)n * K;
+    {
+      SpmvArgs<T> a = spmv_args(L.QT, b, bc);
+      a.skip = skip;
+      spmv_launch<T, K>(a, EPI_PLAIN, false, st);
+    }
+    VcycleFuse<T> cf;
+    cf.skip = skip;
+    vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
+    SpmvArgs<T> a = spmv_args(L.M, b, out);
+    a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
+    a.skip = skip;
+    if (want_dot) {
+      CS_REQUIRE(fuse->dotw == b, CSGPU_INTERNAL, "two-product level: fused dot must be with the input vector");
+      a.dotw = nullptr;  // dot with x itself (captured at the diagonal entry of S)
+      a.partials = fuse->partials;
+    }
+    spmv_launch_wide<T, K>(a, want_dot, st);
     return;
   }
   // pre-smoothing (first sweep from x = 0 is a scaling)
@@ -225,19 +251,23 @@ struct PcgWork {
     for (auto& g : graphs) hipGraphExecDestroy(g.second);
     graphs.clear();
   }
-  void ensure(int64_t n_, int K_) {
-    if (n == n_ && K == K_) return;
+  int64_t tail = 0;
+  // tail_rows: rows of the level-1 solution kept right behind the V-cycle's input vector (rp, or r when TP == T)
+  void ensure(int64_t n_, int K_, int64_t tail_rows = 0) {
+    if (n == n_ && K == K_ && tail == tail_rows) return;
     drop_graphs();
     n = n_;
     K = K_;
+    tail = tail_rows;
     const size_t bytes = (size_t)n * K * sizeof(T);
+    constexpr bool SAME = std::is_same<T, TP>::value;
     x.alloc(bytes);
-    r.alloc(bytes);
+    r.alloc(bytes + (SAME ? (size_t)tail * K * sizeof(T) : 0));
     p.alloc((size_t)n * K * sizeof(TP));
     Ap.alloc(bytes);
     b.alloc(bytes);
     z.alloc((size_t)n * K * sizeof(TP));
-    if (!std::is_same<T, TP>::value) rp.alloc((size_t)n * K * sizeof(TP));
+    if (!SAME) rp.alloc((size_t)(n + tail) * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
     const size_t pb = (size_t)16384 * kMaxK * sizeof(double);  // >= spmv_grid() and kMaxGrid partial rows
     part_a.alloc(pb);
@@ -292,8 +322,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   const int spmv_gp = spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
-  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1;
+  const bool two_product = H.levels.size() > 1 && L0.M.nnz > 0 && pp.nu_pre == 1 && pp.nu_post == 1 &&
+                           W.tail >= H.levels[1].A.nrows;
+  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product;
   VcycleFuse<TP> fuse;
+  fuse.b_has_tail = two_product;
   fuse.dotw = rp;
   fuse.partials = pa;
 

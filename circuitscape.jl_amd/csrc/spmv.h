@@ -46,6 +46,7 @@ static const int kSpmvTile = 2560;  // nonzeros staged in LDS per tile
 template <class T, class XT = T>
 struct SpmvArgs {
   int nrows;
+  long long nnz;    // number of stored entries (selects the long-row kernel for plain products)
   const int* rowptr;
   const int* col;
   const T* val;
@@ -67,7 +68,7 @@ struct alignas(sizeof(T) * N) SpmvVec {
   T e[N];
 };
 
-template <class T, int K, int EPI, bool DOT, class XT>
+template <class T, int K, int EPI, bool DOT, class XT, int TPL = kSpmvTile / 256>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
   // K = 16: half-size row blocks (128 rows / 1280 nonzeros per tile) keep the per-lane state (rows owned by a lane) the
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // at half-block granularity.
   constexpr int SPLIT = K >= 16 ? 2 : 1;
   constexpr int ROWS = kSpmvRows / SPLIT;
-  constexpr int TILE = kSpmvTile / SPLIT;
+  constexpr int TILE = 256 * TPL / SPLIT;  // TPL = nonzeros per lane and 256-row tile (10; 16 for the [S Q] product)
+  static_assert(TILE % 256 == 0, "every lane streams TILE / 256 nonzeros per tile");
   __shared__ int s_rp[ROWS + 1];
   __shared__ T s_val[TILE];
   __shared__ int s_col[K > 1 ? TILE : 1];
@@ -289,6 +291,154 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
     if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
   }
 }
+// ---- long rows (restriction: R = P^T has ~25 nonzeros per row on rasters, Q^T ~49) --------------------------------
+// The kernel above gives every row one lane group for the whole 256-row block; with rows of 25-50 nonzeros a block
+// spans several LDS tiles and in each tile only the rows whose nonzeros fall inside it have work (20-40 % of the
+// lanes). Here a workgroup owns ROWS (64 / 32) rows -- about one tile of nonzeros -- and SL lane groups share a row:
+// slice s takes the row's nonzeros s, s+SL, ... inside the tile, the SL partial sums are combined with wave shuffles
+// (fixed order: deterministic). Plain product only (y = A x), no fused dot.
+template <class T, int K, int ROWS>
+__global__ __launch_bounds__(256) void spmm_longrow_kernel(SpmvArgs<T, T> a) {
+  constexpr int TILE = kSpmvTile;
+  __shared__ int s_rp[ROWS + 1];
+  __shared__ T s_val[TILE];
+  __shared__ int s_col[TILE];
+  if (a.skip && *a.skip) return;
+  const int tid = threadIdx.x;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CPL = K < VEC ? K : VEC;
+  constexpr int LPR = K / CPL;                                     // lanes covering the K columns
+  constexpr int SL = (ROWS * LPR >= 256) ? 1 : 256 / (ROWS * LPR);  // slices per row
+  constexpr int LR = LPR * SL;                                     // lanes per row (<= 64: inside one wave)
+  constexpr int RPP = 256 / LR;
+  constexpr int NPASS = ROWS / RPP;
+  static_assert(LR <= 64 && RPP * NPASS == ROWS, "lane layout");
+  typedef SpmvVec<T, CPL> XV;
+  const int c0 = (tid % LPR) * CPL;
+  const int sl = (tid / LPR) % SL;
+  const int rloc = tid / LR;
+  const int nblocks = (a.nrows + ROWS - 1) / ROWS;
+  // same XCD-aware mapping as spmv_kernel: each XCD marches through one contiguous eighth of the row blocks, so the
+  // x rows neighbouring aggregates share are re-used out of that XCD's L2
+  int rb_first = blockIdx.x, rb_last = nblocks, rb_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, chunk = (nblocks + 7) >> 3;
+    rb_first = xcd * chunk + (blockIdx.x >> 3);
+    rb_last = min(nblocks, (xcd + 1) * chunk);
+    rb_step = gridDim.x >> 3;
+  }
+  for (int rb = rb_first; rb < rb_last; rb += rb_step) {
+    const int row0 = rb * ROWS;
+    const int nr = min(ROWS, a.nrows - row0);
+    __syncthreads();
+    for (int t = tid; t <= nr; t += 256) s_rp[t] = a.rowptr[row0 + t];
+    __syncthreads();
+    const int kbeg = s_rp[0], kend = s_rp[nr];
+    T acc[NPASS][CPL];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) acc[p][q] = T(0);
+    for (int ts = kbeg; ts < kend; ts += TILE) {
+      const int te = min(kend, ts + TILE);
+      if (ts != kbeg) __syncthreads();
+      {
+        constexpr int U = TILE / 256;
+        T vv[U];
+        int cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = ts + tid + u * 256;
+          vv[u] = k < te ? a.val[k] : T(0);
+          cc[u] = k < te ? a.col[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ts + tid + u * 256 < te) {
+            s_val[tid + u * 256] = vv[u];
+            s_col[tid + u * 256] = cc[u];
+          }
+      }
+      __syncthreads();
+      int lo[NPASS], len[NPASS];
+      int maxlen = 0;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int r = rloc + p * RPP;
+        lo[p] = 0;
+        len[p] = 0;
+        if (r < nr) {
+          const int l = max(s_rp[r], ts), h = min(s_rp[r + 1], te);
+          lo[p] = l - ts + sl;
+          len[p] = h - l > sl ? (h - l - sl + SL - 1) / SL : 0;  // entries l+sl, l+sl+SL, ... below h
+        }
+        maxlen = max(maxlen, len[p]);
+      }
+      constexpr int JU = NPASS >= 8 ? 1 : (8 / NPASS);
+      for (int j = 0; j < maxlen; j += JU) {
+        XV xv[JU][NPASS];
+        T vv[JU][NPASS];
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+#pragma unroll
+          for (int p = 0; p < NPASS; ++p) {
+            const bool on = j + u < len[p];
+            const int i = on ? lo[p] + (j + u) * SL : 0;
+            vv[u][p] = on ? s_val[i] : T(0);
+            if (on) {
+              xv[u][p] = *reinterpret_cast<const XV*>(a.x + (size_t)s_col[i] * K + c0);
+            } else {
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = T(0);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u)
+#pragma unroll
+          for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) acc[p][q] += vv[u][p] * xv[u][p].e[q];
+      }
+    }
+    // combine the SL slices of a row (lanes LPR apart inside the row's LR-lane group), then slice 0 writes
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        T v = acc[p][q];
+#pragma unroll
+        for (int o = LPR; o < LR; o <<= 1) v += __shfl_xor(v, o, 64);
+        acc[p][q] = v;
+      }
+      const int r = rloc + p * RPP;
+      if (sl == 0 && r < nr) {
+        XV out;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) out.e[q] = acc[p][q];
+        *reinterpret_cast<XV*>(a.y + (size_t)(row0 + r) * K + c0) = out;
+      }
+    }
+  }
+}
+
+template <class T, int K>
+inline bool spmm_longrow_launch(const SpmvArgs<T, T>& a, hipStream_t st) {
+  if (a.nnz < 16 * (long long)a.nrows) return false;
+  static const bool off = getenv("CSGPU_NO_LONGROW") != nullptr;
+  if (off) return false;
+  auto grid = [&](int rows) {
+    int g = std::max(1, std::min(16384, ceil_div(a.nrows, rows)));
+    if (g >= 64) g &= ~7;  // multiple of 8: XCD-aware mapping active
+    return g;
+  };
+  if (a.nnz < 40 * (long long)a.nrows)
+    hipLaunchKernelGGL((spmm_longrow_kernel<T, K, 64>), dim3(grid(64)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((spmm_longrow_kernel<T, K, 32>), dim3(grid(32)), dim3(256), 0, st, a);
+  return true;
+}
+
 // grid (= number of dot partials per column) for an nrows-row product; a multiple of 8 once there is enough
 // work, so that the kernel's XCD-aware row-block mapping applies.
 // Workgroups per product: enough (64 per CU) that the hardware dispatcher, which starts workgroups in blockIdx
@@ -333,7 +483,10 @@ inline void spmv_launch(const SpmvArgs<T>& a, int epi, bool dot, hipStream_t st)
   if (a.nrows <= 0) return;
   switch (epi) {
     case EPI_PLAIN:
-      dot ? spmv_launch_t<T, K, EPI_PLAIN, true>(a, st) : spmv_launch_t<T, K, EPI_PLAIN, false>(a, st);
+      if (dot)
+        spmv_launch_t<T, K, EPI_PLAIN, true>(a, st);
+      else if (!spmm_longrow_launch<T, K>(a, st))
+        spmv_launch_t<T, K, EPI_PLAIN, false>(a, st);
       break;
     case EPI_RESID:
       spmv_launch_t<T, K, EPI_RESID, false>(a, st);
@@ -347,6 +500,26 @@ inline void spmv_launch(const SpmvArgs<T>& a, int epi, bool dot, hipStream_t st)
     case EPI_QADD:
       dot ? spmv_launch_t<T, K, EPI_QADD, true>(a, st) : spmv_launch_t<T, K, EPI_QADD, false>(a, st);
       break;
+  }
+}
+
+// Plain product with the 4096-nonzero tile (rows of ~14 nonzeros: the [S Q] matrix of the two-product V(1,1) level)
+template <class T, int K>
+inline void spmv_launch_wide(const SpmvArgs<T>& a, bool dot, hipStream_t st) {
+  if (a.nrows <= 0) return;
+  static const bool narrow = getenv("CSGPU_NARROW_TILE") != nullptr;
+  const bool wide = !narrow && a.nnz > 11 * (long long)a.nrows;
+  const dim3 g(spmv_grid<T, K>(a.nrows));
+  if (wide) {
+    if (dot)
+      hipLaunchKernelGGL((spmv_kernel<T, K, EPI_PLAIN, true, T, 16>), g, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((spmv_kernel<T, K, EPI_PLAIN, false, T, 16>), g, dim3(256), 0, st, a);
+  } else {
+    if (dot)
+      hipLaunchKernelGGL((spmv_kernel<T, K, EPI_PLAIN, true, T, 10>), g, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((spmv_kernel<T, K, EPI_PLAIN, false, T, 10>), g, dim3(256), 0, st, a);
   }
 }
 
@@ -404,6 +577,7 @@ template <class T, class XT = T>
 inline SpmvArgs<T, XT> spmv_args(const Csr<T>& A, const XT* x, T* y) {
   SpmvArgs<T, XT> a;
   a.nrows = A.nrows;
+  a.nnz = A.nnz;
   a.rowptr = A.rp();
   a.col = A.ci();
   a.val = A.va();

@@ -19,7 +19,7 @@ mutable struct CsgpuOpts
     nu_pre::Int32; nu_post::Int32; criterion::Int32; itmax::Int32; batch::Int32; check_every::Int32; nu_coarse::Int32
     theta::Float64; omega_p::Float64; omega_s::Float64; rtol::Float64; atol::Float64
     node_row::Ptr{Int32}; node_col::Ptr{Int32}
-    precond_bytes::Int32; use_graph::Int32
+    precond_bytes::Int32; use_graph::Int32; two_product::Int32; reserved2::Int32
     CsgpuOpts() = new()
 end
 

@@ -21,7 +21,8 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
-    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_get_level_matrix",
+    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
+    "csgpu_get_level_matrix",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -42,6 +43,7 @@ class Opts(ctypes.Structure):
         ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
         ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),
         ("precond_bytes", ctypes.c_int32), ("use_graph", ctypes.c_int32),
+        ("two_product", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
 
 
@@ -85,6 +87,7 @@ def _bind(L):
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
+    L.csgpu_level_spmv_host.argtypes = [vp, i32, i32, vp, vp, i32, vp]
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
     L.csgpu_free.argtypes = [vp]
@@ -246,9 +249,27 @@ class Handle:
         _check(lib().csgpu_spmv_host(self._p, xi.ctypes.data, y.ctypes.data, k))
         return y[:, 0] if x.ndim == 1 else y
 
+    def level_spmv(self, lvl, which, x):
+        """y = (level operator) x through the V-cycle's launcher for that operator; returns (y, dots) where dots is
+        the fused x[:n].y per column for which == "M", else None. x has shape (ncols,) or (ncols, k)."""
+        w = {"A": 0, "P": 1, "R": 2, "Q": 3, "QT": 4, "M": 5}[which]
+        info = self.info
+        dt = np.float32 if (info["precond_bytes"] or info["val_bytes"]) == 4 else np.float64
+        nr, nc, nz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().csgpu_get_level_matrix(self._p, lvl, w, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nz),
+                                            None, None, None))
+        x = np.asarray(x, dtype=dt)
+        k = 1 if x.ndim == 1 else x.shape[1]
+        assert x.shape[0] == nc.value
+        xi = np.ascontiguousarray(x.reshape(nc.value, k))
+        y = np.zeros((nr.value, k), dtype=dt)
+        dots = np.zeros(k, dtype=np.float64)
+        _check(lib().csgpu_level_spmv_host(self._p, lvl, w, xi.ctypes.data, y.ctypes.data, k, dots.ctypes.data))
+        return (y[:, 0] if x.ndim == 1 else y), (dots if which == "M" else None)
+
     def level_matrix(self, lvl, which="A"):
         import scipy.sparse as sp
-        w = {"A": 0, "P": 1, "R": 2}[which]
+        w = {"A": 0, "P": 1, "R": 2, "Q": 3, "QT": 4, "M": 5}[which]
         nr, nc, nz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         _check(lib().csgpu_get_level_matrix(self._p, lvl, w, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nz),
                                             None, None, None))

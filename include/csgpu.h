@@ -98,6 +98,10 @@ typedef struct csgpu_opts {
   /* Replay the PCG iteration as a captured hipGraph of check_every iterations between two host polls:
    * 0 = auto (on when n*batch <= 2^25, the launch-latency-bound regime), 1 = always, -1 = never. Default 0. */
   int32_t use_graph;
+  /* Level 0 of a V(1,1) cycle as two products, b_c = Q^T b and out = [S Q][b; x_c], instead
+   * of residual + restriction + fused prolongation: 0 = on whenever nu_pre == nu_post == 1 (default), -1 = off. */
+  int32_t two_product;
+  int32_t reserved2;
 } csgpu_opts;
 
 typedef struct csgpu_info {
@@ -180,7 +184,14 @@ int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms);
 /* y = A x on the device for host vectors (tests: parity of the SpMV kernel itself). */
 int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k);
 
-/* Copy level `lvl`'s operator (which: 0 = A, 1 = P, 2 = R) back to the host for inspection by tests.
+/* y = (level `lvl` operator `which`, numbering as in csgpu_get_level_matrix) x, launched the way the V-cycle launches
+ * that operator (tests: parity of the restriction / [S Q] kernels). Host arrays in the hierarchy's precision
+ * (precond_bytes, else val_bytes), interleaved [ncols][k] -> [nrows][k]. For which == 5 `dots` (k doubles, may be
+ * NULL) receives the fused dot products sum_i x[i][c] * y[i][c] over the first nrows entries of x. */
+int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, void* y, int k, double* dots);
+
+/* Copy level `lvl`'s operator (which: 0 = A, 1 = P, 2 = R, 3 = Q, 4 = Q^T, 5 = [S Q]; the
+ * last two exist on level 0 of a two-product hierarchy only) back to the host for inspection by tests.
  * Pass NULL arrays to query sizes only. */
 int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz,
                            int32_t* rowptr, int32_t* colidx, void* vals);

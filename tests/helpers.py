@@ -102,3 +102,26 @@ def run_network_advanced_fixture(case, solver):
     sources, grounds, finite = ps.resolve_conflicts(sources, grounds, case["remove_src_or_gnd"])
     v = ps.advanced_kernel(G, cc, sources, grounds, finite, solver)
     return np.column_stack([np.arange(1, m + 1), v])
+
+
+def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0):
+    """Every operator of level 0 (A, P, R, Q, Q^T, [S Q]) times a random block of vectors, through the launcher the
+    V-cycle uses for it, against scipy on the matrices read back from the handle; plus the dot fused into [S Q]."""
+    _, g = rg.synthetic_raster_problem(n_side, n_side, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    for k in ks:
+        h = L.raster_setup(g, L.default_opts(batch=k, precond_bytes=precond_bytes))
+        tol = 1e-12 if precond_bytes == 0 else 3e-5
+        for which in ("A", "P", "R", "Q", "QT", "M"):
+            M = h.level_matrix(0, which).astype(np.float64)
+            x = rng.standard_normal((M.shape[1], k))
+            y, dots = h.level_spmv(0, which, x if k > 1 else x[:, 0])
+            xs = x.astype(np.float32).astype(np.float64) if precond_bytes == 4 else x
+            ref = M @ xs
+            refc = ref if k > 1 else ref[:, 0]
+            scale = max(1.0, np.abs(ref).max())
+            assert np.max(np.abs(y - refc)) <= tol * scale, (which, k, np.max(np.abs(y - refc)))
+            if which == "M":
+                refd = np.einsum("ik,ik->k", xs[:M.shape[0]], ref)
+                assert np.max(np.abs(dots - refd)) <= tol * max(1.0, np.abs(refd).max()) * 10, (k, dots, refd)
+        h.close()

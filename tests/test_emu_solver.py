@@ -381,3 +381,53 @@ def test_graph_auto_mode_and_itmax_tail(emu_lib):
     with pytest.raises(emu_lib.CsgpuError):
         h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
     h.close()
+
+
+@pytest.mark.parametrize("batch,precond_bytes", [(1, 0), (4, 0), (8, 4), (16, 4)])
+def test_two_product_level_matches_classic_vcycle(emu_lib, batch, precond_bytes):
+    """Level 0 of the V(1,1) cycle as b_c = Q^T b, out = [S Q][b; x_c] is the same linear operator as
+    pre-smooth / residual / restrict / prolongate / post-smooth: same iteration counts, same answers (up to rounding);
+    Q^T and [S Q] are what the algebra says they are."""
+    import scipy.sparse as sp
+    from oracle import refgraph as rg
+    N = 45
+    _, g = rg.synthetic_raster_problem(N, N, seed=2)
+    cells = np.random.default_rng(8).choice(N * N, size=6, replace=False)
+    src, dst = cells[:-1], cells[1:]
+    res = {}
+    for tp in (0, -1):
+        h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=batch, precond_bytes=precond_bytes, two_product=tp,
+                                                         rtol=1e-10, atol=0.0, criterion=emu_lib.CRIT_TRUE_RESIDUAL))
+        R, _, V, st = h.solve_pairs(src, dst, want_voltages=True)
+        assert st["not_converged"] == 0
+        res[tp] = (R, V, st["total_iters"])
+        if tp == 0:
+            A, Q, QT, M = (h.level_matrix(0, w) for w in ("A", "Q", "QT", "M"))
+            n, nc = Q.shape
+            assert QT.shape == (nc, n) and M.shape == (n, n + nc)
+            assert abs(QT - Q.T).max() == 0
+            assert abs(M[:, n:] - Q).max() == 0
+            # S = 2 w D^-1 - w D^-1 A w D^-1 with w D^-1 recovered from Q = P - w D^-1 A P
+            P = h.level_matrix(0, "P")
+            AP = (A @ P).tocsr()
+            i = int(np.argmax(np.abs(AP).sum(axis=1)))
+            wd_i = ((P - Q)[i].toarray().ravel() @ AP[i].toarray().ravel()) / (AP[i].toarray().ravel() @ AP[i].toarray().ravel())
+            omega = wd_i * A[i, i]
+            wd = omega / A.diagonal()
+            S = 2 * sp.diags(wd) - sp.diags(wd) @ A @ sp.diags(wd)
+            tol = 1e-12 if precond_bytes == 0 else 2e-6
+            assert abs(M[:, :n] - S).max() <= tol * abs(S).max()
+        else:
+            assert h.level_matrix(0, "M").nnz == 0
+        h.close()
+    assert abs(res[0][2] - res[-1][2]) <= len(src)
+    assert np.max(np.abs(res[0][0] - res[-1][0]) / res[-1][0]) < 1e-8
+    assert np.max(np.abs(res[0][1] - res[-1][1])) < 1e-7 * np.abs(res[-1][1]).max()
+
+
+@pytest.mark.parametrize("precond_bytes", [0, 4])
+def test_level_products_all_operators(emu_lib, precond_bytes):
+    """Restriction-type operators go through the long-row kernel, [S Q] through the wide-tile kernel with the fused
+    dot: each against scipy, every batch width (several row blocks and tiles per operator at this size)."""
+    from helpers import check_level_products
+    check_level_products(emu_lib, 70, precond_bytes)

@@ -142,3 +142,11 @@ def test_graph_replay_matches_direct_launches(gpu_lib, precond_bytes):
     assert sa["graph_launches"] == 0 and sb["graph_launches"] > 0
     assert sa["total_iters"] == sb["total_iters"] and sb["not_converged"] == 0
     assert np.array_equal(Ra, Rb) and np.array_equal(Va, Vb)
+
+
+@pytest.mark.parametrize("precond_bytes", [0, 4])
+def test_level_products_all_operators(gpu_lib, precond_bytes):
+    """A, P, R, Q, Q^T (long-row kernel) and [S Q] (wide-tile kernel + fused dot) against scipy at every batch width;
+    the raster is large enough that the XCD-chunked, band-ordered traversal is active (n > 64 row blocks)."""
+    from helpers import check_level_products
+    check_level_products(gpu_lib, 200, precond_bytes)
