@@ -21,6 +21,8 @@
 //
 // Parity with the reference is at the level of converged solutions (the reference pins nothing else).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -684,6 +686,8 @@ struct Level {
   Csr<T> QT, M;         // level 0 with V(1,1) smoothing only: Q^T and [S Q] of the two-product form (see build_sq_kernel)
   DBuf dinv;            // 1/a_ii
   DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
+  DBuf orderQT;         // traversal order of the long-row kernel on Q^T (two-product level; may be empty)
+  long long periodA = 0;  // band period detected on A (0: none)
   double omega = 0;     // damped-Jacobi weight
   double rho = 0;       // Gershgorin bound on rho(D^-1 A)
   int n = 0;
@@ -787,7 +791,7 @@ inline void level_stats(Level<T>& L, DBuf& diag, DBuf& labs, double omega_s, hip
   L.rho = rho;
   L.omega = omega_s / rho;
   L.n = n;
-  spmv_block_order(L.A, L.orderA, st);
+  spmv_block_order(L.A, L.orderA, st, &L.periodA);
 }
 
 // Build the hierarchy. A0 is moved into level 0. node_row/node_col (device, may be null) are raster coordinates.
@@ -860,6 +864,7 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
         (int64_t)n + nagg < 0x7fffffffLL) {
       transpose(L.Q, L.QT, st);
+      spmv_block_order_rect(L.QT, L.periodA, L.orderQT, st);
       Csr<T>& M = L.M;
       M.nrows = n;
       M.ncols = n + nagg;
@@ -872,6 +877,9 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       hipLaunchKernelGGL((build_sq_kernel<T>), dim3(g), dim3(256), 0, st, n, L.A.rp(), L.A.ci(), L.A.va(), L.Q.rp(),
                          L.Q.ci(), L.Q.va(), dptr<T>(L.dinv), L.omega, M.rp(), M.ci(), M.va());
       check_launch("build [S Q]");
+      if (getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: two-product level: nnz(Q^T)=%lld nnz([S Q])=%lld periodA=%lld orderA=%s orderQT=%s\n",
+                (long long)L.QT.nnz, (long long)M.nnz, L.periodA, L.orderA.p ? "yes" : "no", L.orderQT.p ? "yes" : "no");
     }
     // next level
     size_prev = std::move(size_c);  // unsigned long long and long long share the representation for these counts

@@ -444,7 +444,8 @@ struct Solver : ISolver {
         info->level_nnz[l] = L.A.nnz;
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
-                         L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes);
+                         L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
+                         L.M.device_bytes() + L.orderQT.bytes);
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
@@ -523,6 +524,7 @@ struct Solver : ISolver {
     SpmvArgs<TP> a = spmv_args(M, (const TP*)dptr<TP>(x), dptr<TP>(y));
     const bool sq = which == 5;
     if (which == 0 || sq) a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
+    if (which == 4) a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
     if (sq) a.partials = dptr<double>(part);
     if (sq) {
       CS_DISPATCH_K(k, spmv_launch_wide<TP, KK>(a, true, st));

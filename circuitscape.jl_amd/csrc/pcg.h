@@ -105,6 +105,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     {
       SpmvArgs<T> a = spmv_args(L.QT, b, bc);
       a.skip = skip;
+      a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
       spmv_launch<T, K>(a, EPI_PLAIN, false, st);
     }
     VcycleFuse<T> cf;

@@ -485,6 +485,10 @@ inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED);
 template <class T>
 inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 
+// clang builtins used by the kernels
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
 // ---- kernel launch
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                         \
   do {                                                                                                     \

@@ -104,10 +104,10 @@ def run_network_advanced_fixture(case, solver):
     return np.column_stack([np.arange(1, m + 1), v])
 
 
-def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0):
+def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0, n_cols=None):
     """Every operator of level 0 (A, P, R, Q, Q^T, [S Q]) times a random block of vectors, through the launcher the
     V-cycle uses for it, against scipy on the matrices read back from the handle; plus the dot fused into [S Q]."""
-    _, g = rg.synthetic_raster_problem(n_side, n_side, seed=seed)
+    _, g = rg.synthetic_raster_problem(n_side, n_cols or n_side, seed=seed)
     rng = np.random.default_rng(seed + 1)
     for k in ks:
         h = L.raster_setup(g, L.default_opts(batch=k, precond_bytes=precond_bytes))

@@ -431,3 +431,11 @@ def test_level_products_all_operators(emu_lib, precond_bytes):
     dot: each against scipy, every batch width (several row blocks and tiles per operator at this size)."""
     from helpers import check_level_products
     check_level_products(emu_lib, 70, precond_bytes)
+
+
+def test_level_products_band_ordered_traversal(emu_lib):
+    """A tall raster (1100 x 24, column-major node numbering => band period 1101) is the smallest shape on which both
+    traversal orders are built: the 256-row block order of A / [S Q] and the long-row block order of Q^T (>= 64 row
+    blocks, period >= 4 blocks). Products must not depend on the order the row blocks are visited in."""
+    from helpers import check_level_products
+    check_level_products(emu_lib, 1100, 4, ks=(1, 8, 16), n_cols=24)

@@ -150,3 +150,10 @@ def test_level_products_all_operators(gpu_lib, precond_bytes):
     the raster is large enough that the XCD-chunked, band-ordered traversal is active (n > 64 row blocks)."""
     from helpers import check_level_products
     check_level_products(gpu_lib, 200, precond_bytes)
+
+
+def test_level_products_band_ordered_traversal(gpu_lib):
+    """Tall raster on which both band-aware traversal orders (A / [S Q] and Q^T) are active; see the emulator twin."""
+    from helpers import check_level_products
+    check_level_products(gpu_lib, 1100, 4, ks=(1, 8, 16), n_cols=24)
+    check_level_products(gpu_lib, 2000, 0, ks=(16,), n_cols=64)
