@@ -84,6 +84,24 @@ struct alignas(sizeof(T) * N) SpmvVec {
   T e[N];
 };
 
+// y is written once and (at these sizes) not re-read before it has left the caches: -DCSGPU_NT_STORE=1 stores it
+// non-temporally so the write stream does not allocate in L2 next to the x rows being re-used.
+#ifndef CSGPU_NT_STORE
+#define CSGPU_NT_STORE 0
+#endif
+template <class T, int N>
+__device__ __forceinline__ void stream_store(SpmvVec<T, N>* p, const SpmvVec<T, N>& v) {
+#if CSGPU_NT_STORE && defined(__HIPCC__)
+  typedef T VT __attribute__((ext_vector_type(N)));
+  VT t;
+#pragma unroll
+  for (int q = 0; q < N; ++q) t[q] = v.e[q];
+  __builtin_nontemporal_store(t, reinterpret_cast<VT*>(p));
+#else
+  *p = v;
+#endif
+}
+
 template <class T, int K, int EPI, bool DOT, class XT, int TPL = kSpmvTile / 256>
 __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // (K == 1: products staged in LDS; K > 1: matrix staged in LDS, 4 gathers in flight per lane)
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
           out.e[q] = v;
           if (DOT) dot_acc[q] += (double)dw.e[q] * (double)v;
         }
-        *reinterpret_cast<YV*>(a.y + e0) = out;
+        stream_store(reinterpret_cast<YV*>(a.y + e0), out);
       }
     }
   }
