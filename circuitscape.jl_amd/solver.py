@@ -66,6 +66,9 @@ def initialize_cum_maps(cellmap, write_max=False):
 class Flags:  # the subset of RasterFlags / NetworkFlags the solver layer reads (raster/pairwise.jl:1-12)
     is_raster: bool = True
     outputflags: OutputFlags = field(default_factory=OutputFlags)
+    is_onetoall: bool = False
+    is_alltoone: bool = False
+    policy: str = "keepall"          # remove_src_or_gnd: keepall | rmvsrc | rmvgnd | rmvall
 
 
 @dataclass
@@ -195,6 +198,118 @@ def advanced_kernel(G, cc, sources, grounds, finitegrounds, solver, cfg=None, ch
 def _colmajor_nonzero(mask):
     jj, ii = np.nonzero(np.asarray(mask).T)
     return ii, jj
+
+
+@dataclass
+class AdvancedProblem:
+    """src/raster/advanced.jl:1-15. Node ids 1-based, 0 = no node; `check_node` = -1 solves every component that has
+    both a source and a ground, otherwise only the component holding that node (one-to-all / all-to-one)."""
+    G: sp.csr_matrix
+    cc: List[np.ndarray]
+    nodemap: np.ndarray
+    polymap: Optional[np.ndarray]
+    sources: np.ndarray
+    grounds: np.ndarray
+    finitegrounds: np.ndarray
+    cellmap: np.ndarray
+    solver: HIPAMGSolver = field(default_factory=HIPAMGSolver)
+    source_map: Optional[np.ndarray] = None
+    check_node: int = -1
+    src: int = 0
+
+
+def get_sources_and_grounds(source_map, ground_map, G, nodemap, policy):
+    """Raster branch of _get_sources_and_grounds (src/raster/advanced.jl:84-116): per-node source currents and ground
+    conductances accumulated from the rasters (cells of one polygon share a node), then resolve_conflicts."""
+    n = G.shape[0]
+    nodemap = np.asarray(nodemap)
+    sources = np.zeros(n)
+    grounds = np.zeros(n)
+    for raster, acc in ((np.asarray(source_map, dtype=np.float64), sources),
+                        (np.asarray(ground_map, dtype=np.float64), grounds)):
+        m = (raster != 0) & (nodemap != 0)
+        np.add.at(acc, nodemap[m] - 1, raster[m])
+    return resolve_conflicts(sources, grounds, policy)
+
+
+def get_node_currents(G, voltages, finitegrounds):
+    """get_node_currents (src/out.jl:178-207) with the finite-ground branch, evaluated on the host: advanced modes
+    need it once per solved component (the per-pair flavour of pairwise mode runs on the device, currents.h).
+    Branch currents |g_ij| (v_i - v_j) below 1e-8 of the largest are dropped; a node's current is the larger of its
+    total inflow and outflow, the flow through its own ground conductance included."""
+    G = sp.csr_matrix(G)
+    v = np.asarray(voltages, dtype=np.float64)
+    up = sp.triu(G, k=1).tocoo()
+    flow = np.abs(up.data) * (v[up.row] - v[up.col])          # current from row to col along each branch
+    n = G.shape[0]
+    fg = np.asarray(finitegrounds, dtype=np.float64)
+    have_fg = not (len(fg) == 1 and fg[0] == -9999)
+    totals = []
+    for sign in (1.0, -1.0):
+        b = sign * flow
+        top = b.max() if len(b) else 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = np.where(np.abs(b / top) < 1e-8, 0.0, b)
+        # B - B' clipped at 0, summed over rows: what flows INTO each column node (sign = +1: along row -> col)
+        into = np.bincount(up.col, weights=np.maximum(b, 0.0), minlength=n) + \
+            np.bincount(up.row, weights=np.maximum(-b, 0.0), minlength=n)
+        if have_fg:
+            gc = fg * v
+            into = into + (np.where(gc < 0, -gc, 0.0) if sign > 0 else np.where(gc > 0, gc, 0.0))
+        totals.append(into)
+    return np.maximum(totals[0], totals[1])
+
+
+def raster_advanced_kernel(prob, flags, cfg=None):
+    """advanced_kernel, raster branch (src/raster/advanced.jl:151-271): one grounded solve per connected component
+    that holds a source and a ground, voltages and node currents scattered to rasters.
+    Returns (ret, outcurr, maps): `ret` as the reference returns it (cell voltages; one-to-all: voltage / source
+    strength at the source cells; all-to-one: [[0]]; [[-1]] when nothing was solved), the raw accumulated current map,
+    and maps = {'voltmap', 'curmap'} post-processed the way write_grid does (only those the flags ask for)."""
+    G = sp.csr_matrix(prob.G)
+    nodemap = np.asarray(prob.nodemap)
+    of = flags.outputflags
+    outvolt = np.zeros(nodemap.shape)
+    outcurr = np.zeros(nodemap.shape)
+    volt = np.zeros(nodemap.shape)
+    voltages = np.zeros(G.shape[0])
+    no_finite = len(prob.finitegrounds) == 1 and prob.finitegrounds[0] == -9999
+    solver_called = False
+    for c in prob.cc:
+        c = np.asarray(c, dtype=np.int64)
+        if prob.check_node != -1 and prob.check_node not in c:
+            continue
+        idx = c - 1
+        s_local, g_local = prob.sources[idx], prob.grounds[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        f_local = prob.finitegrounds if no_finite else prob.finitegrounds[idx]
+        a_local = G[idx][:, idx]
+        voltages[idx] += multiple_solver(cfg, prob.solver, a_local, s_local, g_local, f_local)
+        local_nodemap = construct_local_node_map(nodemap, c, prob.polymap)
+        solver_called = True
+        if of.write_volt_maps:
+            outvolt += _scatter(voltages[idx], local_nodemap)
+        if of.write_cur_maps:
+            outcurr += _scatter(get_node_currents(a_local, voltages[idx], f_local), local_nodemap)
+        m = local_nodemap > 0
+        volt[m] = voltages[idx][local_nodemap[m] - 1]
+    maps = {}
+    if of.write_volt_maps:
+        maps["voltmap"] = _process_grid(outvolt, prob.cellmap, False, of.set_null_voltages_to_nodata)
+    if of.write_cur_maps or of.write_cum_cur_map_only:
+        maps["curmap"] = _process_grid(outcurr, prob.cellmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+    if not solver_called:
+        return np.array([[-1.0]]), outcurr, maps
+    if flags.is_onetoall:
+        ii, jj = _colmajor_nonzero(np.asarray(prob.source_map) != 0)
+        val = volt[ii, jj] / np.asarray(prob.source_map, dtype=np.float64)[ii, jj]
+        if np.isclose(val[0], 0.0, rtol=float(np.sqrt(np.finfo(np.float64).eps)), atol=0.0):
+            return np.array([[-1.0]]), outcurr, maps
+        return val.reshape(-1, 1), outcurr, maps
+    if flags.is_alltoone:
+        return np.array([[0.0]]), outcurr, maps
+    return volt, outcurr, maps
 
 
 def _construct_node_map(gmap, polymap):

@@ -206,3 +206,88 @@ def network_pairwise_tables_from_fixture(case, mode="direct"):
     bc = np.column_stack([np.array(case["edges_i"]), np.array(case["edges_j"]), cum_branch])
     return {"pairs": out, "branch_cum": bc[~np.isclose(bc[:, 2], 0.0, atol=1e-6)],
             "node_cum": np.column_stack([np.arange(1, m + 1), cum_node])}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# advanced mode, raster flavour (scope row N2). Restates
+#   compute_advanced_data / _get_sources_and_grounds (raster branch)   src/raster/advanced.jl:36-116
+#   advanced_kernel (raster branch: voltage map, current map)           src/raster/advanced.jl:151-271
+#   get_node_currents with finite grounds                               src/out.jl:178-207
+def get_node_currents_grounded(G, voltages, finitegrounds):
+    """out.jl:178-207 including the finite-ground branch: the current a node sends to ground through its finite
+    ground conductance (g_i * v_i) is added to the node's outgoing (v > 0: 'neg' pass) or incoming flow."""
+    G = sp.csr_matrix(G)
+    fg = np.asarray(finitegrounds, dtype=np.float64)
+    if len(fg) == 1 and fg[0] == -9999:
+        return get_node_currents(G, voltages)
+    coo = sp.triu(G, k=1).tocoo()
+    g = np.abs(coo.data)
+    v = np.asarray(voltages, dtype=np.float64)
+    n = G.shape[0]
+    out = []
+    for pos in (True, False):
+        b = g * (v[coo.row] - v[coo.col]) if pos else g * (v[coo.col] - v[coo.row])
+        maxcur = b.max() if len(b) else 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = np.where(np.abs(b / maxcur) < 1e-8, 0.0, b)
+        B = sp.coo_matrix((b, (coo.row, coo.col)), shape=(n, n)).tocsr()
+        C = (B - B.T).tocsr()
+        C.data[C.data < 0] = 0.0
+        fc = fg * v
+        fc = np.where(fc < 0, -fc, 0.0) if pos else np.where(fc > 0, fc, 0.0)
+        out.append(np.asarray(C.sum(axis=0)).ravel() + fc)
+    return np.maximum(out[0], out[1])
+
+
+def _maps_from_fixture(case):
+    def arr(m):
+        return np.array([[float(x) for x in row] for row in m], dtype=np.float64)
+    return arr(case["source_map"]), arr(case["ground_map"])
+
+
+def raster_advanced_from_fixture(case, mode="direct", solve=None):
+    """raster_advanced (raster/advanced.jl:17-34) on a tests/golden mgVerify fixture.
+    Returns {'voltmap': processed voltage map, 'curmap': processed current map, 'volt': raw per-cell voltages}."""
+    o = case["options"]
+    gmap = np.asarray(case["cellmap"], dtype=np.float64)
+    polymap = np.asarray(case["polymap"], dtype=np.int64) if case.get("polymap") is not None else None
+    source_map, ground_map = _maps_from_fixture(case)
+    nodemap = rg.construct_node_map(gmap, polymap)
+    A = rg.construct_graph(gmap, nodemap, o["connect_using_avg_resistances"], o["connect_four_neighbors_only"])
+    G = rg.laplacian(A)
+    cc = rg.connected_components(A)
+    n = G.shape[0]
+    sources = np.zeros(n)
+    grounds = np.zeros(n)
+    for smap, acc in ((source_map, sources), (ground_map, grounds)):
+        ii, jj = rg._colmajor_nonzero(smap != 0)
+        for i, j in zip(ii, jj):
+            v = nodemap[i, j]
+            if v != 0:
+                acc[v - 1] += smap[i, j]
+    sources, grounds, finitegrounds = rs.resolve_conflicts(sources, grounds, o["remove_src_or_gnd"])
+    no_finite = len(finitegrounds) == 1 and finitegrounds[0] == -9999
+    solve = solve or rs._oracle_multiple_solve(mode)
+    outvolt = np.zeros(gmap.shape)
+    outcurr = np.zeros(gmap.shape)
+    volt = np.zeros(gmap.shape)
+    voltages = np.zeros(n)
+    G = sp.csr_matrix(G)
+    for c in cc:
+        idx = np.asarray(c) - 1
+        s_local, g_local = sources[idx], grounds[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        f_local = finitegrounds if no_finite else finitegrounds[idx]
+        a_local = G[idx][:, idx]
+        voltages[idx] += rs.multiple_solver(a_local, s_local, g_local, f_local, solve)
+        local_nodemap = construct_local_node_map(nodemap, c, polymap)
+        outvolt += scatter(voltages[idx], local_nodemap)
+        outcurr += scatter(get_node_currents_grounded(a_local, voltages[idx], f_local), local_nodemap)
+        m = local_nodemap > 0
+        volt[m] = voltages[idx][local_nodemap[m] - 1]
+    return {
+        "voltmap": process_grid(outvolt, gmap, False, o["set_null_voltages_to_nodata"]),
+        "curmap": process_grid(outcurr, gmap, o["log_transform_maps"], o["set_null_currents_to_nodata"]),
+        "volt": volt,
+    }

@@ -26,6 +26,16 @@ def advanced_cases():
     return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgNetwork"))
 
 
+def raster_advanced_cases():
+    """raster advanced-mode cases (mgVerify1..6: voltage / current map goldens)"""
+    return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgVerify"))
+
+
+def compare_aagrid(expected, got, tol=1e-6):
+    """the reference's map criterion (test/test_utils.jl:196): sum of squared differences below tol"""
+    return float(np.sum((np.asarray(expected, dtype=float) - np.asarray(got, dtype=float)) ** 2)) < tol
+
+
 def load_case(name):
     with open(os.path.join(GOLDEN, name + ".json")) as f:
         return json.load(f)

@@ -61,6 +61,8 @@ def read_aagrid(path):
 
 def resolve(path):
     p = os.path.join(REF, path)
+    if p.endswith(".tif.gz"):
+        p = p[:-3]
     if p.endswith(".tif"):
         alt = p[:-4] + ".asc"
         assert os.path.exists(alt), "no .asc twin for " + p
@@ -314,11 +316,87 @@ def network_advanced_case(idx):
     }
 
 
+def _txt_list(path, hb):
+    """_txt_list_reader (io.jl:315-326): rows (value, X, Y) -> (value, row, col), 1-based."""
+    with _open(path) as f:
+        a = np.array([ln.split() for ln in f if ln.strip()], dtype=np.float64)
+    nrows = int(hb["nrows"])
+    r = np.ceil(nrows - (a[:, 2] - hb["yllcorner"]) / hb["cellsize"]).astype(int)
+    c = np.ceil((a[:, 1] - hb["xllcorner"]) / hb["cellsize"]).astype(int)
+    return a[:, 0], r, c
+
+
+def read_source_and_ground_maps(d, hb):
+    """io.jl:252-313: source map (nodata -> 0), ground map (nodata -> 0, resistances inverted so that a zero
+    resistance becomes an infinite conductance = direct ground), use_unit_currents / use_direct_grounds."""
+    shape = (int(hb["nrows"]), int(hb["ncols"]))
+    gpath = resolve(d["ground_file"])
+    if guess_type(gpath) == "aagrid":
+        ground, _ = read_polymap(gpath, nodata_as=-1)
+    else:
+        v, r, c = _txt_list(gpath, hb)
+        ground = -9999.0 * np.ones(shape)
+        ground[r - 1, c - 1] = v
+    spath = resolve(d["source_file"])
+    if guess_type(spath) == "aagrid":
+        source, _ = read_polymap(spath)
+        source[source == -9999] = 0
+    else:
+        v, r, c = _txt_list(spath, hb)
+        source = np.zeros(shape)
+        source[r - 1, c - 1] = v
+    nod = ground == -9999
+    if truthy(d, "ground_file_is_resistances"):
+        with np.errstate(divide="ignore"):
+            ground = 1.0 / ground
+    ground[nod] = 0
+    if truthy(d, "use_unit_currents"):
+        source[source != 0] = 1
+    if truthy(d, "use_direct_grounds"):
+        ground[ground != 0] = np.inf
+    return source, ground
+
+
+def _jsonable(a):
+    """nested lists with +-inf spelled as strings (strict JSON has no Infinity)."""
+    a = np.asarray(a, dtype=np.float64)
+    return [[("inf" if v == np.inf else "-inf" if v == -np.inf else float(v)) for v in row] for row in a]
+
+
+def raster_advanced_case(idx):
+    """mgVerify<idx>: raster advanced mode (test/test_utils.jl:116-121) -- inputs after load_raster_data
+    (io.jl:420-510) and the golden voltage / current maps."""
+    name = "mgVerify%d" % idx
+    d = parse_ini(os.path.join(REF, "input/raster/advanced/%d/%s.ini" % (idx, name)))
+    g, hb = read_cellmap(resolve(d["habitat_file"]), truthy(d, "habitat_map_is_resistances"))
+    opts = {k: truthy(d, k) for k in (
+        "connect_four_neighbors_only", "connect_using_avg_resistances", "use_polygons", "use_mask", "write_volt_maps",
+        "write_cur_maps", "write_cum_cur_map_only", "write_max_cur_maps", "log_transform_maps",
+        "set_null_currents_to_nodata", "set_null_voltages_to_nodata")}
+    opts["remove_src_or_gnd"] = d.get("remove_src_or_gnd", "keepall")
+    polymap = None
+    if opts["use_polygons"]:
+        polymap = read_polymap(resolve(d["polygon_file"]))[0].astype(int).tolist()
+    if opts["use_mask"]:
+        mk, _ = read_polymap(resolve(d["mask_file"]))
+        g = g * (mk > 0)
+    source, ground = read_source_and_ground_maps(d, hb)
+    ov = os.path.join(REF, "output_verify")
+    exp = {}
+    for key in ("voltmap", "curmap"):
+        fn = os.path.join(ov, "%s_%s.asc" % (name, key))
+        if os.path.exists(fn):
+            exp[key] = read_aagrid(fn)[0].tolist()
+    return {"name": name, "kind": "raster_advanced", "ini_solver": d.get("solver", "cg+amg"), "options": opts,
+            "cellmap": g.tolist(), "polymap": polymap, "source_map": _jsonable(source), "ground_map": _jsonable(ground),
+            "expected": exp}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     cases = ([raster_case(k) for k in range(1, 18)] + [network_case(k) for k in range(1, 4)] +
-             [network_advanced_case(k) for k in range(1, 4)])
+             [network_advanced_case(k) for k in range(1, 4)] + [raster_advanced_case(k) for k in range(1, 7)])
     for c in cases:
         with open(os.path.join(OUT, c["name"] + ".json"), "w") as f:
             json.dump(c, f, separators=(",", ":"))

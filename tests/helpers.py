@@ -104,6 +104,33 @@ def run_network_advanced_fixture(case, solver):
     return np.column_stack([np.arange(1, m + 1), v])
 
 
+def _float_map(m):
+    return np.array([[float(x) for x in row] for row in m], dtype=np.float64)
+
+
+def run_raster_advanced_fixture(case, solver):
+    """raster_advanced (src/raster/advanced.jl:17-34) through the product's host mirror; graph construction is the
+    oracle-side restatement (outside the hot-path boundary, stays in the reference)."""
+    from circuitscape_jl_amd import solver as ps
+    o = case["options"]
+    gmap = np.asarray(case["cellmap"], dtype=np.float64)
+    polymap = np.asarray(case["polymap"], dtype=np.int64) if case.get("polymap") is not None else None
+    nodemap = rg.construct_node_map(gmap, polymap)
+    A = rg.construct_graph(gmap, nodemap, o["connect_using_avg_resistances"], o["connect_four_neighbors_only"])
+    G = rg.laplacian(A)
+    cc = rg.connected_components(A)
+    flags = flags_from_case(case, True)
+    flags.policy = o["remove_src_or_gnd"]
+    # the golden set holds both maps for every case, whatever the INI asked to be written
+    flags.outputflags.write_volt_maps = True
+    flags.outputflags.write_cur_maps = True
+    source_map, ground_map = _float_map(case["source_map"]), _float_map(case["ground_map"])
+    sources, grounds, finite = ps.get_sources_and_grounds(source_map, ground_map, G, nodemap, flags.policy)
+    prob = ps.AdvancedProblem(G=G, cc=cc, nodemap=nodemap, polymap=polymap, sources=sources, grounds=grounds,
+                              finitegrounds=finite, cellmap=gmap, solver=solver, source_map=source_map)
+    return ps.raster_advanced_kernel(prob, flags)
+
+
 def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0, n_cols=None):
     """Every operator of level 0 (A, P, R, Q, Q^T, [S Q]) times a random block of vectors, through the launcher the
     V-cycle uses for it, against scipy on the matrices read back from the handle; plus the dot fused into [S Q]."""

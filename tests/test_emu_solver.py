@@ -439,3 +439,20 @@ def test_level_products_band_ordered_traversal(emu_lib):
     blocks, period >= 4 blocks). Products must not depend on the order the row blocks are visited in."""
     from helpers import check_level_products
     check_level_products(emu_lib, 1100, 4, ks=(1, 8, 16), n_cols=24)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").raster_advanced_cases())
+def test_raster_advanced_through_product_path(emu_lib, name):
+    """scope row N2: raster advanced mode (mgVerify1..6) through the product's host mirror -- per-component grounded
+    solves on the kernels, voltage and current maps -- against the reference's goldens (its own criterion) and
+    against the oracle's maps."""
+    from circuitscape_jl_amd import solver as ps
+    from conftest import compare_aagrid
+    from helpers import run_raster_advanced_fixture
+    from oracle import refmaps
+    case = load_case(name)
+    _, _, maps = run_raster_advanced_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
+    ref = refmaps.raster_advanced_from_fixture(case, mode="direct")
+    for key, exp in case["expected"].items():
+        assert compare_aagrid(exp, maps[key]), (name, key)
+        assert np.max(np.abs(maps[key] - ref[key])) < 1e-7 * max(1.0, np.abs(ref[key]).max()), (name, key)

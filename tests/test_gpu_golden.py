@@ -127,3 +127,16 @@ def test_network_current_tables_on_gpu(gpu_lib, name):
     st = {"want_tables": True}
     run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
     assert _check_network_tables(case, st) > 0
+
+
+@pytest.mark.parametrize("name", __import__("conftest").raster_advanced_cases())
+def test_raster_advanced_on_gpu(gpu_lib, name):
+    """scope row N2: raster advanced mode (mgVerify1..6) on the device with the reference's stopping rule; maps
+    against the goldens with the reference's criterion."""
+    from circuitscape_jl_amd import solver as ps
+    from conftest import compare_aagrid, load_case
+    from helpers import run_raster_advanced_fixture
+    case = load_case(name)
+    _, _, maps = run_raster_advanced_fixture(case, ps.HIPAMGSolver(bs=1))
+    for key, exp in case["expected"].items():
+        assert compare_aagrid(exp, maps[key]), (name, key)

@@ -53,3 +53,18 @@ def test_oracle_network_advanced_matches_golden(oracle, name, mode):
     exp = np.array(case["expected_voltages"])
     assert np.array_equal(exp[:, 0] + 1, got[:, 0])
     assert np.max(np.abs(exp[:, 1] - got[:, 1])) <= 1e-6 * max(1.0, np.abs(exp[:, 1]).max())
+
+
+@pytest.mark.parametrize("name", __import__("conftest").raster_advanced_cases())
+@pytest.mark.parametrize("mode", ["direct", "reference"])
+def test_oracle_raster_advanced_matches_golden(oracle, name, mode):
+    """scope row N2: the restated raster advanced driver (grounded solves per component, voltage map, node-current
+    map with finite-ground currents) against the reference's mgVerify goldens, with the reference's own criterion
+    (sum of squared differences < 1e-6, test/test_utils.jl:160,196)."""
+    from conftest import compare_aagrid, load_case
+    from oracle import refmaps
+    case = load_case(name)
+    got = refmaps.raster_advanced_from_fixture(case, mode=mode)
+    assert case["expected"], name
+    for key, exp in case["expected"].items():
+        assert compare_aagrid(exp, got[key]), (name, key)
