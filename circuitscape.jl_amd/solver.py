@@ -195,6 +195,123 @@ def advanced_kernel(G, cc, sources, grounds, finitegrounds, solver, cfg=None, ch
     return voltages
 
 
+def create_new_polymap(polymap, points_rc, point_map):
+    """create_new_polymap, point-map branch (src/raster/pairwise.jl:374-404): focal regions become short-circuit
+    polygons. Focal cells outside any polygon get fresh polygon numbers; a focal region overlapping a polygon takes
+    the polygon over (all its cells are renumbered to the focal id)."""
+    if polymap is None or np.size(polymap) == 0:
+        return point_map
+    polymap = np.asarray(polymap, dtype=np.int64)
+    newpoly = polymap.copy()
+    ids = list(points_rc[2])
+    ii, jj = _colmajor_nonzero(point_map != 0)
+    if len(ids) == len(set(ids)):       # point file without multi-cell regions
+        free = polymap[ii, jj] == 0
+        newpoly[ii[free], jj[free]] = point_map[ii[free], jj[free]] + int(polymap.max())
+        return newpoly
+    k = max(int(polymap.max()), int(point_map.max()))
+    for i, j in zip(ii, jj):
+        v1, v2 = point_map[i, j], newpoly[i, j]
+        if v2 == 0:
+            newpoly[i, j] = k + v1
+        elif v1 != v2:
+            newpoly[newpoly == v2] = v1
+    return newpoly
+
+
+def onetoall_kernel(gmap, polymap, points_rc, flags, solver, build_graph, strengths=None, included_pairs=None,
+                    cfg=None):
+    """onetoall_kernel (src/raster/onetoall.jl:13-162) for one-to-all (flags.is_onetoall) and all-to-one mode.
+
+    gmap: conductance raster; polymap: short-circuit polygons or None; points_rc: (rows, cols, ids), 1-based, as
+    read_point_map returns them; strengths: (id, strength) rows or None; included_pairs: {'mode', 'point_ids',
+    'matrix'} or None. `build_graph(gmap, polymap) -> (nodemap, G, cc)` is the reference's construct_node_map /
+    construct_graph / laplacian! / connected_components, which stay on the reference's side of the boundary.
+
+    Every focal point is one grounded solve on the component holding it (advanced_kernel with check_node):
+    one-to-all injects `strength` at the point and ties every other focal point to ground, all-to-one grounds the
+    point and injects at all the others. Returns (res, cum, points): res = [id, value] rows (one-to-all: voltage per
+    unit source current at the point; all-to-one: 0; -1 when the point is alone), cum = Cumulative of the per-point
+    current maps, points = {id: {'voltmap', 'curmap'}} as the flags ask.
+    """
+    gmap = np.asarray(gmap, dtype=np.float64)
+    of = flags.outputflags
+    one_to_all = flags.is_onetoall
+    pr = [list(x) for x in points_rc]
+    use_var = strengths is not None and len(strengths) > 0
+    use_inc = included_pairs is not None
+    st = np.array(strengths, dtype=np.float64) if use_var else None
+    if use_inc:
+        ids = list(included_pairs["point_ids"])
+        keep = [k for k, p in enumerate(pr[2]) if p in ids]                      # prune_points! (onetoall.jl:167-178)
+        pr = [[col[k] for k in keep] for col in pr]
+        if use_var:
+            st = st[[k for k, p in enumerate(st[:, 0]) if p in ids]]             # prune_strengths (:180-194)
+        mode = 0 if included_pairs["mode"] == "include" else 1
+        inc_mat = np.asarray(included_pairs["matrix"])
+    rows = np.asarray(pr[0], dtype=np.int64) - 1
+    cols = np.asarray(pr[1], dtype=np.int64) - 1
+    pids = np.asarray(pr[2], dtype=np.int64)
+    point_map0 = np.zeros(gmap.shape, dtype=np.int64)
+    point_map0[rows, cols] = pids                                                # later entries win, as in the loop
+    points_unique = list(dict.fromkeys(pr[2]))
+    newpoly0 = create_new_polymap(polymap, pr, point_map0)
+    nodemap0, G, cc = build_graph(gmap, newpoly0)
+    G = sp.csr_matrix(G)
+    unique_point_map = np.zeros(gmap.shape, dtype=np.int64)
+    for n in points_unique:
+        k = pr[2].index(n)
+        unique_point_map[rows[k], cols[k]] = n
+    res = np.zeros(len(points_unique))
+    cum = initialize_cum_maps(gmap, of.write_max_cur_maps)
+    per_point = {}
+    sub = Flags(is_raster=True, outputflags=of, is_onetoall=one_to_all, is_alltoone=not one_to_all)
+    for i, n in enumerate(points_unique):
+        point_map, nodemap, newpoly = point_map0, nodemap0, newpoly0
+        strength = st[i, 1] if use_var else 1.0
+        if use_inc:
+            point_map = point_map0.copy()
+            for j in range(len(ids)):
+                if i != j and inc_mat[i, j] == mode:
+                    point_map[point_map == ids[j]] = 0
+            newpoly = create_new_polymap(polymap, pr, point_map)
+            nodemap = _construct_node_map(gmap, polymap)   # the reference rebuilds from the ORIGINAL polygons (:92)
+        if use_var:
+            s_i = st.copy()
+            s_i[point_map[rows, cols] == 0, 1] = 1
+            strength_map = np.zeros(gmap.shape)
+            strength_map[rows, cols] = s_i[:, 1]
+        if point_map.sum() == n:                             # no other focal point left
+            res[i] = -1
+            continue
+        if one_to_all:
+            source_map = np.where(unique_point_map == n, float(strength), 0.0)
+            ground_map = np.where((point_map != n) & (point_map > 0), np.inf, 0.0)
+        else:
+            if use_var:
+                source_map = np.where(unique_point_map == n, 0.0, strength_map)
+            else:
+                source_map = np.where((unique_point_map != 0) & (point_map != n), 1.0, 0.0)
+            ground_map = np.where(point_map == n, np.inf, 0.0)
+        check_node = int(nodemap[rows[i], cols[i]])          # the i-th entry of the point list (:124)
+        sources, grounds, finite = get_sources_and_grounds(source_map, ground_map, G, nodemap,
+                                                           "rmvgnd" if one_to_all else "rmvsrc")
+        prob = AdvancedProblem(G=G, cc=cc, nodemap=nodemap, polymap=newpoly, sources=sources, grounds=grounds,
+                               finitegrounds=finite, cellmap=gmap, solver=solver, source_map=source_map,
+                               check_node=check_node, src=n)
+        ret, curr, maps = raster_advanced_kernel(prob, sub, cfg)
+        res[i] = ret[0, 0]
+        per_point[n] = maps
+        cum.cum_curr += curr
+        if of.write_max_cur_maps:
+            cum.max_curr = np.maximum(cum.max_curr, curr)
+    if of.write_cur_maps or of.write_cum_cur_map_only:
+        cum.cum_curr = _process_grid(cum.cum_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+        if of.write_max_cur_maps:
+            cum.max_curr = _process_grid(cum.max_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+    return np.column_stack([np.asarray(points_unique, dtype=np.float64), res]), cum, per_point
+
+
 def _colmajor_nonzero(mask):
     jj, ii = np.nonzero(np.asarray(mask).T)
     return ii, jj

@@ -31,6 +31,12 @@ def raster_advanced_cases():
     return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgVerify"))
 
 
+def onetoall_cases():
+    """raster one-to-all (13) and all-to-one (12) cases"""
+    return sorted(f[:-5] for f in os.listdir(GOLDEN)
+                  if f.endswith(".json") and (f.startswith("oneToAllVerify") or f.startswith("allToOneVerify")))
+
+
 def compare_aagrid(expected, got, tol=1e-6):
     """the reference's map criterion (test/test_utils.jl:196): sum of squared differences below tol"""
     return float(np.sum((np.asarray(expected, dtype=float) - np.asarray(got, dtype=float)) ** 2)) < tol

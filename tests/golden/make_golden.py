@@ -392,11 +392,58 @@ def raster_advanced_case(idx):
             "expected": exp}
 
 
+def onetoall_case(kind, idx):
+    """oneToAllVerify<idx> / allToOneVerify<idx> (test/test_utils.jl:123-140): inputs after load_raster_data and the
+    golden per-point resistances, per-point voltage / current maps, cumulative and maximum current maps."""
+    name = ("oneToAllVerify%d" if kind == "one_to_all" else "allToOneVerify%d") % idx
+    d = parse_ini(os.path.join(REF, "input/raster/%s/%d/%s.ini" % (kind, idx, name)))
+    assert d["scenario"] == ("one-to-all" if kind == "one_to_all" else "all-to-one")
+    g, hb = read_cellmap(resolve(d["habitat_file"]), truthy(d, "habitat_map_is_resistances"))
+    opts = {k: truthy(d, k) for k in (
+        "connect_four_neighbors_only", "connect_using_avg_resistances", "use_polygons", "use_mask", "write_volt_maps",
+        "write_cur_maps", "write_cum_cur_map_only", "write_max_cur_maps", "log_transform_maps",
+        "set_null_currents_to_nodata", "set_null_voltages_to_nodata", "use_included_pairs",
+        "use_variable_source_strengths")}
+    polymap = None
+    if opts["use_polygons"]:
+        polymap = read_polymap(resolve(d["polygon_file"]))[0].astype(int).tolist()
+    if opts["use_mask"]:
+        mk, _ = read_polymap(resolve(d["mask_file"]))
+        g = g * (mk > 0)
+    strengths = None
+    if opts["use_variable_source_strengths"]:
+        with open(resolve(d["variable_source_file"])) as f:
+            a = np.array([ln.split() for ln in f if ln.strip()], dtype=np.float64)
+        if a[:, 0].min() == 0:   # read_point_strengths, io.jl:84-89
+            a[:, 0] += 1
+        strengths = a.tolist()
+    ov = os.path.join(REF, "output_verify")
+    with open(os.path.join(ov, name + "_resistances.out")) as f:
+        res = [[float(x) for x in ln.split()] for ln in f if ln.strip()]
+    maps = {"points": {}}
+    for key in ("cum_curmap", "max_curmap"):
+        fn = os.path.join(ov, "%s_%s.asc" % (name, key))
+        if os.path.exists(fn):
+            maps[key] = read_aagrid(fn)[0].tolist()
+    for fn in sorted(os.listdir(ov)):
+        for key in ("curmap", "voltmap"):
+            pre = "%s_%s_" % (name, key)
+            if fn.startswith(pre) and fn.endswith(".asc"):
+                maps["points"].setdefault(fn[len(pre):-4], {})[key] = read_aagrid(os.path.join(ov, fn))[0].tolist()
+    return {"name": name, "kind": kind, "ini_solver": d.get("solver", "cg+amg"), "options": opts,
+            "cellmap": g.tolist(), "polymap": polymap, "points_rc": read_point_map(resolve(d["point_file"]), hb),
+            "included_pairs": (read_included_pairs(resolve(d["included_pairs_file"]))
+                               if opts["use_included_pairs"] else None),
+            "strengths": strengths, "expected": res, "maps": maps}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     cases = ([raster_case(k) for k in range(1, 18)] + [network_case(k) for k in range(1, 4)] +
-             [network_advanced_case(k) for k in range(1, 4)] + [raster_advanced_case(k) for k in range(1, 7)])
+             [network_advanced_case(k) for k in range(1, 4)] + [raster_advanced_case(k) for k in range(1, 7)] +
+             [onetoall_case("one_to_all", k) for k in range(1, 14)] +
+             [onetoall_case("all_to_one", k) for k in range(1, 13)])
     for c in cases:
         with open(os.path.join(OUT, c["name"] + ".json"), "w") as f:
             json.dump(c, f, separators=(",", ":"))

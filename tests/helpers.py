@@ -131,6 +131,53 @@ def run_raster_advanced_fixture(case, solver):
     return ps.raster_advanced_kernel(prob, flags)
 
 
+def _build_graph(o):
+    def build(gmap, polymap):
+        nodemap = rg.construct_node_map(gmap, polymap)
+        a = rg.construct_graph(gmap, nodemap, o["connect_using_avg_resistances"], o["connect_four_neighbors_only"])
+        return nodemap, rg.laplacian(a), rg.connected_components(a)
+    return build
+
+
+def run_onetoall_fixture(case, solver):
+    """raster_one_to_all (src/raster/onetoall.jl:1-11) for a oneToAllVerify / allToOneVerify fixture through the
+    product's host mirror. Returns (res, cum, per-point maps)."""
+    from circuitscape_jl_amd import solver as ps
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.is_onetoall = case["kind"] == "one_to_all"
+    flags.is_alltoone = not flags.is_onetoall
+    polymap = np.asarray(case["polymap"], dtype=np.int64) if case.get("polymap") is not None else None
+    return ps.onetoall_kernel(np.asarray(case["cellmap"], dtype=np.float64), polymap, case["points_rc"], flags, solver,
+                              _build_graph(o), strengths=case.get("strengths"),
+                              included_pairs=case.get("included_pairs"))
+
+
+def check_onetoall_against_golden(case, res, cum, points):
+    """What the reference's own test compares (test/test_utils.jl:123-140,158-176): the resistances file and every
+    map the run writes under its INI flags, maps with the sum-of-squares criterion."""
+    from conftest import compare_aagrid
+    o = case["options"]
+    exp = np.array(case["expected"])
+    assert exp.shape == res.shape and np.array_equal(exp[:, 0], res[:, 0])
+    assert np.max(np.abs(exp[:, 1] - res[:, 1])) < 1e-6 * max(1.0, np.abs(exp[:, 1]).max()), (exp, res)
+    m = case["maps"]
+    if (o["write_cur_maps"] or o["write_cum_cur_map_only"]) and "cum_curmap" in m:
+        assert compare_aagrid(m["cum_curmap"], cum.cum_curr), "cum_curmap"
+        if o["write_max_cur_maps"] and "max_curmap" in m:
+            assert compare_aagrid(m["max_curmap"], cum.max_curr), "max_curmap"
+    checked = 0
+    for pid, got in points.items():
+        gold = m["points"].get(str(int(pid)), {})
+        if o["write_cur_maps"] and not o["write_cum_cur_map_only"] and "curmap" in gold:
+            assert compare_aagrid(gold["curmap"], got["curmap"]), ("curmap", pid)
+            checked += 1
+        if o["write_volt_maps"] and "voltmap" in gold:
+            assert compare_aagrid(gold["voltmap"], got["voltmap"]), ("voltmap", pid)
+            checked += 1
+    return checked
+
+
 def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0, n_cols=None):
     """Every operator of level 0 (A, P, R, Q, Q^T, [S Q]) times a random block of vectors, through the launcher the
     V-cycle uses for it, against scipy on the matrices read back from the handle; plus the dot fused into [S Q]."""

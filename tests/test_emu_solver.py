@@ -456,3 +456,15 @@ def test_raster_advanced_through_product_path(emu_lib, name):
     for key, exp in case["expected"].items():
         assert compare_aagrid(exp, maps[key]), (name, key)
         assert np.max(np.abs(maps[key] - ref[key])) < 1e-7 * max(1.0, np.abs(ref[key]).max()), (name, key)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").onetoall_cases())
+def test_onetoall_alltoone_through_product_path(emu_lib, name):
+    """scope row N2: one-to-all / all-to-one (25 reference cases, including the included-pairs + variable-strength
+    ones) through the product's host mirror and the kernels: resistances, per-point voltage / current maps,
+    cumulative and maximum current maps against the goldens."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import check_onetoall_against_golden, run_onetoall_fixture
+    case = load_case(name)
+    res, cum, pts = run_onetoall_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
+    check_onetoall_against_golden(case, res, cum, pts)

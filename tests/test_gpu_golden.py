@@ -140,3 +140,14 @@ def test_raster_advanced_on_gpu(gpu_lib, name):
     _, _, maps = run_raster_advanced_fixture(case, ps.HIPAMGSolver(bs=1))
     for key, exp in case["expected"].items():
         assert compare_aagrid(exp, maps[key]), (name, key)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").onetoall_cases())
+def test_onetoall_alltoone_on_gpu(gpu_lib, name):
+    """scope row N2: the 25 one-to-all / all-to-one cases on the device with the reference's stopping rule."""
+    from circuitscape_jl_amd import solver as ps
+    from conftest import load_case
+    from helpers import check_onetoall_against_golden, run_onetoall_fixture
+    case = load_case(name)
+    res, cum, pts = run_onetoall_fixture(case, ps.HIPAMGSolver(bs=1))
+    check_onetoall_against_golden(case, res, cum, pts)

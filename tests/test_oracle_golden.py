@@ -68,3 +68,19 @@ def test_oracle_raster_advanced_matches_golden(oracle, name, mode):
     assert case["expected"], name
     for key, exp in case["expected"].items():
         assert compare_aagrid(exp, got[key]), (name, key)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").onetoall_cases())
+@pytest.mark.parametrize("mode", ["direct", "reference"])
+def test_oracle_onetoall_alltoone_matches_golden(oracle, name, mode):
+    """scope row N2: the restated one-to-all / all-to-one drivers against the reference's 25 goldens: the
+    resistances file of every case, and every map the run writes under its INI flags (what the reference's own
+    test compares, test/test_utils.jl:123-140,158-176) with the sum-of-squares criterion."""
+    from types import SimpleNamespace
+    from conftest import load_case
+    from helpers import check_onetoall_against_golden
+    from oracle import refonetoall
+    case = load_case(name)
+    r = refonetoall.onetoall_from_fixture(case, mode=mode)
+    cum = SimpleNamespace(cum_curr=r["cum"], max_curr=r["max"])
+    check_onetoall_against_golden(case, r["res"], cum, {int(k): v for k, v in r["points"].items()})
