@@ -312,6 +312,25 @@ def onetoall_kernel(gmap, polymap, points_rc, flags, solver, build_graph, streng
     return np.column_stack([np.asarray(points_unique, dtype=np.float64), res]), cum, per_point
 
 
+def compute_omniscape_current(conductance, source, ground, cs_cfg, build_graph, solver=None):
+    """compute_omniscape_current (src/utils.jl:145-257), the entry point Omniscape.jl calls for every moving-window
+    solve: advanced mode on in-memory rasters (no polygons, policy rmvsrc, conductances never averaged as
+    resistances), returning the raw accumulated node-current map. `cs_cfg`: mapping with the reference's INI keys
+    ('connect_four_neighbors_only', 'solver', 'cholmod_batch_size'); build_graph as in onetoall_kernel (receives the
+    four-neighbour flag through the closure the caller builds from the same cfg)."""
+    conductance = np.asarray(conductance, dtype=np.float64)
+    solver = solver or get_solver({"solver": cs_cfg.get("solver", "hip") if cs_cfg.get("solver") in HIP else "hip",
+                                   "cholmod_batch_size": cs_cfg.get("cholmod_batch_size", 8)})
+    nodemap, G, cc = build_graph(conductance, None)
+    G = sp.csr_matrix(G)
+    sources, grounds, finite = get_sources_and_grounds(source, ground, G, nodemap, "rmvsrc")
+    of = OutputFlags(write_cur_maps=True)
+    prob = AdvancedProblem(G=G, cc=cc, nodemap=nodemap, polymap=None, sources=sources, grounds=grounds,
+                           finitegrounds=finite, cellmap=conductance, solver=solver, source_map=np.asarray(source))
+    _, outcurr, _ = raster_advanced_kernel(prob, Flags(is_raster=True, outputflags=of, policy="rmvsrc"))
+    return outcurr
+
+
 def _colmajor_nonzero(mask):
     jj, ii = np.nonzero(np.asarray(mask).T)
     return ii, jj

@@ -291,3 +291,14 @@ def raster_advanced_from_fixture(case, mode="direct", solve=None):
         "curmap": process_grid(outcurr, gmap, o["log_transform_maps"], o["set_null_currents_to_nodata"]),
         "volt": volt,
     }
+
+
+def compute_omniscape_current(conductance, source, ground, four_neighbors=False, mode="direct", solve=None):
+    """compute_omniscape_current (src/utils.jl:145-257): advanced mode on in-memory rasters -- no polygons, policy
+    :rmvsrc, avg_res = false (utils.jl:193-196) -- returning the raw accumulated current map."""
+    case = {"options": {"connect_using_avg_resistances": False, "connect_four_neighbors_only": four_neighbors,
+                        "remove_src_or_gnd": "rmvsrc", "set_null_voltages_to_nodata": False,
+                        "set_null_currents_to_nodata": False, "log_transform_maps": False},
+            "cellmap": np.asarray(conductance, dtype=np.float64), "polymap": None,
+            "source_map": np.asarray(source, dtype=np.float64), "ground_map": np.asarray(ground, dtype=np.float64)}
+    return raster_advanced_from_fixture(case, mode=mode, solve=solve)["curmap"]

@@ -468,3 +468,37 @@ def test_onetoall_alltoone_through_product_path(emu_lib, name):
     case = load_case(name)
     res, cum, pts = run_onetoall_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
     check_onetoall_against_golden(case, res, cum, pts)
+
+
+def _omniscape_window(n, seed):
+    """A moving-window style problem: circular window of valid cells, unit sources scattered inside, the centre
+    cell grounded with conductance 1 (what Omniscape hands to compute_omniscape_current)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:n, 0:n]
+    inside = (yy - n // 2) ** 2 + (xx - n // 2) ** 2 <= (n // 2) ** 2
+    cond = np.where(inside, np.exp(rng.standard_normal((n, n))), 0.0)
+    source = np.where(inside & (rng.random((n, n)) < 0.05), rng.random((n, n)) + 0.5, 0.0)
+    ground = np.zeros((n, n))
+    ground[n // 2, n // 2] = 1.0
+    source[n // 2, n // 2] = 0.0
+    return cond, source, ground
+
+
+def test_compute_omniscape_current(emu_lib):
+    """scope row N3 (entry point only): compute_omniscape_current on the reference's own 3x3 smoke input
+    (test/internal.jl:6-43) and on a circular moving window, product path against the oracle's direct solve."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import _build_graph
+    from oracle import refmaps
+    cfg = {"connect_four_neighbors_only": "False", "solver": "hip", "cholmod_batch_size": "1"}
+    build = _build_graph({"connect_using_avg_resistances": False, "connect_four_neighbors_only": False})
+    tight = ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1})
+    cases = [(np.array([[1, 5, 1.0], [2, 1, 1], [9, 1, 6]]), np.array([[1, 0, 0.0], [0, 0, 0], [0, 1, 0]]),
+              np.array([[0, 0, 1.0], [0, 0, 0], [0, 0, 0]])), _omniscape_window(31, 3)]
+    for cond, src, gnd in cases:
+        got = ps.compute_omniscape_current(cond, src, gnd, cfg, build, solver=tight)
+        ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
+        assert got.shape == cond.shape and np.all(got[cond == 0] == 0)
+        assert np.max(np.abs(got - ref)) < 1e-8 * max(1.0, ref.max())
+        # all injected current leaves through the ground cell
+        assert abs(got[gnd > 0].sum() - src[(cond > 0)].sum()) < 1e-6 * src.sum()

@@ -151,3 +151,18 @@ def test_onetoall_alltoone_on_gpu(gpu_lib, name):
     case = load_case(name)
     res, cum, pts = run_onetoall_fixture(case, ps.HIPAMGSolver(bs=1))
     check_onetoall_against_golden(case, res, cum, pts)
+
+
+def test_compute_omniscape_current_on_gpu(gpu_lib):
+    """scope row N3 (entry point only): a 201-cell-wide circular moving window through compute_omniscape_current on
+    the device (reference stopping rule) against the oracle's direct solve of the same grounded system."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import _build_graph
+    from oracle import refmaps
+    from test_emu_solver import _omniscape_window
+    cond, src, gnd = _omniscape_window(201, 5)
+    build = _build_graph({"connect_using_avg_resistances": False, "connect_four_neighbors_only": False})
+    got = ps.compute_omniscape_current(cond, src, gnd, {"solver": "hip"}, build, solver=ps.HIPAMGSolver(bs=1))
+    ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
+    assert np.max(np.abs(got - ref)) < 2e-5 * ref.max()
+    assert abs(got[gnd > 0].sum() - src[cond > 0].sum()) < 1e-4 * src.sum()
