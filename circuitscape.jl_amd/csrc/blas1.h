@@ -246,4 +246,21 @@ __global__ __launch_bounds__(256) void relres_kernel(CgScalars* S, const double*
   }
 }
 
+// Re-open columns that stopped on the configured rule but whose explicit residual ||Ax-b||/||b|| is not below `limit`:
+// they continue on the true-residual criterion until ||r|| <= target * ||b||. The CG state of a finished column is
+// r = b - A x (invariant of the updates), z = M^-1 r, p = z, gamma = r'z, beta = 0 -- exactly a restart from x.
+template <int K>
+__global__ void cg_reopen_kernel(CgScalars* S, double limit, double target, int ncols_active) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int all = 1;
+  for (int c = 0; c < K; ++c) {
+    if (c < ncols_active && S->done[c] == 1 && !(S->relres[c] < limit)) {
+      S->done[c] = 0;
+      S->eps[c] = target * S->bnorm[c];
+    }
+    if (!S->done[c]) all = 0;
+  }
+  S->all_done = all;
+}
+
 }  // namespace csgpu

@@ -91,13 +91,15 @@ struct Solver : ISolver {
     sp.two_product = opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0 && !no_two_product;
     return sp;
   }
-  PcgParams pcg_params() const {
+  PcgParams pcg_params(int K = 1) const {
     PcgParams pp;
     pp.rtol = opts.rtol;
     pp.atol = opts.atol;
     pp.criterion = opts.criterion;
     pp.itmax = opts.itmax;
-    pp.check_every = opts.check_every > 0 ? opts.check_every : 4;
+    // auto: poll every iteration once an iteration takes milliseconds (a 20 us host round trip is then free and no
+    // surplus iteration is ever enqueued), every 4th in the launch-latency regime
+    pp.check_every = opts.check_every > 0 ? opts.check_every : ((int64_t)n * K >= ((int64_t)1 << 25) ? 1 : 4);
     pp.nu_pre = opts.nu_pre;
     pp.nu_post = opts.nu_post;
     pp.nu_coarse = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
@@ -224,7 +226,7 @@ struct Solver : ISolver {
 
   template <int K>
   PcgBatchResult run_batch(int ncols) {
-    return pcg_solve<T, TP, K>(cg_matrix(), H, W, pcg_params(), ncols, st);
+    return pcg_solve<T, TP, K>(cg_matrix(), H, W, pcg_params(K), ncols, st);
   }
   PcgBatchResult run_batch_k(int K, int ncols) {
     switch (K) {
@@ -249,6 +251,7 @@ struct Solver : ISolver {
     s->cg_spmv_ms += r.spmv_ms;
     s->cg_spmv_calls += r.spmv_calls;
     s->graph_launches += r.graph_launches;
+    s->polished_batches += r.polished;
   }
 
 #define CS_DISPATCH_K(K, ...)                               \
@@ -618,7 +621,7 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->criterion = CSGPU_CRIT_KRYLOV;
   o->itmax = 100000;
   o->batch = 8;
-  o->check_every = 4;
+  o->check_every = 0;
   o->nu_coarse = 3;
   o->theta = 0.0;
   o->omega_p = 1.6;

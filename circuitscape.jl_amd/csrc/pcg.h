@@ -287,6 +287,7 @@ struct PcgBatchResult {
   double spmv_ms = 0;
   int64_t spmv_calls = 0;
   int64_t graph_launches = 0;
+  int polished = 0;
 };
 
 // Solve A X = B for the K interleaved columns held in W.b; solution left in W.x.
@@ -355,6 +356,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int graph_launches = 0;
   fuse.xa_ready = fuse_xa;
   fuse.skip = &S->all_done;
+  int criterion = pp.criterion;  // switches to the true residual for the polishing phase (below)
   // one PCG iteration as a sequence of launches on `st` (no host interaction: this is what gets captured)
   auto iteration = [&](bool time_it) {
     // Ap = A p, fused partials of p'Ap
@@ -384,7 +386,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pc, spmv_g);
     // r -= alpha Ap, fused with the TP copy of r, the level-0 first pre-smoothing sweep xa = omega D^-1 r and
     // (when the true residual is monitored) the partials of r'r
-    if (pp.criterion == CSGPU_CRIT_TRUE_RESIDUAL)
+    if (criterion == CSGPU_CRIT_TRUE_RESIDUAL)
       hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
                          (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
                          (const TP*)dptr<TP>(L0.dinv), omega0, pb);
@@ -394,7 +396,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
                          (const TP*)dptr<TP>(L0.dinv), omega0, pb);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
     hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
-                       pp.criterion, pp.rtol, atol, 0, ncols_active);
+                       criterion, pp.rtol, atol, 0, ncols_active);
     // x += alpha p ; p = z + beta p   (one pass over p)
     hipLaunchKernelGGL((cg_update_xp_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p,
                        (const TP*)z);
@@ -410,7 +412,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   PcgGraphKey gkey;
   gkey.K = K;
   gkey.ncols_active = ncols_active;
-  gkey.criterion = pp.criterion;
+  gkey.criterion = criterion;
   gkey.nu_pre = pp.nu_pre;
   gkey.nu_post = pp.nu_post;
   gkey.nu_coarse = pp.nu_coarse;
@@ -448,32 +450,57 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     return ge;
   };
 
-  while (!host_done && it < pp.itmax) {
-    const int todo = (int)std::min<int64_t>(chunk, (int64_t)pp.itmax - it);
-    hipGraphExec_t ge = (want_graph && it > 0 && todo == chunk) ? chunk_graph() : nullptr;
-    if (ge) {
-      CS_HIP(hipGraphLaunch(ge, st));
-      ++graph_launches;
-    } else {
-      for (int c = 0; c < todo; ++c) iteration(true);
+  auto run_loop = [&]() {
+    while (!host_done && it < pp.itmax) {
+      const int todo = (int)std::min<int64_t>(chunk, (int64_t)pp.itmax - it);
+      gkey.criterion = criterion;
+      hipGraphExec_t ge = (want_graph && it > 0 && todo == chunk) ? chunk_graph() : nullptr;
+      if (ge) {
+        CS_HIP(hipGraphLaunch(ge, st));
+        ++graph_launches;
+      } else {
+        for (int c = 0; c < todo; ++c) iteration(true);
+      }
+      it += todo;
+      check_launch("pcg iteration");
+      CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
     }
-    it += todo;
-    check_launch("pcg iteration");
-    CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
-    CS_HIP(hipStreamSynchronize(st));
-  }
+  };
   // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
-  {
+  PcgBatchResult res;
+  auto post_check = [&]() {
     SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
     a.order = orderA;
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);
     hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
     hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv);
+    CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+  };
+  run_loop();
+  post_check();
+  // Polishing. Krylov.jl's rule stops on the PRECONDITIONED residual norm; on nearly singular grounded systems (one
+  // weak ground in a large component) that norm can be 100x more optimistic than ||Ax-b||/||b||, and the reference's
+  // own 1e-4 check (core.jl:640) is then decided by how the preconditioner happens to weight the near-null space.
+  // A column that stopped "converged" but would fail that check is re-opened and iterated on the true residual
+  // (CG restarts from x with p = z: state is consistent, see cg_reopen_kernel) until ||r||/||b|| <= 2.5e-5. Columns
+  // that pass -- every case in which the reference's rule is adequate -- are untouched, bit for bit.
+  {
+    bool reopen = false;
+    for (int c = 0; c < ncols_active && c < kMaxK; ++c)
+      if (res.s.done[c] == 1 && !(res.s.relres[c] < 1e-4)) reopen = true;
+    if (reopen && it < pp.itmax) {
+      criterion = CSGPU_CRIT_TRUE_RESIDUAL;
+      hipLaunchKernelGGL((cg_reopen_kernel<K>), dim3(1), dim3(64), 0, st, S, 1e-4, 2.5e-5, ncols_active);
+      host_done = 0;
+      run_loop();
+      post_check();
+      res.polished = 1;
+    }
   }
   CS_HIP(hipEventRecord(e1, st));
-  PcgBatchResult res;
-  CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
   check_launch("pcg finish");
   float ms = 0;

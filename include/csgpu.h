@@ -76,7 +76,8 @@ typedef struct csgpu_opts {
   int32_t criterion;      /* CSGPU_CRIT_*, default KRYLOV (the reference's rule) */
   int32_t itmax;          /* default 100000 (core.jl:639) */
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
-  int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 4 */
+  int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
+                             every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
   int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 3 */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
   double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting: P = T - omega_p Dl^-1 A T.
@@ -134,6 +135,8 @@ typedef struct csgpu_stats {
   int32_t batch;                /* batch width actually used */
   int32_t not_converged;        /* number of rhs that hit itmax / broke down / failed the 1e-4 check */
   int64_t graph_launches;       /* hipGraph replays issued (each = check_every PCG iterations) */
+  int64_t polished_batches;     /* batches that were re-opened on the true residual because a column stopped on the
+                                   configured rule with ||Ax-b||/||b|| >= 1e-4 (the reference would have errored) */
 } csgpu_stats;
 
 int csgpu_device_count(void);
