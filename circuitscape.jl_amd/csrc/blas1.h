@@ -70,6 +70,23 @@ __device__ __forceinline__ double reduce_partials(const double* partials, int np
   return block_sum_256(s, sm);
 }
 
+// Collapse `nparts` partial rows to kCollapsedParts rows (row r = sum of a contiguous chunk of input rows, in order:
+// deterministic), so that the single-workgroup scalar kernels below never walk more than a few hundred rows however
+// many workgroups the producing SpMM launch had. One thread per (output row, column).
+static const int kCollapsedParts = 256;
+template <int K>
+__global__ __launch_bounds__(256) void collapse_partials_kernel(const double* __restrict__ in, int nparts,
+                                                                double* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= kCollapsedParts * K) return;
+  const int r = t / K, c = t % K;
+  const int chunk = (nparts + kCollapsedParts - 1) / kCollapsedParts;
+  const int lo = r * chunk, hi = min(nparts, lo + chunk);
+  double s = 0.0;
+  for (int i = lo; i < hi; ++i) s += in[(size_t)i * K + c];
+  out[(size_t)r * K + c] = s;
+}
+
 // ---- scalar kernel 1: pAp -> alpha
 template <int K>
 __global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const double* partials, int nparts) {

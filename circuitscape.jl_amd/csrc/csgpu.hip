@@ -522,7 +522,7 @@ struct Solver : ISolver {
     const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
     CS_REQUIRE(M.nnz > 0, CSGPU_BAD_ARGS, "level has no such operator");
     DBuf x((size_t)M.ncols * k * sizeof(TP)), y((size_t)M.nrows * k * sizeof(TP));
-    DBuf part = dalloc<double>((size_t)16384 * kMaxK);
+    DBuf part = dalloc<double>(std::max<size_t>(16384, spmv_grid_upper(M.nrows)) * kMaxK);
     CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
     SpmvArgs<TP> a = spmv_args(M, (const TP*)dptr<TP>(x), dptr<TP>(y));
     const bool sq = which == 5;

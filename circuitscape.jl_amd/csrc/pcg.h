@@ -245,6 +245,7 @@ struct PcgWork {
   DBuf z, rp;                 // TP: preconditioned residual; TP copy of r (aliases r when TP == T)
   DBuf scalars;               // CgScalars
   DBuf part_a, part_b, part_c;
+  DBuf part_ca, part_cc;      // collapsed copies of part_a / part_c (collapse_partials_kernel)
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
   std::vector<std::pair<PcgGraphKey, hipGraphExec_t>> graphs;  // captured iteration chunks
   bool graph_broken = false;                                   // capture failed once: stay on direct launches
@@ -270,10 +271,13 @@ struct PcgWork {
     z.alloc((size_t)n * K * sizeof(TP));
     if (!SAME) rp.alloc((size_t)(n + tail) * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
-    const size_t pb = (size_t)16384 * kMaxK * sizeof(double);  // >= spmv_grid() and kMaxGrid partial rows
+    // one row of kMaxK partials per workgroup of the largest launch: spmv_grid() and grid_for() (<= kMaxGrid)
+    const size_t pb = std::max<size_t>(16384, spmv_grid_upper(n)) * kMaxK * sizeof(double);
     part_a.alloc(pb);
     part_b.alloc(pb);
     part_c.alloc(pb);
+    part_ca.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
+    part_cc.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
   }
   ~PcgWork() {
     drop_graphs();
@@ -341,8 +345,20 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
   hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
                      (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
-  hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
-                     pp.criterion, pp.rtol, atol, 1, ncols_active);
+  // partial rows of the big SpMM-shaped launches are collapsed before the single-workgroup scalar kernels read them
+  double* pac = dptr<double>(W.part_ca);
+  double* pcc = dptr<double>(W.part_cc);
+  auto collapsed = [&](double* src, int nparts, double* dst) -> std::pair<const double*, int> {
+    if (nparts <= 4 * kCollapsedParts) return {src, nparts};
+    hipLaunchKernelGGL((collapse_partials_kernel<K>), dim3(ceil_div(kCollapsedParts * K, 256)), dim3(256), 0, st,
+                       (const double*)src, nparts, dst);
+    return {dst, kCollapsedParts};
+  };
+  {
+    auto rz = collapsed(pa, spmv_gp, pac);
+    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
+                       pp.criterion, pp.rtol, atol, 1, ncols_active);
+  }
   CS_HIP(hipMemcpyAsync(p, z, (size_t)n * K * sizeof(TP), hipMemcpyDeviceToDevice, st));
   check_launch("pcg init");
 
@@ -383,7 +399,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
         ++timed;
       }
     }
-    hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pc, spmv_g);
+    {
+      auto pap = collapsed(pc, spmv_g, pcc);
+      hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, pap.first, pap.second);
+    }
     // r -= alpha Ap, fused with the TP copy of r, the level-0 first pre-smoothing sweep xa = omega D^-1 r and
     // (when the true residual is monitored) the partials of r'r
     if (criterion == CSGPU_CRIT_TRUE_RESIDUAL)
@@ -395,8 +414,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
                          (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
                          (const TP*)dptr<TP>(L0.dinv), omega0, pb);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
-    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, spmv_gp, (const double*)pb, gv,
-                       criterion, pp.rtol, atol, 0, ncols_active);
+    {
+      auto rz = collapsed(pa, spmv_gp, pac);
+      hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
+                         criterion, pp.rtol, atol, 0, ncols_active);
+    }
     // x += alpha p ; p = z + beta p   (one pass over p)
     hipLaunchKernelGGL((cg_update_xp_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p,
                        (const TP*)z);

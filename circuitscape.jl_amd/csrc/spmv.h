@@ -53,6 +53,8 @@ enum SpmvEpi {
   EPI_QADD = 4     // y = xadd + omega * dinv .* b + A x   (fused prolongation + first post-smoothing sweep, A = Q)
 };
 
+inline int spmv_grid_cap();  // workgroups per launch (defined with spmv_grid below)
+
 static const int kSpmvRows = 256;   // rows per workgroup pass (row-block granularity of the traversal order)
 static const int kSpmvTile = 2560;  // nonzeros staged in LDS per tile
 
@@ -470,7 +472,7 @@ inline bool spmm_longrow_launch(const SpmvArgs<T, T>& a, hipStream_t st) {
   const int rows = longrow_rows(a.nnz, a.nrows);
   if (rows == 0) return false;
   auto grid = [&](int rows) {
-    int g = std::max(1, std::min(16384, ceil_div(a.nrows, rows)));
+    int g = std::max(1, std::min(std::max(1024, spmv_grid_cap()), ceil_div(a.nrows, rows)));
     if (g >= 64) g &= ~7;  // multiple of 8: XCD-aware mapping active
     return g;
   };
@@ -486,13 +488,21 @@ inline bool spmm_longrow_launch(const SpmvArgs<T, T>& a, hipStream_t st) {
 // Workgroups per product: enough (64 per CU) that the hardware dispatcher, which starts workgroups in blockIdx
 // order as slots free up, keeps every XCD's resident set on a contiguous window of its row-block range (that is what
 // makes the band re-use hit in L2); capped so the dot-partial arrays stay small. Measured on MI355X, 10000^2 fp64:
-// 4096 -> 16384 workgroups: K=1 3.22 -> 2.84 ms, K=8 5.74 -> 5.52 ms.
+// 4096 -> 16384 workgroups: K=1 3.22 -> 2.84 ms, K=8 5.74 -> 5.52 ms; 16384 -> 65536 at K=16: 8.12 -> 7.51 ms (262144:
+// 7.79 ms). The partial rows are collapsed to 256 by collapse_partials_kernel before the scalar kernels read them.
 inline int spmv_grid_cap() {  // tuning knob (CSGPU_SPMV_GRID_CAP): 0 = one workgroup per row block
   static int cap = [] {
     const char* e = getenv("CSGPU_SPMV_GRID_CAP");
-    return e ? atoi(e) : 16384;
+    return e ? atoi(e) : 65536;
   }();
   return cap;
+}
+
+// upper bound of spmv_grid() over all K for an nrows-row product (sizes the dot-partial arrays)
+inline size_t spmv_grid_upper(int64_t nrows) {
+  const int cap = spmv_grid_cap();
+  const size_t nb = (size_t)(2 * ((nrows + kSpmvRows - 1) / kSpmvRows) + 8);
+  return cap > 0 ? std::min<size_t>(nb, (size_t)cap) : nb;
 }
 
 template <class T, int K>

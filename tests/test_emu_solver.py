@@ -543,3 +543,19 @@ def test_polishing_reopens_columns_that_would_fail_the_residual_check(emu_lib, b
     _, _, _, st = h.solve_pairs([0, 7, 100, 900][:batch], [3599, 3000, 2000, 1000][:batch])
     assert st["polished_batches"] == 0 and st["not_converged"] == 0
     h.close()
+
+
+def test_collapsed_partials_path(emu_lib, oracle):
+    """More than 1024 row blocks per SpMM launch (370^2 raster at batch 16): the dot partials are collapsed to 256
+    rows before the scalar alpha / beta kernels read them. Resistances against the tight oracle."""
+    from oracle import refgraph as rg
+    N = 370
+    G, g = rg.synthetic_raster_problem(N, N, seed=21)
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=16, precond_bytes=4))
+    cells = np.random.default_rng(3).choice(N * N, size=10, replace=False)
+    src, dst = list(cells[:-1]), list(cells[1:])      # 9 pairs -> one batch of width 16
+    R, _, _, st = h.solve_pairs(src, dst)
+    assert st["not_converged"] == 0 and st["batch"] == 16
+    Ro, _, _ = oracle.OracleAMG(oracle.regularize(G)).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-5
+    h.close()
