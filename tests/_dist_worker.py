@@ -26,9 +26,12 @@ def main():
     h = lib.raster_setup(g, lib.default_opts(batch=4))
     full, stats = shard.solve_pairs_sharded(h, src, dst, batch=4, dist=dist)
     mine = shard.shard_batches(len(src), 4, rank, world)
+    # scope row N1 across ranks: cumulative / maximum node-current vectors, one all_reduce(SUM) + one all_reduce(MAX)
+    R2, cum, mx, _ = shard.solve_pairs_currents_sharded(h, src, dst, batch=4, dist=dist, want_max=True)
     h.close()
     if rank == 0:
-        json.dump({"R": full.tolist(), "src": src, "dst": dst, "n_mine_rank0": int(len(mine)), "world": world}, open(out_path, "w"))
+        json.dump({"R": full.tolist(), "src": src, "dst": dst, "n_mine_rank0": int(len(mine)), "world": world,
+                   "R2": R2.tolist(), "cum": cum.tolist(), "max": mx.tolist()}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -33,3 +33,13 @@ def test_two_ranks_gloo_match_oracle(emu_lib, oracle, tmp_path):
     A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
     Ro, _, _ = oracle.OracleAMG(A).solve_pairs(d["src"], d["dst"], rtol=1e-12, atol=0.0, criterion=1)
     assert np.max(np.abs(np.array(d["R"]) - Ro) / Ro) < 1e-6
+    # current maps reduced across the two ranks == the single-process accumulation over all pairs
+    assert np.array_equal(np.array(d["R2"]), np.array(d["R"]))
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=4))
+    n = N * N
+    cum = np.zeros(n)
+    mx = np.full(n, -9999.0)
+    h.solve_pairs_currents(d["src"], d["dst"], want_currents=False, cum=cum, mx=mx)
+    h.close()
+    assert np.max(np.abs(np.array(d["cum"]) - cum)) < 1e-12 * cum.max()
+    assert np.array_equal(np.array(d["max"]), mx)
