@@ -559,3 +559,26 @@ def test_collapsed_partials_path(emu_lib, oracle):
     Ro, _, _ = oracle.OracleAMG(oracle.regularize(G)).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
     assert np.max(np.abs(R - Ro) / Ro) < 1e-5
     h.close()
+
+
+def test_device_raster_laplacian_reproduces_model_problems(emu_lib):
+    """test/internal.jl:176-203: the 2-D model problems (4-neighbour unit-conductance rasters) are what the device
+    graph builder (csgpu_raster_setup, scope row N4) must produce, entry for entry; plus all four connection schemes
+    of construct_graph against the oracle's graph construction on a random raster."""
+    from oracle import refgraph as rg
+    size2 = np.array([[2, -1, -1, 0], [-1, 2, 0, -1], [-1, 0, 2, -1], [0, -1, -1, 2.0]])
+    size3 = np.array([[2, -1, 0, -1, 0, 0, 0, 0, 0], [-1, 3, -1, 0, -1, 0, 0, 0, 0], [0, -1, 2, 0, 0, -1, 0, 0, 0],
+                      [-1, 0, 0, 3, -1, 0, -1, 0, 0], [0, -1, 0, -1, 4, -1, 0, -1, 0], [0, 0, -1, 0, -1, 3, 0, 0, -1],
+                      [0, 0, 0, -1, 0, 0, 2, -1, 0], [0, 0, 0, 0, -1, 0, -1, 3, -1], [0, 0, 0, 0, 0, -1, 0, -1, 2.0]])
+    for n, exp in ((2, size2), (3, size3)):
+        h = emu_lib.raster_setup(np.ones((n, n)), emu_lib.default_opts(batch=1), four_neighbors=True, reg=False)
+        assert np.array_equal(h.level_matrix(0, "A").toarray(), exp)
+        h.close()
+    g = np.exp(np.random.default_rng(9).standard_normal((13, 7)))
+    for four in (False, True):
+        for avg_res in (False, True):
+            h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=1), four_neighbors=four, avg_resistances=avg_res,
+                                     reg=False)
+            ref = rg.raster_laplacian_from_conductance(g, four, avg_res)
+            assert abs(h.level_matrix(0, "A") - ref).max() < 1e-13
+            h.close()
