@@ -23,6 +23,8 @@ struct ISolver {
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
   virtual void spmv_host(const void* x, void* y, int k) = 0;
+  virtual void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) = 0;
+  virtual int64_t components(int32_t* out) = 0;
   virtual void level_spmv_host(int lvl, int which, const void* x, void* y, int k, double* dots) = 0;
   virtual void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz, int32_t* rowptr,
                                 int32_t* colidx, void* vals) const = 0;
@@ -64,6 +66,8 @@ struct Solver : ISolver {
   PcgWork<T, TP> W;
   double upload_ms = 0;
   int64_t n = 0, nnz = 0;
+  DBuf nodemap;                       // csgpu_raster_setup: row-major [rows][cols], 1-based node id, 0 = no node
+  int64_t raster_rows = 0, raster_cols = 0;
   std::mutex mu;
 
   explicit Solver(const csgpu_opts& o) : opts(o) {
@@ -182,23 +186,35 @@ struct Solver : ISolver {
 
   void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg) {
     auto t0 = std::chrono::steady_clock::now();
-    n = R * C;
-    DBuf dcond((size_t)n * sizeof(T));
-    CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+    const int64_t ncells = R * C;
+    DBuf dcond((size_t)ncells * sizeof(T));
+    CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    // node numbering: exclusive scan of the valid-cell flags in column-major order
+    DBuf node = dalloc<int>((size_t)ncells + 1);
+    CS_HIP(hipMemsetAsync(node.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+    const int gc = grid_for(ncells);
+    hipLaunchKernelGGL((raster_valid_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, dptr<T>(dcond), dptr<int>(node));
+    DBuf total = dalloc<int>(1);
+    exclusive_scan_i32(dptr<int>(node), ncells + 1, st, dptr<int>(total));
+    n = read_int(dptr<int>(total), st);
+    CS_REQUIRE(n > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
+    raster_rows = R;
+    raster_cols = C;
+    nodemap.alloc((size_t)ncells * sizeof(int));
     Csr<T> A;
     A.nrows = A.ncols = (int)n;
     A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
     CS_HIP(hipMemsetAsync(A.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
-    hipLaunchKernelGGL(raster_count_kernel, dim3(grid_for(n)), dim3(256), 0, st, (int)R, (int)C, four, A.rp());
-    DBuf total = dalloc<int>(1);
+    hipLaunchKernelGGL((raster_count_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, dptr<T>(dcond),
+                       dptr<int>(node), A.rp(), dptr<int>(nodemap));
     exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
     nnz = read_int(dptr<int>(total), st);
     A.nnz = nnz;
     A.col.alloc((size_t)nnz * sizeof(int));
     A.val.alloc((size_t)nnz * sizeof(T));
     DBuf drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int));
-    hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
-                       dptr<T>(dcond), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol));
+    hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       dptr<T>(dcond), dptr<int>(node), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol));
     if (reg) {
       const int g = grid_for(nnz);
       DBuf part = dalloc<double>(g);
@@ -211,8 +227,28 @@ struct Solver : ISolver {
     check_launch("raster build");
     CS_HIP(hipStreamSynchronize(st));
     dcond.release();
+    node.release();
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol));
+  }
+
+  void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    CS_REQUIRE(nodemap.p != nullptr, CSGPU_BAD_ARGS, "handle was not built by csgpu_raster_setup");
+    if (rows) *rows = raster_rows;
+    if (cols) *cols = raster_cols;
+    if (out) CS_HIP(hipMemcpy(out, nodemap.p, (size_t)raster_rows * raster_cols * sizeof(int), hipMemcpyDeviceToHost));
+  }
+
+  int64_t components(int32_t* out) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    const Csr<T>& A = cg_matrix();
+    DBuf label = dalloc<int>((size_t)n);
+    const int nc = connected_components((int)n, A.rp(), A.ci(), dptr<int>(label), st);
+    if (out) CS_HIP(hipMemcpy(out, label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return nc;
   }
 
   int pick_k(int64_t ncols) const {
@@ -717,6 +753,29 @@ int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_b
     s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
   }
   *out = h.release();
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_raster_nodemap(csgpu_handle* h, int32_t* nodemap_out, int64_t* nrows, int64_t* ncols) {
+  CS_API_BEGIN
+  if (!h) {
+    g_last_error = "null handle";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->raster_nodemap(nodemap_out, nrows, ncols);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_components(csgpu_handle* h, int32_t* component_out, int64_t* ncomponents) {
+  CS_API_BEGIN
+  if (!h) {
+    g_last_error = "null handle";
+    return CSGPU_BAD_ARGS;
+  }
+  const int64_t nc = h->solver->components(component_out);
+  if (ncomponents) *ncomponents = nc;
   return CSGPU_OK;
   CS_API_END
 }

@@ -1,9 +1,10 @@
 // raster.h -- device-side construction of the raster graph Laplacian (scope row N4, used by bench.py and tests).
 //
-// GPU counterpart, for an ALL-VALID raster without polygons, of
+// GPU counterpart, for a raster without polygons (NODATA = conductance <= 0 allowed), of
 //   construct_node_map   src/raster/pairwise.jl:271-301  (column-major numbering of cells with conductance > 0)
 //   construct_graph      src/raster/pairwise.jl:316-362  (E, S, SE, NE neighbours; cond_avg / res_avg, diagonals / sqrt 2)
 //   laplacian!           src/core.jl:608-634
+//   connected_components src/raster/pairwise.jl:233 (Graphs.jl), as min-label hooking + pointer jumping
 // producing the CSR Laplacian directly in HBM (no COO, no host transient): one thread per cell writes its own
 // sorted row. Also emits each node's (row, col) for the tile-seeded aggregation.
 #pragma once
@@ -16,30 +17,62 @@ __device__ __forceinline__ double raster_edge(double x, double y, bool diag, boo
   return diag ? v / 1.4142135623730951 : v;
 }
 
-__global__ __launch_bounds__(256) void raster_count_kernel(int R, int C, int four, int* __restrict__ counts) {
+// Cells with conductance <= 0 (or NaN) are NODATA and get no node (construct_node_map numbers the cells with
+// gmap > 0 in column-major order, pairwise.jl:273-275). flag: one int per cell in COLUMN-major order (id = j*R + i).
+template <class T>
+__global__ __launch_bounds__(256) void raster_valid_kernel(int R, int C, const T* __restrict__ cond,
+                                                           int* __restrict__ flag) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
     const int i = (int)(id % R), j = (int)(id / R);
-    const int up = i > 0, dn = i < R - 1, lf = j > 0, rt = j < C - 1;
-    int cnt = 1 + up + dn + lf + rt;
-    if (!four) cnt += (up & lf) + (dn & lf) + (up & rt) + (dn & rt);
-    counts[id] = cnt;
+    flag[id] = cond[(size_t)i * C + j] > T(0) ? 1 : 0;
   }
 }
 
-// cond: device array, row-major [R][C] (cell (i,j) at i*C + j), all entries > 0.
+// node[id] = exclusive scan of the valid flags (the node index of a valid cell). counts[node] = stored entries of
+// the node's Laplacian row (itself + its valid neighbours); nodemap (row-major, 1-based, 0 = no node) for the host.
 template <class T>
-__global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four, int avg_res,
-                                                          const T* __restrict__ cond, const int* __restrict__ rp,
-                                                          int* __restrict__ ci, T* __restrict__ va,
-                                                          int* __restrict__ nrow, int* __restrict__ ncol) {
+__global__ __launch_bounds__(256) void raster_count_kernel(int R, int C, int four, const T* __restrict__ cond,
+                                                           const int* __restrict__ node, int* __restrict__ counts,
+                                                           int* __restrict__ nodemap) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
     const int i = (int)(id % R), j = (int)(id / R);
-    nrow[id] = i;
-    ncol[id] = j;
+    const bool valid = cond[(size_t)i * C + j] > T(0);
+    nodemap[(size_t)i * C + j] = valid ? node[id] + 1 : 0;
+    if (!valid) continue;
+    int cnt = 1;
+    for (int dj = -1; dj <= 1; ++dj) {
+      const int jj = j + dj;
+      if (jj < 0 || jj >= C) continue;
+      for (int di = -1; di <= 1; ++di) {
+        const int ii = i + di;
+        if (ii < 0 || ii >= R || (di == 0 && dj == 0)) continue;
+        if (four && di != 0 && dj != 0) continue;
+        cnt += cond[(size_t)ii * C + jj] > T(0) ? 1 : 0;
+      }
+    }
+    counts[node[id]] = cnt;
+  }
+}
+
+// cond: device array, row-major [R][C] (cell (i,j) at i*C + j). One thread per valid cell writes its sorted row
+// (neighbours visited in column-major order, and the node numbering is monotone in that order).
+template <class T>
+__global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four, int avg_res,
+                                                          const T* __restrict__ cond, const int* __restrict__ node,
+                                                          const int* __restrict__ rp, int* __restrict__ ci,
+                                                          T* __restrict__ va, int* __restrict__ nrow,
+                                                          int* __restrict__ ncol) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
     const double g0 = (double)cond[(size_t)i * C + j];
-    int k = rp[id];
+    if (!(g0 > 0.0)) continue;
+    const int me = node[id];
+    nrow[me] = i;
+    ncol[me] = j;
+    int k = rp[me];
     int kdiag = -1;
     double deg = 0.0;
     for (int dj = -1; dj <= 1; ++dj) {
@@ -51,11 +84,14 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
         const bool self = (di == 0 && dj == 0);
         const bool diag = (di != 0 && dj != 0);
         if (diag && four) continue;
-        ci[k] = (int)((int64_t)jj * R + ii);
         if (self) {
+          ci[k] = me;
           kdiag = k;
         } else {
-          const double w = raster_edge(g0, (double)cond[(size_t)ii * C + jj], diag, avg_res != 0);
+          const double g1 = (double)cond[(size_t)ii * C + jj];
+          if (!(g1 > 0.0)) continue;
+          ci[k] = node[(int64_t)jj * R + ii];
+          const double w = raster_edge(g0, g1, diag, avg_res != 0);
           va[k] = (T)(-w);
           deg += w;
         }
@@ -64,6 +100,69 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
     }
     va[kdiag] = (T)deg;
   }
+}
+
+// ---- connected components of a symmetric CSR graph (connected_components(SimpleGraph(G)), pairwise.jl:233,
+// advanced.jl:59): min-label hooking + pointer jumping. Invariant: f[x] <= x and f[x] lies in x's component; at the
+// fixed point every node of a component carries the component's smallest node id.
+__global__ __launch_bounds__(256) void cc_hook_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                      int* __restrict__ f, int* __restrict__ changed) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const int fu = f[u];
+    int m = fu;
+    for (int k = rp[u]; k < rp[u + 1]; ++k) m = min(m, f[ci[k]]);
+    if (m < fu) {
+      atomicMin(&f[fu], m);  // hook u's current representative under the smaller label seen next door
+      atomicMin(&f[u], m);
+      *changed = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cc_jump_kernel(int n, int* __restrict__ f, int* __restrict__ changed) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const int p = f[u];
+    const int gp = f[p];
+    if (gp != p) {
+      f[u] = gp;
+      *changed = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cc_root_flag_kernel(int n, const int* __restrict__ f, int* __restrict__ flag) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) flag[u] = f[u] == u ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void cc_relabel_kernel(int n, const int* __restrict__ f, const int* __restrict__ idx,
+                                                         int* __restrict__ label) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) label[u] = idx[f[u]];
+}
+
+// label[u] = dense component index (components ordered by their smallest node id); returns the number of components.
+inline int connected_components(int n, const int* rp, const int* ci, int* label, hipStream_t st) {
+  if (n <= 0) return 0;
+  DBuf f = dalloc<int>(n), flag = dalloc<int>((size_t)n + 1), changed = dalloc<int>(1);
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(256), 0, st, dptr<int>(f), (int64_t)n);
+  for (int round = 0; round < 256; ++round) {
+    CS_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(cc_hook_kernel, dim3(g), dim3(256), 0, st, n, rp, ci, dptr<int>(f), dptr<int>(changed));
+    if (read_int(dptr<int>(changed), st) == 0) break;
+    for (int pass = 0; pass < 64; ++pass) {
+      CS_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));
+      hipLaunchKernelGGL(cc_jump_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(f), dptr<int>(changed));
+      if (read_int(dptr<int>(changed), st) == 0) break;
+    }
+    CS_REQUIRE(round < 255, CSGPU_INTERNAL, "connected components did not converge");
+  }
+  CS_HIP(hipMemsetAsync(flag.p, 0, ((size_t)n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(cc_root_flag_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(f), dptr<int>(flag));
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(dptr<int>(flag), (int64_t)n + 1, st, dptr<int>(total));
+  hipLaunchKernelGGL(cc_relabel_kernel, dim3(g), dim3(256), 0, st, n, dptr<int>(f), dptr<int>(flag), label);
+  check_launch("connected components");
+  return read_int(dptr<int>(total), st);
 }
 
 // nzval .+= eps(T) * norm(nzval)   (src/core.jl:161); norm2 partials come from dot_kernel<T,1,false>

@@ -22,7 +22,7 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
-    "csgpu_get_level_matrix",
+    "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -89,6 +89,8 @@ def _bind(L):
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
     L.csgpu_level_spmv_host.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+    L.csgpu_raster_nodemap.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.csgpu_components.argtypes = [vp, vp, ctypes.POINTER(i64)]
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
     L.csgpu_free.argtypes = [vp]
@@ -249,6 +251,21 @@ class Handle:
         y = np.zeros_like(xi)
         _check(lib().csgpu_spmv_host(self._p, xi.ctypes.data, y.ctypes.data, k))
         return y[:, 0] if x.ndim == 1 else y
+
+    def raster_nodemap(self):
+        """Node map (1-based ids, 0 = NODATA) of a handle built by raster_setup, shape (nrows, ncols)."""
+        r, c = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().csgpu_raster_nodemap(self._p, None, ctypes.byref(r), ctypes.byref(c)))
+        nm = np.zeros((r.value, c.value), dtype=np.int32)
+        _check(lib().csgpu_raster_nodemap(self._p, nm.ctypes.data, None, None))
+        return nm
+
+    def components(self):
+        """(labels, count): dense 0-based component index per node, ordered by smallest node id (device CC)."""
+        lab = np.zeros(self.info["n"], dtype=np.int32)
+        nc = ctypes.c_int64(0)
+        _check(lib().csgpu_components(self._p, lab.ctypes.data, ctypes.byref(nc)))
+        return lab, nc.value
 
     def level_spmv(self, lvl, which, x):
         """y = (level operator) x through the V-cycle's launcher for that operator; returns (y, dots) where dots is

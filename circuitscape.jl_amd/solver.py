@@ -755,6 +755,58 @@ def single_ground_all_pairs(prob, flags, cfg=None, log=True, **kw):
     return solve(prob, prob.solver, flags, cfg, log, **kw)
 
 
+def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, avg_res=False, exclude_pairs=(),
+                              stats=None):
+    """Pairwise mode for a raster WITHOUT polygons with the whole graph layer on the device (scope row N4):
+    csgpu_raster_setup numbers the valid cells, writes the CSR Laplacian in HBM and regularises it (core.jl:161),
+    csgpu_components labels the connected components, and every solvable pair goes to csgpu_solve_pairs in ONE
+    call on ONE handle (the Laplacian of all components is block diagonal; a pair's right-hand side lives in one
+    block). No n-sized array is built on the host except the node map it asks for.
+
+    points_rc: (rows, cols, ids), 1-based, unique ids. Returns the padded resistance matrix of
+    single_ground_all_pairs (core.jl:130,294-299): -1 for pairs in different components or excluded, 0 on the
+    diagonal and for focal points sharing a node."""
+    rows = np.asarray(points_rc[0], dtype=np.int64) - 1
+    cols = np.asarray(points_rc[1], dtype=np.int64) - 1
+    ids = np.asarray(points_rc[2], dtype=np.int64)
+    with lib.raster_setup(np.asarray(cellmap), _opts_for(solver), four_neighbors=four_neighbors,
+                          avg_resistances=avg_res, reg=True) as h:
+        nodemap = h.raster_nodemap()
+        node = nodemap[rows, cols].astype(np.int64)          # 1-based, 0 = focal point on NODATA
+        labels, _ = h.components()
+        comp = np.where(node > 0, labels[np.maximum(node, 1) - 1], -1)
+        npt = len(ids)
+        excl = {(int(a), int(b)) for a, b in exclude_pairs} | {(int(b), int(a)) for a, b in exclude_pairs}
+        res = -np.ones((npt, npt))
+        np.fill_diagonal(res, 0.0)
+        pi, pj = [], []
+        for i in range(npt):
+            for j in range(i + 1, npt):
+                if node[i] == 0 or node[j] == 0 or comp[i] != comp[j] or (int(ids[i]), int(ids[j])) in excl:
+                    continue
+                if node[i] == node[j]:
+                    res[i, j] = res[j, i] = 0.0
+                    continue
+                pi.append(i)
+                pj.append(j)
+        if pi:
+            try:
+                R, _, _, st = h.solve_pairs(node[pi] - 1, node[pj] - 1)
+            except lib.CsgpuError as e:
+                if e.code == lib.CSGPU_NOT_CONVERGED:
+                    _raise_not_converged(e)
+                raise
+            if stats is not None:
+                stats.update(st)
+            res[pi, pj] = R
+            res[pj, pi] = R
+    out = np.zeros((npt + 1, npt + 1))
+    out[0, 1:] = ids
+    out[1:, 0] = ids
+    out[1:, 1:] = res
+    return out
+
+
 def compute_3col(r):
     """out.jl:12-26."""
     fp = r[1:, 0]

@@ -22,7 +22,7 @@
  *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
  *   csgpu_free             <-> GC finalizer of the factor object (PardisoFactorize, Pardiso ext :8-13)
  *   csgpu_last_error       <-> error(msg) strings (core.jl:641,650)
- *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for an all-valid raster
+ *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for a raster without polygons (NODATA allowed)
  *                              (src/raster/pairwise.jl:271-362, src/core.jl:608-634) -- "next" row N4, used by
  *                              bench.py so the synthetic Laplacian is born in HBM
  *
@@ -146,12 +146,23 @@ void csgpu_default_opts(csgpu_opts* opts);
 int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
                 int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out);
 
-/* Build the 4/8-neighbour Laplacian of an all-valid conductance raster directly in HBM and set up AMG.
+/* Build the 4/8-neighbour Laplacian of a conductance raster (no polygons) directly in HBM and set up AMG.
+ * Cells with conductance <= 0 are NODATA (no node), as in construct_node_map.
  * cond: host pointer, nrows*ncols values (row-major, the orientation of the reference's cellmap[i,j]),
  * all > 0; node numbering is column-major like construct_node_map (raster/pairwise.jl:273-275).
  * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). */
 int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
                        int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
+
+/* Node map of a handle built by csgpu_raster_setup: nodemap_out[i*ncols + j] = 1-based node id of cell (i, j) in the
+ * reference's column-major numbering (construct_node_map, src/raster/pairwise.jl:271-301), 0 where the cell is NODATA
+ * (conductance <= 0). Pass NULL to query the raster size only. */
+int csgpu_raster_nodemap(csgpu_handle* h, int32_t* nodemap_out, int64_t* nrows, int64_t* ncols);
+
+/* Connected components of the handle's graph (connected_components(SimpleGraph(G)), src/raster/pairwise.jl:233,
+ * src/raster/advanced.jl:59), computed on the device: component_out[node] (n entries, may be NULL) = dense 0-based
+ * component index, components ordered by their smallest node id; *ncomponents = their number. */
+int csgpu_components(csgpu_handle* h, int32_t* component_out, int64_t* ncomponents);
 
 int csgpu_get_info(const csgpu_handle* h, csgpu_info* info);
 

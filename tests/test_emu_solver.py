@@ -582,3 +582,50 @@ def test_device_raster_laplacian_reproduces_model_problems(emu_lib):
             ref = rg.raster_laplacian_from_conductance(g, four, avg_res)
             assert abs(h.level_matrix(0, "A") - ref).max() < 1e-13
             h.close()
+
+
+@pytest.mark.parametrize("shape,hole_frac,four", [((37, 29), 0.0, False), ((40, 33), 0.35, False), ((31, 44), 0.45, True)])
+def test_device_graph_build_with_nodata(emu_lib, shape, hole_frac, four):
+    """scope row N4: node map, CSR Laplacian and connected components built on the device for rasters with NODATA
+    cells, against the oracle's construct_node_map / construct_graph / laplacian! / connected_components."""
+    from oracle import refgraph as rg
+    rng = np.random.default_rng(shape[0])
+    g = np.exp(rng.standard_normal(shape))
+    g[rng.random(shape) < hole_frac] = 0.0
+    g[0, 0] = 1.0
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=1), four_neighbors=four, reg=False)
+    nodemap = rg.construct_node_map(g, None)
+    assert np.array_equal(h.raster_nodemap(), nodemap)
+    ref = rg.laplacian(rg.construct_graph(g, nodemap, False, four))
+    A = h.level_matrix(0, "A")
+    assert A.shape == ref.shape and abs(A - ref).max() < 1e-13
+    labels, nc = h.components()
+    cc = rg.connected_components(ref)
+    assert nc == len(cc)
+    for c in cc:
+        lab = labels[np.asarray(c) - 1]
+        assert np.all(lab == lab[0])
+    firsts = [labels[min(c) - 1] for c in sorted(cc, key=min)]
+    assert firsts == list(range(nc))      # dense labels ordered by the component's smallest node id
+    h.close()
+
+
+@pytest.mark.parametrize("name", ["sgVerify4", "sgVerify13", "sgVerify17"])
+def test_raster_pairwise_with_device_built_graph(emu_lib, name):
+    """scope row N4 end to end: the reference's pairwise cases that have NODATA, several components and no polygons
+    (two of them with an included-pairs file), graph layer on the device, against the golden resistances."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refgraph as rg
+    case = load_case(name)
+    o = case["options"]
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    exclude = []
+    if case["included_pairs"] is not None:
+        exclude, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+    got = ps.raster_pairwise_on_device(np.array(case["cellmap"], dtype=np.float64), points_rc,
+                                       ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}),
+                                       four_neighbors=o["connect_four_neighbors_only"],
+                                       avg_res=o["connect_using_avg_resistances"], exclude_pairs=exclude)
+    exp = np.array(case["expected"])
+    assert np.array_equal(exp[1:, 0], got[1:, 0])
+    compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)

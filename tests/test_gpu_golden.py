@@ -166,3 +166,23 @@ def test_compute_omniscape_current_on_gpu(gpu_lib):
     ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
     assert np.max(np.abs(got - ref)) < 2e-5 * ref.max()
     assert abs(got[gnd > 0].sum() - src[cond > 0].sum()) < 1e-4 * src.sum()
+
+
+@pytest.mark.parametrize("name", ["sgVerify4", "sgVerify13", "sgVerify17"])
+def test_raster_pairwise_with_device_built_graph_on_gpu(gpu_lib, name):
+    """scope row N4 end to end on the device: graph layer (node map, Laplacian, regularisation, components) and all
+    pair solves on one handle, reference stopping rule, against the golden resistances."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refgraph as rg
+    case = load_case(name)
+    o = case["options"]
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    exclude = []
+    if case["included_pairs"] is not None:
+        exclude, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+    got = ps.raster_pairwise_on_device(np.array(case["cellmap"], dtype=np.float64), points_rc, ps.HIPAMGSolver(bs=8),
+                                       four_neighbors=o["connect_four_neighbors_only"],
+                                       avg_res=o["connect_using_avg_resistances"], exclude_pairs=exclude)
+    exp = np.array(case["expected"])
+    assert np.array_equal(exp[1:, 0], got[1:, 0])
+    compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)

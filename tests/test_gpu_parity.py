@@ -157,3 +157,31 @@ def test_level_products_band_ordered_traversal(gpu_lib):
     from helpers import check_level_products
     check_level_products(gpu_lib, 1100, 4, ks=(1, 8, 16), n_cols=24)
     check_level_products(gpu_lib, 2000, 0, ks=(16,), n_cols=64)
+
+
+@pytest.mark.parametrize("shape,hole_frac,four", [((700, 500), 0.0, False), ((640, 333), 0.4, False), ((301, 777), 0.45, True)])
+def test_device_graph_build_with_nodata(gpu_lib, shape, hole_frac, four):
+    """scope row N4: node map, CSR Laplacian and connected components built on the device for rasters with NODATA
+    cells, against the oracle's graph construction (see the emulator twin)."""
+    import scipy.sparse.csgraph as csg
+    from oracle import refgraph as rg
+    rng = np.random.default_rng(shape[0])
+    g = np.exp(rng.standard_normal(shape))
+    g[rng.random(shape) < hole_frac] = 0.0
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=1), four_neighbors=four, reg=False)
+    nodemap = rg.construct_node_map(g, None)
+    assert np.array_equal(h.raster_nodemap(), nodemap)
+    ref = rg.laplacian(rg.construct_graph(g, nodemap, False, four))
+    A = h.level_matrix(0, "A")
+    assert A.shape == ref.shape and abs(A - ref).max() < 1e-12
+    labels, nc = h.components()
+    nref, lref = csg.connected_components(ref, directed=False)
+    assert nc == nref
+    # same partition: the map device label -> scipy label is a bijection
+    pairs = np.unique(np.stack([labels, lref]), axis=1)
+    assert pairs.shape[1] == nc
+    # dense labels ordered by smallest node id
+    first = np.full(nc, ref.shape[0], dtype=np.int64)
+    np.minimum.at(first, labels, np.arange(ref.shape[0]))
+    assert np.all(np.diff(first) > 0)
+    h.close()
