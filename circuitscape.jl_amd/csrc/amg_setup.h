@@ -841,6 +841,15 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     check_launch("tentative");
     // P = T - omega_p Dl^-1 A T
     spgemm(L.A, Tm, L.P, st);
+    if ((double)L.P.nnz > 0.75 * (double)L.A.nnz) {
+      // (nearly) every neighbour of every node lies in a different aggregate: the graph has no locality for
+      // aggregation to exploit (expander-like networks, e.g. random graphs; rasters sit at 0.3). The Galerkin
+      // operator would be dense (measured on a 1e6-node random graph: 2.6e8 nonzeros on 16081 coarse nodes,
+      // operator complexity 13, 52 s of setup) while such graphs are well conditioned to begin with: stop here,
+      // this level becomes the coarsest one (damped-Jacobi sweeps, or the dense inverse if it is small).
+      L.P = Csr<T>();
+      break;
+    }
     DBuf missing = dalloc<int>(1);
     CS_HIP(hipMemsetAsync(missing.p, 0, sizeof(int), st));
     hipLaunchKernelGGL((smooth_prolongator_kernel<T>), dim3(g), dim3(256), 0, st, n, L.P.rp(), L.P.ci(), L.P.va(),

@@ -104,16 +104,28 @@ def test_mis2_fallback_and_network_graph(emu_lib, oracle):
     big = np.flatnonzero(lab == np.bincount(lab).argmax())
     a = a[big][:, big]
     L = (sp.diags(np.asarray(a.sum(axis=1)).ravel()) - a).tocsr()
-    A = oracle.regularize(L)
-    h = emu_lib.setup(A, emu_lib.default_opts(batch=2))
-    assert h.info["levels"] >= 2
-    src, dst = [0, 5, 9], [17, 3, 100]
-    R, _, _, st = h.solve_pairs(src, dst)
-    S = oracle.OracleAMG(A)
-    Ro, _, _ = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
-    assert st["not_converged"] == 0
-    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
-    h.close()
+    # a lattice with shuffled node ids: a network graph WITH locality (several levels of hashed-priority MIS(2))
+    m = 45
+    idx = np.arange(m * m).reshape(m, m)
+    ei = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    ej = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    perm = rng.permutation(m * m)
+    lat = sp.coo_matrix((rng.uniform(0.5, 2.0, size=len(ei)), (perm[ei], perm[ej])), shape=(m * m, m * m)).tocsr()
+    lat = lat + lat.T
+    Llat = (sp.diags(np.asarray(lat.sum(axis=1)).ravel()) - lat).tocsr()
+    for Lg, min_levels in ((L, 1), (Llat, 3)):
+        # the random sparse graph is an expander: aggregation finds no locality (nnz(P) ~ nnz(A)) and the setup stops
+        # coarsening instead of building a dense Galerkin operator; the shuffled lattice coarsens normally
+        A = oracle.regularize(Lg)
+        h = emu_lib.setup(A, emu_lib.default_opts(batch=2))
+        assert h.info["levels"] >= min_levels and h.info["operator_complexity"] < 2.0
+        src, dst = [0, 5, 9], [17, 3, 100]
+        R, _, _, st = h.solve_pairs(src, dst)
+        S = oracle.OracleAMG(A)
+        Ro, _, _ = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+        assert st["not_converged"] == 0
+        assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+        h.close()
 
 
 def test_general_rhs_true_residual_fp32_and_fp64(emu_lib, oracle):

@@ -1,0 +1,64 @@
+"""BASELINE config 5 (scaled): random network, advanced one-to-all semantics (scope row N2).
+n nodes, 10*n undirected edges (endpoints from rng(424242), deduplicated, giant component kept), conductances U(0.5, 2);
+K focal nodes; for each of S sources: unit current at the source, the other K-1 focal nodes tied to ground (rows
+deleted, src/raster/advanced.jl:282-288) => S independent grounded solves with DIFFERENT matrices, each = one
+csgpu_setup + one csgpu_solve_rhs (multiple_solve, advanced.jl:307-312).
+Usage: python tools/network_bench.py [n] [sources] [--emu]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.csgraph as csg
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import circuitscape_jl_amd  # noqa: F401,E402
+from circuitscape_jl_amd import lib  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 100000
+S = int(args[1]) if len(args) > 1 else 4
+if "--emu" in sys.argv:
+    lib.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "emu", "libcsgpu_emu.so"))
+rng = np.random.default_rng(424242)
+m = 10 * n
+i = rng.integers(0, n, size=m)
+j = rng.integers(0, n, size=m)
+keep = i != j
+lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+key = np.unique(lo.astype(np.int64) * n + hi)
+lo, hi = key // n, key % n
+w = rng.uniform(0.5, 2.0, size=len(lo))
+A = sp.coo_matrix((w, (lo, hi)), shape=(n, n)).tocsr()
+A = (A + A.T).tocsr()
+nc, lab = csg.connected_components(A, directed=False)
+giant = np.flatnonzero(lab == np.bincount(lab).argmax())
+A = A[giant][:, giant]
+n = A.shape[0]
+G = (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A).tocsr()
+K = 8
+focal = rng.choice(n, size=K, replace=False)
+rows = []
+for s in range(min(S, K)):
+    src = focal[s]
+    ground = np.setdiff1d(focal, [src])
+    keepn = np.setdiff1d(np.arange(n), ground)
+    M = G[keepn][:, keepn].tocsr()
+    b = np.zeros(len(keepn))
+    b[np.searchsorted(keepn, src)] = 1.0
+    t0 = time.perf_counter()
+    h = lib.setup(M, lib.default_opts(batch=1, precond_bytes=4, itmax=2000), index_dtype=np.int32, index_base=0)
+    t1 = time.perf_counter()
+    x, st = h.solve_rhs(b)
+    t2 = time.perf_counter()
+    info = h.info
+    r = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
+    rows.append({"source": int(s), "n": int(M.shape[0]), "nnz": int(M.nnz), "levels": info["levels"],
+                 "level_n": info["level_n"][:info["levels"]], "level_nnz": info["level_nnz"][:info["levels"]],
+                 "operator_complexity": info["operator_complexity"], "setup_wall_s": t1 - t0,
+                 "setup_device_ms": info["setup_ms"], "upload_ms": info["upload_ms"], "solve_wall_s": t2 - t1,
+                 "iters": st["max_iters"], "relres": r, "polished": st["polished_batches"]})
+    print(json.dumps(rows[-1]), flush=True)
+    h.close()
