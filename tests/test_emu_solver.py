@@ -641,3 +641,37 @@ def test_raster_pairwise_with_device_built_graph(emu_lib, name):
     exp = np.array(case["expected"])
     assert np.array_equal(exp[1:, 0], got[1:, 0])
     compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+
+
+def test_components_of_a_network_graph(emu_lib):
+    """csgpu_components on a general (non-raster) CSR graph: several random blobs of different sizes plus isolated
+    nodes, node ids shuffled; partition and label order against scipy."""
+    import scipy.sparse.csgraph as csg
+    rng = np.random.default_rng(17)
+    sizes = [1, 400, 1, 37, 900, 2, 1, 150]
+    n = sum(sizes)
+    ei, ej = [], []
+    off = 0
+    for s_ in sizes:
+        if s_ > 1:
+            a = rng.integers(0, s_, size=3 * s_) + off
+            b = rng.integers(0, s_, size=3 * s_) + off
+            chain = np.arange(off, off + s_ - 1)            # keeps each blob connected
+            ei += [a, chain]
+            ej += [b, chain + 1]
+        off += s_
+    ei, ej = np.concatenate(ei), np.concatenate(ej)
+    keep = ei != ej
+    perm = rng.permutation(n)
+    A = sp.coo_matrix((np.ones(keep.sum()), (perm[ei[keep]], perm[ej[keep]])), shape=(n, n)).tocsr()
+    A = ((A + A.T) > 0).astype(np.float64)
+    L = (sp.diags(np.asarray(A.sum(axis=1)).ravel() + 1e-3) - A).tocsr()
+    h = emu_lib.setup(L, emu_lib.default_opts(batch=1, max_levels=1))
+    labels, nc = h.components()
+    nref, lref = csg.connected_components(A, directed=False)
+    assert nc == nref == len(sizes)
+    assert np.unique(np.stack([labels, lref]), axis=1).shape[1] == nc
+    first = np.full(nc, n, dtype=np.int64)
+    np.minimum.at(first, labels, np.arange(n))
+    assert np.all(np.diff(first) > 0)
+    h.close()
