@@ -130,6 +130,41 @@ function solve_pairs_currents(factor::HIPFactor, ::Type{T}, n::Int, nnzA::Int, s
     res, volt, curr, br, st
 end
 
+"""
+Device graph layer (scope row N4) for a raster without polygons: `raster_factor(cellmap, s; four_neighbors, avg_res)`
+numbers the cells with conductance > 0 (construct_node_map), writes the Laplacian in HBM (construct_graph,
+laplacian!, regularisation of core.jl:161) and sets up AMG -- no COO / SparseMatrixCSC on the host. `raster_nodemap`
+returns the node map (1-based, 0 = NODATA), `components` the connected components (0-based dense labels).
+`cellmap` is Julia's column-major Matrix; the C side wants row-major, hence the permutedims.
+"""
+function raster_factor(cellmap::Matrix{T}, s::HIPAMGSolver; four_neighbors = false, avg_res = false) where {T}
+    o = default_opts(s.bs)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rm = permutedims(cellmap)                      # row-major [nrows][ncols] as seen from C
+    rc = GC.@preserve rm ccall((:csgpu_raster_setup, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Cint, Ref{CsgpuOpts}, Ref{Ptr{Cvoid}}),
+              rm, size(cellmap, 1), size(cellmap, 2), sizeof(T), four_neighbors, avg_res, 1, o, h)
+    rc == 0 || error("csgpu_raster_setup failed: $(csgpu_error())")
+    HIPFactor(h[])
+end
+
+function raster_nodemap(factor::HIPFactor)
+    r = Ref{Int64}(0); c = Ref{Int64}(0)
+    ccall((:csgpu_raster_nodemap, LIBCSGPU), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int64}, Ref{Int64}), factor.ptr, C_NULL, r, c)
+    nm = Matrix{Int32}(undef, c[], r[])            # row-major from C == transposed column-major
+    rc = GC.@preserve nm ccall((:csgpu_raster_nodemap, LIBCSGPU), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int64}, Ptr{Int64}),
+                               factor.ptr, nm, C_NULL, C_NULL)
+    rc == 0 || error("csgpu_raster_nodemap failed: $(csgpu_error())")
+    permutedims(nm)
+end
+
+function components(factor::HIPFactor, n::Int)
+    lab = Vector{Int32}(undef, n); nc = Ref{Int64}(0)
+    rc = GC.@preserve lab ccall((:csgpu_components, LIBCSGPU), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int64}), factor.ptr, lab, nc)
+    rc == 0 || error("csgpu_components failed: $(csgpu_error())")
+    lab, Int(nc[])
+end
+
 # solve(prob, ::HIPAMGSolver, flags, cfg, log): identical bookkeeping to solve(prob, ::AMGSolver, ...) (core.jl:96-305)
 # except that per connected component the pair list is handed to `solve_pairs` in ONE call (no Threads.@spawn fan-out
 # over blocking ccalls) -- the Python mirror of exactly this method is circuitscape.jl_amd/solver.py::solve and is what
