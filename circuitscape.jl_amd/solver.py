@@ -756,7 +756,7 @@ def single_ground_all_pairs(prob, flags, cfg=None, log=True, **kw):
 
 
 def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, avg_res=False, exclude_pairs=(),
-                              stats=None):
+                              stats=None, cum=None):
     """Pairwise mode for a raster WITHOUT polygons with the whole graph layer on the device (scope row N4):
     csgpu_raster_setup numbers the valid cells, writes the CSR Laplacian in HBM and regularises it (core.jl:161),
     csgpu_components labels the connected components, and every solvable pair goes to csgpu_solve_pairs in ONE
@@ -765,7 +765,9 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
 
     points_rc: (rows, cols, ids), 1-based, unique ids. Returns the padded resistance matrix of
     single_ground_all_pairs (core.jl:130,294-299): -1 for pairs in different components or excluded, 0 on the
-    diagonal and for focal points sharing a node."""
+    diagonal and for focal points sharing a node. With `cum` (a Cumulative from initialize_cum_maps) the node currents
+    of every solved pair are accumulated on the device as well (N1: cumulative / maximum current maps) and scattered
+    into cum.cum_curr / cum.max_curr through the device-built node map."""
     rows = np.asarray(points_rc[0], dtype=np.int64) - 1
     cols = np.asarray(points_rc[1], dtype=np.int64) - 1
     ids = np.asarray(points_rc[2], dtype=np.int64)
@@ -791,7 +793,17 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
                 pj.append(j)
         if pi:
             try:
-                R, _, _, st = h.solve_pairs(node[pi] - 1, node[pj] - 1)
+                if cum is None:
+                    R, _, _, st = h.solve_pairs(node[pi] - 1, node[pj] - 1)
+                else:
+                    n_nodes = h.info["n"]
+                    node_cum = np.zeros(n_nodes)
+                    node_max = np.zeros(n_nodes) if cum.max_curr is not None else None
+                    R, _, _, st = h.solve_pairs_currents(node[pi] - 1, node[pj] - 1, want_currents=False, cum=node_cum,
+                                                         mx=node_max)
+                    cum.cum_curr += _scatter(node_cum, nodemap)
+                    if node_max is not None:
+                        np.maximum(cum.max_curr, _scatter(node_max, nodemap), out=cum.max_curr)
             except lib.CsgpuError as e:
                 if e.code == lib.CSGPU_NOT_CONVERGED:
                     _raise_not_converged(e)

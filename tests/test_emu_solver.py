@@ -641,6 +641,16 @@ def test_raster_pairwise_with_device_built_graph(emu_lib, name):
     exp = np.array(case["expected"])
     assert np.array_equal(exp[1:, 0], got[1:, 0])
     compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+    if "cum_curmap" in case["maps"]:
+        # N1 on top of N4: cumulative current map accumulated on the device over all pairs, scattered through the
+        # device-built node map, against the reference's golden map (its criterion: sum of squares < 1e-6)
+        from conftest import compare_aagrid
+        cum = ps.initialize_cum_maps(np.array(case["cellmap"]), False)
+        ps.raster_pairwise_on_device(np.array(case["cellmap"], dtype=np.float64), points_rc,
+                                     ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}),
+                                     four_neighbors=o["connect_four_neighbors_only"],
+                                     avg_res=o["connect_using_avg_resistances"], exclude_pairs=exclude, cum=cum)
+        assert compare_aagrid(case["maps"]["cum_curmap"], cum.cum_curr)
 
 
 def test_components_of_a_network_graph(emu_lib):
