@@ -25,6 +25,7 @@ struct ISolver {
   virtual void spmv_host(const void* x, void* y, int k) = 0;
   virtual void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) = 0;
   virtual int64_t components(int32_t* out) = 0;
+  virtual void solve_raster(const void* source, void* curr_out, void* volt_out, csgpu_stats* stats) = 0;
   virtual void level_spmv_host(int lvl, int which, const void* x, void* y, int k, double* dots) = 0;
   virtual void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz, int32_t* rowptr,
                                 int32_t* colidx, void* vals) const = 0;
@@ -67,6 +68,9 @@ struct Solver : ISolver {
   double upload_ms = 0;
   int64_t n = 0, nnz = 0;
   DBuf nodemap;                       // csgpu_raster_setup: row-major [rows][cols], 1-based node id, 0 = no node
+  DBuf ground_node;                   // csgpu_raster_setup_grounded: finite ground conductance per node (T)
+  DBuf comp_label;                    // connected-component label per node (computed on first use)
+  int64_t ncomp = -1;
   int64_t raster_rows = 0, raster_cols = 0;
   std::mutex mu;
 
@@ -184,11 +188,17 @@ struct Solver : ISolver {
     }
   }
 
-  void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg) {
+  void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg,
+                         const void* ground = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     const int64_t ncells = R * C;
     DBuf dcond((size_t)ncells * sizeof(T));
     CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    DBuf dground;
+    if (ground) {
+      dground.alloc((size_t)ncells * sizeof(T));
+      CS_HIP(hipMemcpyAsync(dground.p, ground, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    }
     // node numbering: exclusive scan of the valid-cell flags in column-major order
     DBuf node = dalloc<int>((size_t)ncells + 1);
     CS_HIP(hipMemsetAsync(node.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
@@ -213,8 +223,11 @@ struct Solver : ISolver {
     A.col.alloc((size_t)nnz * sizeof(int));
     A.val.alloc((size_t)nnz * sizeof(T));
     DBuf drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int));
+    if (ground) ground_node.alloc((size_t)n * sizeof(T));
     hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
-                       dptr<T>(dcond), dptr<int>(node), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol));
+                       dptr<T>(dcond), dptr<int>(node), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol),
+                       ground ? (const T*)dptr<T>(dground) : (const T*)nullptr,
+                       ground ? dptr<T>(ground_node) : (T*)nullptr);
     if (reg) {
       const int g = grid_for(nnz);
       DBuf part = dalloc<double>(g);
@@ -241,14 +254,73 @@ struct Solver : ISolver {
     if (out) CS_HIP(hipMemcpy(out, nodemap.p, (size_t)raster_rows * raster_cols * sizeof(int), hipMemcpyDeviceToHost));
   }
 
+  void ensure_components() {
+    if (ncomp >= 0) return;
+    const Csr<T>& A = cg_matrix();
+    comp_label.alloc((size_t)n * sizeof(int));
+    ncomp = connected_components((int)n, A.rp(), A.ci(), dptr<int>(comp_label), st);
+  }
+
   int64_t components(int32_t* out) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
-    const Csr<T>& A = cg_matrix();
-    DBuf label = dalloc<int>((size_t)n);
-    const int nc = connected_components((int)n, A.rp(), A.ci(), dptr<int>(label), st);
-    if (out) CS_HIP(hipMemcpy(out, label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    return nc;
+    ensure_components();
+    if (out) CS_HIP(hipMemcpy(out, comp_label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return ncomp;
+  }
+
+  // Advanced-mode solve on a raster-built handle, rasters in and out (compute_omniscape_current, utils.jl:145-257, for
+  // one raster or for many windows stacked into one raster with NODATA separators -- every window is a component of
+  // ONE block-diagonal system, solved by ONE PCG). curr_out / volt_out: row-major rasters, 0 where there is no node.
+  void solve_raster(const void* source, void* curr_out, void* volt_out, csgpu_stats* stats) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    CS_REQUIRE(nodemap.p != nullptr, CSGPU_BAD_ARGS, "handle was not built by csgpu_raster_setup");
+    const int64_t ncells = raster_rows * raster_cols;
+    ensure_components();
+    W.ensure(n, 1, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
+    if (stats) {
+      stats->nrhs = 1;
+      stats->batch = 1;
+    }
+    DBuf dsrc((size_t)ncells * sizeof(T)), has = dalloc<int>((size_t)2 * ncomp);
+    CS_HIP(hipMemcpyAsync(dsrc.p, source, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemsetAsync(has.p, 0, (size_t)2 * ncomp * sizeof(int), st));
+    CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * sizeof(T), st));
+    const T* gnode = ground_node.p ? (const T*)dptr<T>(ground_node) : (const T*)nullptr;
+    hipLaunchKernelGGL((raster_rhs_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
+                       (const int*)dptr<int>(nodemap), (const T*)dptr<T>(dsrc), gnode, (const int*)dptr<int>(comp_label),
+                       dptr<T>(W.b), dptr<int>(has));
+    hipLaunchKernelGGL((raster_rhs_mask_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                       (const int*)dptr<int>(comp_label), (const int*)dptr<int>(has), dptr<T>(W.b));
+    PcgBatchResult r = run_batch_k(1, 1);
+    accumulate(stats, r, 1);
+    DBuf draster((size_t)ncells * sizeof(T));
+    if (volt_out) {
+      hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
+                         (const int*)dptr<int>(nodemap), (const T*)dptr<T>(W.x), dptr<T>(draster));
+      CS_HIP(hipMemcpyAsync(volt_out, draster.p, (size_t)ncells * sizeof(T), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (curr_out) {
+      const Csr<T>& A = cg_matrix();
+      const int gc = grid_for(n);
+      DBuf dbpart = dalloc<double>((size_t)gc * 2), dbmax = dalloc<double>(2), dcurr((size_t)n * sizeof(T));
+      hipLaunchKernelGGL((branch_max_kernel<T, 1>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(), A.va(),
+                         (const T*)dptr<T>(W.x), dptr<double>(dbpart));
+      hipLaunchKernelGGL((branch_max_final_kernel<1>), dim3(1), dim3(256), 0, st, (const double*)dptr<double>(dbpart), gc,
+                         dptr<double>(dbmax));
+      hipLaunchKernelGGL((node_current_kernel<T, 1>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(), A.va(),
+                         (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax), dptr<T>(dcurr), gnode);
+      hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
+                         (const int*)dptr<int>(nodemap), (const T*)dptr<T>(dcurr), dptr<T>(draster));
+      CS_HIP(hipMemcpyAsync(curr_out, draster.p, (size_t)ncells * sizeof(T), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    check_launch("solve_raster");
+    if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
   int pick_k(int64_t ncols) const {
@@ -386,7 +458,7 @@ struct Solver : ISolver {
                                             (const double*)dptr<double>(dbpart), gc, dptr<double>(dbmax)));
         CS_DISPATCH_K(K, hipLaunchKernelGGL((node_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
                                             A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
-                                            dptr<T>(dcurr)));
+                                            dptr<T>(dcurr), (const T*)nullptr));
         if (branch_out) {
           CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
                                               A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
@@ -722,8 +794,9 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
   CS_API_END
 }
 
-int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
-                       int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out) {
+int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nrows, int64_t ncols, int val_bytes,
+                                int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
+                                csgpu_handle** out) {
   CS_API_BEGIN
   if (!cond || !out || nrows <= 0 || ncols <= 0) {
     g_last_error = "bad arguments";
@@ -742,17 +815,43 @@ int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_b
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);
     h->solver.reset(s);
-    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
   } else if (val_bytes == 8) {
     auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);
-    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
   } else {
     auto* s = new csgpu::Solver<float, float>(o);
     h->solver.reset(s);
-    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg);
+    s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
   }
   *out = h.release();
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
+                       int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out) {
+  return csgpu_raster_setup_grounded(cond, nullptr, nrows, ncols, val_bytes, four_neighbors, avg_resistances, reg, opts,
+                                     out);
+}
+
+int csgpu_solve_raster(csgpu_handle* h, const void* source, void* curr_out, void* volt_out, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || !source) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  h->solver->solve_raster(source, curr_out, volt_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
   return CSGPU_OK;
   CS_API_END
 }

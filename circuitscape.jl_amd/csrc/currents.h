@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void branch_max_final_kernel(const double* __r
 template <class T, int K>
 __global__ __launch_bounds__(256) void node_current_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                            const T* __restrict__ va, const T* __restrict__ x,
-                                                           const double* __restrict__ maxcur, T* __restrict__ curr) {
+                                                           const double* __restrict__ maxcur, T* __restrict__ curr,
+                                                           const T* __restrict__ ground) {
   const int c = threadIdx.x % K;
   const double mp = maxcur[2 * c], mn = maxcur[2 * c + 1];
   const int64_t total = (int64_t)n * K;
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(256) void node_current_kernel(int n, const int* __r
       const double outof = col > row ? -keep_neg : keep_neg;  // g (v_row - v_col), thresholded with maxcur_neg
       if (into > 0.0) in += into;
       if (outof > 0.0) out += outof;
+    }
+    if (ground) {
+      // advanced modes: the current through the node's own finite ground conductance (out.jl:192-201) -- towards
+      // ground when the node sits above it (counts as outflow), from ground otherwise (inflow)
+      const double gc = (double)ground[row] * vr;
+      if (gc < 0.0) in -= gc;
+      if (gc > 0.0) out += gc;
     }
     curr[it] = (T)(in > out ? in : out);
   }

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
                                                           const T* __restrict__ cond, const int* __restrict__ node,
                                                           const int* __restrict__ rp, int* __restrict__ ci,
                                                           T* __restrict__ va, int* __restrict__ nrow,
-                                                          int* __restrict__ ncol) {
+                                                          int* __restrict__ ncol, const T* __restrict__ ground,
+                                                          T* __restrict__ ground_node) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
     const int i = (int)(id % R), j = (int)(id / R);
@@ -98,7 +99,47 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
         ++k;
       }
     }
-    va[kdiag] = (T)deg;
+    // finite ground conductance of the cell (advanced-mode `asolve = a + spdiagm(finitegrounds)`, advanced.jl:277-280)
+    const double gnd = ground ? (double)ground[(size_t)i * C + j] : 0.0;
+    if (ground_node) ground_node[me] = (T)gnd;
+    va[kdiag] = (T)(deg + gnd);
+  }
+}
+
+// Right-hand side of an advanced-mode solve from a source raster (row-major): b[node] = source at the node's cell,
+// 0 where the node is grounded (policy :rmvsrc, the one compute_omniscape_current uses, utils.jl:193-196).
+// has[2*comp + 0/1] flags the components that hold a source / a ground (advanced_kernel solves only those that
+// hold both, advanced.jl:186-191).
+template <class T>
+__global__ __launch_bounds__(256) void raster_rhs_kernel(int64_t ncells, const int* __restrict__ nodemap,
+                                                         const T* __restrict__ source, const T* __restrict__ ground_node,
+                                                         const int* __restrict__ comp, T* __restrict__ b,
+                                                         int* __restrict__ has) {
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * 256) {
+    const int nd = nodemap[c] - 1;
+    if (nd < 0) continue;
+    const T g = ground_node ? ground_node[nd] : T(0);
+    const T s = g != T(0) ? T(0) : source[c];
+    b[nd] = s;
+    if (s != T(0)) atomicOr(&has[2 * comp[nd]], 1);
+    if (g != T(0)) atomicOr(&has[2 * comp[nd] + 1], 1);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void raster_rhs_mask_kernel(int n, const int* __restrict__ comp,
+                                                              const int* __restrict__ has, T* __restrict__ b) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256)
+    if (!(has[2 * comp[u]] && has[2 * comp[u] + 1])) b[u] = T(0);
+}
+
+// out[cell] = vec[node of the cell], 0 where the cell has no node (_create_current_maps / _create_voltage_map)
+template <class T>
+__global__ __launch_bounds__(256) void raster_scatter_kernel(int64_t ncells, const int* __restrict__ nodemap,
+                                                             const T* __restrict__ vec, T* __restrict__ out) {
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * 256) {
+    const int nd = nodemap[c] - 1;
+    out[c] = nd >= 0 ? vec[nd] : T(0);
   }
 }
 

@@ -22,7 +22,8 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
-    "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components",
+    "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
+    "csgpu_solve_raster",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -91,6 +92,8 @@ def _bind(L):
     L.csgpu_level_spmv_host.argtypes = [vp, i32, i32, vp, vp, i32, vp]
     L.csgpu_raster_nodemap.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.csgpu_components.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    L.csgpu_raster_setup_grounded.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.csgpu_solve_raster.argtypes = [vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
     L.csgpu_free.argtypes = [vp]
@@ -260,6 +263,20 @@ class Handle:
         _check(lib().csgpu_raster_nodemap(self._p, nm.ctypes.data, None, None))
         return nm
 
+    def solve_raster(self, source, want_currents=True, want_voltages=False):
+        """Advanced-mode solve, rasters in and out (csgpu_solve_raster). Returns (current raster or None, voltage
+        raster or None, stats)."""
+        nm_r, nm_c = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().csgpu_raster_nodemap(self._p, None, ctypes.byref(nm_r), ctypes.byref(nm_c)))
+        src = np.ascontiguousarray(source, dtype=self.dtype)
+        assert src.shape == (nm_r.value, nm_c.value)
+        cur = np.zeros(src.shape, dtype=self.dtype) if want_currents else None
+        vol = np.zeros(src.shape, dtype=self.dtype) if want_voltages else None
+        st = Stats()
+        _check(lib().csgpu_solve_raster(self._p, src.ctypes.data, cur.ctypes.data if cur is not None else None,
+                                        vol.ctypes.data if vol is not None else None, ctypes.byref(st)))
+        return cur, vol, st.as_dict()
+
     def components(self):
         """(labels, count): dense 0-based component index per node, ordered by smallest node id (device CC)."""
         lab = np.zeros(self.info["n"], dtype=np.int32)
@@ -327,15 +344,20 @@ def setup(matrix, opts=None, node_row=None, node_col=None, index_dtype=np.int64,
     return Handle(h, dtype)
 
 
-def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True):
-    """csgpu_raster_setup: Laplacian of an all-valid conductance raster built directly in HBM."""
+def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True, ground=None):
+    """csgpu_raster_setup[_grounded]: Laplacian of a conductance raster (NODATA = values <= 0) built directly in HBM;
+    `ground`: optional raster of finite ground conductances added to the diagonal (advanced mode)."""
     cond = np.ascontiguousarray(cond)
     dtype = np.float32 if cond.dtype == np.float32 else np.float64
     cond = np.ascontiguousarray(cond, dtype=dtype)
     o = opts if opts is not None else default_opts()
     h = ctypes.c_void_p(0)
-    rc = lib().csgpu_raster_setup(cond.ctypes.data, cond.shape[0], cond.shape[1], np.dtype(dtype).itemsize,
-                                  int(four_neighbors), int(avg_resistances), int(reg), ctypes.byref(o),
-                                  ctypes.byref(h))
+    gnd = None
+    if ground is not None:
+        gnd = np.ascontiguousarray(ground, dtype=dtype)
+        assert gnd.shape == cond.shape and np.all(np.isfinite(gnd)), "finite ground conductances only"
+    rc = lib().csgpu_raster_setup_grounded(cond.ctypes.data, gnd.ctypes.data if gnd is not None else None,
+                                           cond.shape[0], cond.shape[1], np.dtype(dtype).itemsize, int(four_neighbors),
+                                           int(avg_resistances), int(reg), ctypes.byref(o), ctypes.byref(h))
     _check(rc)
     return Handle(h, dtype)

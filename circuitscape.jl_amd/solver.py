@@ -331,6 +331,43 @@ def compute_omniscape_current(conductance, source, ground, cs_cfg, build_graph, 
     return outcurr
 
 
+def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
+    """Many moving-window solves of compute_omniscape_current (src/utils.jl:145-257) as ONE device job (scope row N3).
+
+    windows: list of (conductance, source, ground) rasters (NODATA = conductance 0, ground = finite conductances to
+    ground, as Omniscape passes them). The windows are stacked into one tall raster separated by NODATA rows; the
+    device graph layer (csgpu_raster_setup_grounded) numbers the cells, writes the block-diagonal Laplacian with the
+    ground conductances on its diagonal and sets up ONE hierarchy; csgpu_solve_raster builds the right-hand side from
+    the stacked source raster (policy :rmvsrc, components without source or ground skipped as in advanced_kernel),
+    runs ONE PCG over all windows -- each window is a connected component, or several, of the same SPD system -- and
+    returns the node-current raster, which is cut back into per-window maps. Nothing n-sized is built on the host.
+    Returns the list of current maps (raw accumulated currents, like the reference's `outcurr`)."""
+    solver = solver or get_solver({"solver": "hip", "cholmod_batch_size": cs_cfg.get("cholmod_batch_size", 8)})
+    four = str(cs_cfg.get("connect_four_neighbors_only", "False")).lower() in ("true", "1")
+    shapes = [np.asarray(w[0]).shape for w in windows]
+    width = max(sh[1] for sh in shapes)
+    height = sum(sh[0] for sh in shapes) + len(shapes) - 1
+    stack = [np.zeros((height, width)) for _ in range(3)]
+    offs = []
+    r0 = 0
+    for (cond, src, gnd), (hh, ww) in zip(windows, shapes):
+        valid = np.asarray(cond, dtype=np.float64) > 0
+        stack[0][r0:r0 + hh, :ww] = np.where(valid, cond, 0.0)
+        stack[1][r0:r0 + hh, :ww] = np.where(valid, src, 0.0)
+        stack[2][r0:r0 + hh, :ww] = np.where(valid, gnd, 0.0)
+        offs.append(r0)
+        r0 += hh + 1                                      # one NODATA row between windows
+    try:
+        with lib.raster_setup(stack[0], _opts_for(solver, batch=1), four_neighbors=four, avg_resistances=False,
+                              reg=False, ground=stack[2]) as h:
+            cur, _, st = h.solve_raster(stack[1], want_currents=True)
+    except lib.CsgpuError as e:
+        if e.code == lib.CSGPU_NOT_CONVERGED:
+            _raise_not_converged(e)
+        raise
+    return [cur[o:o + hh, :ww].copy() for o, (hh, ww) in zip(offs, shapes)], st
+
+
 def _colmajor_nonzero(mask):
     jj, ii = np.nonzero(np.asarray(mask).T)
     return ii, jj

@@ -154,6 +154,22 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
 int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
                        int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
 
+/* csgpu_raster_setup with a raster of finite ground conductances added to the diagonal (advanced mode:
+ * `asolve = a + spdiagm(finitegrounds)`, src/raster/advanced.jl:277-280; `ground` NULL = none). Grounded cells that
+ * also carry a source lose the source (policy :rmvsrc, the one compute_omniscape_current uses). */
+int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nrows, int64_t ncols, int val_bytes,
+                                int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
+                                csgpu_handle** out);
+
+/* Advanced-mode solve with rasters in and out on a handle built by csgpu_raster_setup[_grounded]
+ * (compute_omniscape_current, src/utils.jl:145-257; advanced_kernel, src/raster/advanced.jl:151-271): the source
+ * raster becomes the right-hand side on the device; components without a source or without a ground are skipped as in
+ * the reference (advanced.jl:186-191); one PCG solves all components at once (block-diagonal system -- many moving
+ * windows can be stacked into one raster, separated by NODATA rows); node currents including the current through the
+ * nodes' own ground conductances (src/out.jl:178-207) and/or voltages come back as rasters (row-major, 0 where the cell
+ * has no node). curr_out / volt_out may be NULL. */
+int csgpu_solve_raster(csgpu_handle* h, const void* source, void* curr_out, void* volt_out, csgpu_stats* stats);
+
 /* Node map of a handle built by csgpu_raster_setup: nodemap_out[i*ncols + j] = 1-based node id of cell (i, j) in the
  * reference's column-major numbering (construct_node_map, src/raster/pairwise.jl:271-301), 0 where the cell is NODATA
  * (conductance <= 0). Pass NULL to query the raster size only. */

@@ -685,3 +685,29 @@ def test_components_of_a_network_graph(emu_lib):
     np.minimum.at(first, labels, np.arange(n))
     assert np.all(np.diff(first) > 0)
     h.close()
+
+
+def test_omniscape_batch_of_windows_as_one_block_diagonal_solve(emu_lib):
+    """scope row N3: a batch of moving windows (different sizes, NODATA holes, one of them split into two pieces of
+    which only one holds the ground, one without any source) stacked into ONE raster and solved by ONE PCG on the
+    device-built block-diagonal system; every window's current map against the oracle's per-window direct solve of
+    compute_omniscape_current (which skips components lacking a source or a ground, advanced.jl:186-191)."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    wins = [_omniscape_window(n, s) for n, s in ((31, 3), (21, 4), (41, 5), (25, 6))]
+    # window 1: a NODATA wall cuts it in two; the piece without the ground cell must come back all zero
+    cond, src, gnd = wins[1]
+    cond[:, 5] = 0.0
+    # window 3: no source at all
+    wins[3] = (wins[3][0], np.zeros_like(wins[3][1]), wins[3][2])
+    # a grounded cell that also carries a source loses the source (policy rmvsrc)
+    wins[2][1][20, 20] = 2.5
+    maps, st = ps.compute_omniscape_current_batch(
+        wins, {"connect_four_neighbors_only": "False"},
+        solver=ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
+    assert st["not_converged"] == 0 and len(maps) == len(wins)
+    for k, ((cond, src, gnd), got) in enumerate(zip(wins, maps)):
+        ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) < 1e-7 * max(1.0, ref.max()), k
+    assert np.all(maps[3] == 0) and np.all(maps[1][:, :5] == 0)

@@ -186,3 +186,18 @@ def test_raster_pairwise_with_device_built_graph_on_gpu(gpu_lib, name):
     exp = np.array(case["expected"])
     assert np.array_equal(exp[1:, 0], got[1:, 0])
     compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+
+
+def test_omniscape_batch_on_gpu(gpu_lib):
+    """scope row N3: 12 moving windows stacked into one raster, one block-diagonal PCG on the device (reference
+    stopping rule + polishing); every window against the oracle's direct solve."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    from test_emu_solver import _omniscape_window
+    wins = [_omniscape_window(61 + 10 * (k % 4), 100 + k) for k in range(12)]
+    maps, st = ps.compute_omniscape_current_batch(wins, {"connect_four_neighbors_only": "False"},
+                                                  solver=ps.HIPAMGSolver(bs=1))
+    assert st["not_converged"] == 0
+    for (cond, src, gnd), got in zip(wins, maps):
+        ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
+        assert np.max(np.abs(got - ref)) < 5e-5 * ref.max()
