@@ -348,8 +348,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // partial rows of the big SpMM-shaped launches are collapsed before the single-workgroup scalar kernels read them
   double* pac = dptr<double>(W.part_ca);
   double* pcc = dptr<double>(W.part_cc);
+  // (CSGPU_COLLAPSE_MIN: test knob, read per call so that a test can exercise the path on a small problem)
+  const char* cm_env = getenv("CSGPU_COLLAPSE_MIN");
+  const int collapse_min = cm_env ? std::max(1, atoi(cm_env)) : 4 * kCollapsedParts;
   auto collapsed = [&](double* src, int nparts, double* dst) -> std::pair<const double*, int> {
-    if (nparts <= 4 * kCollapsedParts) return {src, nparts};
+    if (nparts <= collapse_min) return {src, nparts};
     hipLaunchKernelGGL((collapse_partials_kernel<K>), dim3(ceil_div(kCollapsedParts * K, 256)), dim3(256), 0, st,
                        (const double*)src, nparts, dst);
     return {dst, kCollapsedParts};

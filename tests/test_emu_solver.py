@@ -557,20 +557,31 @@ def test_polishing_reopens_columns_that_would_fail_the_residual_check(emu_lib, b
     h.close()
 
 
-def test_collapsed_partials_path(emu_lib, oracle):
-    """More than 1024 row blocks per SpMM launch (370^2 raster at batch 16): the dot partials are collapsed to 256
-    rows before the scalar alpha / beta kernels read them. Resistances against the tight oracle."""
+def test_collapsed_partials_path(emu_lib, oracle, monkeypatch):
+    """Launches with many row blocks have their dot partials collapsed to 256 rows before the scalar alpha / beta
+    kernels read them (> 1024 row blocks in production; CSGPU_COLLAPSE_MIN lowers the trigger so that a 90^2 raster at
+    batch 16 -- 64 half-size row blocks -- goes through the same kernels). Resistances against the tight oracle, and
+    identical bits with and without the collapse stage (the summation order per column is fixed either way... but
+    differs between the two, hence a tolerance, not equality)."""
     from oracle import refgraph as rg
-    N = 370
+    N = 90
     G, g = rg.synthetic_raster_problem(N, N, seed=21)
-    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=16, precond_bytes=4))
     cells = np.random.default_rng(3).choice(N * N, size=10, replace=False)
     src, dst = list(cells[:-1]), list(cells[1:])      # 9 pairs -> one batch of width 16
-    R, _, _, st = h.solve_pairs(src, dst)
-    assert st["not_converged"] == 0 and st["batch"] == 16
     Ro, _, _ = oracle.OracleAMG(oracle.regularize(G)).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
-    assert np.max(np.abs(R - Ro) / Ro) < 1e-5
-    h.close()
+    out = []
+    for env in ("8", None):
+        if env is None:
+            monkeypatch.delenv("CSGPU_COLLAPSE_MIN", raising=False)
+        else:
+            monkeypatch.setenv("CSGPU_COLLAPSE_MIN", env)
+        h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=16, precond_bytes=4))
+        R, _, _, st = h.solve_pairs(src, dst)
+        assert st["not_converged"] == 0 and st["batch"] == 16
+        assert np.max(np.abs(R - Ro) / Ro) < 1e-5
+        out.append((R, st["total_iters"]))
+        h.close()
+    assert out[0][1] == out[1][1] and np.max(np.abs(out[0][0] - out[1][0]) / out[1][0]) < 1e-9
 
 
 def test_device_raster_laplacian_reproduces_model_problems(emu_lib):
