@@ -148,6 +148,33 @@ function raster_factor(cellmap::Matrix{T}, s::HIPAMGSolver; four_neighbors = fal
     HIPFactor(h[])
 end
 
+"""
+compute_omniscape_current on the device (utils.jl:145-257), rasters in and out: `grounded_raster_factor(cond, ground, s)`
+builds the graph with the finite ground conductances on the diagonal, `solve_raster(factor, source)` returns the
+node-current map. Many moving windows can be stacked into one raster separated by NODATA rows: one setup, one PCG.
+"""
+function grounded_raster_factor(cellmap::Matrix{T}, ground::Matrix{T}, s::HIPAMGSolver; four_neighbors = false) where {T}
+    o = default_opts(1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rm = permutedims(cellmap); gm = permutedims(ground)
+    rc = GC.@preserve rm gm ccall((:csgpu_raster_setup_grounded, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Cint, Ref{CsgpuOpts}, Ref{Ptr{Cvoid}}),
+              rm, gm, size(cellmap, 1), size(cellmap, 2), sizeof(T), four_neighbors, 0, 0, o, h)
+    rc == 0 || error("csgpu_raster_setup_grounded failed: $(csgpu_error())")
+    HIPFactor(h[])
+end
+
+function solve_raster(factor::HIPFactor, source::Matrix{T}) where {T}
+    sm = permutedims(source)
+    cur = similar(sm)
+    st = CsgpuStats()
+    rc = GC.@preserve sm cur ccall((:csgpu_solve_raster, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}), factor.ptr, sm, cur, C_NULL, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_raster failed: $(csgpu_error())")
+    permutedims(cur)
+end
+
 function raster_nodemap(factor::HIPFactor)
     r = Ref{Int64}(0); c = Ref{Int64}(0)
     ccall((:csgpu_raster_nodemap, LIBCSGPU), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int64}, Ref{Int64}), factor.ptr, C_NULL, r, c)
