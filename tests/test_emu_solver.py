@@ -722,3 +722,37 @@ def test_omniscape_batch_of_windows_as_one_block_diagonal_solve(emu_lib):
         assert got.shape == ref.shape
         assert np.max(np.abs(got - ref)) < 1e-7 * max(1.0, ref.max()), k
     assert np.all(maps[3] == 0) and np.all(maps[1][:, :5] == 0)
+
+
+def test_raster_entry_points_error_paths_and_fp32(emu_lib):
+    """Edge cases of the raster entry points: all-NODATA raster, raster calls on a handle that was not built from a
+    raster, source raster of the wrong shape; and the fp32 flavour (val_bytes = 4) of the grounded raster solve."""
+    from oracle import refmaps
+    with pytest.raises(emu_lib.CsgpuError) as e:
+        emu_lib.raster_setup(np.zeros((5, 7)))
+    assert e.value.code == emu_lib.CSGPU_BAD_ARGS
+    h = emu_lib.setup(sp.identity(10, format="csr") * 2.0)
+    with pytest.raises(emu_lib.CsgpuError):
+        h.raster_nodemap()
+    labels, nc = h.components()                 # components work on any handle: 10 isolated nodes
+    assert nc == 10 and np.array_equal(labels, np.arange(10))
+    h.close()
+    cond, src, gnd = _omniscape_window(25, 2)
+    h = emu_lib.raster_setup(cond, emu_lib.default_opts(batch=1), reg=False, ground=gnd)
+    with pytest.raises(AssertionError):
+        h.solve_raster(src[:-1])
+    cur, vol, st = h.solve_raster(src, want_currents=True, want_voltages=True)
+    assert st["not_converged"] == 0 and np.all(cur[cond == 0] == 0) and np.all(vol[cond == 0] == 0)
+    h.close()
+    # fp32: a single unit ground under 500 cells puts the residual floor eps32 * |A| |x| / |b| at ~1e-4 (the reference's
+    # own check fails there too); leak a little conductance to ground under 30 % of the cells
+    leak = (cond > 0) & (np.random.default_rng(1).random(cond.shape) < 0.3)     # (grounded cells lose their sources)
+    gnd = np.where(leak, gnd + 0.05, gnd)
+    assert np.any((src != 0) & (gnd == 0))
+    ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
+    h32 = emu_lib.raster_setup(cond.astype(np.float32), emu_lib.default_opts(batch=1, rtol=1e-5, atol=0.0), reg=False,
+                               ground=gnd.astype(np.float32))
+    cur32, _, st32 = h32.solve_raster(src.astype(np.float32))
+    assert cur32.dtype == np.float32 and st32["not_converged"] == 0
+    assert np.max(np.abs(cur32 - ref)) < 2e-3 * ref.max()
+    h32.close()
