@@ -124,29 +124,78 @@ __global__ __launch_bounds__(256) void convert_kernel(int64_t total, const U* __
 // ---- r -= alpha Ap, fused with: the preconditioner-precision copy of r (rp, when TP != T), the first damped-Jacobi
 //      sweep of the next preconditioner application from a zero guess (xa = omega * dinv .* r; skipped when xa is
 //      null) and, optionally, the partials of r'r.
+// N adjacent vector elements moved with one memory instruction (16 bytes for the T-typed vectors)
+template <class V, int N>
+struct alignas(sizeof(V) * N) VecN {
+  V e[N];
+};
+
+// The two streaming kernels below move 28 bytes per vector element and nothing else: every lane handles VEC adjacent
+// columns of a node (one 16-byte access to the T vectors, one 8/16-byte access to the TP vectors) and two such groups
+// per loop trip (independent loads in flight), grid-stride over the node-column pairs.
+template <class T, int K>
+struct CgVec {
+  static constexpr int RAW = 16 / (int)sizeof(T);
+  static constexpr int VEC = K < RAW ? K : RAW;  // columns per lane
+  static constexpr int LPR = K / VEC;            // lanes covering one node's K columns
+};
+
 template <class T, class TP, int K, bool RR>
 __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgScalars* S, T* __restrict__ r,
                                                           const T* __restrict__ Ap, TP* __restrict__ rp,
                                                           TP* __restrict__ xa, const TP* __restrict__ dinv, TP omega,
                                                           double* __restrict__ partials) {
+  constexpr int VEC = CgVec<T, K>::VEC, LPR = CgVec<T, K>::LPR;
+  typedef VecN<T, VEC> VT;
+  typedef VecN<TP, VEC> VP;
   __shared__ double s_red[4 * K];
   if (S->all_done) return;
-  const int c = threadIdx.x % K;
-  const T alpha = (T)S->alpha[c];
-  double s = 0.0;
-  const int64_t total = n * K;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const T rn = r[e] - alpha * Ap[e];
-    r[e] = rn;
-    if (rp) rp[e] = (TP)rn;
-    if (xa) xa[e] = omega * dinv[e / K] * (TP)rn;
-    if (RR) s += (double)rn * (double)rn;
+  const int c0 = (threadIdx.x % LPR) * VEC;
+  T alpha[VEC];
+  double s[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    alpha[q] = (T)S->alpha[c0 + q];
+    s[q] = 0.0;
+  }
+  const int64_t nv = n * K / VEC;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto body = [&](int64_t v, const VT& rv, const VT& av) {
+    VT rn;
+    VP rq, xq;
+    const TP wd = xa ? omega * dinv[v / LPR] : TP(0);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      rn.e[q] = rv.e[q] - alpha[q] * av.e[q];
+      rq.e[q] = (TP)rn.e[q];
+      xq.e[q] = wd * (TP)rn.e[q];
+      if (RR) s[q] += (double)rn.e[q] * (double)rn.e[q];
+    }
+    reinterpret_cast<VT*>(r)[v] = rn;
+    if (rp) reinterpret_cast<VP*>(rp)[v] = rq;
+    if (xa) reinterpret_cast<VP*>(xa)[v] = xq;
+  };
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += 2 * stride) {
+    const int64_t v2 = v + stride;
+    const bool two = v2 < nv;
+    const VT r1 = reinterpret_cast<const VT*>(r)[v], a1 = reinterpret_cast<const VT*>(Ap)[v];
+    VT r2 = r1, a2 = a1;
+    if (two) {
+      r2 = reinterpret_cast<const VT*>(r)[v2];
+      a2 = reinterpret_cast<const VT*>(Ap)[v2];
+    }
+    body(v, r1, a1);
+    if (two) body(v2, r2, a2);
   }
   if (RR) {
-#pragma unroll
-    for (int o = 32; o >= K; o >>= 1) s += __shfl_xor(s, o, 64);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane < K) s_red[w * K + lane] = s;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      double t = s[q];
+#pragma unroll
+      for (int o = 32; o >= LPR; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane < LPR) s_red[w * K + lane * VEC + q] = t;
+    }
     __syncthreads();
     if (threadIdx.x < K) {
       const int t = threadIdx.x;
@@ -160,15 +209,45 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
 template <class T, class TP, int K>
 __global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
                                                            TP* __restrict__ p, const TP* __restrict__ z) {
+  constexpr int VEC = CgVec<T, K>::VEC, LPR = CgVec<T, K>::LPR;
+  typedef VecN<T, VEC> VT;
+  typedef VecN<TP, VEC> VP;
   if (S->all_done == 2) return;  // 2 = the final x update has already been applied
-  const int c = threadIdx.x % K;
-  const T alpha = (T)S->alpha[c];
-  const T beta = (T)S->beta[c];
-  const int64_t total = n * K;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const T pe = (T)p[e];
-    x[e] += alpha * pe;
-    p[e] = (TP)((T)z[e] + beta * pe);
+  const int c0 = (threadIdx.x % LPR) * VEC;
+  T alpha[VEC], beta[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    alpha[q] = (T)S->alpha[c0 + q];
+    beta[q] = (T)S->beta[c0 + q];
+  }
+  const int64_t nv = n * K / VEC;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto body = [&](int64_t v, const VT& xv, const VP& pv, const VP& zv) {
+    VT xn;
+    VP pn;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const T pe = (T)pv.e[q];
+      xn.e[q] = xv.e[q] + alpha[q] * pe;
+      pn.e[q] = (TP)((T)zv.e[q] + beta[q] * pe);
+    }
+    reinterpret_cast<VT*>(x)[v] = xn;
+    reinterpret_cast<VP*>(p)[v] = pn;
+  };
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += 2 * stride) {
+    const int64_t v2 = v + stride;
+    const bool two = v2 < nv;
+    const VT x1 = reinterpret_cast<const VT*>(x)[v];
+    const VP p1 = reinterpret_cast<const VP*>(p)[v], z1 = reinterpret_cast<const VP*>(z)[v];
+    VT x2 = x1;
+    VP p2 = p1, z2 = z1;
+    if (two) {
+      x2 = reinterpret_cast<const VT*>(x)[v2];
+      p2 = reinterpret_cast<const VP*>(p)[v2];
+      z2 = reinterpret_cast<const VP*>(z)[v2];
+    }
+    body(v, x1, p1, z1);
+    if (two) body(v2, x2, p2, z2);
   }
 }
 
