@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
   }
 }
 
-// Right-hand side of an advanced-mode solve from a source raster (row-major): b[node] = source at the node's cell,
-// 0 where the node is grounded (policy :rmvsrc, the one compute_omniscape_current uses, utils.jl:193-196).
+// Right-hand side of an advanced-mode solve from a source raster (row-major): b[node] = source at the node's cell.
+// The source / ground conflict policy (remove_src_or_gnd) is applied by the caller to the rasters it hands over.
 // has[2*comp + 0/1] flags the components that hold a source / a ground (advanced_kernel solves only those that
 // hold both, advanced.jl:186-191).
 template <class T>
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void raster_rhs_kernel(int64_t ncells, const i
     const int nd = nodemap[c] - 1;
     if (nd < 0) continue;
     const T g = ground_node ? ground_node[nd] : T(0);
-    const T s = g != T(0) ? T(0) : source[c];
+    const T s = source[c];
     b[nd] = s;
     if (s != T(0)) atomicOr(&has[2 * comp[nd]], 1);
     if (g != T(0)) atomicOr(&has[2 * comp[nd] + 1], 1);

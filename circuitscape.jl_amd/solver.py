@@ -331,6 +331,72 @@ def compute_omniscape_current(conductance, source, ground, cs_cfg, build_graph, 
     return outcurr
 
 
+def _edge_weight(x, y, diag, avg_res):
+    """construct_graph's edge conductance (raster/pairwise.jl:356-367): mean conductance or mean resistance, /sqrt(2)
+    on diagonals."""
+    with np.errstate(divide="ignore"):
+        w = 1.0 / ((1.0 / x + 1.0 / y) / 2.0) if avg_res else (x + y) / 2.0
+    return w / np.sqrt(2.0) if diag else w
+
+
+def raster_advanced_on_device(cellmap, source_map, ground_map, flags, solver, four_neighbors=False, avg_res=False):
+    """Raster advanced mode WITHOUT polygons with graph layer, solve and current map on the device (scope rows N2 + N4):
+    the mirror of compute_advanced_data + advanced_kernel (src/raster/advanced.jl:36-271) for node == cell.
+
+    * conflict policy (resolve_conflicts, advanced.jl:118-149) applied to the rasters;
+    * a direct (infinite) ground -- whose row the reference deletes (multiple_solver, advanced.jl:282-288) -- becomes a
+      NODATA cell, and the conductance of every edge into it is added to the ground conductance of the neighbour at the
+      other end: exactly the matrix the deletion leaves behind;
+    * csgpu_raster_setup_grounded + csgpu_solve_raster do the rest: all components that hold a source and a ground
+      in one PCG, voltages and node currents (ground currents included) back as rasters;
+    * the current into each direct ground (its own node current in the reference) is the sum of what its neighbours
+      send it, evaluated here from the voltage raster for those few cells.
+    Returns (voltmap, curmap) post-processed like write_grid does."""
+    gmap = np.asarray(cellmap, dtype=np.float64)
+    src = np.where(gmap > 0, np.asarray(source_map, dtype=np.float64), 0.0)
+    gnd = np.where(gmap > 0, np.asarray(ground_map, dtype=np.float64), 0.0)
+    conflicts = (src != 0) & (gnd != 0)
+    if flags.policy in ("rmvsrc", "rmvall"):
+        src[conflicts] = 0
+    elif flags.policy == "rmvgnd":
+        gnd[conflicts] = 0
+    gnd[(gnd == np.inf) & (src > 0)] = 0          # a source on an infinite ground wins (advanced.jl:144-146)
+    direct = gnd == np.inf
+    cond = np.where(direct, 0.0, gmap)
+    leak = np.where(direct, 0.0, gnd)
+    R, C = gmap.shape
+    nbrs = [(-1, 0), (1, 0), (0, -1), (0, 1)] + ([] if four_neighbors else [(-1, -1), (-1, 1), (1, -1), (1, 1)])
+    di, dj = np.nonzero(direct)
+    links = []                                     # (direct cell, neighbour cell, edge conductance)
+    for i, j in zip(di, dj):
+        for a, b in nbrs:
+            ii, jj = i + a, j + b
+            if 0 <= ii < R and 0 <= jj < C and cond[ii, jj] > 0:
+                w = _edge_weight(gmap[i, j], gmap[ii, jj], a != 0 and b != 0, avg_res)
+                leak[ii, jj] += w
+                links.append((i, j, ii, jj, w))
+    of = flags.outputflags
+    try:
+        with lib.raster_setup(cond, _opts_for(solver, batch=1), four_neighbors=four_neighbors, avg_resistances=avg_res,
+                              reg=False, ground=leak) as h:
+            cur, vol, _ = h.solve_raster(src, want_currents=True, want_voltages=True)
+    except lib.CsgpuError as e:
+        if e.code == lib.CSGPU_NOT_CONVERGED:
+            _raise_not_converged(e)
+        raise
+    inflow = np.zeros(gmap.shape)
+    outflow = np.zeros(gmap.shape)
+    for i, j, ii, jj, w in links:                  # the direct ground sits at voltage 0
+        f = w * vol[ii, jj]
+        if f > 0:
+            inflow[i, j] += f
+        else:
+            outflow[i, j] -= f
+    cur = np.where(direct, np.maximum(inflow, outflow), cur)
+    return (_process_grid(vol, gmap, False, of.set_null_voltages_to_nodata),
+            _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata))
+
+
 def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
     """Many moving-window solves of compute_omniscape_current (src/utils.jl:145-257) as ONE device job (scope row N3).
 
@@ -353,8 +419,9 @@ def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
     for (cond, src, gnd), (hh, ww) in zip(windows, shapes):
         valid = np.asarray(cond, dtype=np.float64) > 0
         stack[0][r0:r0 + hh, :ww] = np.where(valid, cond, 0.0)
-        stack[1][r0:r0 + hh, :ww] = np.where(valid, src, 0.0)
-        stack[2][r0:r0 + hh, :ww] = np.where(valid, gnd, 0.0)
+        gnd = np.where(valid, gnd, 0.0)
+        stack[1][r0:r0 + hh, :ww] = np.where(valid & (gnd == 0), src, 0.0)   # policy :rmvsrc (utils.jl:193-196)
+        stack[2][r0:r0 + hh, :ww] = gnd
         offs.append(r0)
         r0 += hh + 1                                      # one NODATA row between windows
     try:

@@ -155,8 +155,10 @@ int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_b
                        int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
 
 /* csgpu_raster_setup with a raster of finite ground conductances added to the diagonal (advanced mode:
- * `asolve = a + spdiagm(finitegrounds)`, src/raster/advanced.jl:277-280; `ground` NULL = none). Grounded cells that
- * also carry a source lose the source (policy :rmvsrc, the one compute_omniscape_current uses). */
+ * `asolve = a + spdiagm(finitegrounds)`, src/raster/advanced.jl:277-280; `ground` NULL = none). The source / ground
+ * conflict policy (remove_src_or_gnd) and direct (infinite) grounds are the caller's business: it applies them to the
+ * rasters it hands over (circuitscape.jl_amd/solver.py::raster_advanced_on_device shows how a direct ground becomes
+ * a NODATA cell plus ground conductance on its neighbours). */
 int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nrows, int64_t ncols, int val_bytes,
                                 int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
                                 csgpu_handle** out);

@@ -752,7 +752,33 @@ def test_raster_entry_points_error_paths_and_fp32(emu_lib):
     ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
     h32 = emu_lib.raster_setup(cond.astype(np.float32), emu_lib.default_opts(batch=1, rtol=1e-5, atol=0.0), reg=False,
                                ground=gnd.astype(np.float32))
-    cur32, _, st32 = h32.solve_raster(src.astype(np.float32))
+    # (the conflict policy is the caller's: compute_omniscape_current drops sources on grounded cells, rmvsrc)
+    cur32, _, st32 = h32.solve_raster(np.where(gnd != 0, 0.0, src).astype(np.float32))
     assert cur32.dtype == np.float32 and st32["not_converged"] == 0
     assert np.max(np.abs(cur32 - ref)) < 2e-3 * ref.max()
     h32.close()
+
+
+@pytest.mark.parametrize("name", ["mgVerify2", "mgVerify6"])
+def test_raster_advanced_on_device_with_direct_grounds(emu_lib, name):
+    """scope rows N2 + N4: the polygon-free raster advanced cases of the reference (each with a direct = infinite
+    ground, mgVerify6 also with the rmvsrc policy and sources on NODATA) with graph layer, solve and current map on the
+    device; the direct ground becomes a NODATA cell plus ground conductance on its neighbours. Golden voltage / current
+    maps with the reference's criterion, and the host-mirror path of the same case."""
+    from circuitscape_jl_amd import solver as ps
+    from conftest import compare_aagrid
+    from helpers import _float_map, flags_from_case, run_raster_advanced_fixture
+    case = load_case(name)
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.policy = o["remove_src_or_gnd"]
+    tight = ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1})
+    vm, cm = ps.raster_advanced_on_device(np.array(case["cellmap"]), _float_map(case["source_map"]),
+                                          _float_map(case["ground_map"]), flags, tight,
+                                          four_neighbors=o["connect_four_neighbors_only"],
+                                          avg_res=o["connect_using_avg_resistances"])
+    got = {"voltmap": vm, "curmap": cm}
+    _, _, host = run_raster_advanced_fixture(case, tight)
+    for key, exp in case["expected"].items():
+        assert compare_aagrid(exp, got[key]), (name, key)
+        assert np.max(np.abs(got[key] - host[key])) < 1e-7 * max(1.0, np.abs(host[key]).max())

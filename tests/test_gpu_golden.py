@@ -201,3 +201,23 @@ def test_omniscape_batch_on_gpu(gpu_lib):
     for (cond, src, gnd), got in zip(wins, maps):
         ref = refmaps.compute_omniscape_current(cond, src, gnd, four_neighbors=False, mode="direct")
         assert np.max(np.abs(got - ref)) < 5e-5 * ref.max()
+
+
+@pytest.mark.parametrize("name", ["mgVerify2", "mgVerify6"])
+def test_raster_advanced_on_device_with_direct_grounds_on_gpu(gpu_lib, name):
+    """scope rows N2 + N4 on the device: polygon-free raster advanced cases (direct grounds) through
+    csgpu_raster_setup_grounded + csgpu_solve_raster, reference stopping rule, golden maps."""
+    from circuitscape_jl_amd import solver as ps
+    from conftest import compare_aagrid
+    from helpers import _float_map, flags_from_case
+    case = load_case(name)
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.policy = o["remove_src_or_gnd"]
+    vm, cm = ps.raster_advanced_on_device(np.array(case["cellmap"]), _float_map(case["source_map"]),
+                                          _float_map(case["ground_map"]), flags, ps.HIPAMGSolver(bs=1),
+                                          four_neighbors=o["connect_four_neighbors_only"],
+                                          avg_res=o["connect_using_avg_resistances"])
+    got = {"voltmap": vm, "curmap": cm}
+    for key, exp in case["expected"].items():
+        assert compare_aagrid(exp, got[key]), (name, key)
