@@ -397,6 +397,62 @@ def raster_advanced_on_device(cellmap, source_map, ground_map, flags, solver, fo
             _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata))
 
 
+def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, avg_res=False):
+    """One-to-all / all-to-one (src/raster/onetoall.jl:13-162) for a raster without polygons and with single-cell focal
+    points, every solve with graph layer, PCG and current map on the device (raster_advanced_on_device): per focal
+    point n, one-to-all injects unit current at n and ties every other focal cell directly to ground (policy rmvgnd);
+    all-to-one grounds n directly and injects unit current at every other focal cell (policy rmvsrc).
+    Returns (res, cum, points) like onetoall_kernel."""
+    gmap = np.asarray(cellmap, dtype=np.float64)
+    rows = np.asarray(points_rc[0], dtype=np.int64) - 1
+    cols = np.asarray(points_rc[1], dtype=np.int64) - 1
+    ids = [int(v) for v in points_rc[2]]
+    assert len(ids) == len(set(ids)), "single-cell focal points only (regions need polygon merging on the host path)"
+    of = flags.outputflags
+    point_map = np.zeros(gmap.shape, dtype=np.int64)
+    point_map[rows, cols] = ids
+    res = np.zeros(len(ids))
+    cum = initialize_cum_maps(gmap, of.write_max_cur_maps)
+    per_point = {}
+    raw = OutputFlags()                       # raw maps from the solve; write_grid options applied once, below
+    for i, n in enumerate(ids):
+        if point_map.sum() == n:
+            res[i] = -1
+            continue
+        me = point_map == n
+        others = (point_map != 0) & ~me
+        if flags.is_onetoall:
+            source_map = np.where(me, 1.0, 0.0)
+            ground_map = np.where(others, np.inf, 0.0)
+            policy = "rmvgnd"
+        else:
+            source_map = np.where(others, 1.0, 0.0)
+            ground_map = np.where(me, np.inf, 0.0)
+            policy = "rmvsrc"
+        sub = Flags(is_raster=True, outputflags=raw, policy=policy)
+        vol, cur = raster_advanced_on_device(gmap, source_map, ground_map, sub, solver, four_neighbors, avg_res)
+        solved = bool(np.any(cur != 0))
+        if flags.is_onetoall:
+            v = vol[rows[i], cols[i]]
+            res[i] = v if (solved and v != 0) else -1
+        else:
+            res[i] = 0 if solved else -1
+        maps = {}
+        if of.write_volt_maps:
+            maps["voltmap"] = _process_grid(vol, gmap, False, of.set_null_voltages_to_nodata)
+        if of.write_cur_maps:
+            maps["curmap"] = _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+            cum.cum_curr += cur
+            if of.write_max_cur_maps:
+                cum.max_curr = np.maximum(cum.max_curr, cur)
+        per_point[n] = maps
+    if of.write_cur_maps or of.write_cum_cur_map_only:
+        cum.cum_curr = _process_grid(cum.cum_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+        if of.write_max_cur_maps:
+            cum.max_curr = _process_grid(cum.max_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+    return np.column_stack([np.asarray(ids, dtype=np.float64), res]), cum, per_point
+
+
 def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
     """Many moving-window solves of compute_omniscape_current (src/utils.jl:145-257) as ONE device job (scope row N3).
 

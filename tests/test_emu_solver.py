@@ -782,3 +782,21 @@ def test_raster_advanced_on_device_with_direct_grounds(emu_lib, name):
     for key, exp in case["expected"].items():
         assert compare_aagrid(exp, got[key]), (name, key)
         assert np.max(np.abs(got[key] - host[key])) < 1e-7 * max(1.0, np.abs(host[key]).max())
+
+
+@pytest.mark.parametrize("name", ["oneToAllVerify4", "allToOneVerify4"])
+def test_onetoall_on_device_built_graph(emu_lib, name):
+    """scope rows N2 + N4: the polygon-free one-to-all / all-to-one cases with single-cell focal points, every per-point
+    solve on the device-built graph (direct grounds at the other focal cells): golden resistances and maps."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import check_onetoall_against_golden, flags_from_case
+    case = load_case(name)
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.is_onetoall = case["kind"] == "one_to_all"
+    flags.is_alltoone = not flags.is_onetoall
+    res, cum, pts = ps.onetoall_on_device(np.array(case["cellmap"], dtype=np.float64), case["points_rc"], flags,
+                                          ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}),
+                                          four_neighbors=o["connect_four_neighbors_only"],
+                                          avg_res=o["connect_using_avg_resistances"])
+    assert check_onetoall_against_golden(case, res, cum, pts) > 0

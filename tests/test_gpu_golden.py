@@ -221,3 +221,20 @@ def test_raster_advanced_on_device_with_direct_grounds_on_gpu(gpu_lib, name):
     got = {"voltmap": vm, "curmap": cm}
     for key, exp in case["expected"].items():
         assert compare_aagrid(exp, got[key]), (name, key)
+
+
+@pytest.mark.parametrize("name", ["oneToAllVerify4", "allToOneVerify4"])
+def test_onetoall_on_device_built_graph_on_gpu(gpu_lib, name):
+    """scope rows N2 + N4 on the device: polygon-free one-to-all / all-to-one with single-cell focal points, every
+    per-point solve on the device-built graph; golden resistances and maps."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import check_onetoall_against_golden, flags_from_case
+    case = load_case(name)
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.is_onetoall = case["kind"] == "one_to_all"
+    flags.is_alltoone = not flags.is_onetoall
+    res, cum, pts = ps.onetoall_on_device(np.array(case["cellmap"], dtype=np.float64), case["points_rc"], flags,
+                                          ps.HIPAMGSolver(bs=1), four_neighbors=o["connect_four_neighbors_only"],
+                                          avg_res=o["connect_using_avg_resistances"])
+    assert check_onetoall_against_golden(case, res, cum, pts) > 0
