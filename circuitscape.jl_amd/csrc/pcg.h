@@ -324,8 +324,12 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_HIP(hipEventCreate(&e1));
   CS_HIP(hipEventRecord(e0, st));
 
-  const int spmv_g = spmv_grid<T, K>((int)n);
-  const int spmv_gp = spmv_grid<TP, K>((int)n);
+  // rows of dot partials the CG product / the last product of the V-cycle write (one per workgroup)
+  const bool wave = K > 1 && spmv_wave_enabled();
+  const bool two_product_early = H.levels.size() > 1 && L0.M.nnz > 0 && pp.nu_pre == 1 && pp.nu_post == 1 &&
+                                 W.tail >= H.levels[1].A.nrows;
+  const int spmv_g = wave ? spmv_wave_grid<T, K>((int)n) : spmv_grid<T, K>((int)n);
+  const int spmv_gp = (wave && two_product_early) ? spmv_wave_grid<TP, K>((int)n) : spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
   const bool two_product = H.levels.size() > 1 && L0.M.nnz > 0 && pp.nu_pre == 1 && pp.nu_post == 1 &&
