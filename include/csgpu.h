@@ -25,6 +25,16 @@
  *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for a raster without polygons (NODATA allowed)
  *                              (src/raster/pairwise.jl:271-362, src/core.jl:608-634) -- "next" row N4, used by
  *                              bench.py so the synthetic Laplacian is born in HBM
+ *   csgpu_raster_nodemap   <-> the node map construct_node_map returns (src/raster/pairwise.jl:271-301)
+ *   csgpu_components       <-> connected_components(SimpleGraph(G))       src/raster/pairwise.jl:233,
+ *                              src/raster/advanced.jl:59, src/network/pairwise.jl:52
+ *   csgpu_raster_setup_grounded, csgpu_solve_raster
+ *                          <-> compute_omniscape_current(conductance, source, ground, cfg)  src/utils.jl:145-257 and
+ *                              the raster branch of advanced_kernel (src/raster/advanced.jl:151-271) for rasters
+ *                              without polygons: grounded matrix, right-hand side from the source raster, node
+ *                              currents incl. ground currents (src/out.jl:178-207), maps back -- "next" rows N2/N3
+ *   csgpu_get_info, csgpu_spmv_bench, csgpu_spmv_host, csgpu_level_spmv_host, csgpu_get_level_matrix
+ *                          <-> no reference counterpart: measurement and test hooks
  *
  * Conventions
  *   - The matrix is a symmetric SPD (or singular-consistent) graph Laplacian in compressed sparse
