@@ -125,7 +125,15 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="extra csgpu_opts override key=value (tuning)")
     ap.add_argument("--compare-steps", type=int, default=3,
                     help="N=1 only: also time this many steps with an fp64 preconditioner and report them (0 = skip)")
+    ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="N_FULL",
+                    help="internal: run only the CPU-baseline leg on a --cpu-sample raster, scale to N_FULL nodes, print "
+                         "its JSON object and exit (the bench runs this in a child process so that nothing on the host "
+                         "side can take the GPU line down)")
     args = ap.parse_args()
+    if args.cpu_baseline_only > 0:
+        print(json.dumps(cpu_baseline_entry(cpu_baseline(args.cpu_sample), args.cpu_baseline_only, args.size,
+                                            args.cpu_sample)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,7 +284,11 @@ def main():
             h2.close()
         if args.cpu_sample > 0 and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline_entry(cpu_baseline(args.cpu_sample), info["n"], size, args.cpu_sample)
+                import subprocess
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(info["n"]),
+                                        "--cpu-sample", str(args.cpu_sample), "--size", str(size)],
+                                       capture_output=True, text=True, timeout=600)
+                out["cpu_baseline"] = json.loads(child.stdout.strip().splitlines()[-1])
             except Exception as e:  # the GPU line must be printed whatever happens to the host-side leg
                 out["cpu_baseline"] = {"value": None, "unit": "pair-solves/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
