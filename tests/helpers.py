@@ -199,3 +199,59 @@ def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0, 
                 refd = np.einsum("ik,ik->k", xs[:M.shape[0]], ref)
                 assert np.max(np.abs(dots - refd)) <= tol * max(1.0, np.abs(refd).max()) * 10, (k, dots, refd)
         h.close()
+
+
+def check_closed_form_circuits(L):
+    """Effective resistances with textbook closed forms, independent of the oracle: a path of unequal resistors
+    (series sum), the cycle C_n (d (n - d) / n), the complete graph K_n (2 / n), a star (sum of the two spokes), and
+    two parallel chains; plus symmetry and the triangle inequality of the resistance metric."""
+    import scipy.sparse as sp
+
+    def lap(n, edges):
+        i = np.array([e[0] for e in edges]); j = np.array([e[1] for e in edges]); w = np.array([e[2] for e in edges], dtype=float)
+        a = sp.coo_matrix((w, (i, j)), shape=(n, n)).tocsr()
+        a = a + a.T
+        return (sp.diags(np.asarray(a.sum(axis=1)).ravel()) - a).tocsr()
+
+    def solve(Lm, src, dst):
+        h = L.setup(Lm, L.default_opts(batch=4, criterion=L.CRIT_TRUE_RESIDUAL, rtol=1e-11, atol=0.0))
+        R, _, _, st = h.solve_pairs(src, dst)
+        h.close()
+        assert st["not_converged"] == 0
+        return R
+
+    rng = np.random.default_rng(0)
+    n = 200
+    g = rng.uniform(0.5, 3.0, size=n - 1)
+    R = solve(lap(n, [(k, k + 1, g[k]) for k in range(n - 1)]), [0, 10, 50], [n - 1, 150, 51])
+    exp = [np.sum(1 / g), np.sum(1 / g[10:150]), 1 / g[50]]
+    assert np.max(np.abs(R - exp) / exp) < 1e-8
+    n = 101
+    R = solve(lap(n, [(k, (k + 1) % n, 1.0) for k in range(n)]), [0, 0, 7], [1, 50, 90])
+    exp = [d * (n - d) / n for d in (1, 50, 83)]
+    assert np.max(np.abs(R - exp) / exp) < 1e-8
+    n = 40
+    R = solve(lap(n, [(a, b, 1.0) for a in range(n) for b in range(a + 1, n)]), [0, 3], [1, 39])
+    assert np.max(np.abs(R - 2.0 / n)) < 1e-9
+    n = 60
+    spokes = rng.uniform(0.5, 2.0, size=n - 1)
+    R = solve(lap(n, [(0, k + 1, spokes[k]) for k in range(n - 1)]), [1, 5], [2, 0])
+    exp = [1 / spokes[0] + 1 / spokes[1], 1 / spokes[4]]
+    assert np.max(np.abs(R - exp) / exp) < 1e-8
+    # two chains of 10 and 30 unit resistors in parallel between nodes 0 and 1: 10 * 30 / 40
+    edges, nxt = [], 2
+    for length in (10, 30):
+        prev = 0
+        for _ in range(length - 1):
+            edges.append((prev, nxt, 1.0)); prev = nxt; nxt += 1
+        edges.append((prev, 1, 1.0))
+    R = solve(lap(nxt, edges), [0], [1])
+    assert abs(R[0] - 7.5) < 1e-8
+    # metric properties on a random raster
+    _, gr = rg.synthetic_raster_problem(30, 30, seed=4)
+    h = L.raster_setup(gr, L.default_opts(batch=8, criterion=L.CRIT_TRUE_RESIDUAL, rtol=1e-11, atol=0.0))
+    a, b, c = 17, 455, 871
+    R, _, _, _ = h.solve_pairs([a, b, a, b, c, c], [b, a, c, c, a, b])
+    h.close()
+    assert abs(R[0] - R[1]) < 1e-9 * R[0] and abs(R[2] - R[4]) < 1e-9 * R[2] and abs(R[3] - R[5]) < 1e-9 * R[3]
+    assert R[2] <= R[0] + R[3] and R[0] <= R[2] + R[3] and R[3] <= R[0] + R[2]

@@ -817,3 +817,10 @@ def test_experimental_single_wave_spmm_variant():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_closed_form_circuits(emu_lib):
+    """Known-answer circuits (series, cycle, complete graph, star, parallel chains) and the metric properties of the
+    effective resistance -- checks that do not go through the oracle at all."""
+    from helpers import check_closed_form_circuits
+    check_closed_form_circuits(emu_lib)

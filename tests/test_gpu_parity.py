@@ -185,3 +185,9 @@ def test_device_graph_build_with_nodata(gpu_lib, shape, hole_frac, four):
     np.minimum.at(first, labels, np.arange(ref.shape[0]))
     assert np.all(np.diff(first) > 0)
     h.close()
+
+
+def test_closed_form_circuits(gpu_lib):
+    """Known-answer circuits and metric properties of the effective resistance on the device (see the emulator twin)."""
+    from helpers import check_closed_form_circuits
+    check_closed_form_circuits(gpu_lib)
