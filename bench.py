@@ -58,9 +58,11 @@ def focal_pairs(size, npts=15, seed=67890):
     return cells, pairs
 
 
-def cpu_baseline(sample_size, nsolve=2, max_threads=32):
+def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16):
     """Oracle (CPU restatement of the reference CG+AMG path) on a bounded sample of the same workload: one thread, and
-    all host cores the way the reference parallelises (one pair per task, src/core.jl:262-272)."""
+    all host cores the way the reference parallelises (one pair per task, src/core.jl:262-272). Also returns the
+    TIGHT oracle's resistances (true-residual rtol 1e-12) of the first `ntight` pairs: the parity reference the GPU
+    path is compared with on the same sample raster (`parity` in the bench line)."""
     from oracle import refgraph as rg, refsolve as rs
     g = make_raster(sample_size)
     G = rg.raster_laplacian_from_conductance(g)
@@ -82,6 +84,13 @@ def cpu_baseline(sample_size, nsolve=2, max_threads=32):
         t0 = time.time()
         _, _, res_mt = S.solve_pairs([p[0] for p in pairs[:npar]], [p[1] for p in pairs[:npar]], nthreads=npar)
         out.update(mt_threads=npar, mt_wall_s=time.time() - t0, mt_pairs=npar, mt_iters=[r["iters"] for r in res_mt])
+    if ntight > 0:
+        nt = min(ntight, len(pairs))
+        t0 = time.time()
+        Rt, _, res_t = S.solve_pairs([p[0] for p in pairs[:nt]], [p[1] for p in pairs[:nt]], rtol=1e-12, atol=0.0,
+                                     criterion=1, nthreads=max(1, min(nthreads, nt)))
+        out.update(tight_R=Rt.tolist(), tight_pairs=nt, tight_wall_s=time.time() - t0,
+                   tight_max_true_relres=max(r["true_relres"] for r in res_t))
     return out
 
 
@@ -103,6 +112,10 @@ def cpu_baseline_entry(cb, n_full, size, sample_size):
         entry["cores"] = cb["mt_threads"]
         entry["sample"] = sample + ("; then %d pairs on %d threads (one pair per thread) in %.2fs"
                                     % (cb["mt_pairs"], cb["mt_threads"], cb["mt_wall_s"]))
+    entry["sample_n"] = cb["n"]
+    if "tight_R" in cb:  # consumed by the parent (parity), not part of the published object
+        entry["_tight"] = {"R": cb["tight_R"], "pairs": cb["tight_pairs"], "max_true_relres": cb["tight_max_true_relres"],
+                           "wall_s": cb["tight_wall_s"]}
     return entry
 
 
@@ -114,7 +127,7 @@ def main():
     ap.add_argument("--size", type=int, default=10000)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--precision", default="double", choices=["double", "single"])
-    ap.add_argument("--cpu-sample", type=int, default=1500, help="raster edge of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="raster edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
     ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
                     help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "

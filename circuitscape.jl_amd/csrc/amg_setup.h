@@ -684,6 +684,9 @@ struct Level {
   Csr<T> A, P, R;       // P, R empty on the coarsest level
   Csr<T> Q;             // Q = P - omega D^-1 A P: prolongation fused with the first post-smoothing sweep
   Csr<T> QT, M;         // level 0 with V(1,1) smoothing only: Q^T and [S Q] of the two-product form (see build_sq_kernel)
+  Dia<T> Sdia;          // ... or S in lattice form (stencil.h) when the fine matrix is a raster lattice: the second
+                        // product is then evaluated as S b + Q x_c and M is not built
+  bool two_product() const { return M.nnz > 0 || Sdia.n > 0; }
   DBuf dinv;            // 1/a_ii
   DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
   DBuf orderQT;         // traversal order of the long-row kernel on Q^T (two-product level; may be empty)
@@ -713,7 +716,26 @@ struct SetupParams {
   double omega_p = 1.6;
   double omega_s = 1.5;
   bool two_product = false;  // build Q^T and [S Q] on level 0 (the solve phase runs V(1,1) there)
+  bool lattice_s = false;    // the caller provides S in lattice form (Level::Sdia): build Q^T only, not [S Q]
 };
+
+// [S Q] of the two-product form as one CSR matrix with n + n_c columns (build_sq_kernel)
+template <class T>
+inline void build_sq_matrix(Level<T>& L, hipStream_t st) {
+  const int n = L.A.nrows, nagg = L.Q.ncols;
+  Csr<T>& M = L.M;
+  M.nrows = n;
+  M.ncols = n + nagg;
+  M.nnz = L.A.nnz + L.Q.nnz;
+  M.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+  M.col.alloc((size_t)M.nnz * sizeof(int));
+  M.val.alloc((size_t)M.nnz * sizeof(T));
+  hipLaunchKernelGGL((sq_rowptr_kernel<T>), dim3(grid_for((int64_t)n + 1)), dim3(256), 0, st, n, L.A.rp(), L.Q.rp(),
+                     M.rp());
+  hipLaunchKernelGGL((build_sq_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, n, L.A.rp(), L.A.ci(), L.A.va(), L.Q.rp(),
+                     L.Q.ci(), L.Q.va(), dptr<T>(L.dinv), L.omega, M.rp(), M.ci(), M.va());
+  check_launch("build [S Q]");
+}
 
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
 template <class T>
@@ -874,21 +896,10 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
         (int64_t)n + nagg < 0x7fffffffLL) {
       transpose(L.Q, L.QT, st);
       spmv_block_order_rect(L.QT, L.periodA, L.orderQT, st);
-      Csr<T>& M = L.M;
-      M.nrows = n;
-      M.ncols = n + nagg;
-      M.nnz = L.A.nnz + L.Q.nnz;
-      M.rowptr.alloc((size_t)(n + 1) * sizeof(int));
-      M.col.alloc((size_t)M.nnz * sizeof(int));
-      M.val.alloc((size_t)M.nnz * sizeof(T));
-      hipLaunchKernelGGL((sq_rowptr_kernel<T>), dim3(grid_for((int64_t)n + 1)), dim3(256), 0, st, n, L.A.rp(), L.Q.rp(),
-                         M.rp());
-      hipLaunchKernelGGL((build_sq_kernel<T>), dim3(g), dim3(256), 0, st, n, L.A.rp(), L.A.ci(), L.A.va(), L.Q.rp(),
-                         L.Q.ci(), L.Q.va(), dptr<T>(L.dinv), L.omega, M.rp(), M.ci(), M.va());
-      check_launch("build [S Q]");
+      if (!sp.lattice_s) build_sq_matrix(L, st);
       if (getenv("CSGPU_VERBOSE"))
         fprintf(stderr, "csgpu: two-product level: nnz(Q^T)=%lld nnz([S Q])=%lld periodA=%lld orderA=%s orderQT=%s\n",
-                (long long)L.QT.nnz, (long long)M.nnz, L.periodA, L.orderA.p ? "yes" : "no", L.orderQT.p ? "yes" : "no");
+                (long long)L.QT.nnz, (long long)L.M.nnz, L.periodA, L.orderA.p ? "yes" : "no", L.orderQT.p ? "yes" : "no");
     }
     // next level
     size_prev = std::move(size_c);  // unsigned long long and long long share the representation for these counts

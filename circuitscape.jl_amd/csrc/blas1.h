@@ -91,12 +91,7 @@ __global__ __launch_bounds__(256) void collapse_partials_kernel(const double* __
 template <int K>
 __global__ __launch_bounds__(256) void cg_alpha_kernel(CgScalars* S, const double* partials, int nparts) {
   __shared__ double sm[4];
-  if (S->all_done) {
-    // a surplus iteration enqueued before the host saw the flag: neutralise it (the final x update is already in)
-    if (threadIdx.x < K) S->alpha[threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) S->all_done = 2;
-    return;
-  }
+  if (S->all_done) return;  // a surplus iteration enqueued before the host saw the flag: every kernel of it is a no-op
   for (int c = 0; c < K; ++c) {
     const double pAp = reduce_partials<K>(partials, nparts, c, sm);
     if (threadIdx.x == 0) {
@@ -140,11 +135,14 @@ struct CgVec {
   static constexpr int LPR = K / VEC;            // lanes covering one node's K columns
 };
 
-template <class T, class TP, int K, bool RR>
+// XUP: also x += alpha p in the same pass (solves whose caller needs the whole solution vector; resistance-only pair
+// solves accumulate x at their focal nodes only, cg_focal_x_kernel).
+template <class T, class TP, int K, bool RR, bool XUP>
 __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgScalars* S, T* __restrict__ r,
                                                           const T* __restrict__ Ap, TP* __restrict__ rp,
                                                           TP* __restrict__ xa, const TP* __restrict__ dinv, TP omega,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, T* __restrict__ x,
+                                                          const TP* __restrict__ p) {
   constexpr int VEC = CgVec<T, K>::VEC, LPR = CgVec<T, K>::LPR;
   typedef VecN<T, VEC> VT;
   typedef VecN<TP, VEC> VP;
@@ -175,17 +173,37 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
     if (rp) reinterpret_cast<VP*>(rp)[v] = rq;
     if (xa) reinterpret_cast<VP*>(xa)[v] = xq;
   };
+  auto xbody = [&](int64_t v, const VT& xv, const VP& pv) {
+    VT xn;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) xn.e[q] = fma(alpha[q], (T)pv.e[q], xv.e[q]);
+    reinterpret_cast<VT*>(x)[v] = xn;
+  };
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += 2 * stride) {
     const int64_t v2 = v + stride;
     const bool two = v2 < nv;
     const VT r1 = reinterpret_cast<const VT*>(r)[v], a1 = reinterpret_cast<const VT*>(Ap)[v];
     VT r2 = r1, a2 = a1;
+    VT x1, x2;
+    VP p1, p2;
+    if (XUP) {
+      x1 = reinterpret_cast<const VT*>(x)[v];
+      p1 = reinterpret_cast<const VP*>(p)[v];
+    }
     if (two) {
       r2 = reinterpret_cast<const VT*>(r)[v2];
       a2 = reinterpret_cast<const VT*>(Ap)[v2];
+      if (XUP) {
+        x2 = reinterpret_cast<const VT*>(x)[v2];
+        p2 = reinterpret_cast<const VP*>(p)[v2];
+      }
     }
     body(v, r1, a1);
-    if (two) body(v2, r2, a2);
+    if (XUP) xbody(v, x1, p1);
+    if (two) {
+      body(v2, r2, a2);
+      if (XUP) xbody(v2, x2, p2);
+    }
   }
   if (RR) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -204,50 +222,52 @@ __global__ __launch_bounds__(256) void cg_update_r_kernel(int64_t n, const CgSca
   }
 }
 
-// ---- x += alpha p ; p = z + beta p   (alpha, beta of the iteration that just finished). p and z live in the
-//      preconditioner's precision TP; x is updated with exactly the stored p, like r was (r -= alpha A p).
+// ---- p = z + beta p   (beta of the iteration that just finished; the first iteration runs with beta = 0 on a zeroed
+//      p). p and z live in the preconditioner's precision TP; the combination is evaluated in T. pin / pout may be the
+//      same buffer (in-place update, CSR path) or the two halves of a ping-pong pair.
 template <class T, class TP, int K>
-__global__ __launch_bounds__(256) void cg_update_xp_kernel(int64_t n, const CgScalars* S, T* __restrict__ x,
-                                                           TP* __restrict__ p, const TP* __restrict__ z) {
+__global__ __launch_bounds__(256) void cg_update_p_kernel(int64_t n, const CgScalars* S, const TP* pin,
+                                                          TP* pout, const TP* __restrict__ z) {
   constexpr int VEC = CgVec<T, K>::VEC, LPR = CgVec<T, K>::LPR;
-  typedef VecN<T, VEC> VT;
   typedef VecN<TP, VEC> VP;
-  if (S->all_done == 2) return;  // 2 = the final x update has already been applied
+  if (S->all_done) return;
   const int c0 = (threadIdx.x % LPR) * VEC;
-  T alpha[VEC], beta[VEC];
+  T beta[VEC];
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
-    alpha[q] = (T)S->alpha[c0 + q];
-    beta[q] = (T)S->beta[c0 + q];
-  }
+  for (int q = 0; q < VEC; ++q) beta[q] = (T)S->beta[c0 + q];
   const int64_t nv = n * K / VEC;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  auto body = [&](int64_t v, const VT& xv, const VP& pv, const VP& zv) {
-    VT xn;
+  auto body = [&](int64_t v, const VP& pv, const VP& zv) {
     VP pn;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-      const T pe = (T)pv.e[q];
-      xn.e[q] = xv.e[q] + alpha[q] * pe;
-      pn.e[q] = (TP)((T)zv.e[q] + beta[q] * pe);
-    }
-    reinterpret_cast<VT*>(x)[v] = xn;
-    reinterpret_cast<VP*>(p)[v] = pn;
+    for (int q = 0; q < VEC; ++q) pn.e[q] = (TP)fma(beta[q], (T)pv.e[q], (T)zv.e[q]);
+    reinterpret_cast<VP*>(pout)[v] = pn;
   };
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += 2 * stride) {
     const int64_t v2 = v + stride;
     const bool two = v2 < nv;
-    const VT x1 = reinterpret_cast<const VT*>(x)[v];
-    const VP p1 = reinterpret_cast<const VP*>(p)[v], z1 = reinterpret_cast<const VP*>(z)[v];
-    VT x2 = x1;
+    const VP p1 = reinterpret_cast<const VP*>(pin)[v], z1 = reinterpret_cast<const VP*>(z)[v];
     VP p2 = p1, z2 = z1;
     if (two) {
-      x2 = reinterpret_cast<const VT*>(x)[v2];
-      p2 = reinterpret_cast<const VP*>(p)[v2];
+      p2 = reinterpret_cast<const VP*>(pin)[v2];
       z2 = reinterpret_cast<const VP*>(z)[v2];
     }
-    body(v, x1, p1, z1);
-    if (two) body(v2, x2, p2, z2);
+    body(v, p1, z1);
+    if (two) body(v2, p2, z2);
+  }
+}
+
+// ---- focal-node solution: xf[m][c] += alpha_c * p[fnode[m]][c] for the nf nodes whose solution values the caller
+//      consumes (resistance-only pair solves read x at the pair's two nodes and at the gathered focal nodes only:
+//      src/core.jl:231-232, 685-703). Same arithmetic as the fused x-update of cg_update_r_kernel (one fma per
+//      iteration), so the values are bit-identical to the corresponding entries of a full solution vector.
+template <class T, class TP, int K>
+__global__ __launch_bounds__(256) void cg_focal_x_kernel(const CgScalars* S, const int* __restrict__ fnode, int nf,
+                                                         const TP* __restrict__ p, T* __restrict__ xf) {
+  if (S->all_done) return;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nf * K; e += gridDim.x * 256) {
+    const int m = e / K, c = e % K;
+    xf[e] = fma((T)S->alpha[c], (T)p[(size_t)fnode[m] * K + c], xf[e]);
   }
 }
 

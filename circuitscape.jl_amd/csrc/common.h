@@ -112,6 +112,18 @@ struct Csr {
   size_t device_bytes() const { return rowptr.bytes + col.bytes + val.bytes; }
 };
 
+// Lattice ("symmetric diagonal") form of a symmetric matrix whose node i is coupled to i+-1, i+-(R-1), i+-R, i+-(R+1)
+// only (an all-valid raster in column-major numbering, see stencil.h):
+//   rows[i] = { M[i,i], M[i,i+1], M[i,i+R-1], M[i,i+R], M[i,i+R+1] }   (0 where the entry is absent)
+template <class T>
+struct Dia {
+  int64_t n = 0;
+  int R = 0;   // lattice period (raster height)
+  DBuf rows;   // [n][5] of T
+  const T* data() const { return rows.as<T>(); }
+  size_t device_bytes() const { return rows.bytes; }
+};
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid size for grid-stride elementwise / reduction kernels: fixed cap so partial-sum layouts (and hence

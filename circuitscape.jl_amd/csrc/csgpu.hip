@@ -29,6 +29,8 @@ struct ISolver {
   virtual void level_spmv_host(int lvl, int which, const void* x, void* y, int k, double* dots) = 0;
   virtual void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz, int32_t* rowptr,
                                 int32_t* colidx, void* vals) const = 0;
+  virtual void dia_product_host(const void* z, const void* pin, const double* beta, void* pout, void* y, int k,
+                                double* dots) = 0;
 };
 
 // index conversion kernels (Julia hands Int64 / 1-based arrays by default: src/run.jl:34, src/config.jl:28)
@@ -64,6 +66,7 @@ struct Solver : ISolver {
   csgpu_opts opts;
   Csr<T> Aouter;      // the matrix CG sees when MIXED (otherwise level 0 of the hierarchy is used)
   Hierarchy<TP> H;
+  Dia<T> dia;         // lattice form of the CG matrix (all-valid rasters; empty otherwise)
   PcgWork<T, TP> W;
   double upload_ms = 0;
   int64_t n = 0, nnz = 0;
@@ -113,6 +116,26 @@ struct Solver : ISolver {
     pp.nu_coarse = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
     pp.use_graph = opts.use_graph;
     return pp;
+  }
+  const Dia<T>* dia_ptr() const { return dia.n > 0 ? &dia : nullptr; }
+
+  // Lattice form of the CG matrix: period known (raster built here, every cell valid) or detected from the band
+  // structure of a host-built matrix (candidates around the dominant band offset found by spmv_block_order).
+  void detect_lattice(const Csr<T>& A, int known_period) {
+    static const bool off = getenv("CSGPU_NO_STENCIL") != nullptr;  // A/B knob
+    dia = Dia<T>();
+    if (off || opts.stencil < 0 || known_period < 0) return;
+    if (known_period > 0) {
+      dia_from_csr(A, known_period, dia, st);
+      return;
+    }
+    // node 0 of a lattice is coupled to 1, R and (8 neighbours) R+1: its last column gives the period
+    if (A.nrows < 16 || A.nnz < 1) return;
+    const int len0 = read_int(A.rp() + 1, st);
+    if (len0 < 2 || len0 > 4) return;
+    const long long last = read_int(A.ci() + (len0 - 1), st);
+    for (long long cand : {last - 1, last})
+      if (cand >= 4 && cand < (1ll << 30) && dia_from_csr(A, (int)cand, dia, st)) return;
   }
 
   void setup_from_host(const void* rowptr, const void* colidx, const void* vals, int64_t n_, int64_t nnz_,
@@ -166,7 +189,7 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     opts.node_row = opts.node_col = nullptr;  // host pointers are never retained
-    finish_setup(std::move(A), prow, pcol);
+    finish_setup(std::move(A), prow, pcol, 0);
   }
 
   const Csr<T>& cg_matrix() const {
@@ -177,14 +200,35 @@ struct Solver : ISolver {
     }
   }
 
-  void finish_setup(Csr<T>&& A, const int* prow, const int* pcol) {
+  // known_period: raster height when the matrix was built here from an all-valid raster, 0 = detect, -1 = no lattice
+  void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period) {
+    detect_lattice(A, known_period);
+    SetupParams sp = setup_params();
+    static const bool no_lattice_s = getenv("CSGPU_NO_LATTICE_S") != nullptr;  // A/B knob
+    sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
     if constexpr (MIXED) {
       Csr<TP> Ap;
       convert_csr(A, Ap, st);
       Aouter = std::move(A);
-      amg_setup(H, std::move(Ap), setup_params(), prow, pcol, st);
+      amg_setup(H, std::move(Ap), sp, prow, pcol, st);
     } else {
-      amg_setup(H, std::move(A), setup_params(), prow, pcol, st);
+      amg_setup(H, std::move(A), sp, prow, pcol, st);
+    }
+    Level<TP>& L0 = H.levels[0];
+    if (sp.lattice_s && L0.QT.nnz > 0) {
+      // second product of the two-product level from the lattice form: out = S b + Q x_c (stencil.h)
+      hipEvent_t e0, e1;
+      CS_HIP(hipEventCreate(&e0));
+      CS_HIP(hipEventCreate(&e1));
+      CS_HIP(hipEventRecord(e0, st));
+      dia_build_s(dia, (const TP*)dptr<TP>(L0.dinv), L0.omega, L0.Sdia, st);
+      CS_HIP(hipEventRecord(e1, st));
+      CS_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+      H.setup_ms += ms;
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
     }
   }
 
@@ -242,7 +286,8 @@ struct Solver : ISolver {
     dcond.release();
     node.release();
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol));
+    // every cell valid: node i couples to i+-1, i+-(R-1), i+-R, i+-(R+1) -> lattice form (stencil.h)
+    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), n == ncells ? (int)R : -1);
   }
 
   void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) override {
@@ -280,7 +325,7 @@ struct Solver : ISolver {
     CS_REQUIRE(nodemap.p != nullptr, CSGPU_BAD_ARGS, "handle was not built by csgpu_raster_setup");
     const int64_t ncells = raster_rows * raster_cols;
     ensure_components();
-    W.ensure(n, 1, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
+    W.ensure(n, 1, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = 1;
       stats->batch = 1;
@@ -333,16 +378,18 @@ struct Solver : ISolver {
   }
 
   template <int K>
-  PcgBatchResult run_batch(int ncols) {
-    return pcg_solve<T, TP, K>(cg_matrix(), H, W, pcg_params(K), ncols, st);
+  PcgBatchResult run_batch(int ncols, bool need_x) {
+    PcgParams pp = pcg_params(K);
+    pp.need_x = need_x;
+    return pcg_solve<T, TP, K>(cg_matrix(), H, W, pp, ncols, st, dia_ptr());
   }
-  PcgBatchResult run_batch_k(int K, int ncols) {
+  PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true) {
     switch (K) {
-      case 1: return run_batch<1>(ncols);
-      case 2: return run_batch<2>(ncols);
-      case 4: return run_batch<4>(ncols);
-      case 8: return run_batch<8>(ncols);
-      default: return run_batch<16>(ncols);
+      case 1: return run_batch<1>(ncols, need_x);
+      case 2: return run_batch<2>(ncols, need_x);
+      case 4: return run_batch<4>(ncols, need_x);
+      case 8: return run_batch<8>(ncols, need_x);
+      default: return run_batch<16>(ncols, need_x);
     }
   }
 
@@ -383,7 +430,7 @@ struct Solver : ISolver {
     for (int64_t g = 0; g < ngather; ++g)
       CS_REQUIRE(gather[g] >= 0 && gather[g] < n, CSGPU_BAD_ARGS, "gather node id out of range");
     const int K = pick_k(npairs);
-    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = (int)npairs;
       stats->batch = K;
@@ -401,6 +448,11 @@ struct Solver : ISolver {
     if (volt_out || curr_out) dvolt.alloc((size_t)n * K * sizeof(T));
     // N1: node currents of every pair, optional cumulative / maximum accumulation over the pairs of this call
     const bool want_curr = curr_out || cum_inout || max_inout || branch_out;
+    // resistance-only calls consume x at the pairs' nodes and the gathered focal nodes only (core.jl:231-232,
+    // 685-703): accumulate just those entries instead of carrying the n x K solution through every iteration
+    const bool need_x = volt_out || want_curr || opts.explicit_check > 0;
+    std::vector<int> focal;
+    if (!need_x) focal.resize((size_t)ngather + 2 * K);
     DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax, dbranch, dbranch2;
     if (branch_out) {
       dbranch.alloc((size_t)std::max<int64_t>(nnz, 1) * K * sizeof(T));
@@ -432,12 +484,26 @@ struct Solver : ISolver {
       CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * K * sizeof(T), st));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, dptr<T>(W.b),
                                            dptr<int>(dsrc), dptr<int>(ddst), ncols));
-      PcgBatchResult r = run_batch_k(K, ncols);
+      if (!need_x) {  // focal list: [gathered nodes..., src of every column..., dst of every column...]
+        for (int64_t g = 0; g < ngather; ++g) focal[g] = (int)gather[g];
+        for (int c = 0; c < K; ++c) {
+          focal[ngather + c] = s32[c];
+          focal[ngather + K + c] = d32[c];
+        }
+        W.set_focal(focal, st);
+      }
+      PcgBatchResult r = run_batch_k(K, ncols, need_x);
       accumulate(stats, r, ncols);
       const int ge = grid_for((int64_t)ncols * (ngather + 1));
-      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_extract_kernel<T, KK>), dim3(ge), dim3(256), 0, st,
-                                           (const T*)dptr<T>(W.x), dptr<int>(dsrc), dptr<int>(ddst), ncols,
-                                           dptr<int>(dgather), (int)ngather, dptr<T>(dres), dptr<T>(dgath)));
+      if (need_x) {
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_extract_kernel<T, KK>), dim3(ge), dim3(256), 0, st,
+                                             (const T*)dptr<T>(W.x), dptr<int>(dsrc), dptr<int>(ddst), ncols,
+                                             dptr<int>(dgather), (int)ngather, dptr<T>(dres), dptr<T>(dgath)));
+      } else {
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_extract_focal_kernel<T, KK>), dim3(ge), dim3(256), 0, st,
+                                             (const T*)dptr<T>(W.xf), ncols, (int)ngather, dptr<T>(dres),
+                                             dptr<T>(dgath)));
+      }
       if (resist_out)
         CS_HIP(hipMemcpyAsync((T*)resist_out + p0, dres.p, (size_t)ncols * sizeof(T), hipMemcpyDeviceToHost, st));
       if (gathered_out && ngather > 0)
@@ -507,7 +573,7 @@ struct Solver : ISolver {
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
     const int K = pick_k(nrhs);
-    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].M.nnz > 0 ? H.levels[1].A.nrows : 0);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = (int)nrhs;
       stats->batch = K;
@@ -544,8 +610,9 @@ struct Solver : ISolver {
     info->levels = (int)H.levels.size();
     info->val_bytes = (int)sizeof(T);
     info->precond_bytes = (int)sizeof(TP);
+    info->lattice_period = dia.n > 0 ? dia.R : 0;
     double nnz_sum = 0, n_sum = 0;
-    int64_t bytes = (int64_t)Aouter.device_bytes();
+    int64_t bytes = (int64_t)(Aouter.device_bytes() + dia.device_bytes() + W.p2.bytes);
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
       nnz_sum += (double)L.A.nnz;
@@ -556,7 +623,7 @@ struct Solver : ISolver {
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
                          L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
-                         L.M.device_bytes() + L.orderQT.bytes);
+                         L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes());
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
@@ -627,6 +694,7 @@ struct Solver : ISolver {
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     Level<TP>& L = H.levels[lvl];
+    if (which == 5 && L.M.nnz == 0 && L.Sdia.n > 0) build_sq_matrix(L, st);  // CSR form for the size query only
     const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
     CS_REQUIRE(M.nnz > 0, CSGPU_BAD_ARGS, "level has no such operator");
     DBuf x((size_t)M.ncols * k * sizeof(TP)), y((size_t)M.nrows * k * sizeof(TP));
@@ -637,7 +705,11 @@ struct Solver : ISolver {
     if (which == 0 || sq) a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
     if (which == 4) a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
     if (sq) a.partials = dptr<double>(part);
-    if (sq) {
+    const bool sq_lattice = sq && L.Sdia.n > 0;
+    if (sq_lattice) {  // the kernel the V-cycle runs on a lattice level: S b + Q x_c with x = [b; x_c]
+      CS_DISPATCH_K(k, dia_sq_product<TP, KK>(L.Sdia, L.Q, (const TP*)dptr<TP>(x), (const TP*)dptr<TP>(x) + (size_t)M.nrows * k,
+                                             dptr<TP>(y), dptr<double>(part), nullptr, st));
+    } else if (sq) {
       CS_DISPATCH_K(k, spmv_launch_wide<TP, KK>(a, true, st));
     } else {
       CS_DISPATCH_K(k, spmv_launch<TP, KK>(a, EPI_PLAIN, false, st));
@@ -647,7 +719,8 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
     if (sq && dots) {
       int g = 1;
-      CS_DISPATCH_K(k, g = (KK > 1 && spmv_wave_enabled()) ? spmv_wave_grid<TP, KK>(M.nrows) : spmv_grid<TP, KK>(M.nrows));
+      CS_DISPATCH_K(k, g = sq_lattice ? dia_grid<TP, TP, KK>(L.Sdia)
+                             : (KK > 1 && spmv_wave_enabled()) ? spmv_wave_grid<TP, KK>(M.nrows) : spmv_grid<TP, KK>(M.nrows));
       std::vector<double> ph((size_t)g * k);
       CS_HIP(hipMemcpy(ph.data(), part.p, ph.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int c = 0; c < k; ++c) {
@@ -662,6 +735,11 @@ struct Solver : ISolver {
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     const Level<TP>& L = H.levels[lvl];
+    if (which == 5 && L.M.nnz == 0 && L.Sdia.n > 0) {
+      // lattice level: the CSR form of [S Q] is not kept; build it (by the independent CSR builder) for inspection
+      build_sq_matrix(const_cast<Level<TP>&>(L), st);
+      CS_HIP(hipStreamSynchronize(st));
+    }
     const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
     if (nrows) *nrows = M.nrows;
     if (ncols) *ncols = M.ncols;
@@ -678,6 +756,41 @@ struct Solver : ISolver {
         for (size_t i = 0; i < tmp.size(); ++i) out[i] = (T)tmp[i];
       }
     }
+  }
+
+  void dia_product_host(const void* zh, const void* ph, const double* beta, void* pout_h, void* yh, int k,
+                        double* dots) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    CS_REQUIRE(dia.n > 0, CSGPU_BAD_ARGS, "matrix has no lattice form");
+    const size_t xb = (size_t)n * k * sizeof(TP), yb = (size_t)n * k * sizeof(T);
+    DBuf z(xb), pin(xb), pout(xb), y(yb), dbeta = dalloc<double>(kMaxK);
+    DBuf part = dalloc<double>(std::max<size_t>(16384, spmv_grid_upper(n)) * kMaxK);
+    CS_HIP(hipMemcpyAsync(z.p, zh, xb, hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemcpyAsync(pin.p, ph, xb, hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemsetAsync(dbeta.p, 0, kMaxK * sizeof(double), st));
+    CS_HIP(hipMemcpyAsync(dbeta.p, beta, (size_t)k * sizeof(double), hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemsetAsync(pout.p, 0, xb, st));
+    int g = 1;
+    switch (k) {
+      case 1: g = dia_grid<T, TP, 1>(dia); dia_cg_product<T, TP, 1>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+      case 2: g = dia_grid<T, TP, 2>(dia); dia_cg_product<T, TP, 2>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+      case 4: g = dia_grid<T, TP, 4>(dia); dia_cg_product<T, TP, 4>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+      case 8: g = dia_grid<T, TP, 8>(dia); dia_cg_product<T, TP, 8>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+      default: g = dia_grid<T, TP, 16>(dia); dia_cg_product<T, TP, 16>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+    }
+    check_launch("dia_product_host");
+    CS_HIP(hipMemcpyAsync(pout_h, pout.p, xb, hipMemcpyDeviceToHost, st));
+    CS_HIP(hipMemcpyAsync(yh, y.p, yb, hipMemcpyDeviceToHost, st));
+    std::vector<double> phost((size_t)g * k);
+    CS_HIP(hipMemcpyAsync(phost.data(), part.p, phost.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    if (dots)
+      for (int c = 0; c < k; ++c) {
+        double s = 0;
+        for (int b = 0; b < g; ++b) s += phost[(size_t)b * k + c];
+        dots[c] = s;
+      }
   }
 };
 
@@ -741,7 +854,9 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->precond_bytes = 0;
   o->use_graph = 0;
   o->two_product = 0;
-  o->reserved2 = 0;
+  o->stencil = 0;
+  o->explicit_check = 0;
+  o->reserved3 = 0;
 }
 
 static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts* opts) {
@@ -1002,6 +1117,18 @@ int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* n
     return CSGPU_BAD_ARGS;
   }
   h->solver->get_level_matrix(lvl, which, nrows, ncols, nnz, rowptr, colidx, vals);
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, const double* beta, void* p_out, void* y,
+                           int k, double* dots) {
+  CS_API_BEGIN
+  if (!h || !z || !p_in || !beta || !p_out || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  h->solver->dia_product_host(z, p_in, beta, p_out, y, k, dots);
   return CSGPU_OK;
   CS_API_END
 }

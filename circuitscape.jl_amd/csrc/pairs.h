@@ -39,6 +39,23 @@ __global__ __launch_bounds__(256) void pairs_extract_kernel(const T* __restrict_
   }
 }
 
+// the same from the focal-node accumulation of a resistance-only solve: xf is [ngather + 2K][K] with the gathered
+// nodes first, then the K source nodes, then the K destination nodes (PcgWork::set_focal)
+template <class T, int K>
+__global__ __launch_bounds__(256) void pairs_extract_focal_kernel(const T* __restrict__ xf, int ncols, int ngather,
+                                                                  T* __restrict__ resist, T* __restrict__ gathered) {
+  const int64_t total = (int64_t)ncols * (ngather + 1);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c = (int)(t / (ngather + 1));
+    const int g = (int)(t % (ngather + 1));
+    const T vs = xf[(size_t)(ngather + c) * K + c];
+    if (g == ngather)
+      resist[c] = xf[(size_t)(ngather + K + c) * K + c] - vs;
+    else
+      gathered[(size_t)c * ngather + g] = xf[(size_t)g * K + c] - vs;
+  }
+}
+
 // out (column-major n x ncols) = x[:, c] - x[src_c, c]     (de-interleave + grounding shift)
 template <class T, int K>
 __global__ __launch_bounds__(256) void pairs_volt_kernel(int64_t n, const T* __restrict__ x,

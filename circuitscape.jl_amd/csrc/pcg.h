@@ -13,6 +13,7 @@
 #include "amg_setup.h"
 #include "blas1.h"
 #include "spmv.h"
+#include "stencil.h"
 
 namespace csgpu {
 
@@ -97,7 +98,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     }
     return;
   }
-  if (l == 0 && fuse && fuse->b_has_tail && nu_pre == 1 && nu_post == 1 && L.M.nnz > 0) {
+  if (l == 0 && fuse && fuse->b_has_tail && nu_pre == 1 && nu_post == 1 && L.two_product()) {
     // two-product form of the level (build_sq_kernel): b_c = Q^T b ; x_c = coarse(b_c) ; out = [S Q][b; x_c]
     Level<T>& Lc = H.levels[l + 1];
     T* bc = dptr<T>(Lc.b);
@@ -111,11 +112,16 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     VcycleFuse<T> cf;
     cf.skip = skip;
     vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
+    if (want_dot) CS_REQUIRE(fuse->dotw == b, CSGPU_INTERNAL, "two-product level: fused dot must be with the input vector");
+    if (L.Sdia.n > 0) {
+      // S in lattice form + Q in CSR form, one marching kernel (stencil.h); partials of b'out always written
+      dia_sq_product<T, K>(L.Sdia, L.Q, b, (const T*)xc, out, fuse->partials, skip, st);
+      return;
+    }
     SpmvArgs<T> a = spmv_args(L.M, b, out);
     a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
     a.skip = skip;
     if (want_dot) {
-      CS_REQUIRE(fuse->dotw == b, CSGPU_INTERNAL, "two-product level: fused dot must be with the input vector");
       a.dotw = nullptr;  // dot with x itself (captured at the diagonal entry of S)
       a.partials = fuse->partials;
     }
@@ -216,6 +222,12 @@ struct PcgParams {
   int check_every = 4;
   int nu_pre = 1, nu_post = 1, nu_coarse = 3;
   int use_graph = 0;  // 0 = auto (small problems, where launch latency dominates), 1 = always, -1 = never
+  // true: the whole solution vector is carried (x += alpha p over all n rows, fused into the r-update) and the
+  // reference's post-check (core.jl:640) is evaluated as ||A x - b|| / ||b|| with one extra product.
+  // false: only the focal entries listed in PcgWork::fnode are accumulated (resistance-only pair solves consume
+  // nothing else: core.jl:231-232, 685-703) and the post-check uses the fp64 recurrence residual r (= b - A x up to
+  // rounding: x and r are updated with the same alpha and the same stored p).
+  bool need_x = true;
 };
 
 // One captured chunk of `check_every` PCG iterations. Kernel arguments are baked in at capture time, so a graph is
@@ -226,10 +238,11 @@ struct PcgGraphKey {
   int K = 0, ncols_active = 0, criterion = 0, nu_pre = 0, nu_post = 0, nu_coarse = 0, iters = 0;
   double rtol = 0, atol = 0;
   const void* matrix = nullptr;
+  int need_x = 0, nf = 0, parity = 0;
   bool operator==(const PcgGraphKey& o) const {
     return K == o.K && ncols_active == o.ncols_active && criterion == o.criterion && nu_pre == o.nu_pre &&
            nu_post == o.nu_post && nu_coarse == o.nu_coarse && iters == o.iters && rtol == o.rtol && atol == o.atol &&
-           matrix == o.matrix;
+           matrix == o.matrix && need_x == o.need_x && nf == o.nf && parity == o.parity;
   }
 };
 
@@ -243,6 +256,11 @@ struct PcgWork {
   DBuf p;                     // TP: search direction (x and r are updated with exactly these stored values, so the
                               // invariant r = b - A x holds in T precision whatever p's storage precision)
   DBuf z, rp;                 // TP: preconditioned residual; TP copy of r (aliases r when TP == T)
+  DBuf p2;                    // TP: second search-direction buffer (stencil path: p = z + beta p is fused into the
+                              // product and must not overwrite values neighbouring workgroups still read)
+  DBuf fnode, xf;             // focal mode (PcgParams::need_x == false): nf node ids, solution values [nf][K] (T)
+  int nf = 0;
+  bool have_x = false;        // x holds the solution of the last solve (need_x was set)
   DBuf scalars;               // CgScalars
   DBuf part_a, part_b, part_c;
   DBuf part_ca, part_cc;      // collapsed copies of part_a / part_c (collapse_partials_kernel)
@@ -263,7 +281,8 @@ struct PcgWork {
     tail = tail_rows;
     const size_t bytes = (size_t)n * K * sizeof(T);
     constexpr bool SAME = std::is_same<T, TP>::value;
-    x.alloc(bytes);
+    x.release();  // allocated by the first solve that needs the whole solution vector
+    p2.release();
     r.alloc(bytes + (SAME ? (size_t)tail * K * sizeof(T) : 0));
     p.alloc((size_t)n * K * sizeof(TP));
     Ap.alloc(bytes);
@@ -278,6 +297,20 @@ struct PcgWork {
     part_c.alloc(pb);
     part_ca.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
     part_cc.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
+  }
+  // focal nodes of the next solve (host ids); values land in xf[m*K + c]
+  void set_focal(const std::vector<int>& nodes, hipStream_t st) {
+    nf = (int)nodes.size();
+    const size_t cap = std::max<size_t>(nodes.size(), 64);
+    if (fnode.bytes < cap * sizeof(int) || xf.bytes < cap * K * sizeof(T)) {
+      drop_graphs();  // captured launches hold the old pointers
+      fnode.alloc(2 * cap * sizeof(int));
+      xf.alloc(2 * cap * K * sizeof(T));
+    }
+    if (nf > 0) {
+      CS_HIP(hipMemcpyAsync(fnode.p, nodes.data(), nodes.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipStreamSynchronize(st));
+    }
   }
   ~PcgWork() {
     drop_graphs();
@@ -294,18 +327,32 @@ struct PcgBatchResult {
   int polished = 0;
 };
 
-// Solve A X = B for the K interleaved columns held in W.b; solution left in W.x.
+// Solve A X = B for the K interleaved columns held in W.b. With pp.need_x the solution is left in W.x; otherwise only
+// the entries at W.fnode are accumulated (W.xf) and W.x is not touched (not even allocated).
 // A is the matrix CG sees (precision T); H is the hierarchy (precision TP) whose level 0 has A's sparsity pattern.
+// `dia`: optional symmetric-diagonal (lattice) form of A (stencil.h); when given, the product A p is evaluated from it
+// with the search-direction update p = z + beta p fused in, and A's CSR form is only used by the explicit post-check.
 template <class T, class TP, int K>
 inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP>& W, const PcgParams& pp,
-                                int ncols_active, hipStream_t st) {
+                                int ncols_active, hipStream_t st, const Dia<T>* dia = nullptr) {
   constexpr bool MIXED = !std::is_same<T, TP>::value;
   Level<TP>& L0 = H.levels[0];
   const int64_t n = A.nrows;
   ensure_level_work(H, K);
-  T* x = dptr<T>(W.x);
+  const size_t vbytes = (size_t)n * K * sizeof(T);
+  const bool need_x = pp.need_x;
+  if (need_x && W.x.bytes < vbytes) {
+    W.drop_graphs();
+    W.x.alloc(vbytes);
+  }
+  const bool use_dia = dia && dia->n == n;
+  if (use_dia && W.p2.bytes < (size_t)n * K * sizeof(TP)) {
+    W.drop_graphs();
+    W.p2.alloc((size_t)n * K * sizeof(TP));
+  }
+  T* x = need_x ? dptr<T>(W.x) : nullptr;
   T* r = dptr<T>(W.r);
-  TP* p = dptr<TP>(W.p);
+  TP* pbuf[2] = {dptr<TP>(W.p), use_dia ? dptr<TP>(W.p2) : dptr<TP>(W.p)};
   T* Ap = dptr<T>(W.Ap);
   const T* b = dptr<T>(W.b);
   TP* z = dptr<TP>(W.z);
@@ -314,10 +361,12 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   double* pa = dptr<double>(W.part_a);
   double* pb = dptr<double>(W.part_b);
   double* pc = dptr<double>(W.part_c);
-  const size_t vbytes = (size_t)n * K * sizeof(T);
   const int gv = grid_for(n * K);
   const double atol = pp.atol < 0 ? std::sqrt((double)std::numeric_limits<T>::epsilon()) : pp.atol;
   const int* orderA = L0.orderA.p ? dptr<int>(L0.orderA) : nullptr;
+  const int nf = need_x ? 0 : W.nf;
+  T* xf = dptr<T>(W.xf);
+  const int* fnode = dptr<int>(W.fnode);
 
   hipEvent_t e0, e1;
   CS_HIP(hipEventCreate(&e0));
@@ -326,21 +375,23 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
 
   // rows of dot partials the CG product / the last product of the V-cycle write (one per workgroup)
   const bool wave = K > 1 && spmv_wave_enabled();
-  const bool two_product_early = H.levels.size() > 1 && L0.M.nnz > 0 && pp.nu_pre == 1 && pp.nu_post == 1 &&
-                                 W.tail >= H.levels[1].A.nrows;
-  const int spmv_g = wave ? spmv_wave_grid<T, K>((int)n) : spmv_grid<T, K>((int)n);
-  const int spmv_gp = (wave && two_product_early) ? spmv_wave_grid<TP, K>((int)n) : spmv_grid<TP, K>((int)n);
+  const bool two_product = H.levels.size() > 1 && L0.two_product() && pp.nu_pre == 1 && pp.nu_post == 1 &&
+                           W.tail >= H.levels[1].A.nrows;
+  const int spmv_g = use_dia ? dia_grid<T, TP, K>(*dia) : (wave ? spmv_wave_grid<T, K>((int)n) : spmv_grid<T, K>((int)n));
+  const int spmv_gp = (two_product && L0.Sdia.n > 0) ? dia_grid<TP, TP, K>(L0.Sdia)
+                      : (wave && two_product)        ? spmv_wave_grid<TP, K>((int)n)
+                                                     : spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
-  const bool two_product = H.levels.size() > 1 && L0.M.nnz > 0 && pp.nu_pre == 1 && pp.nu_post == 1 &&
-                           W.tail >= H.levels[1].A.nrows;
   const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product;
   VcycleFuse<TP> fuse;
   fuse.b_has_tail = two_product;
   fuse.dotw = rp;
   fuse.partials = pa;
 
-  CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
+  if (need_x) CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
+  if (nf > 0) CS_HIP(hipMemsetAsync(xf, 0, (size_t)nf * K * sizeof(T), st));
+  W.have_x = need_x;
   CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
   if (MIXED)
@@ -366,7 +417,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
                        pp.criterion, pp.rtol, atol, 1, ncols_active);
   }
-  CS_HIP(hipMemcpyAsync(p, z, (size_t)n * K * sizeof(TP), hipMemcpyDeviceToDevice, st));
+  // the first iteration runs p = z + beta p with beta = 0 (set by the init call above) on a zeroed p
+  CS_HIP(hipMemsetAsync(pbuf[0], 0, (size_t)n * K * sizeof(TP), st));
   check_launch("pcg init");
 
   int host_done = 0;
@@ -377,58 +429,79 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int timed = 0;
   int it = 0;
   int graph_launches = 0;
+  int parity = 0;  // pbuf[parity] holds the current search direction (stencil path: ping-pong; CSR path: one buffer)
   fuse.xa_ready = fuse_xa;
   fuse.skip = &S->all_done;
   int criterion = pp.criterion;  // switches to the true residual for the polishing phase (below)
   // one PCG iteration as a sequence of launches on `st` (no host interaction: this is what gets captured)
+  //   p = z + beta p ; Ap = A p, p'Ap ; alpha ; r -= alpha Ap, x += alpha p ; z = M^-1 r, r'z ; beta, stopping rule
   auto iteration = [&](bool time_it) {
-    // Ap = A p, fused partials of p'Ap
-    {
-      SpmvArgs<T, TP> a = spmv_args<T, TP>(A, (const TP*)p, Ap);
+    const TP* pin = pbuf[parity];
+    TP* pcur = use_dia ? pbuf[parity ^ 1] : pbuf[parity];
+    time_it = time_it && timed < max_timed;
+    auto ev_begin = [&]() {
+      if (!time_it) return;
+      if ((int)W.ev.size() < 2 * (timed + 1)) {
+        hipEvent_t ea, eb;
+        CS_HIP(hipEventCreate(&ea));
+        CS_HIP(hipEventCreate(&eb));
+        W.ev.push_back(ea);
+        W.ev.push_back(eb);
+      }
+      CS_HIP(hipEventRecord(W.ev[2 * timed], st));
+    };
+    auto ev_end = [&]() {
+      if (!time_it) return;
+      CS_HIP(hipEventRecord(W.ev[2 * timed + 1], st));
+      ++timed;
+    };
+    if (use_dia) {
+      // fused: p = z + beta p (written to the other buffer), Ap = A p, partials of p'Ap
+      ev_begin();
+      dia_cg_product<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)z, pin, pcur, Ap, pc, st);
+      ev_end();
+      parity ^= 1;
+    } else {
+      hipLaunchKernelGGL((cg_update_p_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, pin, pcur,
+                         (const TP*)z);
+      SpmvArgs<T, TP> a = spmv_args<T, TP>(A, (const TP*)pcur, Ap);
       a.order = orderA;
       a.skip = &S->all_done;
       a.dotw = nullptr;  // dot with x itself: p'Ap
       a.partials = pc;
-      time_it = time_it && timed < max_timed;
-      if (time_it) {
-        if ((int)W.ev.size() < 2 * (timed + 1)) {
-          hipEvent_t ea, eb;
-          CS_HIP(hipEventCreate(&ea));
-          CS_HIP(hipEventCreate(&eb));
-          W.ev.push_back(ea);
-          W.ev.push_back(eb);
-        }
-        CS_HIP(hipEventRecord(W.ev[2 * timed], st));
-      }
+      ev_begin();
       spmv_launch_cg<T, K, TP>(a, st);
-      if (time_it) {
-        CS_HIP(hipEventRecord(W.ev[2 * timed + 1], st));
-        ++timed;
-      }
+      ev_end();
     }
     {
       auto pap = collapsed(pc, spmv_g, pcc);
       hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, pap.first, pap.second);
     }
-    // r -= alpha Ap, fused with the TP copy of r, the level-0 first pre-smoothing sweep xa = omega D^-1 r and
-    // (when the true residual is monitored) the partials of r'r
-    if (criterion == CSGPU_CRIT_TRUE_RESIDUAL)
-      hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, true>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
-                         (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
-                         (const TP*)dptr<TP>(L0.dinv), omega0, pb);
-    else
-      hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, false>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,
-                         (const T*)Ap, MIXED ? rp : (TP*)nullptr, fuse_xa ? xa0 : (TP*)nullptr,
-                         (const TP*)dptr<TP>(L0.dinv), omega0, pb);
+    // r -= alpha Ap (+ x += alpha p when the whole solution is wanted), fused with the TP copy of r, the level-0 first
+    // pre-smoothing sweep xa = omega D^-1 r and (when the true residual is monitored) the partials of r'r
+    {
+      TP* rpo = MIXED ? rp : (TP*)nullptr;
+      TP* xao = fuse_xa ? xa0 : (TP*)nullptr;
+      const TP* dinv0 = dptr<TP>(L0.dinv);
+      const bool rr = criterion == CSGPU_CRIT_TRUE_RESIDUAL;
+#define CS_UPD_R(RR, XUP)                                                                                              \
+  hipLaunchKernelGGL((cg_update_r_kernel<T, TP, K, RR, XUP>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, r,    \
+                     (const T*)Ap, rpo, xao, dinv0, omega0, pb, x, (const TP*)pcur)
+      if (rr && need_x) CS_UPD_R(true, true);
+      else if (rr) CS_UPD_R(true, false);
+      else if (need_x) CS_UPD_R(false, true);
+      else CS_UPD_R(false, false);
+#undef CS_UPD_R
+    }
+    if (nf > 0)
+      hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
+                         fnode, nf, (const TP*)pcur, xf);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
     {
       auto rz = collapsed(pa, spmv_gp, pac);
       hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
                          criterion, pp.rtol, atol, 0, ncols_active);
     }
-    // x += alpha p ; p = z + beta p   (one pass over p)
-    hipLaunchKernelGGL((cg_update_xp_kernel<T, TP, K>), dim3(gv), dim3(256), 0, st, n, (const CgScalars*)S, x, p,
-                       (const TP*)z);
   };
 
   // Launch-bound regime (small rasters: ~75 launches of a few microseconds each per iteration): replay a captured
@@ -436,8 +509,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // directly (it is the one the SpMV timing events sit in); every device-side early-out (skip flag) works unchanged
   // inside the graph because it lives in device memory.
   const int chunk = std::max(1, pp.check_every);
-  const bool want_graph =
-      !W.graph_broken && (pp.use_graph > 0 || (pp.use_graph == 0 && (int64_t)n * K <= ((int64_t)1 << 25)));
+  const bool want_graph = !W.graph_broken && !(use_dia && (chunk & 1)) &&
+                          (pp.use_graph > 0 || (pp.use_graph == 0 && (int64_t)n * K <= ((int64_t)1 << 25)));
   PcgGraphKey gkey;
   gkey.K = K;
   gkey.ncols_active = ncols_active;
@@ -449,6 +522,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   gkey.rtol = pp.rtol;
   gkey.atol = atol;
   gkey.matrix = (const void*)A.val.p;
+  gkey.need_x = need_x ? 1 : 0;
+  gkey.nf = nf;
   auto chunk_graph = [&]() -> hipGraphExec_t {
     for (auto& g : W.graphs)
       if (g.first == gkey) return g.second;
@@ -461,11 +536,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     bool ok = true;
+    const int parity0 = parity;
     try {
       for (int c = 0; c < chunk; ++c) iteration(false);
     } catch (...) {
       ok = false;
     }
+    parity = parity0;  // capturing executed nothing: the launch below advances the parity
     if (hipStreamEndCapture(st, &g) != hipSuccess || !g) ok = false;
     if (ok && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ok = false;
     if (g) hipGraphDestroy(g);
@@ -483,9 +560,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     while (!host_done && it < pp.itmax) {
       const int todo = (int)std::min<int64_t>(chunk, (int64_t)pp.itmax - it);
       gkey.criterion = criterion;
+      gkey.parity = parity;
       hipGraphExec_t ge = (want_graph && it > 0 && todo == chunk) ? chunk_graph() : nullptr;
       if (ge) {
         CS_HIP(hipGraphLaunch(ge, st));
+        if (use_dia && (chunk & 1)) parity ^= 1;
         ++graph_launches;
       } else {
         for (int c = 0; c < todo; ++c) iteration(true);
@@ -496,14 +575,19 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       CS_HIP(hipStreamSynchronize(st));
     }
   };
-  // the reference's post-check (core.jl:640): ||A x - b|| / ||b||
+  // the reference's post-check (core.jl:640): ||A x - b|| / ||b||, explicitly when x is carried, otherwise from the
+  // fp64 recurrence residual
   PcgBatchResult res;
   auto post_check = [&]() {
-    SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
-    a.order = orderA;
-    a.b = b;
-    spmv_launch<T, K>(a, EPI_RESID, false, st);
-    hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
+    if (need_x) {
+      SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
+      a.order = orderA;
+      a.b = b;
+      spmv_launch<T, K>(a, EPI_RESID, false, st);
+      hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
+    } else {
+      hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa, b, b, pb);
+    }
     hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv);
     CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
     CS_HIP(hipStreamSynchronize(st));

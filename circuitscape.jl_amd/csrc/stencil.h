@@ -1,0 +1,448 @@
+// stencil.h -- lattice ("symmetric diagonal") form of a raster Laplacian and the CG product evaluated from it.
+//
+// GPU counterpart of `A*p` inside Krylov.cg (reference call site src/core.jl:639) for the matrices the reference's
+// raster path produces (construct_graph, src/raster/pairwise.jl:316-362): with every cell of an R x C raster valid,
+// node i (column-major numbering, pairwise.jl:273-275) is coupled to i +- 1, i +- (R-1), i +- R, i +- (R+1) only, and
+// the matrix is symmetric. Such a matrix needs no column indices and only half of its off-diagonal values:
+//
+//   rows[i] = { A[i,i], A[i,i+1], A[i,i+R-1], A[i,i+R], A[i,i+R+1] }          (5 values per node, 0 where absent)
+//   y[i]    = rows[i].d x[i] + sum_o ( rows[i].a_o x[i+o] + rows[i-o].a_o x[i-o] ),   o in {1, R-1, R, R+1}
+//
+// i.e. 5*sizeof(T) matrix bytes per row instead of 9*(sizeof(T)+4)+4 for CSR (fp64: 40 B vs 112 B). The form is
+// DETECTED from the CSR matrix the host hands over (dia_from_csr: every entry must sit on one of the nine diagonals
+// and the matrix must be bit-symmetric), so it serves csgpu_setup (Julia-built graphs) and csgpu_raster_setup alike;
+// anything else (NODATA holes, polygons, networks) keeps the CSR product.
+//
+// Kernel shape (dia_cg_kernel): a workgroup owns a 2-D tile of the raster -- TI consecutive rows (TI = 256 / lanes per
+// node) of SEG consecutive raster columns -- and marches through its columns. Per column it streams the column's
+// TI*K vector entries and TI*5 matrix values with fully coalesced, contiguous loads (a raster column segment is
+// contiguous in node numbering) into a 4-slot LDS ring; the nine-point product of the previous column is then taken
+// out of LDS (x) and registers (sliding 3x3 window). Every x entry is fetched from HBM once per tile plus a one-cell
+// halo ((TI+2)(SEG+2)/(TI*SEG) ~ 1.06 at 64 x 64), independent of cache behaviour.
+//
+// Fusion: the search-direction update p = z + beta p of Krylov.cg is evaluated while the column is staged (halo
+// included), so the product reads z and the old p and writes the new p (to a second buffer: neighbouring tiles still
+// read the old values) and A p, plus the partials of p'Ap -- one pass instead of an update pass and a product pass.
+//
+// Algorithmic bytes per launch: n*5*sizeof(T) + n*K*(2*sizeof(XT) [z, p_in] + sizeof(XT) [p_out] + sizeof(T) [Ap]).
+#pragma once
+#include "blas1.h"
+#include "spmv.h"
+
+namespace csgpu {
+
+// slot of a diagonal offset (0 = main diagonal), -1 when the offset is not one of the lattice's
+__device__ __forceinline__ int dia_slot(int64_t d, int R) {
+  if (d == 0) return 0;
+  if (d == 1) return 1;
+  if (d == R - 1) return 2;
+  if (d == R) return 3;
+  if (d == R + 1) return 4;
+  return -1;
+}
+
+// pass 1: scatter the upper-triangle entries (and the diagonal) of every row into rows[]; flag entries off the lattice
+template <class T>
+__global__ __launch_bounds__(256) void dia_fill_kernel(int n, int R, const int* __restrict__ rp,
+                                                       const int* __restrict__ ci, const T* __restrict__ va,
+                                                       T* __restrict__ rows, int* __restrict__ bad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int64_t d = (int64_t)ci[k] - i;
+      const int s = dia_slot(d < 0 ? -d : d, R);
+      if (s < 0) {
+        atomicOr(bad, 1);
+        continue;
+      }
+      if (d >= 0) rows[(size_t)i * 5 + s] = va[k];
+    }
+  }
+}
+
+// pass 2: the lower-triangle entries must equal their mirror images bit for bit
+template <class T>
+__global__ __launch_bounds__(256) void dia_check_kernel(int n, int R, const int* __restrict__ rp,
+                                                        const int* __restrict__ ci, const T* __restrict__ va,
+                                                        const T* __restrict__ rows, int* __restrict__ bad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int64_t d = (int64_t)ci[k] - i;
+      if (d >= 0) continue;
+      const int s = dia_slot(-d, R);
+      if (s < 0 || !(rows[(size_t)ci[k] * 5 + s] == va[k])) atomicOr(bad, 1);
+    }
+  }
+}
+
+// Build the lattice form of A for period R; returns false (out untouched) when A is not such a matrix.
+template <class T>
+inline bool dia_from_csr(const Csr<T>& A, int R, Dia<T>& out, hipStream_t st) {
+  const int n = A.nrows;
+  if (A.nrows != A.ncols || R < 4 || n < 4 * R || (n % R) != 0) return false;
+  DBuf rows((size_t)n * 5 * sizeof(T));
+  DBuf bad = dalloc<int>(1);
+  CS_HIP(hipMemsetAsync(rows.p, 0, rows.bytes, st));
+  CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+  const int g = grid_for(n);
+  hipLaunchKernelGGL((dia_fill_kernel<T>), dim3(g), dim3(256), 0, st, n, R, A.rp(), A.ci(), A.va(), dptr<T>(rows),
+                     dptr<int>(bad));
+  hipLaunchKernelGGL((dia_check_kernel<T>), dim3(g), dim3(256), 0, st, n, R, A.rp(), A.ci(), A.va(),
+                     (const T*)dptr<T>(rows), dptr<int>(bad));
+  check_launch("lattice form");
+  if (read_int(dptr<int>(bad), st) != 0) return false;
+  out.n = n;
+  out.R = R;
+  out.rows = std::move(rows);
+  return true;
+}
+
+// what the marching kernel computes per tile column
+enum DiaMode {
+  DIA_PLAIN = 0,  // y = A x, partials of x'y                                  (x = pin)
+  DIA_CG = 1,     // x = z + beta pin -> pout ; y = A x ; partials of x'y      (Krylov.cg's p-update fused in)
+  DIA_SQ = 2      // y = S x + Q xc, partials of x'y                            (second product of the two-product V(1,1)
+                  //                                                             level, amg_setup.h: A = S in lattice form,
+                  //                                                             Q in CSR form, xc the coarse solution)
+};
+
+template <class T, class XT>
+struct DiaArgs {
+  int64_t n;
+  int R, C;
+  int nstrips, nseg, seg;  // tiles: nstrips (along a raster column) x nseg (across columns), seg columns each
+  const T* rows;
+  const CgScalars* S;      // beta[c], all_done (may be null: beta = `beta0` for every column, never skipped)
+  const XT* z;             // FUSE: p = z + beta * pin; otherwise pin is the input vector and z is unused
+  const XT* pin;
+  XT* pout;                // FUSE: new search direction (must not alias pin)
+  T* y;                    // A p
+  double* partials;        // [gridDim.x][K] partials of p'(A p)
+  const double* beta_dev;  // test hook: per-column beta (device pointer) when S is null; null = 0
+  const int* skip;         // optional device flag: non-zero turns the launch into a no-op
+  const int* qrp;          // DIA_SQ: CSR form of Q (n rows), values in T
+  const int* qci;
+  const T* qva;
+  const XT* xc;            // DIA_SQ: coarse vector, interleaved [ncoarse][K]
+};
+
+template <class T, class XT, int K>
+struct DiaShape {
+  static constexpr int VEC = 16 / (int)sizeof(XT);
+  static constexpr int CPL = K < VEC ? K : VEC;  // columns per lane
+  static constexpr int LPR = K / CPL;            // lanes per node
+  static constexpr int TI = 256 / LPR;           // raster rows per tile
+  static constexpr int MELEMS = 5 * (TI + 2);    // matrix values staged per raster column (halo rows included)
+  static constexpr int MU = (MELEMS + 255) / 256;
+};
+
+template <class T, class XT, int K, int MODE>
+__global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
+  constexpr bool FUSE = MODE == DIA_CG;
+  typedef DiaShape<T, XT, K> SH;
+  constexpr int CPL = SH::CPL, LPR = SH::LPR, TI = SH::TI, MELEMS = SH::MELEMS, MU = SH::MU;
+  typedef SpmvVec<XT, CPL> XV;
+  typedef SpmvVec<T, CPL> YV;
+  __shared__ XV s_x[4][(TI + 2) * LPR];
+  __shared__ T s_m[4][MELEMS];
+  __shared__ double s_red[4 * K];
+  if (a.S && a.S->all_done) return;
+  if (a.skip && *a.skip) return;
+  const int tid = threadIdx.x;
+  const int t = tid / LPR;        // row of the tile owned by this lane
+  const int lq = tid % LPR;       // which CPL-wide slice of the K columns
+  const int c0 = lq * CPL;
+  T beta[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q)
+    beta[q] = FUSE ? (a.S ? (T)a.S->beta[c0 + q] : (a.beta_dev ? (T)a.beta_dev[c0 + q] : T(0))) : T(0);
+  double dot_acc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
+
+  const int ntiles = a.nstrips * a.nseg;
+  // XCD-aware tile walk: workgroup b runs on XCD b % 8; give every XCD a contiguous range of tiles (strip index
+  // fastest), so the one-cell halos shared by neighbouring tiles are re-read out of that XCD's L2
+  int t_first = blockIdx.x, t_last = ntiles, t_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, chunk = (ntiles + 7) >> 3;
+    t_first = xcd * chunk + (blockIdx.x >> 3);
+    t_last = min(ntiles, (xcd + 1) * chunk);
+    t_step = gridDim.x >> 3;
+  }
+  for (int tile = t_first; tile < t_last; tile += t_step) {
+    const int si = tile % a.nstrips, sj = tile / a.nstrips;
+    const int i0 = si * TI;
+    const int j0 = sj * a.seg, j1 = min(a.C, j0 + a.seg);
+    const bool row_on = i0 + t < a.R;  // rows past the raster's last row belong to no tile
+    // staged values of the column being loaded (registers), written to LDS one step later
+    XV xr, xh;
+    T mr[MU];
+    auto load_column = [&](int jc) {
+      // node id of tile row -1 (the halo row above) in raster column jc; ids outside [0, n) read as zero
+      const int64_t base = (int64_t)jc * a.R + i0 - 1;
+      const bool col_in = jc >= j0 && jc < j1;
+      {
+        const int64_t id = base + 1 + t;
+        XV v;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v.e[q] = XT(0);
+        if (id >= 0 && id < a.n) {
+          const size_t e = (size_t)id * K + c0;
+          if (FUSE) {
+            const XV zv = *reinterpret_cast<const XV*>(a.z + e);
+            const XV pv = *reinterpret_cast<const XV*>(a.pin + e);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)pv.e[q], (T)zv.e[q]);
+            if (col_in && row_on) *reinterpret_cast<XV*>(a.pout + e) = v;
+          } else {
+            v = *reinterpret_cast<const XV*>(a.pin + e);
+          }
+        }
+        xr = v;
+      }
+      if (tid < 2 * LPR) {  // halo rows: tile row -1 (lanes 0..LPR-1) and tile row TI (lanes LPR..2LPR-1)
+        const int64_t id = base + (tid < LPR ? 0 : TI + 1);
+        XV v;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v.e[q] = XT(0);
+        if (id >= 0 && id < a.n) {
+          const size_t e = (size_t)id * K + c0;  // (tid < 2 LPR: tid % LPR is the lane's own column slice)
+          if (FUSE) {
+            const XV zv = *reinterpret_cast<const XV*>(a.z + e);
+            const XV pv = *reinterpret_cast<const XV*>(a.pin + e);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)pv.e[q], (T)zv.e[q]);
+          } else {
+            v = *reinterpret_cast<const XV*>(a.pin + e);
+          }
+        }
+        xh = v;
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * 256;
+        const int64_t g = base * 5 + e;
+        mr[u] = (e < MELEMS && g >= 0 && g < a.n * 5) ? a.rows[g] : T(0);
+      }
+    };
+    auto store_column = [&](int jc) {
+      const int slot = jc & 3;
+      s_x[slot][(t + 1) * LPR + lq] = xr;
+      if (tid < 2 * LPR) s_x[slot][(tid < LPR ? 0 : TI + 1) * LPR + lq] = xh;
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * 256;
+        if (e < MELEMS) s_m[slot][e] = mr[u];
+      }
+    };
+    __syncthreads();  // previous tile finished with the ring
+    // prologue: columns j0-1 and j0 into the ring, column j0+1 in flight
+    load_column(j0 - 1);
+    store_column(j0 - 1);
+    load_column(j0);
+    store_column(j0);
+    load_column(j0 + 1);
+    __syncthreads();
+    // sliding 3x3 window of x: xw[dj][di] = x(row t-1+di of the tile, raster column j-1+dj)
+    XV xw[3][3];
+#pragma unroll
+    for (int di = 0; di < 3; ++di) {
+      xw[1][di] = s_x[(j0 - 1) & 3][(t + di) * LPR + lq];
+      xw[2][di] = s_x[j0 & 3][(t + di) * LPR + lq];
+    }
+    for (int j = j0; j < j1; ++j) {
+      store_column(j + 1);                 // the column loaded one step ago
+      if (j + 2 <= j1) load_column(j + 2); // next one in flight while this column is computed
+      __syncthreads();
+#pragma unroll
+      for (int di = 0; di < 3; ++di) {
+        xw[0][di] = xw[1][di];
+        xw[1][di] = xw[2][di];
+        xw[2][di] = s_x[(j + 1) & 3][(t + di) * LPR + lq];
+      }
+      if (row_on) {
+        const T* mc = s_m[j & 3];        // matrix rows of raster column j   (tile rows -1 .. TI at 5*(row+1))
+        const T* mp = s_m[(j - 1) & 3];  // matrix rows of raster column j-1
+        const int me = 5 * (t + 1);
+        // ascending column order, like the CSR row: i-R-1, i-R, i-R+1, i-1, i, i+1, i+R-1, i+R, i+R+1
+        const T w_mm = mp[me - 5 + 4];   // rows[i-R-1].a_{R+1}
+        const T w_m0 = mp[me + 3];       // rows[i-R].a_R
+        const T w_mp = mp[me + 5 + 2];   // rows[i-R+1].a_{R-1}
+        const T w_0m = mc[me - 5 + 1];   // rows[i-1].a_1
+        const T w_00 = mc[me + 0];
+        const T w_0p = mc[me + 1];
+        const T w_pm = mc[me + 2];
+        const T w_p0 = mc[me + 3];
+        const T w_pp = mc[me + 4];
+        YV out;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          T s = w_mm * (T)xw[0][0].e[q];
+          s = fma(w_m0, (T)xw[0][1].e[q], s);
+          s = fma(w_mp, (T)xw[0][2].e[q], s);
+          s = fma(w_0m, (T)xw[1][0].e[q], s);
+          s = fma(w_00, (T)xw[1][1].e[q], s);
+          s = fma(w_0p, (T)xw[1][2].e[q], s);
+          s = fma(w_pm, (T)xw[2][0].e[q], s);
+          s = fma(w_p0, (T)xw[2][1].e[q], s);
+          s = fma(w_pp, (T)xw[2][2].e[q], s);
+          out.e[q] = s;
+        }
+        const int64_t id = (int64_t)j * a.R + i0 + t;
+        if (MODE == DIA_SQ) {
+          // + Q xc: the row's few (<= 9 on rasters) coarse couplings, three gathers in flight
+          const int kb = a.qrp[id], ke = a.qrp[id + 1];
+          for (int k = kb; k < ke; k += 3) {
+            T qv[3];
+            XV xv[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const bool on = k + u < ke;
+              qv[u] = on ? a.qva[k + u] : T(0);
+              const int col = on ? a.qci[k + u] : a.qci[kb];
+              xv[u] = *reinterpret_cast<const XV*>(a.xc + (size_t)col * K + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) out.e[q] = fma(qv[u], (T)xv[u].e[q], out.e[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) dot_acc[q] += (double)(T)xw[1][1].e[q] * (double)out.e[q];
+        stream_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
+      }
+    }
+  }
+  // lanes owning the same columns sit LPR apart: reduce over lane bits >= log2(LPR), then across the 4 waves via LDS
+  const int lane = tid & 63, w = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    double v = dot_acc[q];
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < LPR) s_red[w * K + lane * CPL + q] = v;
+  }
+  __syncthreads();
+  if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
+}
+
+// raster columns per tile (tuning knob CSGPU_DIA_SEG)
+inline int dia_seg() {
+  static int seg = [] {
+    const char* e = getenv("CSGPU_DIA_SEG");
+    const int v = e ? atoi(e) : 64;
+    return v < 4 ? 4 : v;
+  }();
+  return seg;
+}
+
+template <class T, class XT, int K>
+inline void dia_tiling(const Dia<T>& D, int& nstrips, int& nseg, int& seg, int& grid) {
+  const int C = (int)(D.n / D.R);
+  seg = std::min(dia_seg(), std::max(C, 1));
+  nstrips = ceil_div(D.R, DiaShape<T, XT, K>::TI);
+  nseg = ceil_div(C, seg);
+  int64_t g = (int64_t)nstrips * nseg;
+  // never more workgroups than rows in the dot-partial arrays (PcgWork::ensure)
+  const int64_t cap = std::min<int64_t>(std::max(1024, spmv_grid_cap()), std::max<size_t>(16384, spmv_grid_upper(D.n)));
+  if (g > cap) g = cap;
+  if (g >= 64) g &= ~(int64_t)7;
+  grid = (int)std::max<int64_t>(g, 1);
+}
+
+// number of workgroups (= rows of dot partials) of the fused CG product
+template <class T, class XT, int K>
+inline int dia_grid(const Dia<T>& D) {
+  int a, b, c, g;
+  dia_tiling<T, XT, K>(D, a, b, c, g);
+  return g;
+}
+
+// p_out = z + beta p_in ; y = A p_out ; partials of p_out' y   (beta and the skip flag from the CG scalars S)
+template <class T, class XT, int K>
+inline void dia_cg_product(const Dia<T>& D, const CgScalars* S, const XT* z, const XT* pin, XT* pout, T* y,
+                           double* partials, hipStream_t st, const double* beta_dev = nullptr) {
+  DiaArgs<T, XT> a;
+  a.n = D.n;
+  a.R = D.R;
+  a.C = (int)(D.n / D.R);
+  int grid;
+  dia_tiling<T, XT, K>(D, a.nstrips, a.nseg, a.seg, grid);
+  a.rows = D.data();
+  a.S = S;
+  a.z = z;
+  a.pin = pin;
+  a.pout = pout;
+  a.y = y;
+  a.partials = partials;
+  a.beta_dev = beta_dev;
+  a.skip = nullptr;
+  a.qrp = a.qci = nullptr;
+  a.qva = nullptr;
+  a.xc = nullptr;
+  hipLaunchKernelGGL((dia_cg_kernel<T, XT, K, DIA_CG>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// out = S b + Q xc with the partials of b'out: second product of the two-product V(1,1) level (S in lattice form)
+template <class T, int K>
+inline void dia_sq_product(const Dia<T>& Sd, const Csr<T>& Q, const T* b, const T* xc, T* out, double* partials,
+                           const int* skip, hipStream_t st) {
+  DiaArgs<T, T> a;
+  a.n = Sd.n;
+  a.R = Sd.R;
+  a.C = (int)(Sd.n / Sd.R);
+  int grid;
+  dia_tiling<T, T, K>(Sd, a.nstrips, a.nseg, a.seg, grid);
+  a.rows = Sd.data();
+  a.S = nullptr;
+  a.z = nullptr;
+  a.pin = b;
+  a.pout = nullptr;
+  a.y = out;
+  a.partials = partials;
+  a.beta_dev = nullptr;
+  a.skip = skip;
+  a.qrp = Q.rp();
+  a.qci = Q.ci();
+  a.qva = Q.va();
+  a.xc = xc;
+  hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_SQ>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// Lattice form of S = 2 w D^-1 - w D^-1 A w D^-1 (w = damped-Jacobi weight) from the lattice form of A (precision U,
+// rounded to T first -- the hierarchy's level-0 matrix is the element-wise rounded CG matrix) and dinv = 1/diag(A):
+// the same values build_sq_kernel puts into the CSR form of [S Q].
+template <class U, class T>
+__global__ __launch_bounds__(256) void dia_build_s_kernel(int64_t n, int R, const U* __restrict__ arows,
+                                                          const T* __restrict__ dinv, double omega,
+                                                          T* __restrict__ srows) {
+  const int off[5] = {0, 1, R - 1, R, R + 1};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double wi = omega * (double)dinv[i];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int64_t j = i + off[s];
+      const T av = (T)arows[i * 5 + s];
+      double v = 0.0;
+      if (j < n) {
+        v = -wi * (double)av * omega * (double)dinv[j];
+        if (s == 0) v += 2.0 * wi;
+      }
+      srows[i * 5 + s] = (T)v;
+    }
+  }
+}
+
+template <class U, class T>
+inline void dia_build_s(const Dia<U>& A, const T* dinv, double omega, Dia<T>& S, hipStream_t st) {
+  S.n = A.n;
+  S.R = A.R;
+  S.rows.alloc((size_t)A.n * 5 * sizeof(T));
+  hipLaunchKernelGGL((dia_build_s_kernel<U, T>), dim3(grid_for(A.n)), dim3(256), 0, st, A.n, A.R, A.data(), dinv, omega,
+                     dptr<T>(S.rows));
+  check_launch("lattice form of S");
+}
+
+}  // namespace csgpu

@@ -23,7 +23,7 @@ EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
-    "csgpu_solve_raster",
+    "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -44,14 +44,15 @@ class Opts(ctypes.Structure):
         ("rtol", ctypes.c_double), ("atol", ctypes.c_double),
         ("node_row", ctypes.c_void_p), ("node_col", ctypes.c_void_p),
         ("precond_bytes", ctypes.c_int32), ("use_graph", ctypes.c_int32),
-        ("two_product", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("two_product", ctypes.c_int32), ("stencil", ctypes.c_int32),
+        ("explicit_check", ctypes.c_int32), ("reserved3", ctypes.c_int32),
     ]
 
 
 class Info(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int64), ("nnz", ctypes.c_int64), ("levels", ctypes.c_int32), ("val_bytes", ctypes.c_int32),
-        ("precond_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("precond_bytes", ctypes.c_int32), ("lattice_period", ctypes.c_int32),
         ("operator_complexity", ctypes.c_double), ("grid_complexity", ctypes.c_double),
         ("setup_ms", ctypes.c_double), ("upload_ms", ctypes.c_double), ("device_bytes", ctypes.c_int64),
         ("level_n", ctypes.c_int64 * 32), ("level_nnz", ctypes.c_int64 * 32),
@@ -96,6 +97,7 @@ def _bind(L):
     L.csgpu_solve_raster.argtypes = [vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
+    L.csgpu_dia_product_host.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.csgpu_free.argtypes = [vp]
     L.csgpu_free.restype = None
     L.csgpu_last_error.restype = ctypes.c_char_p
@@ -301,6 +303,23 @@ class Handle:
         dots = np.zeros(k, dtype=np.float64)
         _check(lib().csgpu_level_spmv_host(self._p, lvl, w, xi.ctypes.data, y.ctypes.data, k, dots.ctypes.data))
         return (y[:, 0] if x.ndim == 1 else y), (dots if which == "M" else None)
+
+    def dia_product(self, z, p_in, beta):
+        """Fused lattice-form CG product (test hook): returns (p_out, y, dots) with p_out = z + beta * p_in,
+        y = A p_out, dots = column-wise p_out . y. z, p_in: (n, k) arrays, beta: k values."""
+        info = self.info
+        dt = np.float32 if (info["precond_bytes"] or info["val_bytes"]) == 4 else np.float64
+        z = np.ascontiguousarray(z, dtype=dt)
+        p_in = np.ascontiguousarray(p_in, dtype=dt)
+        k = z.shape[1]
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        assert z.shape == p_in.shape == (info["n"], k) and beta.shape == (k,)
+        p_out = np.zeros_like(z)
+        y = np.zeros((info["n"], k), dtype=self.dtype)
+        dots = np.zeros(k, dtype=np.float64)
+        _check(lib().csgpu_dia_product_host(self._p, z.ctypes.data, p_in.ctypes.data, beta.ctypes.data,
+                                            p_out.ctypes.data, y.ctypes.data, k, dots.ctypes.data))
+        return p_out, y, dots
 
     def level_matrix(self, lvl, which="A"):
         import scipy.sparse as sp

@@ -33,8 +33,8 @@
  *                              the raster branch of advanced_kernel (src/raster/advanced.jl:151-271) for rasters
  *                              without polygons: grounded matrix, right-hand side from the source raster, node
  *                              currents incl. ground currents (src/out.jl:178-207), maps back -- "next" rows N2/N3
- *   csgpu_get_info, csgpu_spmv_bench, csgpu_spmv_host, csgpu_level_spmv_host, csgpu_get_level_matrix
- *                          <-> no reference counterpart: measurement and test hooks
+ *   csgpu_get_info, csgpu_spmv_bench, csgpu_spmv_host, csgpu_level_spmv_host, csgpu_get_level_matrix,
+ *   csgpu_dia_product_host <-> no reference counterpart: measurement and test hooks
  *
  * Conventions
  *   - The matrix is a symmetric SPD (or singular-consistent) graph Laplacian in compressed sparse
@@ -112,7 +112,17 @@ typedef struct csgpu_opts {
   /* Level 0 of a V(1,1) cycle as two products, b_c = Q^T b and out = [S Q][b; x_c], instead
    * of residual + restriction + fused prolongation: 0 = on whenever nu_pre == nu_post == 1 (default), -1 = off. */
   int32_t two_product;
-  int32_t reserved2;
+  /* Lattice ("symmetric diagonal") form of the fine-level matrix for the CG product (csrc/stencil.h): detected from
+   * the matrix itself -- an all-valid raster in the reference's column-major numbering couples node i to i+-1,
+   * i+-(R-1), i+-R, i+-(R+1) only -- and used with the search-direction update fused in. 0 = use it when the
+   * matrix has that form (default), -1 = always the CSR product. */
+  int32_t stencil;
+  /* Resistance-only pair solves (csgpu_solve_pairs without volt_out) accumulate the solution at the focal nodes only
+   * and evaluate the reference's 1e-4 post-check (core.jl:640) on the fp64 recurrence residual. 1 = carry the whole
+   * solution vector and evaluate ||A x - b|| / ||b|| with an explicit product, as every other entry point does.
+   * Default 0. */
+  int32_t explicit_check;
+  int32_t reserved3;
 } csgpu_opts;
 
 typedef struct csgpu_info {
@@ -121,7 +131,7 @@ typedef struct csgpu_info {
   int32_t levels;               /* including the coarsest */
   int32_t val_bytes;
   int32_t precond_bytes;
-  int32_t reserved;
+  int32_t lattice_period;       /* raster height R when the CG product runs from the lattice form, else 0 */
   double operator_complexity;   /* sum_l nnz(A_l) / nnz(A_0) */
   double grid_complexity;       /* sum_l n_l / n_0 */
   double setup_ms;              /* device time of the AMG setup (HIP events) */
@@ -237,6 +247,13 @@ int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, vo
  * Pass NULL arrays to query sizes only. */
 int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz,
                            int32_t* rowptr, int32_t* colidx, void* vals);
+
+/* Test hook for the lattice-form CG product (csrc/stencil.h): p_out = z + beta .* p_in (per column), y = A p_out,
+ * dots[c] = p_out[:,c]' y[:,c], evaluated by the fused kernel the PCG loop uses. z, p_in, p_out: host arrays
+ * [n][k] in the search direction's precision (precond_bytes, else val_bytes); y: [n][k] in val_bytes precision; beta,
+ * dots: k doubles. Status 4 when the handle's matrix has no lattice form (or k == 1). */
+int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, const double* beta, void* p_out, void* y,
+                           int k, double* dots);
 
 void csgpu_free(csgpu_handle* h);
 const char* csgpu_last_error(void);

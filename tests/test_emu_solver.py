@@ -824,3 +824,16 @@ def test_closed_form_circuits(emu_lib):
     effective resistance -- checks that do not go through the oracle at all."""
     from helpers import check_closed_form_circuits
     check_closed_form_circuits(emu_lib)
+
+
+def test_lattice_form_cg_product(emu_lib):
+    """csrc/stencil.h on the emulator: see helpers.check_lattice_product."""
+    from helpers import check_lattice_product
+    check_lattice_product(emu_lib, shapes=((70, 40), (130, 9)), ks=(2, 16), pbs=(0, 4))
+    check_lattice_product(emu_lib, shapes=((33, 100),), ks=(4, 8), pbs=(4,))
+
+
+@pytest.mark.parametrize("precond_bytes", [0, 4])
+def test_solve_paths_agree(emu_lib, precond_bytes):
+    from helpers import check_solve_paths_agree
+    check_solve_paths_agree(emu_lib, N=60, batch=8, precond_bytes=precond_bytes)

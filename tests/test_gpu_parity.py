@@ -191,3 +191,68 @@ def test_closed_form_circuits(gpu_lib):
     """Known-answer circuits and metric properties of the effective resistance on the device (see the emulator twin)."""
     from helpers import check_closed_form_circuits
     check_closed_form_circuits(gpu_lib)
+
+
+def _baseline_workload(size, npts):
+    """BASELINE.json synthetic raster workload exactly as bench.py generates it."""
+    import bench
+    g = bench.make_raster(size)
+    cells, pairs = bench.focal_pairs(size, npts=npts)
+    return g, cells, pairs
+
+
+@pytest.mark.parametrize("precond_bytes,two_product", [(4, 0), (0, 0), (4, -1)])
+def test_baseline_config2_bench_defaults_vs_tight_oracle(gpu_lib, oracle, precond_bytes, two_product):
+    """BASELINE.json configs[1]: 1000 x 1000 synthetic raster, 10 focal pairs (5 focal cells, seed 67890), fp64, through
+    csgpu_raster_setup with bench.py's defaults (batch 16, fp32 preconditioner + fp32 search direction, two-product fine
+    level) and also all-fp64 and with the classic V-cycle, against the tight oracle (true-residual rtol 1e-12).
+    Tolerance: 1e-6 relative (north_star; reference tolerance core.jl:639-641)."""
+    from oracle import refgraph as rg
+    N = 1000
+    g, cells, pairs = _baseline_workload(N, 5)
+    assert len(pairs) == 10
+    src = [p[0] for p in pairs]
+    dst = [p[1] for p in pairs]
+    A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
+    Ro, go, res = oracle.OracleAMG(A).solve_pairs(src, dst, gather=cells, rtol=1e-12, atol=0.0, criterion=1, nthreads=8)
+    assert all(r["true_relres"] < 1e-10 for r in res)
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, precond_bytes=precond_bytes, two_product=two_product))
+    assert h.info["n"] == N * N and h.info["nnz"] == 8988004  # SURVEY.md section 8
+    R, gath, _, st = h.solve_pairs(src, dst, gather=cells)
+    assert st["batch"] == 16 and st["not_converged"] == 0 and st["max_relres"] < 1e-4
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    assert np.max(np.abs(gath - go)) < 1e-6 * np.max(np.abs(go))
+    h.close()
+
+
+def test_bench_default_batch16_vs_tight_oracle_2000(gpu_lib, oracle):
+    """The configuration bench.py times (batch 16 with all 16 columns active, fp32 preconditioner, two-product level) on
+    a 2000 x 2000 raster of the bench generator, against the tight oracle (bench.py itself reports the same comparison
+    on its 3000 x 3000 CPU sample in the `parity` field of its JSON line)."""
+    from oracle import refgraph as rg
+    N = 2000
+    g, cells, pairs = _baseline_workload(N, 15)
+    src = [p[0] for p in pairs[:16]]
+    dst = [p[1] for p in pairs[:16]]
+    A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
+    Ro, _, res = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=16)
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, precond_bytes=4))
+    R, _, _, st = h.solve_pairs(src, dst)
+    assert st["batch"] == 16 and st["not_converged"] == 0
+    assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+    h.close()
+
+
+def test_lattice_form_cg_product(gpu_lib):
+    """csrc/stencil.h on the device: fused p-update + nine-point product + p'Ap against scipy (see the emulator twin)."""
+    from helpers import check_lattice_product
+    check_lattice_product(gpu_lib)
+    check_lattice_product(gpu_lib, shapes=((1000, 300),), ks=(8, 16), pbs=(0, 4))
+
+
+@pytest.mark.parametrize("precond_bytes", [0, 4])
+def test_solve_paths_agree(gpu_lib, precond_bytes):
+    """lattice / CSR product x focal / full solution accumulation: identical resistances (see the emulator twin)."""
+    from helpers import check_solve_paths_agree
+    check_solve_paths_agree(gpu_lib, N=300, batch=16, precond_bytes=precond_bytes)
+    check_solve_paths_agree(gpu_lib, N=120, batch=4, precond_bytes=precond_bytes)
