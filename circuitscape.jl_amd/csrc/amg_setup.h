@@ -915,7 +915,9 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     Level<T>& L = H.levels.back();
     const int n = L.A.nrows;
     H.coarse_n = n;
-    H.coarse_dense = n <= 1024;
+    // dense pseudo-inverse by cyclic Jacobi on the host: O(n^3) per sweep, so only for small levels (max_coarse, or a
+    // level left by a stagnation / expander bail-out that happens to be small); larger ones get damped-Jacobi sweeps
+    H.coarse_dense = n <= 400;
     if (H.coarse_dense) {
       std::vector<int> rp(n + 1), ci((size_t)L.A.nnz);
       std::vector<T> va((size_t)L.A.nnz);

@@ -41,6 +41,16 @@ __global__ __launch_bounds__(256) void convert_index_kernel(int64_t n, const I* 
     out[i] = (int)(in[i] - (I)base);
 }
 
+// raster coordinates of the nodes of a lattice matrix (column-major numbering: node i = cell (i % R, i / R)); lets a
+// matrix handed over by a Julia host (no coordinates) get the same tile-seeded aggregation as a raster built here
+__global__ __launch_bounds__(256) void lattice_coords_kernel(int64_t n, int R, int* __restrict__ row,
+                                                             int* __restrict__ col) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    row[i] = (int)(i % R);
+    col[i] = (int)(i / R);
+  }
+}
+
 // element-wise precision conversion of a CSR matrix (pattern copied)
 template <class T, class TP>
 inline void convert_csr(const Csr<T>& A, Csr<TP>& B, hipStream_t st) {
@@ -203,6 +213,14 @@ struct Solver : ISolver {
   // known_period: raster height when the matrix was built here from an all-valid raster, 0 = detect, -1 = no lattice
   void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period) {
     detect_lattice(A, known_period);
+    DBuf lrow, lcol;
+    if (dia.n > 0 && !prow && !pcol) {
+      lrow.alloc((size_t)n * sizeof(int));
+      lcol.alloc((size_t)n * sizeof(int));
+      hipLaunchKernelGGL(lattice_coords_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, dia.R, dptr<int>(lrow), dptr<int>(lcol));
+      prow = dptr<int>(lrow);
+      pcol = dptr<int>(lcol);
+    }
     SetupParams sp = setup_params();
     static const bool no_lattice_s = getenv("CSGPU_NO_LATTICE_S") != nullptr;  // A/B knob
     sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
@@ -340,8 +358,23 @@ struct Solver : ISolver {
                        dptr<T>(W.b), dptr<int>(has));
     hipLaunchKernelGGL((raster_rhs_mask_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
                        (const int*)dptr<int>(comp_label), (const int*)dptr<int>(has), dptr<T>(W.b));
-    PcgBatchResult r = run_batch_k(1, 1);
+    // every component weighs alike in the one stopping rule: exact power-of-two normalisation per component
+    DBuf absmax = dalloc<unsigned long long>((size_t)ncomp);
+    CS_HIP(hipMemsetAsync(absmax.p, 0, absmax.bytes, st));
+    hipLaunchKernelGGL((comp_absmax_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                       (const int*)dptr<int>(comp_label), (const T*)dptr<T>(W.b), dptr<unsigned long long>(absmax));
+    hipLaunchKernelGGL((comp_scale_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                       (const int*)dptr<int>(comp_label), (const unsigned long long*)dptr<unsigned long long>(absmax), 1,
+                       dptr<T>(W.b));
+    PcgParams pp = pcg_params(1);
+    pp.need_x = true;
+    pp.comp_label = dptr<int>(comp_label);
+    pp.ncomp = (int)ncomp;
+    PcgBatchResult r = pcg_solve<T, TP, 1>(cg_matrix(), H, W, pp, 1, st, dia_ptr());
     accumulate(stats, r, 1);
+    hipLaunchKernelGGL((comp_scale_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                       (const int*)dptr<int>(comp_label), (const unsigned long long*)dptr<unsigned long long>(absmax), -1,
+                       dptr<T>(W.x));
     DBuf draster((size_t)ncells * sizeof(T));
     if (volt_out) {
       hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
@@ -352,13 +385,15 @@ struct Solver : ISolver {
     if (curr_out) {
       const Csr<T>& A = cg_matrix();
       const int gc = grid_for(n);
-      DBuf dbpart = dalloc<double>((size_t)gc * 2), dbmax = dalloc<double>(2), dcurr((size_t)n * sizeof(T));
-      hipLaunchKernelGGL((branch_max_kernel<T, 1>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(), A.va(),
-                         (const T*)dptr<T>(W.x), dptr<double>(dbpart));
-      hipLaunchKernelGGL((branch_max_final_kernel<1>), dim3(1), dim3(256), 0, st, (const double*)dptr<double>(dbpart), gc,
-                         dptr<double>(dbmax));
+      // the drop threshold of every component refers to that component's own largest branch current
+      DBuf dcurr((size_t)n * sizeof(T)), cmax = dalloc<unsigned long long>((size_t)2 * ncomp);
+      hipLaunchKernelGGL(compmax_init_kernel, dim3(grid_for(2 * ncomp)), dim3(256), 0, st, (int64_t)2 * ncomp,
+                         dptr<unsigned long long>(cmax));
+      hipLaunchKernelGGL((branch_max_comp_kernel<T>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(), A.va(),
+                         (const T*)dptr<T>(W.x), (const int*)dptr<int>(comp_label), dptr<unsigned long long>(cmax));
       hipLaunchKernelGGL((node_current_kernel<T, 1>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(), A.va(),
-                         (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax), dptr<T>(dcurr), gnode);
+                         (const T*)dptr<T>(W.x), (const double*)nullptr, dptr<T>(dcurr), gnode,
+                         (const int*)dptr<int>(comp_label), (const unsigned long long*)dptr<unsigned long long>(cmax));
       hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
                          (const int*)dptr<int>(nodemap), (const T*)dptr<T>(dcurr), dptr<T>(draster));
       CS_HIP(hipMemcpyAsync(curr_out, draster.p, (size_t)ncells * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -429,6 +464,14 @@ struct Solver : ISolver {
       CS_REQUIRE(src[p] >= 0 && src[p] < n && dst[p] >= 0 && dst[p] < n, CSGPU_BAD_ARGS, "pair node id out of range");
     for (int64_t g = 0; g < ngather; ++g)
       CS_REQUIRE(gather[g] >= 0 && gather[g] < n, CSGPU_BAD_ARGS, "gather node id out of range");
+    if (ncomp > 1) {
+      // a pair across two components is an inconsistent singular system (the reference only pairs points of one
+      // component, core.jl:146-153): refuse it instead of iterating to itmax
+      std::vector<int> lab((size_t)n);
+      CS_HIP(hipMemcpy(lab.data(), comp_label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      for (int64_t p = 0; p < npairs; ++p)
+        CS_REQUIRE(lab[src[p]] == lab[dst[p]], CSGPU_BAD_ARGS, "pair spans two connected components");
+    }
     const int K = pick_k(npairs);
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
@@ -524,7 +567,8 @@ struct Solver : ISolver {
                                             (const double*)dptr<double>(dbpart), gc, dptr<double>(dbmax)));
         CS_DISPATCH_K(K, hipLaunchKernelGGL((node_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
                                             A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
-                                            dptr<T>(dcurr), (const T*)nullptr));
+                                            dptr<T>(dcurr), (const T*)nullptr, (const int*)nullptr,
+                                            (const unsigned long long*)nullptr));
         if (branch_out) {
           CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
                                               A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),

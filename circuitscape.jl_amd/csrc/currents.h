@@ -81,17 +81,65 @@ __global__ __launch_bounds__(256) void branch_max_final_kernel(const double* __r
   }
 }
 
-// pass 2: node currents, interleaved like the voltages
+// order-preserving map double -> uint64 (atomicMax on the keys = maximum of the doubles, in any order)
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_value(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+// Block-diagonal solves (K = 1, many components in one system): the reference post-processes every component
+// separately, so the 1e-8 drop threshold refers to the largest branch current OF THAT COMPONENT (out.jl:250-290 under
+// advanced.jl:186-271). compmax[2*comp + 0/1] = ordered keys of the maxima in both orientations (pre-set to key(-1e300)).
+template <class T>
+__global__ __launch_bounds__(256) void branch_max_comp_kernel(int n, const int* __restrict__ rp,
+                                                              const int* __restrict__ ci, const T* __restrict__ va,
+                                                              const T* __restrict__ x, const int* __restrict__ comp,
+                                                              unsigned long long* __restrict__ compmax) {
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
+    const double vr = (double)x[row];
+    double mpos = -1e300, mneg = -1e300;
+    for (int k = rp[row]; k < rp[row + 1]; ++k) {
+      const int col = ci[k];
+      if (col > row) {
+        const double b = fabs((double)va[k]) * (vr - (double)x[col]);
+        mpos = b > mpos ? b : mpos;
+        mneg = -b > mneg ? -b : mneg;
+      }
+    }
+    if (mpos > -1e300) {
+      atomicMax(&compmax[2 * comp[row]], ordered_key(mpos));
+      atomicMax(&compmax[2 * comp[row] + 1], ordered_key(mneg));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void compmax_init_kernel(int64_t count, unsigned long long* __restrict__ compmax) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    compmax[i] = ordered_key(-1e300);
+}
+
+// pass 2: node currents, interleaved like the voltages. comp / compmax (K = 1 only, may be null): per-component maxima
+// from branch_max_comp_kernel instead of the per-column maxima in `maxcur`.
 template <class T, int K>
 __global__ __launch_bounds__(256) void node_current_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                            const T* __restrict__ va, const T* __restrict__ x,
                                                            const double* __restrict__ maxcur, T* __restrict__ curr,
-                                                           const T* __restrict__ ground) {
+                                                           const T* __restrict__ ground,
+                                                           const int* __restrict__ comp,
+                                                           const unsigned long long* __restrict__ compmax) {
   const int c = threadIdx.x % K;
-  const double mp = maxcur[2 * c], mn = maxcur[2 * c + 1];
+  double mp = maxcur ? maxcur[2 * c] : 0.0, mn = maxcur ? maxcur[2 * c + 1] : 0.0;
   const int64_t total = (int64_t)n * K;
   for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
     const int row = (int)(it / K);
+    if (comp) {
+      mp = ordered_value(compmax[2 * comp[row]]);
+      mn = ordered_value(compmax[2 * comp[row] + 1]);
+    }
     const double vr = (double)x[(size_t)row * K + c];
     double in = 0.0, out = 0.0;
     for (int k = rp[row]; k < rp[row + 1]; ++k) {

@@ -15,7 +15,7 @@ template <class T, int K>
 __global__ __launch_bounds__(64) void pairs_rhs_kernel(T* __restrict__ b, const int* __restrict__ src,
                                                        const int* __restrict__ dst, int ncols) {
   const int c = threadIdx.x;
-  if (c < ncols && c < K) {
+  if (c < ncols && c < K && src[c] != dst[c]) {  // src == dst: zero right-hand side, R = 0 (the reference skips it, core.jl:210)
     b[(size_t)src[c] * K + c] = T(-1);
     b[(size_t)dst[c] * K + c] = T(1);
   }

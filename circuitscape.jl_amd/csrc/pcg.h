@@ -14,6 +14,7 @@
 #include "blas1.h"
 #include "spmv.h"
 #include "stencil.h"
+#include "raster.h"
 
 namespace csgpu {
 
@@ -228,6 +229,11 @@ struct PcgParams {
   // nothing else: core.jl:231-232, 685-703) and the post-check uses the fp64 recurrence residual r (= b - A x up to
   // rounding: x and r are updated with the same alpha and the same stored p).
   bool need_x = true;
+  // Block-diagonal systems (K = 1, one PCG over many components): component label per node and the number of
+  // components. When set, the post-check is the WORST component's ||A x - b|| / ||b|| (the reference checks every
+  // component's solve separately, advanced.jl:186-312 -> core.jl:640).
+  const int* comp_label = nullptr;
+  int ncomp = 0;
 };
 
 // One captured chunk of `check_every` PCG iterations. Kernel arguments are baked in at capture time, so a graph is
@@ -384,6 +390,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
   const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product;
+  // lattice path: the residual update recomputes A p from the lattice form (one read of p, 5 matrix values per row)
+  // instead of the product kernel writing A p and the update reading it back (2 x sizeof(T) per vector element)
+  static const bool no_recompute = getenv("CSGPU_NO_RECOMPUTE") != nullptr;  // A/B knob
+  const bool recompute = use_dia && !fuse_xa && !no_recompute;
   VcycleFuse<TP> fuse;
   fuse.b_has_tail = two_product;
   fuse.dotw = rp;
@@ -458,7 +468,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     if (use_dia) {
       // fused: p = z + beta p (written to the other buffer), Ap = A p, partials of p'Ap
       ev_begin();
-      dia_cg_product<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)z, pin, pcur, Ap, pc, st);
+      dia_cg_product<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)z, pin, pcur, recompute ? (T*)nullptr : Ap, pc, st);
       ev_end();
       parity ^= 1;
     } else {
@@ -479,7 +489,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     }
     // r -= alpha Ap (+ x += alpha p when the whole solution is wanted), fused with the TP copy of r, the level-0 first
     // pre-smoothing sweep xa = omega D^-1 r and (when the true residual is monitored) the partials of r'r
-    {
+    if (recompute) {
+      const bool rr = criterion == CSGPU_CRIT_TRUE_RESIDUAL;
+      dia_residual_update<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, x,
+                                    rr ? pb : (double*)nullptr, st);
+    } else {
       TP* rpo = MIXED ? rp : (TP*)nullptr;
       TP* xao = fuse_xa ? xa0 : (TP*)nullptr;
       const TP* dinv0 = dptr<TP>(L0.dinv);
@@ -499,8 +513,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
     {
       auto rz = collapsed(pa, spmv_gp, pac);
-      hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
-                         criterion, pp.rtol, atol, 0, ncols_active);
+      // r'r partials (true-residual criterion): one row per workgroup of whichever kernel updated r
+      const double* prr = pb;
+      int nrr = gv;
+      if (recompute && criterion == CSGPU_CRIT_TRUE_RESIDUAL) {
+        auto rr = collapsed(pb, spmv_g, pcc);
+        prr = rr.first;
+        nrr = rr.second;
+      }
+      hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, prr, nrr, criterion,
+                         pp.rtol, atol, 0, ncols_active);
     }
   };
 
@@ -585,6 +607,22 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       a.b = b;
       spmv_launch<T, K>(a, EPI_RESID, false, st);
       hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
+      if (K == 1 && pp.comp_label && pp.ncomp > 1) {
+        DBuf nrm = dalloc<double>((size_t)2 * pp.ncomp + 1);
+        CS_HIP(hipMemsetAsync(nrm.p, 0, nrm.bytes, st));
+        double* rr = dptr<double>(nrm);
+        double* bb = rr + pp.ncomp;
+        hipLaunchKernelGGL((comp_norms_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n, pp.comp_label, (const T*)Ap,
+                           b, rr, bb);
+        hipLaunchKernelGGL(comp_relres_kernel, dim3(1), dim3(256), 0, st, pp.ncomp, (const double*)rr, (const double*)bb,
+                           bb + pp.ncomp);
+        hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv);
+        // overwrite column 0's figure with the worst component's
+        CS_HIP(hipMemcpyAsync(&S->relres[0], bb + pp.ncomp, sizeof(double), hipMemcpyDeviceToDevice, st));
+        CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+        CS_HIP(hipStreamSynchronize(st));
+        return;
+      }
     } else {
       hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa, b, b, pb);
     }

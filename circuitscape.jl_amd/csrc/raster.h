@@ -133,6 +133,70 @@ __global__ __launch_bounds__(256) void raster_rhs_mask_kernel(int n, const int* 
     if (!(has[2 * comp[u]] && has[2 * comp[u] + 1])) b[u] = T(0);
 }
 
+// ---- per-component right-hand-side normalisation of a block-diagonal solve -----------------------------------------
+// The reference solves every component of an advanced-mode problem separately, each to its own relative tolerance
+// (src/raster/advanced.jl:186-312). One PCG over the block-diagonal system has ONE stopping rule, so a component whose
+// sources are orders of magnitude weaker than the others' would be under-resolved. Scaling every component's
+// right-hand side by an exact power of two that brings its largest entry into [1, 2) makes all components weigh alike
+// in the stopping rule; the solution is scaled back by the inverse power of two -- both scalings are exact in floating
+// point, and the per-component maximum is order-independent (atomicMax on the bit pattern), so results stay
+// bit-reproducible. absmax[c] holds the bit pattern of max |b| over component c.
+template <class T>
+__global__ __launch_bounds__(256) void comp_absmax_kernel(int n, const int* __restrict__ comp, const T* __restrict__ b,
+                                                          unsigned long long* __restrict__ absmax) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const double a = fabs((double)b[u]);
+    if (a > 0.0) atomicMax(&absmax[comp[u]], (unsigned long long)__double_as_longlong(a));
+  }
+}
+
+// v[u] *= 2^(sign * (1 - exponent(absmax[comp[u]])))   (sign = +1: normalise, -1: undo)
+template <class T>
+__global__ __launch_bounds__(256) void comp_scale_kernel(int n, const int* __restrict__ comp,
+                                                         const unsigned long long* __restrict__ absmax, int sign,
+                                                         T* __restrict__ v) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const double m = __longlong_as_double((long long)absmax[comp[u]]);
+    if (!(m > 0.0)) continue;
+    int e = 0;
+    frexp(m, &e);  // m = f * 2^e, f in [0.5, 1)
+    v[u] = (T)ldexp((double)v[u], sign * (1 - e));
+  }
+}
+
+// per-component residual check of a block-diagonal solve: rr[c] += res[u]^2, bb[c] += b[u]^2 (check only: the order of
+// the atomic additions does not feed back into any result)
+template <class T>
+__global__ __launch_bounds__(256) void comp_norms_kernel(int n, const int* __restrict__ comp, const T* __restrict__ res,
+                                                         const T* __restrict__ b, double* __restrict__ rr,
+                                                         double* __restrict__ bb) {
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const double r = (double)res[u], v = (double)b[u];
+    if (r != 0.0) atomicAdd(&rr[comp[u]], r * r);
+    if (v != 0.0) atomicAdd(&bb[comp[u]], v * v);
+  }
+}
+
+// worst[0] = max over components with a right-hand side of sqrt(rr / bb)
+__global__ __launch_bounds__(256) void comp_relres_kernel(int ncomp, const double* __restrict__ rr,
+                                                          const double* __restrict__ bb, double* __restrict__ worst) {
+  __shared__ double sm[4];
+  double m = 0.0;
+  for (int c = threadIdx.x; c < ncomp; c += 256)
+    if (bb[c] > 0.0) {
+      const double q = sqrt(rr[c] / bb[c]);
+      m = q > m ? q : m;
+    }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double w = sm[0];
+    for (int i = 1; i < 4; ++i) w = sm[i] > w ? sm[i] : w;
+    worst[0] = w;
+  }
+}
+
 // out[cell] = vec[node of the cell], 0 where the cell has no node (_create_current_maps / _create_voltage_map)
 template <class T>
 __global__ __launch_bounds__(256) void raster_scatter_kernel(int64_t ncells, const int* __restrict__ nodemap,

@@ -100,9 +100,14 @@ inline bool dia_from_csr(const Csr<T>& A, int R, Dia<T>& out, hipStream_t st) {
 enum DiaMode {
   DIA_PLAIN = 0,  // y = A x, partials of x'y                                  (x = pin)
   DIA_CG = 1,     // x = z + beta pin -> pout ; y = A x ; partials of x'y      (Krylov.cg's p-update fused in)
-  DIA_SQ = 2      // y = S x + Q xc, partials of x'y                            (second product of the two-product V(1,1)
+  DIA_SQ = 2,     // y = S x + Q xc, partials of x'y                            (second product of the two-product V(1,1)
                   //                                                             level, amg_setup.h: A = S in lattice form,
                   //                                                             Q in CSR form, xc the coarse solution)
+  DIA_RUPD = 3    // r -= alpha (A x) -> r, rp ; optionally xsol += alpha x     (Krylov.cg's residual update with the
+                  //                                                             product A p RECOMPUTED from the lattice
+                  //                                                             form instead of stored by DIA_CG and
+                  //                                                             re-read: x = pin = the new p; partials
+                  //                                                             of r'r when `partials` is set)
 };
 
 template <class T, class XT>
@@ -123,6 +128,9 @@ struct DiaArgs {
   const int* qci;
   const T* qva;
   const XT* xc;            // DIA_SQ: coarse vector, interleaved [ncoarse][K]
+  T* r;                    // DIA_RUPD: residual (in/out), interleaved [n][K]
+  XT* rp;                  // DIA_RUPD: copy of the new residual in the preconditioner's precision (null when XT == T)
+  T* xsol;                 // DIA_RUPD: optional whole solution vector, xsol += alpha x
 };
 
 template <class T, class XT, int K>
@@ -155,6 +163,9 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
 #pragma unroll
   for (int q = 0; q < CPL; ++q)
     beta[q] = FUSE ? (a.S ? (T)a.S->beta[c0 + q] : (a.beta_dev ? (T)a.beta_dev[c0 + q] : T(0))) : T(0);
+  T alpha[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) alpha[q] = (MODE == DIA_RUPD) ? (T)a.S->alpha[c0 + q] : T(0);
   double dot_acc[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
@@ -308,12 +319,36 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
               for (int q = 0; q < CPL; ++q) out.e[q] = fma(qv[u], (T)xv[u].e[q], out.e[q]);
           }
         }
+        if (MODE == DIA_RUPD) {
+          // r -= alpha * (A p): same arithmetic as cg_update_r_kernel on a stored A p
+          const size_t e = (size_t)id * K + c0;
+          const YV rv = *reinterpret_cast<const YV*>(a.r + e);
+          YV rn;
+          XV rq;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) dot_acc[q] += (double)(T)xw[1][1].e[q] * (double)out.e[q];
-        stream_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
+          for (int q = 0; q < CPL; ++q) {
+            rn.e[q] = rv.e[q] - alpha[q] * out.e[q];
+            rq.e[q] = (XT)rn.e[q];
+            if (a.partials) dot_acc[q] += (double)rn.e[q] * (double)rn.e[q];
+          }
+          *reinterpret_cast<YV*>(a.r + e) = rn;
+          if (a.rp) *reinterpret_cast<XV*>(a.rp + e) = rq;
+          if (a.xsol) {
+            const YV xv = *reinterpret_cast<const YV*>(a.xsol + e);
+            YV xn;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xn.e[q] = fma(alpha[q], (T)xw[1][1].e[q], xv.e[q]);
+            *reinterpret_cast<YV*>(a.xsol + e) = xn;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) dot_acc[q] += (double)(T)xw[1][1].e[q] * (double)out.e[q];
+          if (a.y) stream_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
+        }
       }
     }
   }
+  if (!a.partials) return;  // (block-uniform)
   // lanes owning the same columns sit LPR apart: reduce over lane bits >= log2(LPR), then across the 4 waves via LDS
   const int lane = tid & 63, w = tid >> 6;
   __syncthreads();
@@ -382,7 +417,40 @@ inline void dia_cg_product(const Dia<T>& D, const CgScalars* S, const XT* z, con
   a.qrp = a.qci = nullptr;
   a.qva = nullptr;
   a.xc = nullptr;
+  a.r = nullptr;
+  a.rp = nullptr;
+  a.xsol = nullptr;
   hipLaunchKernelGGL((dia_cg_kernel<T, XT, K, DIA_CG>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// r -= alpha (A p) with A p recomputed from the lattice form (p = the search direction dia_cg_product just wrote; it
+// need not have stored A p: y = nullptr there); rp = XT copy of the new r (may be null); xsol += alpha p (may be null);
+// partials of r'r (may be null). alpha and the skip flag from the CG scalars S.
+template <class T, class XT, int K>
+inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p, T* r, XT* rp, T* xsol,
+                                double* partials_rr, hipStream_t st) {
+  DiaArgs<T, XT> a;
+  a.n = D.n;
+  a.R = D.R;
+  a.C = (int)(D.n / D.R);
+  int grid;
+  dia_tiling<T, XT, K>(D, a.nstrips, a.nseg, a.seg, grid);
+  a.rows = D.data();
+  a.S = S;
+  a.z = nullptr;
+  a.pin = p;
+  a.pout = nullptr;
+  a.y = nullptr;
+  a.partials = partials_rr;
+  a.beta_dev = nullptr;
+  a.skip = nullptr;
+  a.qrp = a.qci = nullptr;
+  a.qva = nullptr;
+  a.xc = nullptr;
+  a.r = r;
+  a.rp = rp;
+  a.xsol = xsol;
+  hipLaunchKernelGGL((dia_cg_kernel<T, XT, K, DIA_RUPD>), dim3(grid), dim3(256), 0, st, a);
 }
 
 // out = S b + Q xc with the partials of b'out: second product of the two-product V(1,1) level (S in lattice form)
@@ -408,6 +476,9 @@ inline void dia_sq_product(const Dia<T>& Sd, const Csr<T>& Q, const T* b, const 
   a.qci = Q.ci();
   a.qva = Q.va();
   a.xc = xc;
+  a.r = nullptr;
+  a.rp = nullptr;
+  a.xsol = nullptr;
   hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_SQ>), dim3(grid), dim3(256), 0, st, a);
 }
 

@@ -363,6 +363,18 @@ def setup(matrix, opts=None, node_row=None, node_col=None, index_dtype=np.int64,
     return Handle(h, dtype)
 
 
+def setup_arrays(rowptr, colidx, vals, n, nnz, opts=None, index_base=1):
+    """csgpu_setup on raw CSR/CSC arrays (any of Int32/Int64 indices, Float32/Float64 values) without copies."""
+    assert rowptr.flags["C_CONTIGUOUS"] and colidx.flags["C_CONTIGUOUS"] and vals.flags["C_CONTIGUOUS"]
+    assert rowptr.dtype == colidx.dtype and rowptr.dtype.itemsize in (4, 8) and vals.dtype.itemsize in (4, 8)
+    o = opts if opts is not None else default_opts()
+    h = ctypes.c_void_p(0)
+    rc = lib().csgpu_setup(rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, n, nnz, rowptr.dtype.itemsize,
+                           vals.dtype.itemsize, index_base, ctypes.byref(o), ctypes.byref(h))
+    _check(rc)
+    return Handle(h, np.float32 if vals.dtype.itemsize == 4 else np.float64)
+
+
 def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True, ground=None):
     """csgpu_raster_setup[_grounded]: Laplacian of a conductance raster (NODATA = values <= 0) built directly in HBM;
     `ground`: optional raster of finite ground conductances added to the diagonal (advanced mode)."""

@@ -18,6 +18,39 @@ def shard_batches(npairs, batch, rank, world):
     return np.asarray(mine, dtype=np.int64)
 
 
+def pair_slice(npairs, rank, world):
+    """Contiguous slice [lo, hi) of the global pair list for `rank`: sizes differ by at most one pair, so a job with
+    fewer batches than GPUs (100 pairs in batches of 16 on 8 GPUs) still occupies every GPU."""
+    base, rem = divmod(npairs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_pairs(values, index, npairs, dist=None, device=None):
+    """Full per-pair vector on every rank from each rank's (index, value) list: ONE all_gather of fixed-size slots
+    (the path's only collective; RCCL over xGMI with backend nccl). dist=None: single process."""
+    full = np.full(npairs, np.nan)
+    if dist is None or dist.get_world_size() == 1:
+        full[np.asarray(index, dtype=np.int64)] = values
+        return full
+    import torch
+    world = dist.get_world_size()
+    slot = (npairs + world - 1) // world
+    buf = torch.full((slot, 2), -1.0, dtype=torch.float64)
+    if len(index):
+        buf[: len(index), 0] = torch.from_numpy(np.asarray(index, dtype=np.float64))
+        buf[: len(index), 1] = torch.from_numpy(np.asarray(values, dtype=np.float64))
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    for t in out:
+        a = t.cpu().numpy()
+        ok = a[:, 0] >= 0
+        full[a[ok, 0].astype(np.int64)] = a[ok, 1]
+    return full
+
+
 def solve_pairs_sharded(handle, src, dst, batch, dist=None, device=None):
     """Solve all (src, dst) pairs across the ranks of `dist` (torch.distributed, already initialised) and return the
     full resistance vector on every rank. With dist=None this is a plain single-process solve."""

@@ -849,8 +849,8 @@ def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_p
     need_volt = of.write_volt_maps or want_volt
     weights = np.array([len(c) for c in fan], dtype=np.int32)   # the reference post-processes once per id combination
     linear = not of.log_transform_maps
-    node_cum = np.zeros(n) if linear else None
-    node_max = np.zeros(n) if (linear and prob.cum.max_curr is not None) else None
+    node_cum = np.zeros(n, dtype=factor.dtype) if linear else None     # the handle's value type (float32 problems too)
+    node_max = np.zeros(n, dtype=factor.dtype) if (linear and prob.cum.max_curr is not None) else None
     R, V, C, st = factor.solve_pairs_currents(src_nodes, dst_nodes, weights=weights, want_voltages=need_volt,
                                               want_currents=per_pair_cur, cum=node_cum, mx=node_max)
     cum = prob.cum
@@ -957,8 +957,8 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
                     R, _, _, st = h.solve_pairs(node[pi] - 1, node[pj] - 1)
                 else:
                     n_nodes = h.info["n"]
-                    node_cum = np.zeros(n_nodes)
-                    node_max = np.zeros(n_nodes) if cum.max_curr is not None else None
+                    node_cum = np.zeros(n_nodes, dtype=h.dtype)
+                    node_max = np.zeros(n_nodes, dtype=h.dtype) if cum.max_curr is not None else None
                     R, _, _, st = h.solve_pairs_currents(node[pi] - 1, node[pj] - 1, want_currents=False, cum=node_cum,
                                                          mx=node_max)
                     cum.cum_curr += _scatter(node_cum, nodemap)

@@ -724,6 +724,31 @@ def test_omniscape_batch_of_windows_as_one_block_diagonal_solve(emu_lib):
     assert np.all(maps[3] == 0) and np.all(maps[1][:, :5] == 0)
 
 
+def test_block_diagonal_solve_resolves_weak_windows_at_default_tolerances(emu_lib):
+    """One PCG over many windows has one stopping rule; the reference solves each component to its own relative
+    tolerance (advanced.jl:186-312). A window whose sources are 1e-5 / 1e-8 of the others' must come back as accurate
+    (relative to its own scale) as when it is solved alone: the right-hand side is normalised per component by an exact
+    power of two and the 1e-4 residual check is evaluated per component."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    base = [_omniscape_window(n, s) for n, s in ((31, 3), (27, 4), (35, 5))]
+    for weak in (1e-5, 1e-8):
+        wins = [(c.copy(), s.copy(), g.copy()) for c, s, g in base]
+        wins[1] = (wins[1][0], wins[1][1] * weak, wins[1][2])
+        maps, st = ps.compute_omniscape_current_batch(wins, {"connect_four_neighbors_only": "False"},
+                                                      solver=ps.HIPAMGSolver(bs=1))
+        assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+        alone, _ = ps.compute_omniscape_current_batch([wins[1]], {"connect_four_neighbors_only": "False"},
+                                                      solver=ps.HIPAMGSolver(bs=1))
+        ref = refmaps.compute_omniscape_current(*wins[1], four_neighbors=False, mode="direct")
+        err_batch = np.max(np.abs(maps[1] - ref)) / ref.max()
+        err_alone = np.max(np.abs(alone[0] - ref)) / ref.max()
+        assert err_batch < 1e-5 and err_batch < 10 * err_alone + 1e-7, (weak, err_batch, err_alone)
+        for k in (0, 2):
+            refk = refmaps.compute_omniscape_current(*wins[k], four_neighbors=False, mode="direct")
+            assert np.max(np.abs(maps[k] - refk)) < 1e-5 * refk.max()
+
+
 def test_raster_entry_points_error_paths_and_fp32(emu_lib):
     """Edge cases of the raster entry points: all-NODATA raster, raster calls on a handle that was not built from a
     raster, source raster of the wrong shape; and the fp32 flavour (val_bytes = 4) of the grounded raster solve."""
