@@ -162,24 +162,39 @@ __global__ __launch_bounds__(256) void agg_pass1_kernel(int n, const int* __rest
   }
 }
 
-// pass 2: the rest joins its most strongly coupled neighbour that was aggregated in pass 1
+// pass 2: the rest joins its most strongly coupled neighbour that was aggregated in pass 1. On a raster whose extent
+// is known (gridR x gridC > 0) a left-over cell -- last row / column of a raster whose size is 1 mod 3, tile corners of
+// a 4-neighbour raster -- prefers a neighbour of its OWN 3x3 tile (tile = (min(row/3, Rc-1), min(col/3, Cc-1))), so the
+// aggregates stay the regular tiles and the transfer operators keep their index-free form (lattice.h).
 template <class T>
 __global__ __launch_bounds__(256) void agg_pass2_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                         const T* __restrict__ va, const T* __restrict__ diag,
                                                         double theta2, const int* __restrict__ agg1,
-                                                        int* __restrict__ agg, int* __restrict__ orphan_flag) {
+                                                        int* __restrict__ agg, int* __restrict__ orphan_flag,
+                                                        const int* __restrict__ nrow, const int* __restrict__ ncol,
+                                                        int gridR, int gridC) {
+  const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     int a = agg1[i];
     if (a < 0) {
       double best = -1.0;
+      bool same_tile = false;
+      int ti = 0, tj = 0;
+      if (gridR > 0 && nrow) {
+        ti = min(nrow[i] / 3, Rc - 1);
+        tj = min(ncol[i] / 3, Cc - 1);
+      }
       for (int k = rp[i]; k < rp[i + 1]; ++k) {
         const int j = ci[k];
         if (!is_strong(i, j, va[k], diag, theta2)) continue;
         const int aj = agg1[j];
+        if (aj < 0) continue;
         const double w = fabs((double)va[k]);
-        if (aj >= 0 && w > best) {
+        const bool st = gridR > 0 && nrow && min(nrow[j] / 3, Rc - 1) == ti && min(ncol[j] / 3, Cc - 1) == tj;
+        if ((st && !same_tile) || (st == same_tile && w > best)) {
           best = w;
           a = aj;
+          same_tile = st;
         }
       }
     }
@@ -684,9 +699,11 @@ struct Level {
   Csr<T> A, P, R;       // P, R empty on the coarsest level
   Csr<T> Q;             // Q = P - omega D^-1 A P: prolongation fused with the first post-smoothing sweep
   Csr<T> QT, M;         // level 0 with V(1,1) smoothing only: Q^T and [S Q] of the two-product form (see build_sq_kernel)
-  Dia<T> Sdia;          // ... or S in lattice form (stencil.h) when the fine matrix is a raster lattice: the second
-                        // product is then evaluated as S b + Q x_c and M is not built
-  bool two_product() const { return M.nnz > 0 || Sdia.n > 0; }
+  Dia<T> Sdia;          // ... or, when the fine matrix is a raster lattice with regular 3x3 aggregates: S in lattice form
+  LatticeQ<T> Ql;       // (stencil.h) and Q in its index-free tile form (lattice.h); Q^T and [S Q] are not built then
+  DBuf agg0;            // level 0 aggregate of every node (kept only until Ql has been built)
+  bool lattice_two_product() const { return Sdia.n > 0 && Ql.n > 0; }
+  bool two_product() const { return M.nnz > 0 || lattice_two_product(); }
   DBuf dinv;            // 1/a_ii
   DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
   DBuf orderQT;         // traversal order of the long-row kernel on Q^T (two-product level; may be empty)
@@ -716,8 +733,17 @@ struct SetupParams {
   double omega_p = 1.6;
   double omega_s = 1.5;
   bool two_product = false;  // build Q^T and [S Q] on level 0 (the solve phase runs V(1,1) there)
-  bool lattice_s = false;    // the caller provides S in lattice form (Level::Sdia): build Q^T only, not [S Q]
+  int grid_rows = 0, grid_cols = 0;  // extent of the raster the node coordinates refer to (0 = unknown)
+  bool lattice_s = false;    // the caller builds the lattice forms of the two-product level (Level::Sdia, Level::Ql) from
+                             // the aggregates kept in Level::agg0; Q^T and [S Q] are not built here
 };
+
+// Q^T (with its traversal order) of the two-product form in CSR
+template <class T>
+inline void build_qt_matrix(Level<T>& L, hipStream_t st) {
+  transpose(L.Q, L.QT, st);
+  spmv_block_order_rect(L.QT, L.periodA, L.orderQT, st);
+}
 
 // [S Q] of the two-product form as one CSR matrix with n + n_c columns (build_sq_kernel)
 template <class T>
@@ -740,7 +766,7 @@ inline void build_sq_matrix(Level<T>& L, hipStream_t st) {
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
-                     DBuf& crow, DBuf& ccol, hipStream_t st) {
+                     DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0) {
   const int n = A.nrows;
   const double theta2 = theta * theta;
   DBuf key = dalloc<unsigned long long>(n), k1 = dalloc<unsigned long long>(n), k2 = dalloc<unsigned long long>(n);
@@ -772,7 +798,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
   hipLaunchKernelGGL((agg_pass1_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
                      dptr<unsigned long long>(key), dptr<int>(root_id), dptr<int>(agg1));
   hipLaunchKernelGGL((agg_pass2_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
-                     dptr<int>(agg1), dptr<int>(agg), dptr<int>(orphan));
+                     dptr<int>(agg1), dptr<int>(agg), dptr<int>(orphan), nrow, ncol, gridR, gridC);
   // nodes that could not be attached (cannot happen for a symmetric strength graph; kept as a safety net)
   DBuf orphan_flag = dalloc<int>((size_t)n + 1);
   CS_HIP(hipMemcpyAsync(orphan_flag.p, orphan.p, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -831,6 +857,7 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
   const int* cur_row = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_row;
   const int* cur_col = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_col;
   DBuf size_prev;  // long long fine sizes of the current level (null on level 0 => all ones)
+  int gridR = cur_row ? sp.grid_rows : 0, gridC = cur_row ? sp.grid_cols : 0;  // raster extent of the current level
   for (;;) {
     Level<T>& L = H.levels.back();
     DBuf diag, labs;
@@ -838,11 +865,15 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     const int n = L.A.nrows;
     if (n <= sp.max_coarse || (int)H.levels.size() >= sp.max_levels) break;
     DBuf agg, crow, ccol;
-    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st);
+    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC);
     if (sp.theta > 0.0 && (double)nagg > 0.5 * (double)n) {
       // the strength filter left too few strong couplings to coarsen this level: aggregate on the full pattern
-      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st);
+      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC);
     }
+    // coarse raster extent (tile counts), valid while the aggregates are the regular tiles
+    gridR = gridR > 0 ? (gridR + 1) / 3 : 0;
+    gridC = gridC > 0 ? (gridC + 1) / 3 : 0;
+    if ((int64_t)gridR * gridC != nagg) gridR = gridC = 0;
     if (nagg >= n || nagg < 1 || (double)nagg > 0.8 * (double)n) break;  // coarsening stagnated
     // sizes
     DBuf size_c = dalloc<unsigned long long>(nagg);
@@ -894,9 +925,12 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     }
     if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
         (int64_t)n + nagg < 0x7fffffffLL) {
-      transpose(L.Q, L.QT, st);
-      spmv_block_order_rect(L.QT, L.periodA, L.orderQT, st);
-      if (!sp.lattice_s) build_sq_matrix(L, st);
+      if (sp.lattice_s) {
+        L.agg0 = std::move(agg);  // the caller turns Q into its index-free form (or falls back to the CSR forms)
+      } else {
+        build_qt_matrix(L, st);
+        build_sq_matrix(L, st);
+      }
       if (getenv("CSGPU_VERBOSE"))
         fprintf(stderr, "csgpu: two-product level: nnz(Q^T)=%lld nnz([S Q])=%lld periodA=%lld orderA=%s orderQT=%s\n",
                 (long long)L.QT.nnz, (long long)L.M.nnz, L.periodA, L.orderA.p ? "yes" : "no", L.orderQT.p ? "yes" : "no");

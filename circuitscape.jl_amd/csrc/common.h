@@ -124,6 +124,19 @@ struct Dia {
   size_t device_bytes() const { return rows.bytes; }
 };
 
+// Index-free form of the level-0 transfer operator Q (n x n_c) of a raster whose aggregates are the regular 3x3
+// tiles: fine cell (i, j) belongs to tile (I, J) = (min(i/3, Rc-1), min(j/3, Cc-1)), coarse node id J*Rc + I, and row
+// (i, j) of Q only touches the 3 x 3 block of tiles around (I, J):
+//   q[node][(dJ+1)*3 + (dI+1)] = Q[node, (J+dJ)*Rc + (I+dI)]      (0 where the entry is absent / outside the raster)
+template <class T>
+struct LatticeQ {
+  int64_t n = 0;
+  int R = 0, C = 0, Rc = 0, Cc = 0;
+  DBuf q;  // [n][9] of T
+  const T* data() const { return q.as<T>(); }
+  size_t device_bytes() const { return q.bytes; }
+};
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid size for grid-stride elementwise / reduction kernels: fixed cap so partial-sum layouts (and hence

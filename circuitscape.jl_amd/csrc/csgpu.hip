@@ -222,6 +222,13 @@ struct Solver : ISolver {
       pcol = dptr<int>(lcol);
     }
     SetupParams sp = setup_params();
+    if (dia.n > 0) {  // raster extent known: left-over cells stay with their own 3x3 tile (agg_pass2_kernel)
+      sp.grid_rows = dia.R;
+      sp.grid_cols = (int)(n / dia.R);
+    } else if (known_period > 0 && n % known_period == 0) {  // all-valid raster built here, lattice product switched off
+      sp.grid_rows = known_period;
+      sp.grid_cols = (int)(n / known_period);
+    }
     static const bool no_lattice_s = getenv("CSGPU_NO_LATTICE_S") != nullptr;  // A/B knob
     sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
     if constexpr (MIXED) {
@@ -233,13 +240,26 @@ struct Solver : ISolver {
       amg_setup(H, std::move(A), sp, prow, pcol, st);
     }
     Level<TP>& L0 = H.levels[0];
-    if (sp.lattice_s && L0.QT.nnz > 0) {
-      // second product of the two-product level from the lattice form: out = S b + Q x_c (stencil.h)
+    if (sp.lattice_s && L0.agg0.p) {
+      // two-product level from the lattice: b_c = Q^T b and out = S b + Q x_c with index-free Q (lattice.h) and S in
+      // lattice form (stencil.h); when the aggregates are not the regular tiles the CSR forms are built instead
       hipEvent_t e0, e1;
       CS_HIP(hipEventCreate(&e0));
       CS_HIP(hipEventCreate(&e1));
       CS_HIP(hipEventRecord(e0, st));
-      dia_build_s(dia, (const TP*)dptr<TP>(L0.dinv), L0.omega, L0.Sdia, st);
+      static const bool no_lattice_q = getenv("CSGPU_NO_LATTICE_Q") != nullptr;  // A/B knob
+      const bool ok = !no_lattice_q && lattice_q_from_csr(L0.Q, (const int*)dptr<int>(L0.agg0), dia.R, (int)(n / dia.R),
+                                                          L0.Ql, st);
+      L0.agg0.release();
+      if (getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: two-product level on a %d x %lld lattice: index-free Q %s\n", dia.R, (long long)(n / dia.R),
+                ok ? "built" : "not applicable (CSR forms)");
+      if (ok) {
+        dia_build_s(dia, (const TP*)dptr<TP>(L0.dinv), L0.omega, L0.Sdia, st);
+      } else {
+        build_qt_matrix(L0, st);
+        build_sq_matrix(L0, st);
+      }
       CS_HIP(hipEventRecord(e1, st));
       CS_HIP(hipEventSynchronize(e1));
       float ms = 0;
@@ -442,6 +462,7 @@ struct Solver : ISolver {
     s->cg_spmv_calls += r.spmv_calls;
     s->graph_launches += r.graph_launches;
     s->polished_batches += r.polished;
+    s->cg_spmv_bytes = r.spmv_bytes;
   }
 
 #define CS_DISPATCH_K(K, ...)                               \
@@ -667,7 +688,7 @@ struct Solver : ISolver {
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
                          L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
-                         L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes());
+                         L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes() + L.Ql.device_bytes());
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
@@ -738,7 +759,9 @@ struct Solver : ISolver {
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     Level<TP>& L = H.levels[lvl];
-    if (which == 5 && L.M.nnz == 0 && L.Sdia.n > 0) build_sq_matrix(L, st);  // CSR form for the size query only
+    // lattice level: the CSR forms of Q^T / [S Q] are not kept; build them for the size query only
+    if (which == 5 && L.M.nnz == 0 && L.lattice_two_product()) build_sq_matrix(L, st);
+    if (which == 4 && L.QT.nnz == 0 && L.lattice_two_product()) build_qt_matrix(L, st);
     const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
     CS_REQUIRE(M.nnz > 0, CSGPU_BAD_ARGS, "level has no such operator");
     DBuf x((size_t)M.ncols * k * sizeof(TP)), y((size_t)M.nrows * k * sizeof(TP));
@@ -749,10 +772,12 @@ struct Solver : ISolver {
     if (which == 0 || sq) a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
     if (which == 4) a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
     if (sq) a.partials = dptr<double>(part);
-    const bool sq_lattice = sq && L.Sdia.n > 0;
+    const bool sq_lattice = sq && L.lattice_two_product();
     if (sq_lattice) {  // the kernel the V-cycle runs on a lattice level: S b + Q x_c with x = [b; x_c]
-      CS_DISPATCH_K(k, dia_sq_product<TP, KK>(L.Sdia, L.Q, (const TP*)dptr<TP>(x), (const TP*)dptr<TP>(x) + (size_t)M.nrows * k,
+      CS_DISPATCH_K(k, dia_sq_product<TP, KK>(L.Sdia, L.Ql, (const TP*)dptr<TP>(x), (const TP*)dptr<TP>(x) + (size_t)M.nrows * k,
                                              dptr<TP>(y), dptr<double>(part), nullptr, st));
+    } else if (which == 4 && L.lattice_two_product()) {  // index-free restriction
+      CS_DISPATCH_K(k, lattice_restrict<TP, KK>(L.Ql, (const TP*)dptr<TP>(x), dptr<TP>(y), nullptr, st));
     } else if (sq) {
       CS_DISPATCH_K(k, spmv_launch_wide<TP, KK>(a, true, st));
     } else {
@@ -779,9 +804,10 @@ struct Solver : ISolver {
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     const Level<TP>& L = H.levels[lvl];
-    if (which == 5 && L.M.nnz == 0 && L.Sdia.n > 0) {
-      // lattice level: the CSR form of [S Q] is not kept; build it (by the independent CSR builder) for inspection
-      build_sq_matrix(const_cast<Level<TP>&>(L), st);
+    if (L.lattice_two_product() && ((which == 5 && L.M.nnz == 0) || (which == 4 && L.QT.nnz == 0))) {
+      // lattice level: the CSR forms of Q^T / [S Q] are not kept; build them (independent CSR builders) for inspection
+      if (which == 5) build_sq_matrix(const_cast<Level<TP>&>(L), st);
+      if (which == 4) build_qt_matrix(const_cast<Level<TP>&>(L), st);
       CS_HIP(hipStreamSynchronize(st));
     }
     const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;

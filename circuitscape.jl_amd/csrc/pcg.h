@@ -14,6 +14,7 @@
 #include "blas1.h"
 #include "spmv.h"
 #include "stencil.h"
+#include "lattice.h"
 #include "raster.h"
 
 namespace csgpu {
@@ -104,7 +105,9 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     Level<T>& Lc = H.levels[l + 1];
     T* bc = dptr<T>(Lc.b);
     T* xc = const_cast<T*>(b) + (size_t)n * K;
-    {
+    if (L.lattice_two_product()) {
+      lattice_restrict<T, K>(L.Ql, b, bc, skip, st);  // index-free Q^T b (lattice.h)
+    } else {
       SpmvArgs<T> a = spmv_args(L.QT, b, bc);
       a.skip = skip;
       a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
@@ -114,9 +117,9 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     cf.skip = skip;
     vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
     if (want_dot) CS_REQUIRE(fuse->dotw == b, CSGPU_INTERNAL, "two-product level: fused dot must be with the input vector");
-    if (L.Sdia.n > 0) {
-      // S in lattice form + Q in CSR form, one marching kernel (stencil.h); partials of b'out always written
-      dia_sq_product<T, K>(L.Sdia, L.Q, b, (const T*)xc, out, fuse->partials, skip, st);
+    if (L.lattice_two_product()) {
+      // S in lattice form + index-free Q, one marching kernel (stencil.h); partials of b'out always written
+      dia_sq_product<T, K>(L.Sdia, L.Ql, b, (const T*)xc, out, fuse->partials, skip, st);
       return;
     }
     SpmvArgs<T> a = spmv_args(L.M, b, out);
@@ -331,6 +334,7 @@ struct PcgBatchResult {
   int64_t spmv_calls = 0;
   int64_t graph_launches = 0;
   int polished = 0;
+  int64_t spmv_bytes = 0;  // algorithmic bytes of one of the timed CG-product launches
 };
 
 // Solve A X = B for the K interleaved columns held in W.b. With pp.need_x the solution is left in W.x; otherwise only
@@ -384,7 +388,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   const bool two_product = H.levels.size() > 1 && L0.two_product() && pp.nu_pre == 1 && pp.nu_post == 1 &&
                            W.tail >= H.levels[1].A.nrows;
   const int spmv_g = use_dia ? dia_grid<T, TP, K>(*dia) : (wave ? spmv_wave_grid<T, K>((int)n) : spmv_grid<T, K>((int)n));
-  const int spmv_gp = (two_product && L0.Sdia.n > 0) ? dia_grid<TP, TP, K>(L0.Sdia)
+  const int spmv_gp = (two_product && L0.lattice_two_product()) ? dia_grid<TP, TP, K>(L0.Sdia)
                       : (wave && two_product)        ? spmv_wave_grid<TP, K>((int)n)
                                                      : spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
@@ -668,6 +672,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   }
   res.spmv_calls = counted;
   res.graph_launches = graph_launches;
+  if (use_dia)
+    res.spmv_bytes = n * 5 * (int64_t)sizeof(T) + n * K * (3 * (int64_t)sizeof(TP) + (recompute ? 0 : (int64_t)sizeof(T)));
+  else
+    res.spmv_bytes = A.nnz * (int64_t)(sizeof(T) + 4) + (n + 1) * 4 + n * K * (int64_t)(sizeof(TP) + sizeof(T));
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return res;

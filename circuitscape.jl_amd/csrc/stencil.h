@@ -102,7 +102,9 @@ enum DiaMode {
   DIA_CG = 1,     // x = z + beta pin -> pout ; y = A x ; partials of x'y      (Krylov.cg's p-update fused in)
   DIA_SQ = 2,     // y = S x + Q xc, partials of x'y                            (second product of the two-product V(1,1)
                   //                                                             level, amg_setup.h: A = S in lattice form,
-                  //                                                             Q in CSR form, xc the coarse solution)
+                  //                                                             Q in its index-free 3x3-tile form
+                  //                                                             (LatticeQ), xc the coarse solution,
+                  //                                                             staged tile by tile in LDS)
   DIA_RUPD = 3    // r -= alpha (A x) -> r, rp ; optionally xsol += alpha x     (Krylov.cg's residual update with the
                   //                                                             product A p RECOMPUTED from the lattice
                   //                                                             form instead of stored by DIA_CG and
@@ -124,10 +126,9 @@ struct DiaArgs {
   double* partials;        // [gridDim.x][K] partials of p'(A p)
   const double* beta_dev;  // test hook: per-column beta (device pointer) when S is null; null = 0
   const int* skip;         // optional device flag: non-zero turns the launch into a no-op
-  const int* qrp;          // DIA_SQ: CSR form of Q (n rows), values in T
-  const int* qci;
-  const T* qva;
-  const XT* xc;            // DIA_SQ: coarse vector, interleaved [ncoarse][K]
+  const T* qell;           // DIA_SQ: index-free Q, [n][9] (LatticeQ)
+  int Rc, Cc;              // DIA_SQ: coarse lattice
+  const XT* xc;            // DIA_SQ: coarse vector, interleaved [Rc*Cc][K]
   T* r;                    // DIA_RUPD: residual (in/out), interleaved [n][K]
   XT* rp;                  // DIA_RUPD: copy of the new residual in the preconditioner's precision (null when XT == T)
   T* xsol;                 // DIA_RUPD: optional whole solution vector, xsol += alpha x
@@ -141,6 +142,9 @@ struct DiaShape {
   static constexpr int TI = 256 / LPR;           // raster rows per tile
   static constexpr int MELEMS = 5 * (TI + 2);    // matrix values staged per raster column (halo rows included)
   static constexpr int MU = (MELEMS + 255) / 256;
+  static constexpr int QELEMS = 9 * TI;          // DIA_SQ: values of Q staged per raster column
+  static constexpr int QU = (QELEMS + 255) / 256;
+  static constexpr int CR = TI / 3 + 4;          // DIA_SQ: coarse rows staged per coarse column (one tile above / below)
 };
 
 template <class T, class XT, int K, int MODE>
@@ -150,8 +154,13 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
   constexpr int CPL = SH::CPL, LPR = SH::LPR, TI = SH::TI, MELEMS = SH::MELEMS, MU = SH::MU;
   typedef SpmvVec<XT, CPL> XV;
   typedef SpmvVec<T, CPL> YV;
+  constexpr int QELEMS = SH::QELEMS, QU = SH::QU, CR = SH::CR;
+  constexpr bool SQ = MODE == DIA_SQ;
+  static_assert(CR * LPR <= 256, "one lane per staged coarse entry");
   __shared__ XV s_x[4][(TI + 2) * LPR];
   __shared__ T s_m[4][MELEMS];
+  __shared__ T s_q[SQ ? 4 : 1][SQ ? QELEMS : 1];    // DIA_SQ: Q values of raster columns j-1 .. j+2 (ring)
+  __shared__ XV s_xc[SQ ? 4 : 1][SQ ? CR * LPR : 1];  // DIA_SQ: coarse columns J-1 .. J+2 (ring), rows Ilo .. Ilo+CR-1
   __shared__ double s_red[4 * K];
   if (a.S && a.S->all_done) return;
   if (a.skip && *a.skip) return;
@@ -185,9 +194,27 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     const int i0 = si * TI;
     const int j0 = sj * a.seg, j1 = min(a.C, j0 + a.seg);
     const bool row_on = i0 + t < a.R;  // rows past the raster's last row belong to no tile
+    // DIA_SQ: coarse rows staged = tiles of the strip's rows plus one above and one below
+    const int Ilo = SQ ? min(i0 / 3, a.Rc - 1) - 1 : 0;
+    const int crow = SQ ? min((i0 + t) / 3, a.Rc - 1) - Ilo : 0;  // this lane's tile row inside the staged coarse column
     // staged values of the column being loaded (registers), written to LDS one step later
     XV xr, xh;
     T mr[MU];
+    T qr[SQ ? QU : 1];
+    XV xcr;
+    int pend_c = -1, next_c = 0;
+    auto load_coarse = [&](int Jc) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) xcr.e[q] = XT(0);
+      if (tid < CR * LPR) {
+        const int Ic = Ilo + tid / LPR;
+        if (Jc >= 0 && Jc < a.Cc && Ic >= 0 && Ic < a.Rc)
+          xcr = *reinterpret_cast<const XV*>(a.xc + ((size_t)Jc * a.Rc + Ic) * K + (tid % LPR) * CPL);
+      }
+    };
+    auto store_coarse = [&](int Jc) {
+      if (tid < CR * LPR) s_xc[Jc & 3][tid] = xcr;
+    };
     auto load_column = [&](int jc) {
       // node id of tile row -1 (the halo row above) in raster column jc; ids outside [0, n) read as zero
       const int64_t base = (int64_t)jc * a.R + i0 - 1;
@@ -235,6 +262,15 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
         const int64_t g = base * 5 + e;
         mr[u] = (e < MELEMS && g >= 0 && g < a.n * 5) ? a.rows[g] : T(0);
       }
+      if (SQ) {  // Q values of the PREVIOUS raster column (the one whose product is taken right after this store)
+        const int64_t qb = ((int64_t)(jc - 1) * a.R + i0) * 9;
+#pragma unroll
+        for (int u = 0; u < QU; ++u) {
+          const int e = tid + u * 256;
+          const int64_t g = qb + e;
+          qr[u] = (jc - 1 >= j0 && e < QELEMS && g < a.n * 9) ? a.qell[g] : T(0);
+        }
+      }
     };
     auto store_column = [&](int jc) {
       const int slot = jc & 3;
@@ -245,6 +281,13 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
         const int e = tid + u * 256;
         if (e < MELEMS) s_m[slot][e] = mr[u];
       }
+      if (SQ) {
+#pragma unroll
+        for (int u = 0; u < QU; ++u) {
+          const int e = tid + u * 256;
+          if (e < QELEMS) s_q[(jc - 1) & 3][e] = qr[u];
+        }
+      }
     };
     __syncthreads();  // previous tile finished with the ring
     // prologue: columns j0-1 and j0 into the ring, column j0+1 in flight
@@ -253,6 +296,14 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     load_column(j0);
     store_column(j0);
     load_column(j0 + 1);
+    if (SQ) {  // coarse columns J(j0)-1 .. J(j0)+2 up front; later ones one per step, two steps ahead of their use
+      const int Jb = min(j0 / 3, a.Cc - 1);
+      for (int d = -1; d <= 2; ++d) {
+        load_coarse(Jb + d);
+        store_coarse(Jb + d);
+      }
+      next_c = Jb + 3;
+    }
     __syncthreads();
     // sliding 3x3 window of x: xw[dj][di] = x(row t-1+di of the tile, raster column j-1+dj)
     XV xw[3][3];
@@ -263,7 +314,18 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     }
     for (int j = j0; j < j1; ++j) {
       store_column(j + 1);                 // the column loaded one step ago
+      if (SQ && pend_c >= 0) {
+        store_coarse(pend_c);
+        pend_c = -1;
+      }
       if (j + 2 <= j1) load_column(j + 2); // next one in flight while this column is computed
+      if (SQ) {
+        const int need = min((j + 2) / 3, a.Cc - 1) + 1;  // last coarse column read two steps from now
+        if (need >= next_c) {
+          load_coarse(next_c);
+          pend_c = next_c++;
+        }
+      }
       __syncthreads();
 #pragma unroll
       for (int di = 0; di < 3; ++di) {
@@ -300,23 +362,20 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
           out.e[q] = s;
         }
         const int64_t id = (int64_t)j * a.R + i0 + t;
-        if (MODE == DIA_SQ) {
-          // + Q xc: the row's few (<= 9 on rasters) coarse couplings, three gathers in flight
-          const int kb = a.qrp[id], ke = a.qrp[id + 1];
-          for (int k = kb; k < ke; k += 3) {
-            T qv[3];
-            XV xv[3];
+        if (SQ) {
+          // + Q xc: the 3 x 3 block of tiles around this cell's tile, coarse values out of the staged columns
+          const T* qrow = s_q[j & 3] + 9 * t;
+          const int Jj = min(j / 3, a.Cc - 1);
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const bool on = k + u < ke;
-              qv[u] = on ? a.qva[k + u] : T(0);
-              const int col = on ? a.qci[k + u] : a.qci[kb];
-              xv[u] = *reinterpret_cast<const XV*>(a.xc + (size_t)col * K + c0);
+          for (int dj = 0; dj < 3; ++dj) {
+            const XV* xcol = s_xc[(Jj + dj - 1) & 3];
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+              const T w = qrow[dj * 3 + di];
+              const XV xv = xcol[(crow + di - 1) * LPR + lq];
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) out.e[q] = fma(w, (T)xv.e[q], out.e[q]);
             }
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-              for (int q = 0; q < CPL; ++q) out.e[q] = fma(qv[u], (T)xv[u].e[q], out.e[q]);
           }
         }
         if (MODE == DIA_RUPD) {
@@ -414,8 +473,8 @@ inline void dia_cg_product(const Dia<T>& D, const CgScalars* S, const XT* z, con
   a.partials = partials;
   a.beta_dev = beta_dev;
   a.skip = nullptr;
-  a.qrp = a.qci = nullptr;
-  a.qva = nullptr;
+  a.qell = nullptr;
+  a.Rc = a.Cc = 0;
   a.xc = nullptr;
   a.r = nullptr;
   a.rp = nullptr;
@@ -444,8 +503,8 @@ inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p
   a.partials = partials_rr;
   a.beta_dev = nullptr;
   a.skip = nullptr;
-  a.qrp = a.qci = nullptr;
-  a.qva = nullptr;
+  a.qell = nullptr;
+  a.Rc = a.Cc = 0;
   a.xc = nullptr;
   a.r = r;
   a.rp = rp;
@@ -453,9 +512,10 @@ inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p
   hipLaunchKernelGGL((dia_cg_kernel<T, XT, K, DIA_RUPD>), dim3(grid), dim3(256), 0, st, a);
 }
 
-// out = S b + Q xc with the partials of b'out: second product of the two-product V(1,1) level (S in lattice form)
+// out = S b + Q xc with the partials of b'out: second product of the two-product V(1,1) level (S in lattice form, Q in
+// its index-free tile form)
 template <class T, int K>
-inline void dia_sq_product(const Dia<T>& Sd, const Csr<T>& Q, const T* b, const T* xc, T* out, double* partials,
+inline void dia_sq_product(const Dia<T>& Sd, const LatticeQ<T>& Q, const T* b, const T* xc, T* out, double* partials,
                            const int* skip, hipStream_t st) {
   DiaArgs<T, T> a;
   a.n = Sd.n;
@@ -472,9 +532,9 @@ inline void dia_sq_product(const Dia<T>& Sd, const Csr<T>& Q, const T* b, const 
   a.partials = partials;
   a.beta_dev = nullptr;
   a.skip = skip;
-  a.qrp = Q.rp();
-  a.qci = Q.ci();
-  a.qva = Q.va();
+  a.qell = Q.data();
+  a.Rc = Q.Rc;
+  a.Cc = Q.Cc;
   a.xc = xc;
   a.r = nullptr;
   a.rp = nullptr;

@@ -19,14 +19,16 @@ mutable struct CsgpuOpts
     nu_pre::Int32; nu_post::Int32; criterion::Int32; itmax::Int32; batch::Int32; check_every::Int32; nu_coarse::Int32
     theta::Float64; omega_p::Float64; omega_s::Float64; rtol::Float64; atol::Float64
     node_row::Ptr{Int32}; node_col::Ptr{Int32}
-    precond_bytes::Int32; use_graph::Int32; two_product::Int32; reserved2::Int32
+    precond_bytes::Int32; use_graph::Int32; two_product::Int32; stencil::Int32
+    explicit_check::Int32; reserved3::Int32
     CsgpuOpts() = new()
 end
 
 mutable struct CsgpuStats
     nrhs::Int32; max_iters::Int32; total_iters::Int64; max_relres::Float64; solve_ms::Float64; device_ms::Float64
     cg_spmv_ms::Float64; cg_spmv_calls::Int64; batch::Int32; not_converged::Int32; graph_launches::Int64; polished_batches::Int64
-    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0)
+    cg_spmv_bytes::Int64
+    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
 end
 
 mutable struct HIPFactor          # cf. PardisoFactorize (Pardiso ext :8-13): owns the device-resident hierarchy

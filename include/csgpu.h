@@ -157,6 +157,9 @@ typedef struct csgpu_stats {
   int64_t graph_launches;       /* hipGraph replays issued (each = check_every PCG iterations) */
   int64_t polished_batches;     /* batches that were re-opened on the true residual because a column stopped on the
                                    configured rule with ||Ax-b||/||b|| >= 1e-4 (the reference would have errored) */
+  int64_t cg_spmv_bytes;        /* algorithmic bytes of ONE of the launches timed in cg_spmv_ms:
+                                   CSR product: nnz*(val+4) + (n+1)*4 + n*K*(x + val);  lattice product with the fused
+                                   search-direction update: n*5*val + n*K*3*x, plus n*K*val when it also stores A p */
 } csgpu_stats;
 
 int csgpu_device_count(void);

@@ -338,3 +338,33 @@ def check_solve_paths_agree(L, N=90, batch=8, precond_bytes=4):
     Rc, gc, sc = out[(-1, 0)]
     assert ss["total_iters"] == sc["total_iters"]
     assert np.max(np.abs(Rs - Rc) / Rc) < 1e-9 and np.max(np.abs(gs - gc)) < 1e-9 * np.max(np.abs(gc))
+
+
+def check_lattice_transfer_products(L, shapes=((45, 45), (64, 70), (100, 31), (35, 36), (11, 14)), ks=(1, 4, 16), pbs=(0, 4)):
+    """The two products of the two-product V(1,1) level on raster lattices -- b_c = Q^T b (lattice_restrict_kernel) and
+    out = S b + Q x_c (DIA_SQ marching kernel), both index-free -- against scipy on the CSR forms Q^T and [S Q] built
+    by the independent CSR builders of the same handle: raster sizes 0, 1, 2 mod 3 (left-over cells join their own
+    tile), 8- and 4-neighbour, every batch width class, fp64 and fp32 hierarchies."""
+    for four in (False, True):
+        for (R, C) in shapes:
+            rng = np.random.default_rng(R * 131 + C)
+            g = np.exp(rng.standard_normal((R, C)))
+            for k in ks:
+                for pb in pbs:
+                    h = L.raster_setup(g, L.default_opts(batch=k, precond_bytes=pb), four_neighbors=four)
+                    assert h.info["lattice_period"] == R
+                    tol = 1e-12 if pb == 0 else 3e-5
+                    for which in ("QT", "M"):
+                        M = h.level_matrix(0, which).astype(np.float64)
+                        x = rng.standard_normal((M.shape[1], k))
+                        y, dots = h.level_spmv(0, which, x if k > 1 else x[:, 0])
+                        xs = x.astype(np.float32).astype(np.float64) if pb == 4 else x
+                        ref = M @ xs
+                        refc = ref if k > 1 else ref[:, 0]
+                        assert np.max(np.abs(y - refc)) <= tol * max(1.0, np.abs(ref).max()), (four, R, C, k, pb, which)
+                        if which == "M":
+                            refd = np.einsum("ik,ik->k", xs[:M.shape[0]], ref)
+                            assert np.max(np.abs(dots - refd)) <= 10 * tol * max(1.0, np.abs(refd).max())
+                    h.close()
+            if four:
+                break  # one shape is enough for the 4-neighbour variant

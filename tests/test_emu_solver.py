@@ -862,3 +862,10 @@ def test_lattice_form_cg_product(emu_lib):
 def test_solve_paths_agree(emu_lib, precond_bytes):
     from helpers import check_solve_paths_agree
     check_solve_paths_agree(emu_lib, N=60, batch=8, precond_bytes=precond_bytes)
+
+
+def test_lattice_transfer_products(emu_lib):
+    """lattice.h / stencil.h DIA_SQ on the emulator: see helpers.check_lattice_transfer_products."""
+    from helpers import check_lattice_transfer_products
+    check_lattice_transfer_products(emu_lib, ks=(1, 16), pbs=(4,))
+    check_lattice_transfer_products(emu_lib, shapes=((64, 70), (11, 14)), ks=(4,), pbs=(0,))

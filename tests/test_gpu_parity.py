@@ -256,3 +256,11 @@ def test_solve_paths_agree(gpu_lib, precond_bytes):
     from helpers import check_solve_paths_agree
     check_solve_paths_agree(gpu_lib, N=300, batch=16, precond_bytes=precond_bytes)
     check_solve_paths_agree(gpu_lib, N=120, batch=4, precond_bytes=precond_bytes)
+
+
+def test_lattice_transfer_products(gpu_lib):
+    """index-free restriction and second product of the two-product level on the device (see the emulator twin), plus a
+    raster large enough for many tiles per strip / segment and the XCD-aware tile walk."""
+    from helpers import check_lattice_transfer_products
+    check_lattice_transfer_products(gpu_lib)
+    check_lattice_transfer_products(gpu_lib, shapes=((1000, 700), (1201, 334)), ks=(16,), pbs=(4, 0))
