@@ -285,10 +285,11 @@ __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double
   for (int c = 0; c < K; ++c) {
     const double rz = reduce_partials<K>(partials_rz, nparts_rz, c, sm);
     double rr = 0.0;
-    if (criterion == 1) rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
+    if (criterion == 1 || init) rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
     if (threadIdx.x == 0) {
       const double mon = criterion == 1 ? sqrt(rr) : sqrt(fabs(rz));
       if (init) {
+        S->bnorm[c] = sqrt(rr);  // r0 = b: ||b||_2 for the relative-residual post-check
         S->rnorm0[c] = mon;
         S->eps[c] = atol + rtol * mon;
         S->rnorm[c] = mon;
@@ -347,15 +348,17 @@ __global__ __launch_bounds__(256) void dense_apply_kernel(int n, const T* __rest
 }
 
 // ---- relative residual post-check: partials of ||b - A x||^2 come from a DOT-fused SpMV; this finishes it
+// (partials_bb null: ||b|| as recorded by the init call of cg_beta_kernel)
 template <int K>
 __global__ __launch_bounds__(256) void relres_kernel(CgScalars* S, const double* partials_rr, int nparts_rr,
                                                      const double* partials_bb, int nparts_bb) {
   __shared__ double sm[4];
   for (int c = 0; c < K; ++c) {
     const double rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
-    const double bb = reduce_partials<K>(partials_bb, nparts_bb, c, sm);
+    double bb = S->bnorm[c] * S->bnorm[c];
+    if (partials_bb) bb = reduce_partials<K>(partials_bb, nparts_bb, c, sm);
     if (threadIdx.x == 0) {
-      S->bnorm[c] = sqrt(bb);
+      if (partials_bb) S->bnorm[c] = sqrt(bb);
       S->relres[c] = bb > 0.0 ? sqrt(rr / bb) : sqrt(rr);
     }
     __syncthreads();

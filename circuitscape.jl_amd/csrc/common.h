@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -41,7 +42,7 @@ inline void check_launch(const char* what) {
   if (e != hipSuccess) throw Error(CSGPU_HIP_ERROR, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-static int64_t g_live_bytes = 0;  // bookkeeping for csgpu_info.device_bytes (single-threaded per process use)
+static std::atomic<int64_t> g_live_bytes{0};  // bookkeeping only (handles of a multi-device set are built by concurrent threads)
 
 // Owning device allocation.
 struct DBuf {

@@ -1,8 +1,10 @@
 // csgpu.hip -- C ABI of libcsgpu.so (see include/csgpu.h for the reference interfaces each entry point replaces).
 // Single translation unit: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csgpu.hip -o libcsgpu.so
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "currents.h"
 #include "pairs.h"
@@ -436,6 +438,7 @@ struct Solver : ISolver {
   PcgBatchResult run_batch(int ncols, bool need_x) {
     PcgParams pp = pcg_params(K);
     pp.need_x = need_x;
+    pp.rhs_in_r = !need_x;  // (only solve_pairs runs without the whole solution; it writes the +-1 entries into r)
     return pcg_solve<T, TP, K>(cg_matrix(), H, W, pp, ncols, st, dia_ptr());
   }
   PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true) {
@@ -545,9 +548,11 @@ struct Solver : ISolver {
       }
       CS_HIP(hipMemcpyAsync(dsrc.p, s32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipMemcpyAsync(ddst.p, d32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
-      CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * K * sizeof(T), st));
-      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, dptr<T>(W.b),
-                                           dptr<int>(dsrc), dptr<int>(ddst), ncols));
+      // right-hand side: into b, or -- focal path -- straight into the residual vector (r0 = b; nothing reads b later)
+      T* rhs = need_x ? dptr<T>(W.b) : dptr<T>(W.r);
+      CS_HIP(hipMemsetAsync(rhs, 0, (size_t)n * K * sizeof(T), st));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, rhs, dptr<int>(dsrc),
+                                           dptr<int>(ddst), ncols));
       if (!need_x) {  // focal list: [gathered nodes..., src of every column..., dst of every column...]
         for (int64_t g = 0; g < ngather; ++g) focal[g] = (int)gather[g];
         for (int c = 0; c < K; ++c) {
@@ -1204,5 +1209,218 @@ int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, con
 }
 
 void csgpu_free(csgpu_handle* h) { delete h; }
+
+// ---- several devices behind one handle ---------------------------------------------------------------------------
+}  // extern "C"
+
+struct csgpu_multi {
+  std::vector<csgpu_handle*> handles;  // one per device slot
+  std::vector<int> devices;
+  int val_bytes = 8;
+  int batch = 8;
+  std::vector<double> busy_s;
+  std::vector<int64_t> pairs_done;
+  ~csgpu_multi() {
+    for (csgpu_handle* h : handles) delete h;
+  }
+};
+
+namespace {
+
+// device list of a multi handle: explicit list, or the first ndevices (<= 0: all) visible devices
+int multi_devices(const int32_t* devices, int ndevices, std::vector<int>& out) {
+  const int visible = csgpu_device_count();
+  if (visible < 1) {
+    g_last_error = "no HIP device visible";
+    return CSGPU_HIP_ERROR;
+  }
+  out.clear();
+  if (devices) {
+    for (int i = 0; i < ndevices; ++i) {
+      if (devices[i] < 0 || devices[i] >= visible) {
+        g_last_error = "device ordinal out of range";
+        return CSGPU_BAD_ARGS;
+      }
+      out.push_back(devices[i]);
+    }
+  } else {
+    const int nd = ndevices <= 0 ? visible : std::min(ndevices, visible);
+    for (int i = 0; i < nd; ++i) out.push_back(i);
+  }
+  if (out.empty()) {
+    g_last_error = "empty device list";
+    return CSGPU_BAD_ARGS;
+  }
+  return CSGPU_OK;
+}
+
+// one host thread per device runs `build(device, &handle)`; the first failure is reported
+template <class F>
+int multi_build(const csgpu_opts* opts, const int32_t* devices, int ndevices, int val_bytes, csgpu_multi** out, F build) {
+  std::vector<int> devs;
+  int rc = multi_devices(devices, ndevices, devs);
+  if (rc) return rc;
+  std::unique_ptr<csgpu_multi> m(new csgpu_multi());
+  m->devices = devs;
+  m->val_bytes = val_bytes;
+  csgpu_opts o;
+  if (opts) o = *opts; else csgpu_default_opts(&o);
+  m->batch = std::max(1, std::min(o.batch, (int)csgpu::kMaxK));
+  m->handles.assign(devs.size(), nullptr);
+  m->busy_s.assign(devs.size(), 0.0);
+  m->pairs_done.assign(devs.size(), 0);
+  std::vector<int> codes(devs.size(), CSGPU_OK);
+  std::vector<std::string> msgs(devs.size());
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < devs.size(); ++i)
+    th.emplace_back([&, i] {
+      csgpu_opts oi = o;
+      oi.device = devs[i];
+      codes[i] = build(&oi, &m->handles[i]);
+      if (codes[i]) msgs[i] = csgpu_last_error();  // thread-local message of this worker
+    });
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < devs.size(); ++i)
+    if (codes[i]) {
+      g_last_error = "device " + std::to_string(devs[i]) + ": " + msgs[i];
+      return codes[i];
+    }
+  *out = m.release();
+  return CSGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csgpu_multi_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
+                      int val_bytes, int index_base, const csgpu_opts* opts, const int32_t* devices, int ndevices,
+                      csgpu_multi** out) {
+  CS_API_BEGIN
+  if (!out) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  return multi_build(opts, devices, ndevices, val_bytes, out, [&](const csgpu_opts* o, csgpu_handle** h) {
+    return csgpu_setup(rowptr, colidx, vals, n, nnz, idx_bytes, val_bytes, index_base, o, h);
+  });
+  CS_API_END
+}
+
+int csgpu_multi_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
+                             int avg_resistances, int reg, const csgpu_opts* opts, const int32_t* devices, int ndevices,
+                             csgpu_multi** out) {
+  CS_API_BEGIN
+  if (!out) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  return multi_build(opts, devices, ndevices, val_bytes, out, [&](const csgpu_opts* o, csgpu_handle** h) {
+    return csgpu_raster_setup(cond, nrows, ncols, val_bytes, four_neighbors, avg_resistances, reg, o, h);
+  });
+  CS_API_END
+}
+
+int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
+                            const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
+                            csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!m || npairs < 0 || (npairs > 0 && (!src || !dst)) || ngather < 0 || (ngather > 0 && !gather_idx)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  const size_t nd = m->handles.size();
+  std::fill(m->busy_s.begin(), m->busy_s.end(), 0.0);
+  std::fill(m->pairs_done.begin(), m->pairs_done.end(), 0);
+  if (npairs == 0) return CSGPU_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  // chunk = one batch; fewer batches than devices: shrink the chunk so that every device gets one
+  int64_t chunk = m->batch;
+  if ((npairs + chunk - 1) / chunk < (int64_t)nd) chunk = std::max<int64_t>(1, (npairs + (int64_t)nd - 1) / (int64_t)nd);
+  const int64_t nchunks = (npairs + chunk - 1) / chunk;
+  std::atomic<int64_t> next{0};
+  std::vector<int> codes(nd, CSGPU_OK);
+  std::vector<std::string> msgs(nd);
+  std::vector<csgpu_stats> st(nd);
+  for (auto& x : st) memset(&x, 0, sizeof(x));
+  const size_t vb = (size_t)m->val_bytes;
+  auto worker = [&](size_t slot) {
+    auto w0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const int64_t c = next.fetch_add(1);
+      if (c >= nchunks) break;
+      const int64_t off = c * chunk, cnt = std::min(chunk, npairs - off);
+      csgpu_stats cs;
+      const int rc = csgpu_solve_pairs(m->handles[slot], src + off, dst + off, cnt, nullptr, gather_idx, ngather,
+                                       gathered_out ? (char*)gathered_out + (size_t)off * ngather * vb : nullptr,
+                                       resist_out ? (char*)resist_out + (size_t)off * vb : nullptr, &cs);
+      st[slot].total_iters += cs.total_iters;
+      st[slot].max_iters = std::max(st[slot].max_iters, cs.max_iters);
+      st[slot].max_relres = std::max(st[slot].max_relres, cs.max_relres);
+      st[slot].device_ms += cs.device_ms;
+      st[slot].cg_spmv_ms += cs.cg_spmv_ms;
+      st[slot].cg_spmv_calls += cs.cg_spmv_calls;
+      st[slot].not_converged += cs.not_converged;
+      st[slot].graph_launches += cs.graph_launches;
+      st[slot].polished_batches += cs.polished_batches;
+      st[slot].cg_spmv_bytes = cs.cg_spmv_bytes;
+      st[slot].batch = std::max(st[slot].batch, cs.batch);
+      m->pairs_done[slot] += cnt;
+      if (rc != CSGPU_OK && codes[slot] == CSGPU_OK) {
+        codes[slot] = rc;
+        msgs[slot] = csgpu_last_error();
+        if (rc != CSGPU_NOT_CONVERGED) break;  // hard error: stop this device; a non-converged chunk is only reported
+      }
+    }
+    m->busy_s[slot] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < nd; ++i) th.emplace_back(worker, i);
+  worker(0);
+  for (auto& t : th) t.join();
+  s->nrhs = (int)npairs;
+  int rc_out = CSGPU_OK;
+  for (size_t i = 0; i < nd; ++i) {
+    s->total_iters += st[i].total_iters;
+    s->max_iters = std::max(s->max_iters, st[i].max_iters);
+    s->max_relres = std::max(s->max_relres, st[i].max_relres);
+    s->device_ms = std::max(s->device_ms, st[i].device_ms);
+    s->cg_spmv_ms += st[i].cg_spmv_ms;
+    s->cg_spmv_calls += st[i].cg_spmv_calls;
+    s->not_converged += st[i].not_converged;
+    s->graph_launches += st[i].graph_launches;
+    s->polished_batches += st[i].polished_batches;
+    s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->batch = std::max(s->batch, st[i].batch);
+    if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
+      rc_out = codes[i];
+      g_last_error = "device " + std::to_string(m->devices[i]) + ": " + msgs[i];
+    }
+  }
+  s->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc_out;
+  CS_API_END
+}
+
+int csgpu_multi_device_count(const csgpu_multi* m) { return m ? (int)m->handles.size() : 0; }
+
+csgpu_handle* csgpu_multi_handle(csgpu_multi* m, int slot) {
+  if (!m || slot < 0 || slot >= (int)m->handles.size()) return nullptr;
+  return m->handles[slot];
+}
+
+int csgpu_multi_last_busy(const csgpu_multi* m, double* busy_s, int64_t* pairs_done) {
+  if (!m) return CSGPU_BAD_ARGS;
+  for (size_t i = 0; i < m->handles.size(); ++i) {
+    if (busy_s) busy_s[i] = m->busy_s[i];
+    if (pairs_done) pairs_done[i] = m->pairs_done[i];
+  }
+  return CSGPU_OK;
+}
+
+void csgpu_multi_free(csgpu_multi* m) { delete m; }
 
 }  // extern "C"

@@ -232,6 +232,9 @@ struct PcgParams {
   // nothing else: core.jl:231-232, 685-703) and the post-check uses the fp64 recurrence residual r (= b - A x up to
   // rounding: x and r are updated with the same alpha and the same stored p).
   bool need_x = true;
+  // true: the caller wrote the right-hand side straight into PcgWork::r (W.b is not valid); only with need_x == false
+  // (nothing after the set-up of r0 = b reads b on that path)
+  bool rhs_in_r = false;
   // Block-diagonal systems (K = 1, one PCG over many components): component label per node and the number of
   // components. When set, the post-check is the WORST component's ||A x - b|| / ||b|| (the reference checks every
   // component's solve separately, advanced.jl:186-312 -> core.jl:640).
@@ -406,7 +409,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   if (need_x) CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
   if (nf > 0) CS_HIP(hipMemsetAsync(xf, 0, (size_t)nf * K * sizeof(T), st));
   W.have_x = need_x;
-  CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
+  CS_REQUIRE(!(pp.rhs_in_r && need_x), CSGPU_INTERNAL, "rhs_in_r needs the focal-node path");
+  if (!pp.rhs_in_r) CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
   if (MIXED)
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
@@ -628,7 +632,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
         return;
       }
     } else {
-      hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa, b, b, pb);
+      // fp64 recurrence residual against ||b|| recorded at start-up
+      hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa,
+                         (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+      hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)nullptr, 0);
+      CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      return;
     }
     hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)pb, gv);
     CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));

@@ -24,6 +24,8 @@ EXPORTS = [
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
     "csgpu_solve_raster", "csgpu_dia_product_host",
+    "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
+    "csgpu_multi_handle", "csgpu_multi_last_busy", "csgpu_multi_free",
     "csgpu_free", "csgpu_last_error", "csgpu_version",
 ]
 
@@ -98,6 +100,15 @@ def _bind(L):
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
     L.csgpu_dia_product_host.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+    L.csgpu_multi_setup.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, ctypes.POINTER(Opts), vp, i32, ctypes.POINTER(vp)]
+    L.csgpu_multi_raster_setup.argtypes = [vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), vp, i32, ctypes.POINTER(vp)]
+    L.csgpu_multi_solve_pairs.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_multi_device_count.argtypes = [vp]
+    L.csgpu_multi_handle.argtypes = [vp, i32]
+    L.csgpu_multi_handle.restype = vp
+    L.csgpu_multi_last_busy.argtypes = [vp, vp, vp]
+    L.csgpu_multi_free.argtypes = [vp]
+    L.csgpu_multi_free.restype = None
     L.csgpu_free.argtypes = [vp]
     L.csgpu_free.restype = None
     L.csgpu_last_error.restype = ctypes.c_char_p
@@ -333,6 +344,105 @@ class Handle:
         _check(lib().csgpu_get_level_matrix(self._p, lvl, w, None, None, None, rp.ctypes.data, ci.ctypes.data,
                                             va.ctypes.data))
         return sp.csr_matrix((va[:nz.value], ci[:nz.value], rp), shape=(nr.value, nc.value))
+
+
+class MultiHandle:
+    """Owns a csgpu_multi* (one replicated handle per GPU of the node, chunks of pairs dealt from a shared queue)."""
+
+    def __init__(self, ptr, dtype):
+        self._p = ptr
+        self.dtype = np.dtype(dtype)
+
+    def close(self):
+        if self._p:
+            lib().csgpu_multi_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def ndevices(self):
+        return lib().csgpu_multi_device_count(self._p)
+
+    def info(self, slot=0):
+        i = Info()
+        _check(lib().csgpu_get_info(lib().csgpu_multi_handle(self._p, slot), ctypes.byref(i)))
+        return {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz")}
+
+    def solve_pairs(self, src, dst, gather=None):
+        """As Handle.solve_pairs (no voltages). Returns (resistances, gathered or None, stats dict incl. the per-device
+        busy seconds and pair counts of this call)."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        npairs = len(src)
+        res = np.zeros(npairs, dtype=self.dtype)
+        g = np.ascontiguousarray(gather, dtype=np.int64) if gather is not None and len(gather) else None
+        gathered = np.zeros((npairs, len(g)), dtype=self.dtype) if g is not None else None
+        st = Stats()
+        rc = lib().csgpu_multi_solve_pairs(self._p, src.ctypes.data, dst.ctypes.data, npairs,
+                                           g.ctypes.data if g is not None else None, len(g) if g is not None else 0,
+                                           gathered.ctypes.data if gathered is not None else None, res.ctypes.data,
+                                           ctypes.byref(st))
+        _check(rc)
+        nd = self.ndevices
+        busy = np.zeros(nd)
+        done = np.zeros(nd, dtype=np.int64)
+        lib().csgpu_multi_last_busy(self._p, busy.ctypes.data, done.ctypes.data)
+        d = st.as_dict()
+        d["device_busy_s"] = busy.tolist()
+        d["device_pairs"] = done.tolist()
+        return res, gathered, d
+
+
+def _device_list(devices):
+    if devices is None:
+        return None, 0
+    if isinstance(devices, int):
+        return None, devices
+    arr = np.ascontiguousarray(devices, dtype=np.int32)
+    return arr, len(arr)
+
+
+def multi_raster_setup(cond, opts=None, devices=None, four_neighbors=False, avg_resistances=False, reg=True):
+    """csgpu_multi_raster_setup: one replicated handle per device. devices: None = all visible, an int = the first
+    that many, or a list of ordinals."""
+    cond = np.ascontiguousarray(cond)
+    dtype = np.float32 if cond.dtype == np.float32 else np.float64
+    cond = np.ascontiguousarray(cond, dtype=dtype)
+    o = opts if opts is not None else default_opts()
+    arr, nd = _device_list(devices)
+    h = ctypes.c_void_p(0)
+    _check(lib().csgpu_multi_raster_setup(cond.ctypes.data, cond.shape[0], cond.shape[1], np.dtype(dtype).itemsize,
+                                          int(four_neighbors), int(avg_resistances), int(reg), ctypes.byref(o),
+                                          arr.ctypes.data if arr is not None else None, nd, ctypes.byref(h)))
+    return MultiHandle(h, dtype)
+
+
+def multi_setup(matrix, opts=None, devices=None, index_dtype=np.int64, index_base=1):
+    """csgpu_multi_setup on a scipy sparse symmetric matrix (arrays handed over the way Julia would)."""
+    m = matrix.tocsr()
+    m.sort_indices()
+    dtype = np.float32 if m.dtype == np.float32 else np.float64
+    rp = np.ascontiguousarray(m.indptr.astype(index_dtype) + index_base)
+    ci = np.ascontiguousarray(m.indices.astype(index_dtype) + index_base)
+    va = np.ascontiguousarray(m.data, dtype=dtype)
+    o = opts if opts is not None else default_opts()
+    arr, nd = _device_list(devices)
+    h = ctypes.c_void_p(0)
+    _check(lib().csgpu_multi_setup(rp.ctypes.data, ci.ctypes.data, va.ctypes.data, m.shape[0], m.nnz,
+                                   np.dtype(index_dtype).itemsize, np.dtype(dtype).itemsize, index_base, ctypes.byref(o),
+                                   arr.ctypes.data if arr is not None else None, nd, ctypes.byref(h)))
+    return MultiHandle(h, dtype)
 
 
 def setup(matrix, opts=None, node_row=None, node_col=None, index_dtype=np.int64, index_base=1):

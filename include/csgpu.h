@@ -20,6 +20,9 @@
  *                              batched like the direct-solver driver (core.jl:448-493)
  *   csgpu_solve_pairs_currents <-> the same plus postprocess() -> write_cur_maps -> _create_current_maps
  *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
+ *   csgpu_multi_setup, csgpu_multi_raster_setup, csgpu_multi_solve_pairs, csgpu_multi_free
+ *                          <-> the task fan-out and serial result merge of solve(prob, ::AMGSolver, ...)
+ *                              (Threads.@spawn per source point, src/core.jl:262-285), as one host thread per GPU
  *   csgpu_free             <-> GC finalizer of the factor object (PardisoFactorize, Pardiso ext :8-13)
  *   csgpu_last_error       <-> error(msg) strings (core.jl:641,650)
  *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for a raster without polygons (NODATA allowed)
@@ -257,6 +260,33 @@ int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* n
  * dots: k doubles. Status 4 when the handle's matrix has no lattice form (or k == 1). */
 int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, const double* beta, void* p_out, void* y,
                            int k, double* dots);
+
+/* ---- several GPUs of one node behind ONE handle -------------------------------------------------------------------
+ * The reference runs one task per source point and merges the per-task results serially (src/core.jl:262-285). Here the
+ * independent unit is a chunk of pairs: a csgpu_multi owns one csgpu_handle per device (matrix + hierarchy replicated,
+ * built concurrently by one host thread per device), csgpu_multi_solve_pairs deals chunks of at most opts.batch pairs
+ * to the devices from a shared queue (dynamic balance; the chunk shrinks to ceil(npairs / ndevices) when there are
+ * fewer batches than devices, so every GPU is busy) and every device thread writes its results straight into the
+ * caller's arrays. No device-to-device traffic is needed on this path: the results are a few bytes per pair and the
+ * single host process already owns them. devices == NULL: the first ndevices visible devices (ndevices <= 0: all).
+ * opts->device is ignored. Semantics of the outputs and of the status code as in csgpu_solve_pairs; stats are merged
+ * (sums / maxima over the chunks; solve_ms = wall time of the call; device_ms = the busiest device). */
+typedef struct csgpu_multi csgpu_multi;
+int csgpu_multi_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
+                      int val_bytes, int index_base, const csgpu_opts* opts, const int32_t* devices, int ndevices,
+                      csgpu_multi** out);
+int csgpu_multi_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
+                             int avg_resistances, int reg, const csgpu_opts* opts, const int32_t* devices, int ndevices,
+                             csgpu_multi** out);
+int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
+                            const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
+                            csgpu_stats* stats);
+/* number of devices of the set; handle of device slot i (for csgpu_get_info etc.; owned by the set); per-slot wall
+ * seconds spent inside the last csgpu_multi_solve_pairs (busy_s: ndevices doubles, may be NULL) */
+int csgpu_multi_device_count(const csgpu_multi* m);
+csgpu_handle* csgpu_multi_handle(csgpu_multi* m, int slot);
+int csgpu_multi_last_busy(const csgpu_multi* m, double* busy_s, int64_t* pairs_done);
+void csgpu_multi_free(csgpu_multi* m);
 
 void csgpu_free(csgpu_handle* h);
 const char* csgpu_last_error(void);

@@ -65,7 +65,7 @@ enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureMode
 namespace hipemu {
 inline hipEmuGraph*& capturing() { static thread_local hipEmuGraph* g = nullptr; return g; }
 }
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventDefault = 0 };
 struct hipDeviceProp_t {
@@ -297,6 +297,10 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
     work(0, total);
     return;
   }
+  // one kernel at a time through the shared worker pool (host threads driving different emulated devices serialise
+  // here, like launches on one stream)
+  static std::mutex launch_mu;
+  std::lock_guard<std::mutex> lk(launch_mu);
   pool().run(total, work);
 }
 
@@ -518,9 +522,23 @@ inline double min(double a, double b) { return a < b ? a : b; }
 inline double max(double a, double b) { return a > b ? a : b; }
 
 // ---- runtime API subset
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// HIPEMU_DEVICES emulated devices share the host's memory (multi-device code paths run, nothing is isolated)
+inline int hipemu_device_count() {
+  const char* e = getenv("HIPEMU_DEVICES");
+  const int v = e ? atoi(e) : 1;
+  return v < 1 ? 1 : v;
+}
+inline int& hipemu_current_device() {
+  static thread_local int d = 0;
+  return d;
+}
+inline hipError_t hipGetDeviceCount(int* n) { *n = hipemu_device_count(); return hipSuccess; }
+inline hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= hipemu_device_count()) return hipErrorInvalidDevice;
+  hipemu_current_device() = d;
+  return hipSuccess;
+}
+inline hipError_t hipGetDevice(int* d) { *d = hipemu_current_device(); return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p));
   strcpy(p->name, "hipemu (CPU fiber emulator, tests only)");

@@ -869,3 +869,62 @@ def test_lattice_transfer_products(emu_lib):
     from helpers import check_lattice_transfer_products
     check_lattice_transfer_products(emu_lib, ks=(1, 16), pbs=(4,))
     check_lattice_transfer_products(emu_lib, shapes=((64, 70), (11, 14)), ks=(4,), pbs=(0,))
+
+
+def test_multi_device_handle_matches_single_device(emu_lib, oracle):
+    """csgpu_multi_*: one replicated handle per (emulated) device, chunks of pairs dealt from a shared queue by one
+    host thread per device, results written straight into the caller's arrays. Same resistances / focal voltages as a
+    single-device handle (every chunk is an ordinary csgpu_solve_pairs call; bit for bit where the batch width is the
+    same, to rounding where a short last chunk runs at a narrower width), every device used, also when
+    there are fewer batches than devices; a raster built through the host-CSR entry point likewise."""
+    import subprocess, sys, json, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        from oracle import refgraph as rg, refsolve as rs
+        lib.load(%r)
+        assert lib.device_count() == 3
+        N = 40
+        g = np.exp(np.random.default_rng(5).standard_normal((N, N + 3)))
+        cells = np.random.default_rng(6).choice(N * (N + 3), size=7, replace=False)
+        src = [int(cells[i]) for i in range(7) for j in range(i + 1, 7)]
+        dst = [int(cells[j]) for i in range(7) for j in range(i + 1, 7)]
+        out = {}
+        with lib.raster_setup(g, lib.default_opts(batch=4)) as h:
+            R1, g1, _, st1 = h.solve_pairs(src, dst, gather=cells)
+        with lib.multi_raster_setup(g, lib.default_opts(batch=4)) as m:
+            assert m.ndevices == 3 and m.info(2)["n"] == N * (N + 3)
+            Rm, gm, stm = m.solve_pairs(src, dst, gather=cells)
+            out["busy_pairs"] = stm["device_pairs"]
+            # fewer batches than devices: 5 pairs, batch 4 -> chunks of 2 so that all three devices work
+            R5, _, st5 = m.solve_pairs(src[:5], dst[:5])
+            out["pairs5"] = st5["device_pairs"]
+            R0, _, st0 = m.solve_pairs([], [])
+        A = rs.regularize(rg.raster_laplacian_from_conductance(g))
+        with lib.multi_setup(A, lib.default_opts(batch=4), devices=[2, 0]) as m2:
+            assert m2.ndevices == 2
+            Rc, _, stc = m2.solve_pairs(src, dst)
+        out.update(eq=bool(np.max(np.abs(R1 - Rm) / R1) < 1e-10 and np.max(np.abs(g1 - gm)) < 1e-10 * np.max(np.abs(g1))
+                           and np.array_equal(R1[:20], Rm[:20])),   # full chunks are the very same batches
+                   eq5=bool(np.max(np.abs(R1[:5] - R5) / R1[:5]) < 1e-10),
+                   iters=[st1["total_iters"], stm["total_iters"]], csr_rel=float(np.max(np.abs(Rc - R1) / R1)),
+                   nc=[stm["not_converged"], stc["not_converged"]], R=R1.tolist(), src=src, dst=dst, n0=len(R0))
+        print(json.dumps(out))
+    ''') % (root, os.path.join(root, "tests", "emu", "libcsgpu_emu.so"))
+    env = dict(os.environ, HIPEMU_DEVICES="3", HIPEMU_THREADS="2")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["eq"] and d["eq5"] and d["iters"][0] == d["iters"][1] and d["nc"] == [0, 0] and d["n0"] == 0
+    assert sum(d["busy_pairs"]) == 21 and all(p > 0 for p in d["busy_pairs"])
+    assert sum(d["pairs5"]) == 5 and all(p > 0 for p in d["pairs5"])
+    assert d["csr_rel"] < 1e-9
+    N = 40
+    g = np.exp(np.random.default_rng(5).standard_normal((N, N + 3)))
+    from oracle import refgraph as rg
+    A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(d["src"], d["dst"], rtol=1e-12, atol=0.0, criterion=1)
+    assert np.max(np.abs(np.array(d["R"]) - Ro) / Ro) < 1e-6
