@@ -763,12 +763,41 @@ inline void build_sq_matrix(Level<T>& L, hipStream_t st) {
   check_launch("build [S Q]");
 }
 
+// Regular 3x3 tiles of a full raster (every cell of a gridR x gridC raster is a node, coordinates known): exactly the
+// aggregates the MIS(2) rounds + the two attachment passes below produce on such a level (tile centres win the first
+// round, their neighbours join them, left-over cells join their own tile) -- written down directly, in one pass.
+__global__ __launch_bounds__(256) void tile_aggregate_kernel(int n, const int* __restrict__ nrow,
+                                                             const int* __restrict__ ncol, int Rc, int Cc,
+                                                             int* __restrict__ agg, int* __restrict__ crow,
+                                                             int* __restrict__ ccol) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int I = min(nrow[i] / 3, Rc - 1), J = min(ncol[i] / 3, Cc - 1);
+    const int a = J * Rc + I;
+    agg[i] = a;
+    if (nrow[i] == 3 * I && ncol[i] == 3 * J) {  // one writer per tile
+      crow[a] = I;
+      ccol[a] = J;
+    }
+  }
+}
+
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
                      DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0) {
   const int n = A.nrows;
   const double theta2 = theta * theta;
+  static const bool no_direct_tiles = getenv("CSGPU_NO_DIRECT_TILES") != nullptr;  // A/B knob
+  if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n) {
+    const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
+    agg.alloc((size_t)n * sizeof(int));
+    crow.alloc((size_t)Rc * Cc * sizeof(int));
+    ccol.alloc((size_t)Rc * Cc * sizeof(int));
+    hipLaunchKernelGGL(tile_aggregate_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, nrow, ncol, Rc, Cc, dptr<int>(agg),
+                       dptr<int>(crow), dptr<int>(ccol));
+    check_launch("tile aggregation");
+    return Rc * Cc;
+  }
   DBuf key = dalloc<unsigned long long>(n), k1 = dalloc<unsigned long long>(n), k2 = dalloc<unsigned long long>(n);
   DBuf counter = dalloc<int>(1);
   const int g = grid_for(n);

@@ -4,6 +4,9 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -44,15 +47,68 @@ inline void check_launch(const char* what) {
 
 static std::atomic<int64_t> g_live_bytes{0};  // bookkeeping only (handles of a multi-device set are built by concurrent threads)
 
-// Owning device allocation.
+// ---- device memory pool ---------------------------------------------------------------------------------------------
+// Measured on MI355X (tools/alloc_probe.py): releasing the ~40-100 GB of a 10000^2 handle with hipFree and allocating
+// the next handle's buffers costs 3.5-4.5 s of driver time (page-table teardown / set-up), an order of magnitude more
+// than the whole AMG setup -- and the reference's workloads do exactly that (one factorisation per component, per
+// focal region, per one-to-all source: src/core.jl:146-167, src/raster/onetoall.jl:106-151). Released blocks are
+// therefore kept in a per-device pool and handed out again on an exact size match (the sizes of "the same problem
+// again" repeat exactly); csgpu_trim_memory() / a failed hipMalloc return the pooled blocks to the driver.
+// A block is pooled only after the device has drained (hipDeviceSynchronize -- the implicit synchronisation hipFree has
+// always provided), so a block can never be handed to another stream while kernels of its previous owner still run.
+struct DevicePool {
+  static const int kMaxDev = 64;
+  std::mutex mu;
+  std::multimap<size_t, void*> blocks[kMaxDev];
+  size_t pooled[kMaxDev] = {0};
+  bool enabled = getenv("CSGPU_NO_POOL") == nullptr;
+  void* take(int dev, size_t b) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = blocks[dev].find(b);
+    if (it == blocks[dev].end()) return nullptr;
+    void* p = it->second;
+    blocks[dev].erase(it);
+    pooled[dev] -= b;
+    return p;
+  }
+  void give(int dev, size_t b, void* p) {
+    std::lock_guard<std::mutex> lk(mu);
+    blocks[dev].emplace(b, p);
+    pooled[dev] += b;
+  }
+  // return the pooled blocks of one device (dev < 0: of every device) to the driver; bytes released
+  size_t trim(int dev) {
+    std::vector<void*> victims;
+    size_t freed = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int d = 0; d < kMaxDev; ++d) {
+        if (dev >= 0 && d != dev) continue;
+        for (auto& kv : blocks[d]) victims.push_back(kv.second);
+        freed += pooled[d];
+        blocks[d].clear();
+        pooled[d] = 0;
+      }
+    }
+    for (void* p : victims) hipFree(p);
+    return freed;
+  }
+};
+inline DevicePool& device_pool() {
+  static DevicePool* p = new DevicePool();  // leaked on purpose: device memory is reclaimed at process exit
+  return *p;
+}
+
+// Owning device allocation (pooled, see above).
 struct DBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  int dev = -1;  // device the block lives on
   DBuf() {}
   explicit DBuf(size_t b) { alloc(b); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes), dev(o.dev) {
     o.p = nullptr;
     o.bytes = 0;
   }
@@ -61,6 +117,7 @@ struct DBuf {
       release();
       p = o.p;
       bytes = o.bytes;
+      dev = o.dev;
       o.p = nullptr;
       o.bytes = 0;
     }
@@ -70,13 +127,37 @@ struct DBuf {
   void alloc(size_t b) {
     release();
     if (b == 0) return;
-    CS_HIP(hipMalloc(&p, b));
+    CS_HIP(hipGetDevice(&dev));
+    DevicePool& pool = device_pool();
+    const bool poolable = pool.enabled && dev >= 0 && dev < DevicePool::kMaxDev;
+    if (poolable) p = pool.take(dev, b);
+    if (!p) {
+      hipError_t e = hipMalloc(&p, b);
+      if (e != hipSuccess && poolable && pool.trim(dev) > 0) {  // the pool may be what fills the device
+        (void)hipGetLastError();
+        e = hipMalloc(&p, b);
+      }
+      if (e != hipSuccess) {
+        p = nullptr;
+        CS_HIP(e);
+      }
+    }
     bytes = b;
     g_live_bytes += (int64_t)b;
   }
   void release() {
     if (p) {
-      hipFree(p);
+      DevicePool& pool = device_pool();
+      if (pool.enabled && dev >= 0 && dev < DevicePool::kMaxDev) {
+        int cur = dev;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();  // what hipFree did implicitly: no kernel of the old owner is still running
+        if (cur != dev) (void)hipSetDevice(cur);
+        pool.give(dev, bytes, p);
+      } else {
+        hipFree(p);
+      }
       g_live_bytes -= (int64_t)bytes;
     }
     p = nullptr;

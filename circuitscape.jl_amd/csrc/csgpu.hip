@@ -918,7 +918,7 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->itmax = 100000;
   o->batch = 8;
   o->check_every = 0;
-  o->nu_coarse = 3;
+  o->nu_coarse = 2;
   o->theta = 0.0;
   o->omega_p = 1.6;
   o->omega_s = 1.5;
@@ -1209,6 +1209,8 @@ int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, con
 }
 
 void csgpu_free(csgpu_handle* h) { delete h; }
+
+int64_t csgpu_trim_memory(int device) { return (int64_t)csgpu::device_pool().trim(device); }
 
 // ---- several devices behind one handle ---------------------------------------------------------------------------
 }  // extern "C"

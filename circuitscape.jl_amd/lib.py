@@ -26,7 +26,7 @@ EXPORTS = [
     "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
     "csgpu_multi_handle", "csgpu_multi_last_busy", "csgpu_multi_free",
-    "csgpu_free", "csgpu_last_error", "csgpu_version",
+    "csgpu_free", "csgpu_trim_memory", "csgpu_last_error", "csgpu_version",
 ]
 
 
@@ -111,6 +111,8 @@ def _bind(L):
     L.csgpu_multi_free.restype = None
     L.csgpu_free.argtypes = [vp]
     L.csgpu_free.restype = None
+    L.csgpu_trim_memory.argtypes = [i32]
+    L.csgpu_trim_memory.restype = i64
     L.csgpu_last_error.restype = ctypes.c_char_p
     L.csgpu_version.restype = ctypes.c_char_p
     return L
@@ -149,6 +151,11 @@ def _check(rc):
 
 def device_count():
     return lib().csgpu_device_count()
+
+
+def trim_memory(device=-1):
+    """Return the library's pooled device blocks (of one device, or of all) to the driver; bytes released."""
+    return lib().csgpu_trim_memory(device)
 
 
 def default_opts(**kw):

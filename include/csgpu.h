@@ -91,7 +91,9 @@ typedef struct csgpu_opts {
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
                              every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
-  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 3 */
+  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 2 (measured
+                             on the 10000^2 raster: 3 -> 324.7 ms per batch of 16 at 12.8 iterations, 2 -> 309.2 ms at
+                             12.9, 1 -> 327.4 ms at 14.9; profiles/r2_polling_graph_nucoarse.json) */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
   double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting: P = T - omega_p Dl^-1 A T.
                              The reference's JacobiProlongation uses 4/3; 1.6 (default) measured 35 % fewer PCG
@@ -289,6 +291,11 @@ int csgpu_multi_last_busy(const csgpu_multi* m, double* busy_s, int64_t* pairs_d
 void csgpu_multi_free(csgpu_multi* m);
 
 void csgpu_free(csgpu_handle* h);
+/* Device blocks released by freed handles (and by temporaries of the setup) are kept in a per-device pool and reused
+ * on an exact size match -- freeing and re-allocating tens of GB through the driver costs seconds, and the reference
+ * factorises again and again (per component, per focal region, per one-to-all source). This returns the pooled blocks
+ * of `device` (-1: every device) to the driver and reports the bytes released. CSGPU_NO_POOL=1 disables pooling. */
+int64_t csgpu_trim_memory(int device);
 const char* csgpu_last_error(void);
 const char* csgpu_version(void);
 

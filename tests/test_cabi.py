@@ -44,7 +44,7 @@ def test_binding_struct_sizes_match_library():
     o = lib.Opts()
     L.csgpu_default_opts(ctypes.byref(o))
     assert o.struct_size == ctypes.sizeof(lib.Opts)
-    assert o.batch == 8 and o.max_coarse == 100 and abs(o.rtol - 1e-6) < 1e-20 and o.nu_coarse == 3
+    assert o.batch == 8 and o.max_coarse == 100 and abs(o.rtol - 1e-6) < 1e-20 and o.nu_coarse == 2
 
 
 def test_product_loader_has_no_fallback(tmp_path):
