@@ -1,0 +1,376 @@
+"""Host-side harness: Python restatement of the reference's JULIA-SIDE host code around the solver boundary.
+
+NOT part of the product path. In a real deployment everything in this module keeps running in Circuitscape.jl on its
+side of the C ABI (polygon handling, node maps, one-to-all / all-to-one drivers, the
+advanced-mode kernel, map post-processing, result files); the image has no Julia, so the test-suite needs a stand-in
+that turns the reference's fixtures into calls of the boundary mirror in solver.py (construct_cholesky_factor,
+solve_linear_system, multiple_solve, solve) and of the C ABI. Every function cites the reference code it follows.
+
+  resolve_conflicts / get_sources_and_grounds   src/raster/advanced.jl:86-149
+  multiple_solver / advanced_kernel              src/raster/advanced.jl:151-305
+  raster_advanced_kernel / get_node_currents     src/raster/advanced.jl:151-271, src/out.jl:178-207
+  create_new_polymap / _construct_node_map       src/raster/pairwise.jl:271-301, 369-442
+  onetoall_kernel                                src/raster/onetoall.jl:77-151
+  compute_omniscape_current                      src/utils.jl:145-257
+  write_cum_maps, compute_3col, save_resistances src/out.jl, src/core.jl:294-305
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lib
+from .solver import (HIP, Flags, HIPAMGSolver, OutputFlags, _colmajor_nonzero, _process_grid, _scatter, construct_local_node_map, get_solver, initialize_cum_maps, multiple_solve)
+
+def resolve_conflicts(sources, grounds, policy):
+    """src/raster/advanced.jl:118-149: finite grounds vector (or [-9999]), source/ground conflicts by policy,
+    sources on infinite grounds win over the ground."""
+    sources = np.array(sources, dtype=np.float64)
+    grounds = np.array(grounds, dtype=np.float64)
+    finitegrounds = np.where(grounds < np.inf, grounds, 0.0)
+    if np.count_nonzero(finitegrounds) == 0:
+        finitegrounds = np.array([-9999.0])
+    conflicts = (sources != 0) & (grounds != 0)
+    if conflicts.any():
+        if policy in ("rmvsrc", "rmvall"):
+            sources[conflicts] = 0
+        elif policy == "rmvgnd":
+            grounds[conflicts] = 0
+    infconflicts = (grounds == np.inf) & (sources > 0)
+    grounds[infconflicts] = 0
+    return sources, grounds, finitegrounds
+
+
+def multiple_solver(cfg, solver, a, sources, grounds, finitegrounds):
+    """src/raster/advanced.jl:274-305: finite grounds go on the diagonal, rows/columns of infinite grounds are deleted,
+    the reduced SPD system is handed to multiple_solve, zeros are re-inserted at the grounded nodes."""
+    a = sp.csr_matrix(a)
+    T = np.float32 if a.dtype == np.float32 else np.float64
+    asolve = a
+    if not (len(finitegrounds) == 1 and finitegrounds[0] == -9999):
+        asolve = (a + sp.diags(np.asarray(finitegrounds, dtype=T))).tocsr()
+    inf = np.flatnonzero(np.asarray(grounds) == np.inf)
+    keep = np.setdiff1d(np.arange(a.shape[0]), inf)
+    asolve = asolve[keep][:, keep]
+    volt = multiple_solve(solver, asolve.astype(T), np.asarray(sources, dtype=T)[keep])
+    voltages = np.zeros(a.shape[0], dtype=T)
+    voltages[keep] = volt
+    return voltages
+
+
+def advanced_kernel(G, cc, sources, grounds, finitegrounds, solver, cfg=None, check_node=-1):
+    """Solver-layer part of advanced_kernel (src/raster/advanced.jl:151-271) without map output: per connected component
+    with both a source and a ground, one grounded solve. Returns the node voltages (1-based node order)."""
+    G = sp.csr_matrix(G)
+    voltages = np.zeros(G.shape[0], dtype=np.float64)
+    for c in cc:
+        c = np.asarray(c, dtype=np.int64)
+        if check_node != -1 and check_node not in c:
+            continue
+        idx = c - 1
+        s_local, g_local = np.asarray(sources)[idx], np.asarray(grounds)[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        no_finite = len(finitegrounds) == 1 and finitegrounds[0] == -9999
+        f_local = finitegrounds if no_finite else np.asarray(finitegrounds)[idx]
+        voltages[idx] += multiple_solver(cfg, solver, G[idx][:, idx], s_local, g_local, f_local)
+    return voltages
+
+
+def create_new_polymap(polymap, points_rc, point_map):
+    """create_new_polymap, point-map branch (src/raster/pairwise.jl:374-404): focal regions become short-circuit
+    polygons. Focal cells outside any polygon get fresh polygon numbers; a focal region overlapping a polygon takes
+    the polygon over (all its cells are renumbered to the focal id)."""
+    if polymap is None or np.size(polymap) == 0:
+        return point_map
+    polymap = np.asarray(polymap, dtype=np.int64)
+    newpoly = polymap.copy()
+    ids = list(points_rc[2])
+    ii, jj = _colmajor_nonzero(point_map != 0)
+    if len(ids) == len(set(ids)):       # point file without multi-cell regions
+        free = polymap[ii, jj] == 0
+        newpoly[ii[free], jj[free]] = point_map[ii[free], jj[free]] + int(polymap.max())
+        return newpoly
+    k = max(int(polymap.max()), int(point_map.max()))
+    for i, j in zip(ii, jj):
+        v1, v2 = point_map[i, j], newpoly[i, j]
+        if v2 == 0:
+            newpoly[i, j] = k + v1
+        elif v1 != v2:
+            newpoly[newpoly == v2] = v1
+    return newpoly
+
+
+def onetoall_kernel(gmap, polymap, points_rc, flags, solver, build_graph, strengths=None, included_pairs=None,
+                    cfg=None):
+    """onetoall_kernel (src/raster/onetoall.jl:13-162) for one-to-all (flags.is_onetoall) and all-to-one mode.
+
+    gmap: conductance raster; polymap: short-circuit polygons or None; points_rc: (rows, cols, ids), 1-based, as
+    read_point_map returns them; strengths: (id, strength) rows or None; included_pairs: {'mode', 'point_ids',
+    'matrix'} or None. `build_graph(gmap, polymap) -> (nodemap, G, cc)` is the reference's construct_node_map /
+    construct_graph / laplacian! / connected_components, which stay on the reference's side of the boundary.
+
+    Every focal point is one grounded solve on the component holding it (advanced_kernel with check_node):
+    one-to-all injects `strength` at the point and ties every other focal point to ground, all-to-one grounds the
+    point and injects at all the others. Returns (res, cum, points): res = [id, value] rows (one-to-all: voltage per
+    unit source current at the point; all-to-one: 0; -1 when the point is alone), cum = Cumulative of the per-point
+    current maps, points = {id: {'voltmap', 'curmap'}} as the flags ask.
+    """
+    gmap = np.asarray(gmap, dtype=np.float64)
+    of = flags.outputflags
+    one_to_all = flags.is_onetoall
+    pr = [list(x) for x in points_rc]
+    use_var = strengths is not None and len(strengths) > 0
+    use_inc = included_pairs is not None
+    st = np.array(strengths, dtype=np.float64) if use_var else None
+    if use_inc:
+        ids = list(included_pairs["point_ids"])
+        keep = [k for k, p in enumerate(pr[2]) if p in ids]                      # prune_points! (onetoall.jl:167-178)
+        pr = [[col[k] for k in keep] for col in pr]
+        if use_var:
+            st = st[[k for k, p in enumerate(st[:, 0]) if p in ids]]             # prune_strengths (:180-194)
+        mode = 0 if included_pairs["mode"] == "include" else 1
+        inc_mat = np.asarray(included_pairs["matrix"])
+    rows = np.asarray(pr[0], dtype=np.int64) - 1
+    cols = np.asarray(pr[1], dtype=np.int64) - 1
+    pids = np.asarray(pr[2], dtype=np.int64)
+    point_map0 = np.zeros(gmap.shape, dtype=np.int64)
+    point_map0[rows, cols] = pids                                                # later entries win, as in the loop
+    points_unique = list(dict.fromkeys(pr[2]))
+    newpoly0 = create_new_polymap(polymap, pr, point_map0)
+    nodemap0, G, cc = build_graph(gmap, newpoly0)
+    G = sp.csr_matrix(G)
+    unique_point_map = np.zeros(gmap.shape, dtype=np.int64)
+    for n in points_unique:
+        k = pr[2].index(n)
+        unique_point_map[rows[k], cols[k]] = n
+    res = np.zeros(len(points_unique))
+    cum = initialize_cum_maps(gmap, of.write_max_cur_maps)
+    per_point = {}
+    sub = Flags(is_raster=True, outputflags=of, is_onetoall=one_to_all, is_alltoone=not one_to_all)
+    for i, n in enumerate(points_unique):
+        point_map, nodemap, newpoly = point_map0, nodemap0, newpoly0
+        strength = st[i, 1] if use_var else 1.0
+        if use_inc:
+            point_map = point_map0.copy()
+            for j in range(len(ids)):
+                if i != j and inc_mat[i, j] == mode:
+                    point_map[point_map == ids[j]] = 0
+            newpoly = create_new_polymap(polymap, pr, point_map)
+            nodemap = _construct_node_map(gmap, polymap)   # the reference rebuilds from the ORIGINAL polygons (:92)
+        if use_var:
+            s_i = st.copy()
+            s_i[point_map[rows, cols] == 0, 1] = 1
+            strength_map = np.zeros(gmap.shape)
+            strength_map[rows, cols] = s_i[:, 1]
+        if point_map.sum() == n:                             # no other focal point left
+            res[i] = -1
+            continue
+        if one_to_all:
+            source_map = np.where(unique_point_map == n, float(strength), 0.0)
+            ground_map = np.where((point_map != n) & (point_map > 0), np.inf, 0.0)
+        else:
+            if use_var:
+                source_map = np.where(unique_point_map == n, 0.0, strength_map)
+            else:
+                source_map = np.where((unique_point_map != 0) & (point_map != n), 1.0, 0.0)
+            ground_map = np.where(point_map == n, np.inf, 0.0)
+        check_node = int(nodemap[rows[i], cols[i]])          # the i-th entry of the point list (:124)
+        sources, grounds, finite = get_sources_and_grounds(source_map, ground_map, G, nodemap,
+                                                           "rmvgnd" if one_to_all else "rmvsrc")
+        prob = AdvancedProblem(G=G, cc=cc, nodemap=nodemap, polymap=newpoly, sources=sources, grounds=grounds,
+                               finitegrounds=finite, cellmap=gmap, solver=solver, source_map=source_map,
+                               check_node=check_node, src=n)
+        ret, curr, maps = raster_advanced_kernel(prob, sub, cfg)
+        res[i] = ret[0, 0]
+        per_point[n] = maps
+        cum.cum_curr += curr
+        if of.write_max_cur_maps:
+            cum.max_curr = np.maximum(cum.max_curr, curr)
+    if of.write_cur_maps or of.write_cum_cur_map_only:
+        cum.cum_curr = _process_grid(cum.cum_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+        if of.write_max_cur_maps:
+            cum.max_curr = _process_grid(cum.max_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+    return np.column_stack([np.asarray(points_unique, dtype=np.float64), res]), cum, per_point
+
+
+def compute_omniscape_current(conductance, source, ground, cs_cfg, build_graph, solver=None):
+    """compute_omniscape_current (src/utils.jl:145-257), the entry point Omniscape.jl calls for every moving-window
+    solve: advanced mode on in-memory rasters (no polygons, policy rmvsrc, conductances never averaged as
+    resistances), returning the raw accumulated node-current map. `cs_cfg`: mapping with the reference's INI keys
+    ('connect_four_neighbors_only', 'solver', 'cholmod_batch_size'); build_graph as in onetoall_kernel (receives the
+    four-neighbour flag through the closure the caller builds from the same cfg)."""
+    conductance = np.asarray(conductance, dtype=np.float64)
+    solver = solver or get_solver({"solver": cs_cfg.get("solver", "hip") if cs_cfg.get("solver") in HIP else "hip",
+                                   "cholmod_batch_size": cs_cfg.get("cholmod_batch_size", 8)})
+    nodemap, G, cc = build_graph(conductance, None)
+    G = sp.csr_matrix(G)
+    sources, grounds, finite = get_sources_and_grounds(source, ground, G, nodemap, "rmvsrc")
+    of = OutputFlags(write_cur_maps=True)
+    prob = AdvancedProblem(G=G, cc=cc, nodemap=nodemap, polymap=None, sources=sources, grounds=grounds,
+                           finitegrounds=finite, cellmap=conductance, solver=solver, source_map=np.asarray(source))
+    _, outcurr, _ = raster_advanced_kernel(prob, Flags(is_raster=True, outputflags=of, policy="rmvsrc"))
+    return outcurr
+
+
+@dataclass
+class AdvancedProblem:
+    """src/raster/advanced.jl:1-15. Node ids 1-based, 0 = no node; `check_node` = -1 solves every component that has
+    both a source and a ground, otherwise only the component holding that node (one-to-all / all-to-one)."""
+    G: sp.csr_matrix
+    cc: List[np.ndarray]
+    nodemap: np.ndarray
+    polymap: Optional[np.ndarray]
+    sources: np.ndarray
+    grounds: np.ndarray
+    finitegrounds: np.ndarray
+    cellmap: np.ndarray
+    solver: HIPAMGSolver = field(default_factory=HIPAMGSolver)
+    source_map: Optional[np.ndarray] = None
+    check_node: int = -1
+    src: int = 0
+
+
+def get_sources_and_grounds(source_map, ground_map, G, nodemap, policy):
+    """Raster branch of _get_sources_and_grounds (src/raster/advanced.jl:84-116): per-node source currents and ground
+    conductances accumulated from the rasters (cells of one polygon share a node), then resolve_conflicts."""
+    n = G.shape[0]
+    nodemap = np.asarray(nodemap)
+    sources = np.zeros(n)
+    grounds = np.zeros(n)
+    for raster, acc in ((np.asarray(source_map, dtype=np.float64), sources),
+                        (np.asarray(ground_map, dtype=np.float64), grounds)):
+        m = (raster != 0) & (nodemap != 0)
+        np.add.at(acc, nodemap[m] - 1, raster[m])
+    return resolve_conflicts(sources, grounds, policy)
+
+
+def get_node_currents(G, voltages, finitegrounds):
+    """get_node_currents (src/out.jl:178-207) with the finite-ground branch, evaluated on the host: advanced modes
+    need it once per solved component (the per-pair flavour of pairwise mode runs on the device, currents.h).
+    Branch currents |g_ij| (v_i - v_j) below 1e-8 of the largest are dropped; a node's current is the larger of its
+    total inflow and outflow, the flow through its own ground conductance included."""
+    G = sp.csr_matrix(G)
+    v = np.asarray(voltages, dtype=np.float64)
+    up = sp.triu(G, k=1).tocoo()
+    flow = np.abs(up.data) * (v[up.row] - v[up.col])          # current from row to col along each branch
+    n = G.shape[0]
+    fg = np.asarray(finitegrounds, dtype=np.float64)
+    have_fg = not (len(fg) == 1 and fg[0] == -9999)
+    totals = []
+    for sign in (1.0, -1.0):
+        b = sign * flow
+        top = b.max() if len(b) else 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = np.where(np.abs(b / top) < 1e-8, 0.0, b)
+        # B - B' clipped at 0, summed over rows: what flows INTO each column node (sign = +1: along row -> col)
+        into = np.bincount(up.col, weights=np.maximum(b, 0.0), minlength=n) + \
+            np.bincount(up.row, weights=np.maximum(-b, 0.0), minlength=n)
+        if have_fg:
+            gc = fg * v
+            into = into + (np.where(gc < 0, -gc, 0.0) if sign > 0 else np.where(gc > 0, gc, 0.0))
+        totals.append(into)
+    return np.maximum(totals[0], totals[1])
+
+
+def raster_advanced_kernel(prob, flags, cfg=None):
+    """advanced_kernel, raster branch (src/raster/advanced.jl:151-271): one grounded solve per connected component
+    that holds a source and a ground, voltages and node currents scattered to rasters.
+    Returns (ret, outcurr, maps): `ret` as the reference returns it (cell voltages; one-to-all: voltage / source
+    strength at the source cells; all-to-one: [[0]]; [[-1]] when nothing was solved), the raw accumulated current map,
+    and maps = {'voltmap', 'curmap'} post-processed the way write_grid does (only those the flags ask for)."""
+    G = sp.csr_matrix(prob.G)
+    nodemap = np.asarray(prob.nodemap)
+    of = flags.outputflags
+    outvolt = np.zeros(nodemap.shape)
+    outcurr = np.zeros(nodemap.shape)
+    volt = np.zeros(nodemap.shape)
+    voltages = np.zeros(G.shape[0])
+    no_finite = len(prob.finitegrounds) == 1 and prob.finitegrounds[0] == -9999
+    solver_called = False
+    for c in prob.cc:
+        c = np.asarray(c, dtype=np.int64)
+        if prob.check_node != -1 and prob.check_node not in c:
+            continue
+        idx = c - 1
+        s_local, g_local = prob.sources[idx], prob.grounds[idx]
+        if s_local.sum() == 0 or g_local.sum() == 0:
+            continue
+        f_local = prob.finitegrounds if no_finite else prob.finitegrounds[idx]
+        a_local = G[idx][:, idx]
+        voltages[idx] += multiple_solver(cfg, prob.solver, a_local, s_local, g_local, f_local)
+        local_nodemap = construct_local_node_map(nodemap, c, prob.polymap)
+        solver_called = True
+        if of.write_volt_maps:
+            outvolt += _scatter(voltages[idx], local_nodemap)
+        if of.write_cur_maps:
+            outcurr += _scatter(get_node_currents(a_local, voltages[idx], f_local), local_nodemap)
+        m = local_nodemap > 0
+        volt[m] = voltages[idx][local_nodemap[m] - 1]
+    maps = {}
+    if of.write_volt_maps:
+        maps["voltmap"] = _process_grid(outvolt, prob.cellmap, False, of.set_null_voltages_to_nodata)
+    if of.write_cur_maps or of.write_cum_cur_map_only:
+        maps["curmap"] = _process_grid(outcurr, prob.cellmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+    if not solver_called:
+        return np.array([[-1.0]]), outcurr, maps
+    if flags.is_onetoall:
+        ii, jj = _colmajor_nonzero(np.asarray(prob.source_map) != 0)
+        val = volt[ii, jj] / np.asarray(prob.source_map, dtype=np.float64)[ii, jj]
+        if np.isclose(val[0], 0.0, rtol=float(np.sqrt(np.finfo(np.float64).eps)), atol=0.0):
+            return np.array([[-1.0]]), outcurr, maps
+        return val.reshape(-1, 1), outcurr, maps
+    if flags.is_alltoone:
+        return np.array([[0.0]]), outcurr, maps
+    return volt, outcurr, maps
+
+
+def _construct_node_map(gmap, polymap):
+    """src/raster/pairwise.jl:271-314 (needed by construct_local_node_map when polygons are present)."""
+    gmap = np.asarray(gmap, dtype=np.float64)
+    nodemap = np.zeros(gmap.shape, dtype=np.int64)
+    ii, jj = _colmajor_nonzero(gmap > 0)
+    nodemap[ii, jj] = np.arange(1, len(ii) + 1)
+    if polymap is None or np.size(polymap) == 0:
+        return nodemap
+    polymap = np.asarray(polymap, dtype=np.int64)
+    pruned = np.where(gmap > 0, polymap, 0)
+    for polynum in np.unique(polymap):
+        if polynum == 0:
+            continue
+        i1, j1 = _colmajor_nonzero(pruned == polynum)
+        if len(i1) > 0:
+            nodemap[polymap == polynum] = nodemap[i1[0], j1[0]]
+    ii, jj = _colmajor_nonzero(nodemap != 0)
+    _, inv = np.unique(nodemap[ii, jj], return_inverse=True)
+    nodemap[ii, jj] = inv + 1
+    return nodemap
+
+
+def write_cum_maps(cum):
+    """postprocess_cum_curmap! (utils.jl:114-120) applied like write_cum_maps does (out.jl:467-481)."""
+    cum.cum_curr[cum.cum_curr < -9999] = -9999
+    if cum.max_curr is not None:
+        cum.max_curr[cum.max_curr < -9999] = -9999
+    return cum
+
+
+def compute_3col(r):
+    """out.jl:12-26."""
+    fp = r[1:, 0]
+    l = len(fp)
+    out = np.zeros((l * (l - 1) // 2, 3), dtype=r.dtype)
+    k = 0
+    for i in range(l):
+        for j in range(i + 1, l):
+            out[k] = (fp[i], fp[j], r[j + 1, i + 1])
+            k += 1
+    return out
+
+
+def save_resistances(r, output_file):
+    """out.jl:454-465: <prefix>_resistances.out and <prefix>_resistances_3columns.out."""
+    pref = output_file.split(".out")[0]
+    np.savetxt(pref + "_resistances.out", r, delimiter=" ", fmt="%.10g")
+    np.savetxt(pref + "_resistances_3columns.out", compute_3col(r), delimiter=" ", fmt="%.10g")

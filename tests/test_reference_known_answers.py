@@ -5,6 +5,7 @@ import pytest
 
 import circuitscape_jl_amd  # noqa: F401
 from circuitscape_jl_amd import solver as ps
+from circuitscape_jl_amd import hostmirror as hm
 from oracle import refgraph as rg
 from oracle import refonetoall, refsolve
 
@@ -24,7 +25,7 @@ def test_construct_node_map(gmap, polymap, expected):
     g = np.array(gmap, dtype=np.float64)
     pm = None if polymap is None else np.array(polymap, dtype=np.int64)
     assert np.array_equal(rg.construct_node_map(g, pm), np.array(expected))
-    assert np.array_equal(ps._construct_node_map(g, pm), np.array(expected))
+    assert np.array_equal(hm._construct_node_map(g, pm), np.array(expected))
 
 
 def test_create_new_polymap_point_map_branch():
@@ -35,14 +36,14 @@ def test_create_new_polymap_point_map_branch():
     point_map = np.array([[1, 2, 0, 0, 0], [0, 0, 0, 0, 0], [3, 0, 0, 7, 0], [4, 0, 0, 0, 0], [1, 0, 0, 0, 2]])
     expected = np.array([[1, 2, 0, 0, 0], [0, 0, 0, 0, 0], [12, 0, 0, 2, 0], [1, 0, 0, 0, 0], [1, 0, 0, 0, 2]])
     assert np.array_equal(refonetoall.create_new_polymap_pointmap(polymap, case["points_rc"], point_map), expected)
-    assert np.array_equal(ps.create_new_polymap(polymap, case["points_rc"], point_map), expected)
+    assert np.array_equal(hm.create_new_polymap(polymap, case["points_rc"], point_map), expected)
 
 
 @pytest.mark.parametrize("policy,expected", [  # test/internal.jl:130-133
     ("rmvgnd", ([1, 0, 0], [0, 0, 0], [1, 0, 0])), ("rmvsrc", ([0, 0, 0], [1, 0, 0], [1, 0, 0])),
     ("keepall", ([1, 0, 0], [1, 0, 0], [1, 0, 0])), ("rmvall", ([0, 0, 0], [1, 0, 0], [1, 0, 0]))])
 def test_resolve_conflicts(policy, expected):
-    for f in (ps.resolve_conflicts, refsolve.resolve_conflicts):
+    for f in (hm.resolve_conflicts, refsolve.resolve_conflicts):
         got = f([1.0, 0.0, 0.0], [1.0, 0.0, 0.0], policy)
         for a, b in zip(got, expected):
             assert np.array_equal(np.asarray(a), np.asarray(b, dtype=float))
