@@ -197,8 +197,12 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     // DIA_SQ: coarse rows staged = tiles of the strip's rows plus one above and one below
     const int Ilo = SQ ? min(i0 / 3, a.Rc - 1) - 1 : 0;
     const int crow = SQ ? min((i0 + t) / 3, a.Rc - 1) - Ilo : 0;  // this lane's tile row inside the staged coarse column
-    // staged values of the column being loaded (registers), written to LDS one step later
-    XV xr, xh;
+    // Column in flight: the values of a raster column are loaded into registers one step before the column's turn and
+    // written to the LDS ring right before it, so its loads overlap the product of the column before. In DIA_CG the two
+    // loaded vectors stay raw until then: combining them at load time would make every step wait for its own loads.
+    // (Two columns in flight -- a second register set -- was tried: 150-196 VGPRs, 2-3 waves/SIMD, scratch; dropped.)
+    XV xr, xh;              // vector entries of the tile's rows / of the two halo rows (DIA_CG: the old p)
+    XV zr, zh;              // DIA_CG: z
     T mr[MU];
     T qr[SQ ? QU : 1];
     XV xcr;
@@ -218,43 +222,31 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     auto load_column = [&](int jc) {
       // node id of tile row -1 (the halo row above) in raster column jc; ids outside [0, n) read as zero
       const int64_t base = (int64_t)jc * a.R + i0 - 1;
-      const bool col_in = jc >= j0 && jc < j1;
       {
         const int64_t id = base + 1 + t;
-        XV v;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v.e[q] = XT(0);
+        for (int q = 0; q < CPL; ++q) {
+          xr.e[q] = XT(0);
+          zr.e[q] = XT(0);
+        }
         if (id >= 0 && id < a.n) {
           const size_t e = (size_t)id * K + c0;
-          if (FUSE) {
-            const XV zv = *reinterpret_cast<const XV*>(a.z + e);
-            const XV pv = *reinterpret_cast<const XV*>(a.pin + e);
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)pv.e[q], (T)zv.e[q]);
-            if (col_in && row_on) *reinterpret_cast<XV*>(a.pout + e) = v;
-          } else {
-            v = *reinterpret_cast<const XV*>(a.pin + e);
-          }
+          xr = *reinterpret_cast<const XV*>(a.pin + e);
+          if (FUSE) zr = *reinterpret_cast<const XV*>(a.z + e);
         }
-        xr = v;
       }
       if (tid < 2 * LPR) {  // halo rows: tile row -1 (lanes 0..LPR-1) and tile row TI (lanes LPR..2LPR-1)
         const int64_t id = base + (tid < LPR ? 0 : TI + 1);
-        XV v;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v.e[q] = XT(0);
+        for (int q = 0; q < CPL; ++q) {
+          xh.e[q] = XT(0);
+          zh.e[q] = XT(0);
+        }
         if (id >= 0 && id < a.n) {
           const size_t e = (size_t)id * K + c0;  // (tid < 2 LPR: tid % LPR is the lane's own column slice)
-          if (FUSE) {
-            const XV zv = *reinterpret_cast<const XV*>(a.z + e);
-            const XV pv = *reinterpret_cast<const XV*>(a.pin + e);
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)pv.e[q], (T)zv.e[q]);
-          } else {
-            v = *reinterpret_cast<const XV*>(a.pin + e);
-          }
+          xh = *reinterpret_cast<const XV*>(a.pin + e);
+          if (FUSE) zh = *reinterpret_cast<const XV*>(a.z + e);
         }
-        xh = v;
       }
 #pragma unroll
       for (int u = 0; u < MU; ++u) {
@@ -274,6 +266,16 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
     };
     auto store_column = [&](int jc) {
       const int slot = jc & 3;
+      if (FUSE) {  // p = z + beta p (halo included); the tile's own entries are the new search direction
+        XV v;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)xr.e[q], (T)zr.e[q]);
+        const int64_t id = (int64_t)jc * a.R + i0 + t;
+        if (jc >= j0 && jc < j1 && row_on && id < a.n) *reinterpret_cast<XV*>(a.pout + (size_t)id * K + c0) = v;
+        xr = v;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) xh.e[q] = (XT)fma(beta[q], (T)xh.e[q], (T)zh.e[q]);
+      }
       s_x[slot][(t + 1) * LPR + lq] = xr;
       if (tid < 2 * LPR) s_x[slot][(tid < LPR ? 0 : TI + 1) * LPR + lq] = xh;
 #pragma unroll
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
 inline int dia_seg() {
   static int seg = [] {
     const char* e = getenv("CSGPU_DIA_SEG");
-    const int v = e ? atoi(e) : 64;
+    const int v = e ? atoi(e) : 32;
     return v < 4 ? 4 : v;
   }();
   return seg;
