@@ -255,8 +255,9 @@ def main():
     # untimed warm-up of the setup path on a small raster (first launch of every kernel loads its code object; a fresh
     # process pays ~1 s for that once -- the solve path is warmed by the --warmup batches below)
     for precond in ((args.precond, "same") if (vb == 8 and args.precond == "fp32") else (args.precond,)):
-        hw = lib.raster_setup(np.ascontiguousarray(g[:768, :768]), make_opts(precond))
-        hw.solve_pairs([0] * B, [768 * 768 - 1] * B)
+        wn = min(768, size)
+        hw = lib.raster_setup(np.ascontiguousarray(g[:wn, :wn]), make_opts(precond))
+        hw.solve_pairs([0] * B, [wn * wn - 1] * B)
         hw.close()
     t0 = time.time()
     h = lib.raster_setup(g, make_opts(args.precond))
@@ -431,8 +432,9 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
     g = make_raster(size, dtype=dtype)
     lo, hi = shard.pair_slice(npairs, rank, world)
     # warm-up: one small problem through the same code path (library load, kernel code objects, allocator)
-    hw = lib.raster_setup(g[:768, :768].copy(), make_opts(args.precond))
-    hw.solve_pairs([0] * B, [768 * 768 - 1] * B)
+    wn = min(768, size)
+    hw = lib.raster_setup(g[:wn, :wn].copy(), make_opts(args.precond))
+    hw.solve_pairs([0] * B, [wn * wn - 1] * B)
     hw.close()
     sync()
     t0 = time.perf_counter()

@@ -43,3 +43,46 @@ def test_two_ranks_gloo_match_oracle(emu_lib, oracle, tmp_path):
     h.close()
     assert np.max(np.abs(np.array(d["cum"]) - cum)) < 1e-12 * cum.max()
     assert np.array_equal(np.array(d["max"]), mx)
+
+
+def test_pair_slice_and_gather_single_process():
+    import circuitscape_jl_amd  # noqa: F401
+    from circuitscape_jl_amd import shard
+    for npairs, world in [(100, 8), (5, 8), (0, 3), (1000, 8), (7, 7)]:
+        sl = [shard.pair_slice(npairs, r, world) for r in range(world)]
+        assert sl[0][0] == 0 and sl[-1][1] == npairs and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        sizes = [b - a for a, b in sl]
+        assert max(sizes) - min(sizes) <= 1          # 100 pairs on 8 GPUs: 13,13,13,13,12,12,12,12 -- every GPU busy
+    full = shard.gather_pairs(np.arange(5) * 2.0, np.arange(5), 5)
+    assert np.array_equal(full, np.arange(5) * 2.0)
+
+
+def _run_bench(tmp_path, extra, port):
+    """bench.py under torch.distributed.run with two ranks on the gloo backend, kernels on the CPU emulator build: the
+    N > 1 code path of the bench exactly as the driver launches it (minus RCCL)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2",
+               CSGPU_LIB=os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "60",
+           "--batch", "4", "--cpu-sample", "0"] + extra
+    res = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_weak_scaling_line(emu_lib, tmp_path):
+    d = _run_bench(tmp_path, ["--steps", "2", "--warmup", "1"], 29541)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "pair-solves/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["config"]["batch"] == 4 and d["not_converged"] == 0 and d["max_relres"] < 1e-4
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] > 0
+    # whole-job aggregate: 2 ranks x 2 steps x 4 pairs
+    assert abs(d["solve_only_pairs_per_s"] * d["ms_per_step"] * 1e-3 * 2 - 16) < 1e-6
+
+
+def test_bench_two_ranks_strong_scaling_line(emu_lib, tmp_path):
+    d = _run_bench(tmp_path, ["--scaling", "strong", "--pairs", "11"], 29543)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["all_pairs_gathered"] is True
+    assert len(d["rank_busy_s"]) == 2 and d["pairs_per_rank"] == 6 and d["value"] > 0
