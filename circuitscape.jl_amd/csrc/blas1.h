@@ -271,6 +271,25 @@ __global__ __launch_bounds__(256) void cg_focal_x_kernel(const CgScalars* S, con
   }
 }
 
+// ---- Dirichlet mask: column c of the batch is tied to ground at the nodes gidx[gptr[c] .. gptr[c+1]) -- their entries of
+//      the vectors a (and b, optional, may have another type) are set to zero. One-to-all / all-to-one solves differ
+//      only in WHICH nodes are grounded (src/raster/onetoall.jl:106-151 -> advanced.jl:282-288 deletes those rows and
+//      columns and factorises again); keeping r, z (hence p, x) zero there solves the same reduced system with the
+//      hierarchy of the ungrounded matrix.
+template <class A, class B, int K>
+__global__ __launch_bounds__(256) void mask_grounds_kernel(const int* __restrict__ gptr, const int* __restrict__ gidx,
+                                                           A* __restrict__ a, B* __restrict__ b, const int* skip) {
+  if (skip && *skip) return;
+  const int total = gptr[K];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int c = 0;
+    while (c + 1 < K && e >= gptr[c + 1]) ++c;
+    const size_t at = (size_t)gidx[e] * K + c;
+    if (a) a[at] = A(0);
+    if (b) b[at] = B(0);
+  }
+}
+
 // ---- scalar kernel 2: gamma' = r'z -> convergence test, beta.   criterion 0: monitored norm = sqrt(|r'z|),
 // criterion 1: sqrt(r'r) from `partials_rr`.   `init` != 0: first evaluation (sets rnorm0 / eps, no beta).
 template <int K>

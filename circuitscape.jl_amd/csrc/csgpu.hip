@@ -22,6 +22,8 @@ struct ISolver {
                            csgpu_stats* stats, const int32_t* weights = nullptr, void* curr_out = nullptr,
                            void* cum_inout = nullptr, void* max_inout = nullptr, void* branch_out = nullptr) = 0;
   virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
+  virtual void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
+                              void* curr_out, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
   virtual void spmv_host(const void* x, void* y, int k) = 0;
@@ -667,6 +669,93 @@ struct Solver : ISolver {
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
+  // N2: per-column Dirichlet sets on one hierarchy (see csgpu_solve_grounded in csgpu.h)
+  void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
+                      void* curr_out, csgpu_stats* stats) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (int64_t c = 0; c < nrhs; ++c) {
+      CS_REQUIRE(gptr[c] <= gptr[c + 1], CSGPU_BAD_ARGS, "ground_ptr must be non-decreasing");
+      for (int64_t e = gptr[c]; e < gptr[c + 1]; ++e)
+        CS_REQUIRE(gidx[e] >= 0 && gidx[e] < n, CSGPU_BAD_ARGS, "ground node id out of range");
+    }
+    const int K = pick_k(nrhs);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
+    W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
+    if (stats) {
+      stats->nrhs = (int)nrhs;
+      stats->batch = K;
+    }
+    int64_t maxg = 1;
+    for (int64_t p0 = 0; p0 < nrhs; p0 += K) maxg = std::max(maxg, gptr[std::min(nrhs, p0 + K)] - gptr[p0]);
+    DBuf stage((size_t)n * K * sizeof(T)), dgp = dalloc<int>(K + 1), dgi = dalloc<int>((size_t)maxg);
+    DBuf dcurr, dbpart, dbmax;
+    if (curr_out) {
+      dcurr.alloc((size_t)n * K * sizeof(T));
+      dbpart.alloc((size_t)kMaxGrid * K * 2 * sizeof(double));
+      dbmax.alloc((size_t)K * 2 * sizeof(double));
+    }
+    std::vector<int> hp(K + 1), hi;
+    for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
+      const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
+      hi.clear();
+      for (int c = 0; c < K; ++c) {
+        hp[c] = (int)hi.size();
+        if (c < ncols)
+          for (int64_t e = gptr[p0 + c]; e < gptr[p0 + c + 1]; ++e) hi.push_back((int)gidx[e]);
+      }
+      hp[K] = (int)hi.size();
+      CS_HIP(hipMemcpyAsync(dgp.p, hp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+      if (!hi.empty()) CS_HIP(hipMemcpyAsync(dgi.p, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(stage.p, (const T*)rhs + (size_t)p0 * n, (size_t)n * ncols * sizeof(T),
+                            hipMemcpyHostToDevice, st));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
+      const int gtotal = (int)hi.size();
+      if (gtotal > 0)
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((mask_grounds_kernel<T, T, KK>), dim3(ceil_div(gtotal, 256)), dim3(256), 0, st,
+                                             (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), dptr<T>(W.b),
+                                             (T*)nullptr, (const int*)nullptr));
+      CS_HIP(hipStreamSynchronize(st));  // hp / hi are reused by the next batch
+      PcgBatchResult r;
+      {
+        PcgParams pp = pcg_params(K);
+        pp.need_x = true;
+        pp.gptr = dptr<int>(dgp);
+        pp.gidx = dptr<int>(dgi);
+        pp.gtotal = gtotal;
+        CS_DISPATCH_K(K, r = (pcg_solve<T, TP, KK>(cg_matrix(), H, W, pp, ncols, st, dia_ptr())));
+      }
+      accumulate(stats, r, ncols);
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
+      CS_HIP(hipMemcpyAsync((T*)x_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T), hipMemcpyDeviceToHost,
+                            st));
+      if (curr_out) {
+        const Csr<T>& A = cg_matrix();
+        const int gc = grid_for(n * K);
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_max_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
+                                            A.va(), (const T*)dptr<T>(W.x), dptr<double>(dbpart)));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_max_final_kernel<KK>), dim3(1), dim3(256), 0, st,
+                                            (const double*)dptr<double>(dbpart), gc, dptr<double>(dbmax)));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((node_current_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
+                                            A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
+                                            dptr<T>(dcurr), (const T*)nullptr, (const int*)nullptr,
+                                            (const unsigned long long*)nullptr));
+        CS_HIP(hipStreamSynchronize(st));  // stage still feeds the copy of x
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                            (const T*)dptr<T>(dcurr), ncols, dptr<T>(stage)));
+        CS_HIP(hipMemcpyAsync((T*)curr_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T),
+                              hipMemcpyDeviceToHost, st));
+      }
+      check_launch("solve_grounded batch");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
   template <class U>
   static int64_t spmv_bytes(const Csr<U>& A, int k) {
     return A.nnz * (int64_t)(sizeof(U) + 4) + ((int64_t)A.nrows + 1) * 4 +
@@ -1140,6 +1229,30 @@ int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out,
   memset(s, 0, sizeof(*s));
   if (nrhs == 0) return CSGPU_OK;
   h->solver->solve_rhs(rhs, nrhs, x_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
+                         const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || nrhs < 0 || (nrhs > 0 && (!rhs || !x_out || !ground_ptr)) ||
+      (nrhs > 0 && ground_ptr[nrhs] > ground_ptr[0] && !ground_idx)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  if (nrhs == 0) return CSGPU_OK;
+  h->solver->solve_grounded(rhs, nrhs, ground_ptr, ground_idx, x_out, curr_out, s);
   if (s->not_converged > 0) {
     char buf[256];
     snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",

@@ -240,6 +240,11 @@ struct PcgParams {
   // component's solve separately, advanced.jl:186-312 -> core.jl:640).
   const int* comp_label = nullptr;
   int ncomp = 0;
+  // Per-column Dirichlet sets (device arrays: gptr[K+1] offsets into gidx, total = number of grounded entries of the
+  // batch): the solve runs on the system with those rows / columns removed, x = 0 there (mask_grounds_kernel).
+  const int* gptr = nullptr;
+  const int* gidx = nullptr;
+  int gtotal = 0;
 };
 
 // One captured chunk of `check_every` PCG iterations. Kernel arguments are baked in at capture time, so a graph is
@@ -396,7 +401,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
                                                      : spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
-  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product;
+  const bool grounded = pp.gptr && pp.gtotal > 0;
+  const int gm = grounded ? ceil_div(pp.gtotal, 256) : 1;
+  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product && !grounded;
   // lattice path: the residual update recomputes A p from the lattice form (one read of p, 5 matrix values per row)
   // instead of the product kernel writing A p and the update reading it back (2 x sizeof(T) per vector element)
   static const bool no_recompute = getenv("CSGPU_NO_RECOMPUTE") != nullptr;  // A/B knob
@@ -416,6 +423,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
   vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+  // (the fused r'z partials are unaffected by masking z afterwards: r is zero at the grounded entries)
+  if (grounded)
+    hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
+                       (const int*)nullptr);
   hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
                      (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
   // partial rows of the big SpMM-shaped launches are collapsed before the single-workgroup scalar kernels read them
@@ -515,10 +526,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       else CS_UPD_R(false, false);
 #undef CS_UPD_R
     }
+    if (grounded)  // the update put (A p) at the grounded rows into r: back to zero, in both precisions
+      hipLaunchKernelGGL((mask_grounds_kernel<T, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, r,
+                         MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done);
     if (nf > 0)
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    if (grounded)
+      hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
+                         (const int*)&S->all_done);
     {
       auto rz = collapsed(pa, spmv_gp, pac);
       // r'r partials (true-residual criterion): one row per workgroup of whichever kernel updated r
@@ -553,7 +570,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   gkey.atol = atol;
   gkey.matrix = (const void*)A.val.p;
   gkey.need_x = need_x ? 1 : 0;
-  gkey.nf = nf;
+  gkey.nf = nf + 100000 * pp.gtotal;  // (launch geometry of the mask kernels is baked into a captured chunk)
   auto chunk_graph = [&]() -> hipGraphExec_t {
     for (auto& g : W.graphs)
       if (g.first == gkey) return g.second;
@@ -614,6 +631,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       a.order = orderA;
       a.b = b;
       spmv_launch<T, K>(a, EPI_RESID, false, st);
+      if (grounded)  // rows of the grounded nodes are not equations of the reduced system
+        hipLaunchKernelGGL((mask_grounds_kernel<T, T, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, Ap, (T*)nullptr,
+                           (const int*)nullptr);
       hipLaunchKernelGGL((dot_kernel<T, K, true>), dim3(gv), dim3(256), 0, st, n, (const T*)Ap, (const T*)Ap, pa, b, b, pb);
       if (K == 1 && pp.comp_label && pp.ncomp > 1) {
         DBuf nrm = dalloc<double>((size_t)2 * pp.ncomp + 1);

@@ -21,7 +21,7 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
-    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
+    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
     "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
@@ -90,6 +90,7 @@ def _bind(L):
     L.csgpu_solve_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_grounded.argtypes = [vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
     L.csgpu_level_spmv_host.argtypes = [vp, i32, i32, vp, vp, i32, vp]
@@ -260,6 +261,28 @@ class Handle:
         st = Stats()
         _check(lib().csgpu_solve_rhs(self._p, B.ctypes.data, B.shape[1], X.ctypes.data, ctypes.byref(st)))
         return (X[:, 0] if one else X), st.as_dict()
+
+    def solve_grounded(self, rhs, grounds, want_currents=False):
+        """csgpu_solve_grounded: rhs (n, nrhs) or (n,), grounds = one list of 0-based node ids per column (x = 0
+        there). Returns (x, currents or None, stats)."""
+        rhs = np.asarray(rhs, dtype=self.dtype)
+        one = rhs.ndim == 1
+        B = np.asfortranarray(rhs.reshape(rhs.shape[0], -1))
+        if one:
+            grounds = [grounds] if (len(grounds) == 0 or np.isscalar(grounds[0])) else grounds
+        assert len(grounds) == B.shape[1]
+        gptr = np.zeros(B.shape[1] + 1, dtype=np.int64)
+        gptr[1:] = np.cumsum([len(g) for g in grounds])
+        gidx = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int64) for g in grounds])
+                                    if gptr[-1] > 0 else np.zeros(1, dtype=np.int64))
+        X = np.zeros_like(B, order="F")
+        C = np.zeros_like(B, order="F") if want_currents else None
+        st = Stats()
+        _check(lib().csgpu_solve_grounded(self._p, B.ctypes.data, B.shape[1], gptr.ctypes.data, gidx.ctypes.data,
+                                          X.ctypes.data, C.ctypes.data if C is not None else None, ctypes.byref(st)))
+        if one:
+            return X[:, 0], (C[:, 0] if C is not None else None), st.as_dict()
+        return X, C, st.as_dict()
 
     def spmv_bench(self, k=1, reps=20):
         ms = ctypes.c_double(0)

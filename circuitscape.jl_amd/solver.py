@@ -218,56 +218,74 @@ def raster_advanced_on_device(cellmap, source_map, ground_map, flags, solver, fo
             _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata))
 
 
-def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, avg_res=False):
+def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, avg_res=False, stats=None):
     """One-to-all / all-to-one (src/raster/onetoall.jl:13-162) for a raster without polygons and with single-cell focal
-    points, every solve with graph layer, PCG and current map on the device (raster_advanced_on_device): per focal
-    point n, one-to-all injects unit current at n and ties every other focal cell directly to ground (policy rmvgnd);
-    all-to-one grounds n directly and injects unit current at every other focal cell (policy rmvsrc).
-    Returns (res, cum, points) like onetoall_kernel."""
+    points, with ONE graph build and ONE AMG setup for all focal points (scope rows N2 + N4): per focal point n,
+    one-to-all injects unit current at n and ties every other focal cell directly to ground; all-to-one grounds n and
+    injects unit current at every other focal cell. The reference deletes the grounded rows / columns and factorises
+    again per point (advanced.jl:282-288, 307-312); here the points are columns of csgpu_solve_grounded -- same reduced
+    systems, batches of `solver.bs` points per PCG, hierarchy of the ungrounded Laplacian -- and the node currents come
+    from the device as well. Components without a source or without a ground are skipped like advanced_kernel does
+    (advanced.jl:186-191). Returns (res, cum, points) like the reference's onetoall_kernel."""
     gmap = np.asarray(cellmap, dtype=np.float64)
     rows = np.asarray(points_rc[0], dtype=np.int64) - 1
     cols = np.asarray(points_rc[1], dtype=np.int64) - 1
     ids = [int(v) for v in points_rc[2]]
     assert len(ids) == len(set(ids)), "single-cell focal points only (regions need polygon merging on the host path)"
     of = flags.outputflags
-    point_map = np.zeros(gmap.shape, dtype=np.int64)
-    point_map[rows, cols] = ids
     res = np.zeros(len(ids))
     cum = initialize_cum_maps(gmap, of.write_max_cur_maps)
     per_point = {}
-    raw = OutputFlags()                       # raw maps from the solve; write_grid options applied once, below
-    for i, n in enumerate(ids):
-        if point_map.sum() == n:
+    want_cur = of.write_cur_maps or of.write_cum_cur_map_only
+    try:
+        with lib.raster_setup(gmap, _opts_for(solver), four_neighbors=four_neighbors, avg_resistances=avg_res,
+                              reg=False) as h:
+            nodemap = h.raster_nodemap()
+            n = h.info["n"]
+            node = nodemap[rows, cols].astype(np.int64) - 1          # -1: the focal cell is NODATA
+            comp, _ = h.components()
+            B = np.zeros((n, len(ids)))
+            grounds, solvable = [], []
+            for i in range(len(ids)):
+                others = [int(node[k]) for k in range(len(ids)) if k != i and node[k] >= 0]
+                if flags.is_onetoall:
+                    src, gnd = ([int(node[i])] if node[i] >= 0 else []), others
+                else:
+                    src, gnd = others, ([int(node[i])] if node[i] >= 0 else [])
+                gcomps = set(int(comp[g]) for g in gnd)
+                src = [q for q in src if int(comp[q]) in gcomps]      # a component without a ground is not solved
+                B[src, i] = 1.0
+                grounds.append(gnd)
+                solvable.append(len(src) > 0)
+            X, C, st = h.solve_grounded(B, grounds, want_currents=want_cur)
+            if stats is not None:
+                stats.update(st)
+    except lib.CsgpuError as e:
+        if e.code == lib.CSGPU_NOT_CONVERGED:
+            _raise_not_converged(e)
+        raise
+    for i, nid in enumerate(ids):
+        if len(ids) == 1:
             res[i] = -1
             continue
-        me = point_map == n
-        others = (point_map != 0) & ~me
-        if flags.is_onetoall:
-            source_map = np.where(me, 1.0, 0.0)
-            ground_map = np.where(others, np.inf, 0.0)
-            policy = "rmvgnd"
-        else:
-            source_map = np.where(others, 1.0, 0.0)
-            ground_map = np.where(me, np.inf, 0.0)
-            policy = "rmvsrc"
-        sub = Flags(is_raster=True, outputflags=raw, policy=policy)
-        vol, cur = raster_advanced_on_device(gmap, source_map, ground_map, sub, solver, four_neighbors, avg_res)
-        solved = bool(np.any(cur != 0))
+        vol = _scatter(X[:, i], nodemap)
         if flags.is_onetoall:
             v = vol[rows[i], cols[i]]
-            res[i] = v if (solved and v != 0) else -1
+            res[i] = v if (solvable[i] and v != 0) else -1
         else:
-            res[i] = 0 if solved else -1
+            res[i] = 0 if solvable[i] else -1
         maps = {}
         if of.write_volt_maps:
             maps["voltmap"] = _process_grid(vol, gmap, False, of.set_null_voltages_to_nodata)
-        if of.write_cur_maps:
-            maps["curmap"] = _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
+        if want_cur:
+            cur = _scatter(C[:, i], nodemap)
+            if of.write_cur_maps:
+                maps["curmap"] = _process_grid(cur, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
             cum.cum_curr += cur
             if of.write_max_cur_maps:
                 cum.max_curr = np.maximum(cum.max_curr, cur)
-        per_point[n] = maps
-    if of.write_cur_maps or of.write_cum_cur_map_only:
+        per_point[nid] = maps
+    if want_cur:
         cum.cum_curr = _process_grid(cum.cum_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)
         if of.write_max_cur_maps:
             cum.max_curr = _process_grid(cum.max_curr, gmap, of.log_transform_maps, of.set_null_currents_to_nodata)

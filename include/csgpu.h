@@ -18,6 +18,9 @@
  *                              RHS -1/+1 (core.jl:224-226), solve (:229), grounding shift and resistance
  *                              (:231-232), focal-voltage gather for the shortcut (update_voltmatrix! :685-703);
  *                              batched like the direct-solver driver (core.jl:448-493)
+ *   csgpu_solve_grounded   <-> multiple_solver with infinite grounds (src/raster/advanced.jl:274-305) as the one-to-all /
+ *                              all-to-one drivers call it per focal point (src/raster/onetoall.jl:106-151): many
+ *                              ground sets, one hierarchy
  *   csgpu_solve_pairs_currents <-> the same plus postprocess() -> write_cur_maps -> _create_current_maps
  *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
  *   csgpu_multi_setup, csgpu_multi_raster_setup, csgpu_multi_solve_pairs, csgpu_multi_free
@@ -236,6 +239,19 @@ int csgpu_solve_pairs_currents(csgpu_handle* h, const int64_t* src, const int64_
 
 /* General right-hand sides: rhs and x_out are host column-major n x nrhs arrays of the handle's value type. */
 int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats);
+
+/* Scope row N2 -- right-hand sides whose systems differ only in WHICH nodes are tied directly to ground, solved on ONE
+ * hierarchy. The reference's one-to-all / all-to-one drivers call multiple_solver once per focal point
+ * (src/raster/onetoall.jl:106-151); it deletes the rows / columns of the infinite grounds and runs a fresh
+ * smoothed_aggregation for every call (src/raster/advanced.jl:282-288, 307-312). Here column c of the batch keeps
+ * x = 0 at the nodes ground_idx[ground_ptr[c] .. ground_ptr[c+1]) (0-based node ids; rhs entries there are ignored),
+ * which is the same reduced system, preconditioned by the hierarchy of the matrix the handle was set up with.
+ *   rhs, x_out:  host column-major n x nrhs arrays of the handle's value type (x_out = 0 at the grounded nodes)
+ *   curr_out:    optional (may be NULL) n x nrhs node currents of each solution, computed like
+ *                csgpu_solve_pairs_currents on the handle's matrix (a grounded node reports the current it sinks)
+ * The residual check of core.jl:640 is evaluated on the rows of the reduced system. */
+int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
+                         const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats);
 
 /* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
  * library's stream; returns the average milliseconds per launch. Used by bench.py for the roofline line. */

@@ -374,3 +374,50 @@ def check_lattice_transfer_products(L, shapes=((45, 45), (64, 70), (100, 31), (3
                     h.close()
             if four:
                 break  # one shape is enough for the 4-neighbour variant
+
+
+def check_grounded_solves(L, shape=(50, 46), npts=9, batch=8, tol=5e-6):
+    """csgpu_solve_grounded: one-to-all and all-to-one right-hand sides whose systems differ only in which nodes are
+    grounded, solved as columns of one batch on the hierarchy of the ungrounded Laplacian, against a sparse direct solve
+    of every reduced system (rows / columns of the grounded nodes deleted, src/raster/advanced.jl:282-288); node currents
+    against the host restatement of get_node_currents. Lattice and CSR product, fp64 and fp32 preconditioner."""
+    import scipy.sparse.linalg as spla
+    from oracle import refmaps
+    rng = np.random.default_rng(1)
+    R, C = shape
+    g = np.exp(rng.standard_normal((R, C)))
+    G = rg.raster_laplacian_from_conductance(g).tocsc()
+    n = R * C
+    pts = rng.choice(n, size=npts, replace=False)
+
+    def direct(B, grounds):
+        X = np.zeros_like(B)
+        for c in range(B.shape[1]):
+            keep = np.setdiff1d(np.arange(n), grounds[c])
+            X[keep, c] = spla.spsolve(G[keep][:, keep].tocsc(), B[keep, c])
+        return X
+
+    B1 = np.zeros((n, npts))
+    g1 = []
+    for c, p in enumerate(pts):
+        B1[p, c] = 1.0
+        g1.append([int(q) for q in pts if q != p])
+    B2 = np.zeros((n, npts))
+    g2 = []
+    for c, p in enumerate(pts):
+        B2[[q for q in pts if q != p], c] = 1.0
+        g2.append([int(p)])
+    X1d, X2d = direct(B1, g1), direct(B2, g2)
+    for pb in (0, 4):
+        for stencil in (0, -1):
+            h = L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, stencil=stencil), reg=False)
+            X1, C1, st1 = h.solve_grounded(B1, g1, want_currents=True)
+            X2, _, st2 = h.solve_grounded(B2, g2)
+            h.close()
+            assert st1["not_converged"] == 0 and st2["not_converged"] == 0 and st1["max_relres"] < 1e-4
+            for c in range(npts):
+                assert np.all(X1[g1[c], c] == 0) and np.all(X2[g2[c], c] == 0)
+            assert np.max(np.abs(X1 - X1d)) < tol * np.max(np.abs(X1d)), (pb, stencil)
+            assert np.max(np.abs(X2 - X2d)) < tol * np.max(np.abs(X2d)), (pb, stencil)
+            ref = refmaps.get_node_currents(G.tocsr(), X1[:, 0])
+            assert np.max(np.abs(C1[:, 0] - ref)) < 1e-9 * max(1.0, ref.max())

@@ -942,3 +942,9 @@ def test_multi_device_handle_matches_single_device(emu_lib, oracle):
     A = oracle.regularize(rg.raster_laplacian_from_conductance(g))
     Ro, _, _ = oracle.OracleAMG(A).solve_pairs(d["src"], d["dst"], rtol=1e-12, atol=0.0, criterion=1)
     assert np.max(np.abs(np.array(d["R"]) - Ro) / Ro) < 1e-6
+
+
+def test_grounded_solves_share_one_hierarchy(emu_lib):
+    """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
+    from helpers import check_grounded_solves
+    check_grounded_solves(emu_lib)

@@ -264,3 +264,10 @@ def test_lattice_transfer_products(gpu_lib):
     from helpers import check_lattice_transfer_products
     check_lattice_transfer_products(gpu_lib)
     check_lattice_transfer_products(gpu_lib, shapes=((1000, 700), (1201, 334)), ks=(16,), pbs=(4, 0))
+
+
+def test_grounded_solves_share_one_hierarchy(gpu_lib):
+    """scope row N2: csgpu_solve_grounded on the device (see the emulator twin), also with a full batch of 16 columns."""
+    from helpers import check_grounded_solves
+    check_grounded_solves(gpu_lib)
+    check_grounded_solves(gpu_lib, shape=(300, 211), npts=16, batch=16)
