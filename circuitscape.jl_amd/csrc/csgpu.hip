@@ -332,6 +332,116 @@ struct Solver : ISolver {
     finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), n == ncells ? (int)R : -1);
   }
 
+  // csgpu_raster_setup_poly: raster with short-circuit polygons, graph built on the device (raster.h, second half)
+  void setup_from_raster_poly(const void* cond, const int32_t* polymap, int64_t R, int64_t C, int four, int avg_res,
+                              int reg) {
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t ncells = R * C;
+    const int gc = grid_for(ncells);
+    DBuf dcond((size_t)ncells * sizeof(T)), dpoly = dalloc<int>((size_t)ncells);
+    CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemcpyAsync(dpoly.p, polymap, (size_t)ncells * sizeof(int), hipMemcpyHostToDevice, st));
+    DBuf dmax = dalloc<int>(1);
+    CS_HIP(hipMemsetAsync(dmax.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(poly_max_kernel, dim3(gc), dim3(256), 0, st, ncells, (const int*)dpoly.p, dptr<int>(dmax));
+    const int maxid = read_int(dptr<int>(dmax), st);
+    CS_REQUIRE(maxid < kMaxPolyId, CSGPU_BAD_ARGS, "polygon ids must be below 2^26");
+    // 1. representative cell of every polygon, 2. labels, flags, node ids
+    DBuf rep = dalloc<int>((size_t)maxid + 2), present = dalloc<int>((size_t)maxid + 2);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(maxid + 2)), dim3(256), 0, st, dptr<int>(rep), (int64_t)maxid + 2,
+                       0x7fffffff);
+    hipLaunchKernelGGL((poly_rep_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       (const int*)dpoly.p, dptr<int>(rep));
+    DBuf label = dalloc<int>((size_t)ncells), flag = dalloc<int>((size_t)ncells + 1), total = dalloc<int>(1);
+    CS_HIP(hipMemsetAsync(flag.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+    hipLaunchKernelGGL((poly_label_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       (const int*)dpoly.p, (const int*)dptr<int>(rep), dptr<int>(label), dptr<int>(flag));
+    exclusive_scan_i32(dptr<int>(flag), ncells + 1, st, dptr<int>(total));
+    n = read_int(dptr<int>(total), st);
+    CS_REQUIRE(n > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
+    hipLaunchKernelGGL(poly_present_kernel, dim3(grid_for(maxid + 1)), dim3(256), 0, st, maxid, (const int*)dptr<int>(rep),
+                       dptr<int>(present));
+    CS_HIP(hipMemsetAsync(dptr<int>(present) + maxid + 1, 0, sizeof(int), st));
+    exclusive_scan_i32(dptr<int>(present), (int64_t)maxid + 2, st, dptr<int>(total));
+    const int npoly = read_int(dptr<int>(total), st);  // polygons that own a node; `present` now holds their dense index
+    raster_rows = R;
+    raster_cols = C;
+    nodemap.alloc((size_t)ncells * sizeof(int));
+    DBuf node = dalloc<int>((size_t)ncells), drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int));
+    DBuf node_poly = dalloc<int>((size_t)n), poly_node = dalloc<int>((size_t)std::max(npoly, 1));
+    hipLaunchKernelGGL(poly_node_kernel, dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const int*)dpoly.p,
+                       (const int*)dptr<int>(rep), (const int*)dptr<int>(label), (const int*)dptr<int>(flag),
+                       (const int*)dptr<int>(present), dptr<int>(node), dptr<int>(nodemap), dptr<int>(drow), dptr<int>(dcol),
+                       dptr<int>(node_poly), dptr<int>(poly_node));
+    // 3./4. row lengths: ordinary cells directly, polygon nodes from their sorted candidate lists
+    Csr<T> A;
+    A.nrows = A.ncols = (int)n;
+    A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+    CS_HIP(hipMemsetAsync(A.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+    hipLaunchKernelGGL((poly_cell_rows_kernel<T, false>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       (const T*)dptr<T>(dcond), (const int*)dptr<int>(node), (const int*)dptr<int>(node_poly),
+                       (const int*)dptr<int>(label), A.rp(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+    DBuf cnt = dalloc<int>((size_t)npoly + 1), padded = dalloc<int>((size_t)npoly + 2), seg = dalloc<int64_t>((size_t)npoly + 2);
+    DBuf ckey, cval;
+    std::vector<int64_t> hseg((size_t)npoly + 1, 0);
+    if (npoly > 0) {
+      CS_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)npoly + 1) * sizeof(int), st));
+      hipLaunchKernelGGL((poly_candidates_kernel<T, true>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                         (const T*)dptr<T>(dcond), (const int*)dptr<int>(node), (const int*)dptr<int>(node_poly),
+                         (const int*)dptr<int>(label), dptr<int>(cnt), (const int64_t*)nullptr,
+                         (unsigned long long*)nullptr, (double*)nullptr);
+      hipLaunchKernelGGL(poly_pad_kernel, dim3(grid_for(npoly + 1)), dim3(256), 0, st, npoly, (const int*)dptr<int>(cnt),
+                         dptr<int>(padded));
+      // offsets of the padded segments (64-bit on the host: a handful of integers)
+      std::vector<int> hpad((size_t)npoly + 1);
+      CS_HIP(hipMemcpyAsync(hpad.data(), padded.p, ((size_t)npoly + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      for (int p = 0; p < npoly; ++p) hseg[p + 1] = hseg[p] + hpad[p];
+      CS_HIP(hipMemcpyAsync(seg.p, hseg.data(), ((size_t)npoly + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      const int64_t tot = std::max<int64_t>(hseg[npoly], 1);
+      ckey.alloc((size_t)tot * sizeof(unsigned long long));
+      cval.alloc((size_t)tot * sizeof(double));
+      CS_HIP(hipMemsetAsync(ckey.p, 0xff, (size_t)tot * sizeof(unsigned long long), st));  // padding sorts last
+      CS_HIP(hipMemsetAsync(cval.p, 0, (size_t)tot * sizeof(double), st));
+      CS_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)npoly + 1) * sizeof(int), st));
+      hipLaunchKernelGGL((poly_candidates_kernel<T, false>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                         (const T*)dptr<T>(dcond), (const int*)dptr<int>(node), (const int*)dptr<int>(node_poly),
+                         (const int*)dptr<int>(label), dptr<int>(cnt), (const int64_t*)dptr<int64_t>(seg),
+                         dptr<unsigned long long>(ckey), dptr<double>(cval));
+      hipLaunchKernelGGL(poly_sort_kernel, dim3(npoly), dim3(256), 0, st, (const int64_t*)dptr<int64_t>(seg),
+                         dptr<unsigned long long>(ckey), dptr<double>(cval));
+      hipLaunchKernelGGL((poly_rows_kernel<T, true>), dim3(npoly), dim3(64), 0, st, (const int64_t*)dptr<int64_t>(seg),
+                         (const int*)dptr<int>(cnt), (const unsigned long long*)dptr<unsigned long long>(ckey),
+                         (const double*)dptr<double>(cval), (const int*)dptr<int>(poly_node), A.rp(), (const int*)nullptr,
+                         (int*)nullptr, (T*)nullptr);
+    }
+    exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
+    nnz = read_int(dptr<int>(total), st);
+    A.nnz = nnz;
+    A.col.alloc((size_t)nnz * sizeof(int));
+    A.val.alloc((size_t)nnz * sizeof(T));
+    hipLaunchKernelGGL((poly_cell_rows_kernel<T, true>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       (const T*)dptr<T>(dcond), (const int*)dptr<int>(node), (const int*)dptr<int>(node_poly),
+                       (const int*)dptr<int>(label), (int*)nullptr, (const int*)A.rp(), A.ci(), A.va());
+    if (npoly > 0)
+      hipLaunchKernelGGL((poly_rows_kernel<T, false>), dim3(npoly), dim3(64), 0, st, (const int64_t*)dptr<int64_t>(seg),
+                         (const int*)dptr<int>(cnt), (const unsigned long long*)dptr<unsigned long long>(ckey),
+                         (const double*)dptr<double>(cval), (const int*)dptr<int>(poly_node), (int*)nullptr,
+                         (const int*)A.rp(), A.ci(), A.va());
+    if (reg) {
+      const int g = grid_for(nnz);
+      DBuf part = dalloc<double>(g);
+      hipLaunchKernelGGL((dot_kernel<T, 1, false>), dim3(g), dim3(256), 0, st, nnz, (const T*)A.va(), (const T*)A.va(),
+                         dptr<double>(part), (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+      hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(g), dim3(256), 0, st, nnz, A.va(), dptr<double>(part), g,
+                         (double)std::numeric_limits<T>::epsilon());
+    }
+    check_launch("raster build (polygons)");
+    CS_HIP(hipStreamSynchronize(st));
+    upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), -1);
+  }
+
   void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
@@ -1103,6 +1213,45 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
     auto* s = new csgpu::Solver<float, float>(o);
     h->solver.reset(s);
     s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
+  }
+  *out = h.release();
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nrows, int64_t ncols, int val_bytes,
+                            int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
+                            csgpu_handle** out) {
+  if (!polymap)
+    return csgpu_raster_setup_grounded(cond, nullptr, nrows, ncols, val_bytes, four_neighbors, avg_resistances, reg, opts,
+                                       out);
+  CS_API_BEGIN
+  if (!cond || !out || nrows <= 0 || ncols <= 0) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  int rc = check_common(nrows * ncols, 0, val_bytes, opts);
+  if (rc) return rc;
+  if (nrows * ncols * 9 >= ((int64_t)1 << 31)) {
+    g_last_error = "raster too large for int32 device indexing";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_opts o;
+  if (opts) o = *opts; else csgpu_default_opts(&o);
+  o.node_row = o.node_col = nullptr;
+  std::unique_ptr<csgpu_handle> h(new csgpu_handle());
+  if (val_bytes == 8 && o.precond_bytes == 4) {
+    auto* s = new csgpu::Solver<double, float>(o);
+    h->solver.reset(s);
+    s->setup_from_raster_poly(cond, polymap, nrows, ncols, four_neighbors, avg_resistances, reg);
+  } else if (val_bytes == 8) {
+    auto* s = new csgpu::Solver<double, double>(o);
+    h->solver.reset(s);
+    s->setup_from_raster_poly(cond, polymap, nrows, ncols, four_neighbors, avg_resistances, reg);
+  } else {
+    auto* s = new csgpu::Solver<float, float>(o);
+    h->solver.reset(s);
+    s->setup_from_raster_poly(cond, polymap, nrows, ncols, four_neighbors, avg_resistances, reg);
   }
   *out = h.release();
   return CSGPU_OK;

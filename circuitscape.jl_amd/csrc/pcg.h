@@ -65,7 +65,13 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   const int n = L.A.nrows;
   const bool last = (l + 1 == (int)H.levels.size());
   const int gv = grid_for((int64_t)n * K);
-  const int nu_pre = l == 0 ? nu_pre0 : nu_coarse, nu_post = l == 0 ? nu_post0 : nu_coarse;
+  // Level 1 gets nu_coarse sweeps, the levels below it one more: they hold 1/81 of the fine level's work and the extra
+  // sweep saves an iteration of the slowest column (measured at 10000^2, profiles/r2_sweeps_per_level.json: level 1 with
+  // one sweep costs 2 iterations whatever the deeper levels do). Experiment knobs: CSGPU_NU_L1, CSGPU_NU_DEEP.
+  static const int nu_l1 = getenv("CSGPU_NU_L1") ? atoi(getenv("CSGPU_NU_L1")) : 0;
+  static const int nu_deep = getenv("CSGPU_NU_DEEP") ? atoi(getenv("CSGPU_NU_DEEP")) : 0;
+  const int nu_lvl = l == 1 ? (nu_l1 > 0 ? nu_l1 : nu_coarse) : (nu_deep > 0 ? nu_deep : nu_coarse + 1);
+  const int nu_pre = l == 0 ? nu_pre0 : nu_lvl, nu_post = l == 0 ? nu_post0 : nu_lvl;
   const bool want_dot = fuse && fuse->dotw && l == 0;
   const int* skip = fuse ? fuse->skip : nullptr;
   if (last && H.coarse_dense) {

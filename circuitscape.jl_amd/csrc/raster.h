@@ -282,4 +282,287 @@ __global__ __launch_bounds__(256) void add_scalar_kernel(int64_t nnz, T* __restr
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256) va[k] += shift;
 }
 
+
+// =====================================================================================================================
+// Rasters WITH short-circuit polygons (construct_node_map with a polymap, src/raster/pairwise.jl:276-301): every cell
+// of a polygon -- NODATA cells included, as in the reference -- shares the node of the polygon's first valid cell
+// (column-major order); parallel edges created by the merge are summed (sparse(I, J, V) + a + a', pairwise.jl:357-361)
+// and edges inside a polygon vanish (laplacian! zeroes the stored diagonal, core.jl:608-634).
+//
+// Device scheme. k = column-major cell index j*R + i.
+//   1. rep[p]   = min k over the valid cells of polygon p (atomicMin)            -> the polygon's representative cell
+//   2. label[k] = rep[poly] for polygon cells, k for other valid cells, -1 otherwise; flag[k] = 1 where label[k] == k
+//      node ids = exclusive scan of the flags (= relabel! of the reference: order of the surviving original ids)
+//   3. rows of ordinary cells: <= 8 neighbours, merged by a tiny insertion sort (several neighbours may be cells of the
+//      same polygon), written by one thread per cell like raster_fill_kernel
+//   4. rows of polygon nodes: every (member cell, outside neighbour) pair becomes a candidate keyed by
+//      (column, lower cell index, direction); a segmented bitonic sort (one workgroup per polygon) orders them, runs of
+//      equal columns are summed in key order. Both rows of a coupling sum the same cell pairs in the same canonical
+//      order, so the matrix is bit-symmetric.
+// Only positive polygon ids are polygons; ids must be < 2^26.
+static const int kMaxPolyId = 1 << 26;
+
+__global__ __launch_bounds__(256) void poly_max_kernel(int64_t ncells, const int* __restrict__ poly, int* __restrict__ out) {
+  int m = 0;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * 256) m = max(m, poly[c]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void poly_rep_kernel(int R, int C, const T* __restrict__ cond,
+                                                       const int* __restrict__ poly, int* __restrict__ rep) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const int i = (int)(k % R), j = (int)(k / R);
+    const int p = poly[(size_t)i * C + j];
+    if (p > 0 && cond[(size_t)i * C + j] > T(0)) atomicMin(&rep[p], (int)k);
+  }
+}
+
+// label / flag per cell (column-major), polygon flags for the dense polygon numbering
+template <class T>
+__global__ __launch_bounds__(256) void poly_label_kernel(int R, int C, const T* __restrict__ cond,
+                                                         const int* __restrict__ poly, const int* __restrict__ rep,
+                                                         int* __restrict__ label, int* __restrict__ flag) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const int i = (int)(k % R), j = (int)(k / R);
+    const int p = poly[(size_t)i * C + j];
+    const bool valid = cond[(size_t)i * C + j] > T(0);
+    const bool merged = p > 0 && rep[p] != 0x7fffffff;
+    const int lab = merged ? rep[p] : (valid ? (int)k : -1);
+    label[k] = lab;
+    flag[k] = lab == (int)k ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void poly_present_kernel(int npolyids, const int* __restrict__ rep, int* __restrict__ present) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p <= npolyids; p += gridDim.x * 256)
+    present[p] = (p > 0 && rep[p] != 0x7fffffff) ? 1 : 0;
+}
+
+// node of every cell (column-major, -1 = none), node map for the host (row-major, 1-based), node coordinates, and the
+// polygon (dense index, -1 = ordinary) of every NODE
+__global__ __launch_bounds__(256) void poly_node_kernel(int R, int C, const int* __restrict__ poly,
+                                                        const int* __restrict__ rep, const int* __restrict__ label,
+                                                        const int* __restrict__ scan, const int* __restrict__ pdense,
+                                                        int* __restrict__ node, int* __restrict__ nodemap,
+                                                        int* __restrict__ nrow, int* __restrict__ ncol,
+                                                        int* __restrict__ node_poly, int* __restrict__ poly_node) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const int i = (int)(k % R), j = (int)(k / R);
+    const int lab = label[k];
+    const int nd = lab >= 0 ? scan[lab] : -1;
+    node[k] = nd;
+    nodemap[(size_t)i * C + j] = nd + 1;
+    if (lab == (int)k) {  // this cell carries the node: its coordinates seed the aggregation
+      nrow[nd] = i;
+      ncol[nd] = j;
+      const int p = poly[(size_t)i * C + j];
+      const bool merged = p > 0 && rep[p] != 0x7fffffff;
+      node_poly[nd] = merged ? pdense[p] : -1;
+      if (merged) poly_node[pdense[p]] = nd;
+    }
+  }
+}
+
+// the (up to 8) neighbours of cell (i, j) in ascending column-major order; calls f(ii, jj, diagonal)
+template <class F>
+__device__ __forceinline__ void for_each_neighbour(int i, int j, int R, int C, int four, F f) {
+  for (int dj = -1; dj <= 1; ++dj) {
+    const int jj = j + dj;
+    if (jj < 0 || jj >= C) continue;
+    for (int di = -1; di <= 1; ++di) {
+      const int ii = i + di;
+      if (ii < 0 || ii >= R || (di == 0 && dj == 0)) continue;
+      const bool diag = di != 0 && dj != 0;
+      if (diag && four) continue;
+      f(ii, jj, diag);
+    }
+  }
+}
+
+// Ordinary cells: merged row (columns ascending, duplicates summed in neighbour order). FILL = false: row length only.
+template <class T, bool FILL>
+__global__ __launch_bounds__(256) void poly_cell_rows_kernel(int R, int C, int four, int avg_res,
+                                                             const T* __restrict__ cond, const int* __restrict__ node,
+                                                             const int* __restrict__ node_poly, const int* __restrict__ label,
+                                                             int* __restrict__ rowlen, const int* __restrict__ rp,
+                                                             int* __restrict__ ci, T* __restrict__ va) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    if (label[k] != (int)k) continue;          // not a node-carrying cell
+    const int me = node[k];
+    if (node_poly[me] >= 0) continue;          // polygon rows are assembled from the candidate lists
+    const int i = (int)(k % R), j = (int)(k / R);
+    const double g0 = (double)cond[(size_t)i * C + j];
+    int cols[8];
+    double w[8];
+    int m = 0;
+    for_each_neighbour(i, j, R, C, four, [&](int ii, int jj, bool diag) {
+      const int nb = node[(int64_t)jj * R + ii];
+      if (nb < 0) return;
+      const double wt = raster_edge(g0, (double)cond[(size_t)ii * C + jj], diag, avg_res != 0);
+      int q = 0;
+      while (q < m && cols[q] != nb) ++q;
+      if (q < m) {
+        w[q] += wt;  // another cell of the same polygon: neighbour order = ascending cell index
+      } else {
+        cols[m] = nb;
+        w[m] = wt;
+        ++m;
+      }
+    });
+    if (!FILL) {
+      rowlen[me] = m + 1;
+      continue;
+    }
+    // insertion sort by column, diagonal inserted in place
+    for (int a = 1; a < m; ++a) {
+      const int c = cols[a];
+      const double x = w[a];
+      int b = a - 1;
+      while (b >= 0 && cols[b] > c) {
+        cols[b + 1] = cols[b];
+        w[b + 1] = w[b];
+        --b;
+      }
+      cols[b + 1] = c;
+      w[b + 1] = x;
+    }
+    double deg = 0.0;
+    for (int a = 0; a < m; ++a) deg += w[a];
+    int o = rp[me];
+    bool dput = false;
+    for (int a = 0; a < m; ++a) {
+      if (!dput && cols[a] > me) {
+        ci[o] = me;
+        va[o++] = (T)deg;
+        dput = true;
+      }
+      ci[o] = cols[a];
+      va[o++] = (T)(-w[a]);
+    }
+    if (!dput) {
+      ci[o] = me;
+      va[o] = (T)deg;
+    }
+  }
+}
+
+// Polygon member cells: one candidate per (member, outside neighbour) pair. COUNT: cnt[polygon] += 1; else fill at the
+// polygon's cursor. key = column << 33 | lower cell index << 2 | direction (0: +1, 1: +R-1, 2: +R, 3: +R+1).
+template <class T, bool COUNT>
+__global__ __launch_bounds__(256) void poly_candidates_kernel(int R, int C, int four, int avg_res,
+                                                              const T* __restrict__ cond, const int* __restrict__ node,
+                                                              const int* __restrict__ node_poly,
+                                                              const int* __restrict__ label, int* __restrict__ cnt,
+                                                              const int64_t* __restrict__ seg_off,
+                                                              unsigned long long* __restrict__ key,
+                                                              double* __restrict__ val) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const int me = node[k];
+    if (me < 0) continue;
+    const int pd = node_poly[me];
+    if (pd < 0) continue;
+    const int i = (int)(k % R), j = (int)(k / R);
+    const double g0 = (double)cond[(size_t)i * C + j];
+    for_each_neighbour(i, j, R, C, four, [&](int ii, int jj, bool diag) {
+      const int64_t kn = (int64_t)jj * R + ii;
+      const int nb = node[kn];
+      if (nb < 0 || nb == me) return;
+      const int pos = atomicAdd(&cnt[pd], 1);
+      if (COUNT) return;
+      const int64_t lo = kn < k ? kn : k, d = (kn < k ? k - kn : kn - k);
+      const unsigned long long dir = d == 1 ? 0ull : d == (int64_t)R - 1 ? 1ull : d == (int64_t)R ? 2ull : 3ull;
+      key[seg_off[pd] + pos] = ((unsigned long long)nb << 33) | ((unsigned long long)lo << 2) | dir;
+      val[seg_off[pd] + pos] = raster_edge(g0, (double)cond[(size_t)ii * C + jj], diag, avg_res != 0);
+    });
+  }
+}
+
+// padded (power of two) segment lengths
+__global__ __launch_bounds__(256) void poly_pad_kernel(int npoly, const int* __restrict__ cnt, int* __restrict__ padded) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p <= npoly; p += gridDim.x * 256) {
+    int L = 1;
+    const int c = p < npoly ? cnt[p] : 0;
+    while (L < c) L <<= 1;
+    padded[p] = p < npoly ? (c > 0 ? L : 0) : 0;
+  }
+}
+
+// one workgroup per polygon: bitonic sort of its (padded) segment by key
+__global__ __launch_bounds__(256) void poly_sort_kernel(const int64_t* __restrict__ seg_off, unsigned long long* __restrict__ key,
+                                                        double* __restrict__ val) {
+  const int64_t base = seg_off[blockIdx.x];
+  const int64_t L = seg_off[blockIdx.x + 1] - base;
+  for (int64_t k2 = 2; k2 <= L; k2 <<= 1)
+    for (int64_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      for (int64_t e = threadIdx.x; e < L; e += 256) {
+        const int64_t f = e ^ j2;
+        if (f > e) {
+          const bool up = (e & k2) == 0;
+          const unsigned long long a = key[base + e], b = key[base + f];
+          if ((a > b) == up) {
+            key[base + e] = b;
+            key[base + f] = a;
+            const double t = val[base + e];
+            val[base + e] = val[base + f];
+            val[base + f] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// unique columns per polygon (COUNT) / write the merged row (one workgroup per polygon, thread 0 walks the sorted
+// segment: perimeter-sized, and the order of the additions is the key order)
+template <class T, bool COUNT>
+__global__ __launch_bounds__(64) void poly_rows_kernel(const int64_t* __restrict__ seg_off, const int* __restrict__ cnt,
+                                                       const unsigned long long* __restrict__ key,
+                                                       const double* __restrict__ val, const int* __restrict__ poly_node,
+                                                       int* __restrict__ rowlen, const int* __restrict__ rp,
+                                                       int* __restrict__ ci, T* __restrict__ va) {
+  if (threadIdx.x != 0) return;
+  const int pd = blockIdx.x;
+  const int64_t base = seg_off[pd];
+  const int m = cnt[pd];
+  const int me = poly_node[pd];
+  if (COUNT) {
+    int u = 0;
+    for (int e = 0; e < m; ++e)
+      if (e == 0 || (key[base + e] >> 33) != (key[base + e - 1] >> 33)) ++u;
+    rowlen[me] = u + 1;
+    return;
+  }
+  int o = rp[me];
+  bool dput = false;
+  int e = 0;
+  double degree = 0.0;
+  while (e < m) {
+    const int col = (int)(key[base + e] >> 33);
+    double s = 0.0;
+    while (e < m && (int)(key[base + e] >> 33) == col) s += val[base + e++];
+    if (!dput && col > me) {
+      ci[o] = me;
+      va[o++] = T(0);  // degree written after the walk
+      dput = true;
+    }
+    ci[o] = col;
+    va[o++] = (T)(-s);
+    degree += s;
+  }
+  if (!dput) {
+    ci[o] = me;
+    va[o] = T(0);
+  }
+  // diagonal = sum of the merged off-diagonal weights (laplacian!: sum_off_diag)
+  for (int q = rp[me]; q < rp[me + 1]; ++q)
+    if (ci[q] == me) va[q] = (T)degree;
+}
+
 }  // namespace csgpu

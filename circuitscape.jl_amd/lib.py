@@ -97,6 +97,7 @@ def _bind(L):
     L.csgpu_raster_nodemap.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.csgpu_components.argtypes = [vp, vp, ctypes.POINTER(i64)]
     L.csgpu_raster_setup_grounded.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.csgpu_raster_setup_poly.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
     L.csgpu_solve_raster.argtypes = [vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_get_level_matrix.argtypes = [vp, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
                                          vp, vp, vp]
@@ -515,14 +516,24 @@ def setup_arrays(rowptr, colidx, vals, n, nnz, opts=None, index_base=1):
     return Handle(h, np.float32 if vals.dtype.itemsize == 4 else np.float64)
 
 
-def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True, ground=None):
-    """csgpu_raster_setup[_grounded]: Laplacian of a conductance raster (NODATA = values <= 0) built directly in HBM;
-    `ground`: optional raster of finite ground conductances added to the diagonal (advanced mode)."""
+def raster_setup(cond, opts=None, four_neighbors=False, avg_resistances=False, reg=True, ground=None, polymap=None):
+    """csgpu_raster_setup[_grounded|_poly]: Laplacian of a conductance raster (NODATA = values <= 0) built directly in
+    HBM; `ground`: optional raster of finite ground conductances added to the diagonal (advanced mode); `polymap`:
+    optional raster of short-circuit polygon ids (> 0; cells of a polygon share one node)."""
     cond = np.ascontiguousarray(cond)
     dtype = np.float32 if cond.dtype == np.float32 else np.float64
     cond = np.ascontiguousarray(cond, dtype=dtype)
     o = opts if opts is not None else default_opts()
     h = ctypes.c_void_p(0)
+    if polymap is not None and np.size(polymap) > 0:
+        assert ground is None, "polygons and finite grounds together are not supported on the device path"
+        pm = np.ascontiguousarray(polymap, dtype=np.int32)
+        assert pm.shape == cond.shape
+        rc = lib().csgpu_raster_setup_poly(cond.ctypes.data, pm.ctypes.data, cond.shape[0], cond.shape[1],
+                                           np.dtype(dtype).itemsize, int(four_neighbors), int(avg_resistances), int(reg),
+                                           ctypes.byref(o), ctypes.byref(h))
+        _check(rc)
+        return Handle(h, dtype)
     gnd = None
     if ground is not None:
         gnd = np.ascontiguousarray(ground, dtype=dtype)

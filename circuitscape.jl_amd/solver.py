@@ -627,8 +627,9 @@ def single_ground_all_pairs(prob, flags, cfg=None, log=True, **kw):
 
 
 def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, avg_res=False, exclude_pairs=(),
-                              stats=None, cum=None):
-    """Pairwise mode for a raster WITHOUT polygons with the whole graph layer on the device (scope row N4):
+                              stats=None, cum=None, polymap=None):
+    """Pairwise mode for a raster with the whole graph layer on the device (scope row N4), short-circuit polygons
+    included (`polymap`: cells of a polygon share one node, csgpu_raster_setup_poly):
     csgpu_raster_setup numbers the valid cells, writes the CSR Laplacian in HBM and regularises it (core.jl:161),
     csgpu_components labels the connected components, and every solvable pair goes to csgpu_solve_pairs in ONE
     call on ONE handle (the Laplacian of all components is block diagonal; a pair's right-hand side lives in one
@@ -643,7 +644,7 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
     cols = np.asarray(points_rc[1], dtype=np.int64) - 1
     ids = np.asarray(points_rc[2], dtype=np.int64)
     with lib.raster_setup(np.asarray(cellmap), _opts_for(solver), four_neighbors=four_neighbors,
-                          avg_resistances=avg_res, reg=True) as h:
+                          avg_resistances=avg_res, reg=True, polymap=polymap) as h:
         nodemap = h.raster_nodemap()
         node = nodemap[rows, cols].astype(np.int64)          # 1-based, 0 = focal point on NODATA
         labels, _ = h.components()

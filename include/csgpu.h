@@ -31,6 +31,8 @@
  *   csgpu_raster_setup     <-> construct_node_map/construct_graph/laplacian! for a raster without polygons (NODATA allowed)
  *                              (src/raster/pairwise.jl:271-362, src/core.jl:608-634) -- "next" row N4, used by
  *                              bench.py so the synthetic Laplacian is born in HBM
+ *   csgpu_raster_setup_poly <-> the same with short-circuit polygons (node merging, summed parallel edges;
+ *                              src/raster/pairwise.jl:276-301, 316-362)
  *   csgpu_raster_nodemap   <-> the node map construct_node_map returns (src/raster/pairwise.jl:271-301)
  *   csgpu_components       <-> connected_components(SimpleGraph(G))       src/raster/pairwise.jl:233,
  *                              src/raster/advanced.jl:59, src/network/pairwise.jl:52
@@ -94,7 +96,8 @@ typedef struct csgpu_opts {
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
                              every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
-  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on every level below the finest; default 2 (measured
+  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on level 1; the levels below it (1/81 of the fine level's
+                             work) run one more (profiles/r2_sweeps_per_level.json); default 2 (measured
                              on the 10000^2 raster: 3 -> 324.7 ms per batch of 16 at 12.8 iterations, 2 -> 309.2 ms at
                              12.9, 1 -> 327.4 ms at 14.9; profiles/r2_polling_graph_nucoarse.json) */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
@@ -184,6 +187,16 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
  * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). */
 int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
                        int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
+
+/* csgpu_raster_setup for a raster WITH short-circuit polygons (construct_node_map with a polymap,
+ * src/raster/pairwise.jl:276-301; known answers test/internal.jl:44-175): polymap[i*ncols + j] > 0 names the polygon of
+ * cell (i, j), 0 = none (host pointer, int32, same orientation as cond; NULL = no polygons). Every cell of a polygon --
+ * NODATA cells included, as in the reference -- shares the node of the polygon's first valid cell in column-major
+ * order; parallel edges are summed, edges inside a polygon vanish. Node numbering, merge and the CSR Laplacian are
+ * produced on the device (csrc/raster.h); polygon ids must be < 2^26. */
+int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nrows, int64_t ncols, int val_bytes,
+                            int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
+                            csgpu_handle** out);
 
 /* csgpu_raster_setup with a raster of finite ground conductances added to the diagonal (advanced mode:
  * `asolve = a + spdiagm(finitegrounds)`, src/raster/advanced.jl:277-280; `ground` NULL = none). The source / ground

@@ -421,3 +421,71 @@ def check_grounded_solves(L, shape=(50, 46), npts=9, batch=8, tol=5e-6):
             assert np.max(np.abs(X2 - X2d)) < tol * np.max(np.abs(X2d)), (pb, stencil)
             ref = refmaps.get_node_currents(G.tocsr(), X1[:, 0])
             assert np.max(np.abs(C1[:, 0] - ref)) < 1e-9 * max(1.0, ref.max())
+
+
+def check_polygon_graph_on_device(L, seeds=(1, 2, 3, 4, 5)):
+    """csgpu_raster_setup_poly: node map and Laplacian of rasters with random rectangular polygons (overlapping,
+    touching, covering NODATA cells), NODATA holes, 4/8 neighbours, both averaging rules, against the oracle's
+    construct_node_map / construct_graph / laplacian! (pairwise.jl:271-362, core.jl:608-634): same node numbering, same
+    matrix to rounding, bit-symmetric, sorted rows."""
+    cfgs = [(12, 10, 2, 0.0, False, False), (30, 25, 4, 0.2, False, False), (40, 33, 6, 0.3, True, False),
+            (25, 40, 5, 0.1, False, True), (60, 60, 12, 0.25, False, False)]
+    for (R, C, npoly, hole, four, avg), seed in zip(cfgs, seeds):
+        rng = np.random.default_rng(seed)
+        g = np.exp(rng.standard_normal((R, C)))
+        g[rng.random((R, C)) < hole] = 0.0
+        pm = np.zeros((R, C), dtype=np.int64)
+        for p in range(1, npoly + 1):
+            i0, j0 = rng.integers(0, R - 2), rng.integers(0, C - 2)
+            hh, ww = rng.integers(1, max(2, R // 3)), rng.integers(1, max(2, C // 3))
+            pm[i0:i0 + hh, j0:j0 + ww] = p * 3
+        nodemap = rg.construct_node_map(g, pm)
+        ref = rg.laplacian(rg.construct_graph(g, nodemap, avg, four))
+        h = L.raster_setup(g, L.default_opts(batch=1), four_neighbors=four, avg_resistances=avg, reg=False, polymap=pm)
+        assert np.array_equal(h.raster_nodemap(), nodemap)
+        A = h.level_matrix(0, "A")
+        h.close()
+        assert A.shape == ref.shape and abs(A - ref).max() < 1e-12 * max(1.0, abs(ref).max())
+        assert abs(A - A.T).max() == 0
+        for r in range(A.shape[0]):
+            assert np.all(np.diff(A.indices[A.indptr[r]:A.indptr[r + 1]]) > 0)
+
+
+def run_fixture_device_graph(case, solver):
+    """A raster pairwise fixture with the WHOLE graph layer on the device (node numbering, polygon merge, Laplacian,
+    components; csgpu_raster_setup[_poly]): one handle for all pairs when every focal id is one cell
+    (_pt_file_no_polygons_path, raster/pairwise.jl:40-70), one handle per pair of focal regions otherwise
+    (_pt_file_polygons_path, :72-135 -- the per-pair polygon map is integer raster bookkeeping of the host side)."""
+    from circuitscape_jl_amd import solver as ps
+    o = case["options"]
+    gmap = np.array(case["cellmap"], dtype=np.float64)
+    polymap = np.array(case["polymap"], dtype=np.int64) if case["polymap"] is not None else None
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    avg_res, four = o["connect_using_avg_resistances"], o["connect_four_neighbors_only"]
+    exclude = []
+    if case["included_pairs"] is not None:
+        exclude, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+    if len(points_rc[0]) == len(set(points_rc[2])):
+        return ps.raster_pairwise_on_device(gmap, points_rc, solver, four_neighbors=four, avg_res=avg_res,
+                                            exclude_pairs=exclude, polymap=polymap)
+    excl = set(exclude)
+    pts = []
+    for v in points_rc[2]:
+        if v not in pts:
+            pts.append(v)
+    res = -np.ones((len(pts), len(pts)))
+    for i in range(len(pts)):
+        for j in range(i + 1, len(pts)):
+            if (pts[i], pts[j]) in excl or (pts[j], pts[i]) in excl:
+                continue
+            newpoly = rg.create_new_polymap(gmap, polymap, points_rc, pts[i], pts[j])
+            x, y = list(points_rc[2]).index(pts[i]), list(points_rc[2]).index(pts[j])
+            two = ([points_rc[0][x], points_rc[0][y]], [points_rc[1][x], points_rc[1][y]], [pts[i], pts[j]])
+            pr = ps.raster_pairwise_on_device(gmap, two, solver, four_neighbors=four, avg_res=avg_res, polymap=newpoly)
+            res[i, j] = res[j, i] = pr[1, 2]
+    np.fill_diagonal(res, 0)
+    r = np.zeros((len(pts) + 1, len(pts) + 1))
+    r[0, 1:] = pts
+    r[1:, 0] = pts
+    r[1:, 1:] = res
+    return r

@@ -948,3 +948,22 @@ def test_grounded_solves_share_one_hierarchy(emu_lib):
     """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
     from helpers import check_grounded_solves
     check_grounded_solves(emu_lib)
+
+
+def test_polygon_graph_built_on_device(emu_lib):
+    """scope row N4: short-circuit polygons merged on the device (see helpers.check_polygon_graph_on_device)."""
+    from helpers import check_polygon_graph_on_device
+    check_polygon_graph_on_device(emu_lib)
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases() if not c.startswith("sgNetwork")])
+def test_every_raster_pairwise_golden_with_device_built_graph(emu_lib, name):
+    """All 17 raster pairwise cases of the reference -- polygons, masks, included pairs, focal regions -- with the graph
+    layer on the device (helpers.run_fixture_device_graph), against the golden resistances."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import run_fixture_device_graph
+    case = load_case(name)
+    got = run_fixture_device_graph(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
+    exp = np.array(case["expected"])
+    assert np.array_equal(exp[1:, 0], got[1:, 0])
+    compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)

@@ -251,3 +251,21 @@ def test_onetoall_on_device_built_graph_on_gpu(gpu_lib, name):
                                           ps.HIPAMGSolver(bs=1), four_neighbors=o["connect_four_neighbors_only"],
                                           avg_res=o["connect_using_avg_resistances"])
     assert check_onetoall_against_golden(case, res, cum, pts) > 0
+
+
+def test_polygon_graph_built_on_device(gpu_lib):
+    from helpers import check_polygon_graph_on_device
+    check_polygon_graph_on_device(gpu_lib)
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases() if not c.startswith("sgNetwork")])
+def test_every_raster_pairwise_golden_with_device_built_graph(gpu_lib, name):
+    """All 17 raster pairwise cases of the reference with the graph layer (node numbering, polygon merge with summed
+    parallel edges, Laplacian, components) on the device, default tolerances, against the golden resistances."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import run_fixture_device_graph
+    case = load_case(name)
+    got = run_fixture_device_graph(case, ps.HIPAMGSolver(bs=8))
+    exp = np.array(case["expected"])
+    assert np.array_equal(exp[1:, 0], got[1:, 0])
+    compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
