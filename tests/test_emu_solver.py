@@ -542,11 +542,13 @@ def _weakly_grounded_system(n_side, seed):
 
 @pytest.mark.parametrize("batch", [1, 4])
 def test_polishing_reopens_columns_that_would_fail_the_residual_check(emu_lib, batch):
-    """On a weakly grounded system Krylov.jl's rule (preconditioned residual) stops with ||Ax-b||/||b|| = 1.2e-4:
-    the reference's 1e-4 check would throw. The library re-opens exactly those columns on the true residual; easy
-    columns in the same batch, and well-conditioned problems, are untouched (polished_batches == 0, same bits)."""
+    """On a weakly grounded system Krylov.jl's rule (preconditioned residual) can stop with ||Ax-b||/||b|| above 1e-4
+    (1.2e-4 at the default rtol with round 1's smoother settings): the reference's 1e-4 check would throw. The library
+    re-opens exactly those columns on the true residual; well-conditioned problems are untouched (polished_batches ==
+    0). Whether the default rtol lands above or below 1e-4 depends on the smoother settings, so the scenario is forced
+    here with rtol = 3e-4 on the preconditioned norm (true residual ~1e-2 at the stop)."""
     A, b = _weakly_grounded_system(201, 5)
-    h = emu_lib.setup(A, emu_lib.default_opts(batch=batch, nu_coarse=3))   # (the scenario was found with 3 coarse sweeps)
+    h = emu_lib.setup(A, emu_lib.default_opts(batch=batch, rtol=3e-4))
     easy = np.zeros_like(b)
     easy[A.shape[0] // 2] = 1.0        # a source right next to the ground: converges on the reference's rule
     B = np.column_stack([b, easy, 2 * b, easy][:batch]) if batch > 1 else b
