@@ -382,8 +382,10 @@ def gpu_parity(lib, sample_size, tight, make_opts, dtype, mixed):
     src = [p[0] for p in pairs[:nt]]
     dst = [p[1] for p in pairs[:nt]]
     Ro = np.asarray(tight["R"])
+    # north_star tolerance for fp64; fp32 handles (BASELINE configs[3] precision) are held to 1e-3 (the reference's own
+    # single-precision tolerance is 1e-2 absolute, test/test_utils.jl:72-73)
     out = {"n": sample_size * sample_size, "pairs": nt, "oracle": "tight (true-residual rtol 1e-12)",
-           "oracle_max_true_relres": tight["max_true_relres"], "tolerance": 1e-6}
+           "oracle_max_true_relres": tight["max_true_relres"], "tolerance": 1e-6 if dtype == np.float64 else 1e-3}
     for name, precond in ((("mixed", "fp32"), ("fp64", "same")) if mixed else (("uniform", "same"),)):
         h = lib.raster_setup(g, make_opts(precond))
         R, _, _, st = h.solve_pairs(src, dst)
