@@ -147,8 +147,14 @@ struct DiaShape {
   static constexpr int CR = TI / 3 + 4;          // DIA_SQ: coarse rows staged per coarse column (one tile above / below)
 };
 
+// Second launch bound = waves per SIMD the register allocation must leave room for. The marching kernels are bound by
+// the bytes in flight per CU (a step waits for the loads of the step before), so for the CG product one more resident
+// workgroup per CU is worth two spilled registers: 128 VGPRs / 4 waves instead of 130 / 3 -> 4.27 -> 3.44 ms (measured,
+// profiles/r2_launch_bounds_ab.json). The second product (142 VGPRs) spills 13 registers under the same bound and gets
+// 1.9x slower; the residual update gains nothing from 3 waves instead of 2: both stay unconstrained.
 template <class T, class XT, int K, int MODE>
-__global__ __launch_bounds__(256) void dia_cg_kernel(DiaArgs<T, XT> a) {
+__global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
+    DiaArgs<T, XT> a) {
   constexpr bool FUSE = MODE == DIA_CG;
   typedef DiaShape<T, XT, K> SH;
   constexpr int CPL = SH::CPL, LPR = SH::LPR, TI = SH::TI, MELEMS = SH::MELEMS, MU = SH::MU;
