@@ -180,9 +180,10 @@ def main():
                          "FIXED pair list (--pairs, default 100 = BASELINE configs[2]) is dealt over the ranks at pair "
                          "granularity; --steps is ignored and the line reports the whole job incl. the per-rank setup")
     ap.add_argument("--pairs", type=int, default=100, help="--scaling strong: total number of pairs of the job")
-    ap.add_argument("--host-csr", type=int, default=0,
+    ap.add_argument("--host-csr", type=int, default=1,
                     help="N=1 only: also time csgpu_setup from host CSR arrays the way Julia hands them (Int64, 1-based) "
-                         "at the bench size and report setup_host_csr_s (needs ~25 GB of host memory at 10000^2)")
+                         "at the bench size and report setup_host_csr_s (needs ~30 GB of host memory and ~20 s at "
+                         "10000^2; 0 = skip)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="N_FULL",
                     help="internal: run only the CPU-baseline leg on a --cpu-sample raster, scale to N_FULL nodes, print "
                          "its JSON object and exit (the bench runs this in a child process so that nothing on the host "
@@ -366,7 +367,11 @@ def main():
                                                           for k in range(ncmp)))}
             h2.close()
         if world == 1 and args.host_csr:
-            out.update(host_csr_setup(lib, g, make_opts(args.precond)))
+            try:
+                out.update(host_csr_setup(lib, g, make_opts(args.precond)))
+            except Exception as e:  # never at the expense of the line
+                out["setup_host_csr_s"] = None
+                out["setup_host_csr"] = {"failed": repr(e)}
         del g
         if args.cpu_sample > 0 and world == 1:
             try:

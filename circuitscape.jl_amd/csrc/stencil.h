@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
           // + Q xc: the 3 x 3 block of tiles around this cell's tile, coarse values out of the staged columns
           const T* qrow = s_q[j & 3] + 9 * t;
           const int Jj = min(j / 3, a.Cc - 1);
-#pragma unroll
-          for (int dj = 0; dj < 3; ++dj) {
+#pragma unroll 1
+          for (int dj = 0; dj < 3; ++dj) {  // (not unrolled: three coarse values live at a time instead of nine)
             const XV* xcol = s_xc[(Jj + dj - 1) & 3];
 #pragma unroll
             for (int di = 0; di < 3; ++di) {
