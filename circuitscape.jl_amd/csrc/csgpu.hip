@@ -547,19 +547,21 @@ struct Solver : ISolver {
   }
 
   template <int K>
-  PcgBatchResult run_batch(int ncols, bool need_x) {
+  PcgBatchResult run_batch(int ncols, bool need_x, const double* bb_host = nullptr) {
     PcgParams pp = pcg_params(K);
     pp.need_x = need_x;
-    pp.rhs_in_r = !need_x;  // (only solve_pairs runs without the whole solution; it writes the +-1 entries into r)
+    pp.rhs_in_r = !need_x;  // (only solve_pairs runs without the whole solution; it writes the +-1 entries into r ...
+    pp.rp_ready = !need_x;  //  ... and into its preconditioner-precision copy, and knows ||b||^2 = 2)
+    pp.bb_host = need_x ? nullptr : bb_host;
     return pcg_solve<T, TP, K>(cg_matrix(), H, W, pp, ncols, st, dia_ptr());
   }
-  PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true) {
+  PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true, const double* bb_host = nullptr) {
     switch (K) {
-      case 1: return run_batch<1>(ncols, need_x);
-      case 2: return run_batch<2>(ncols, need_x);
-      case 4: return run_batch<4>(ncols, need_x);
-      case 8: return run_batch<8>(ncols, need_x);
-      default: return run_batch<16>(ncols, need_x);
+      case 1: return run_batch<1>(ncols, need_x, bb_host);
+      case 2: return run_batch<2>(ncols, need_x, bb_host);
+      case 4: return run_batch<4>(ncols, need_x, bb_host);
+      case 8: return run_batch<8>(ncols, need_x, bb_host);
+      default: return run_batch<16>(ncols, need_x, bb_host);
     }
   }
 
@@ -665,6 +667,13 @@ struct Solver : ISolver {
       CS_HIP(hipMemsetAsync(rhs, 0, (size_t)n * K * sizeof(T), st));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, rhs, dptr<int>(dsrc),
                                            dptr<int>(ddst), ncols));
+      double bb[kMaxK];
+      for (int c = 0; c < kMaxK; ++c) bb[c] = (c < K && s32[c] != d32[c]) ? 2.0 : 0.0;
+      if (!need_x && MIXED) {  // the fp32 copy of r0 the V-cycle reads, written directly
+        CS_HIP(hipMemsetAsync(W.rp.p, 0, (size_t)n * K * sizeof(TP), st));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<TP, KK>), dim3(1), dim3(64), 0, st, dptr<TP>(W.rp),
+                                             dptr<int>(dsrc), dptr<int>(ddst), ncols));
+      }
       if (!need_x) {  // focal list: [gathered nodes..., src of every column..., dst of every column...]
         for (int64_t g = 0; g < ngather; ++g) focal[g] = (int)gather[g];
         for (int c = 0; c < K; ++c) {
@@ -673,7 +682,7 @@ struct Solver : ISolver {
         }
         W.set_focal(focal, st);
       }
-      PcgBatchResult r = run_batch_k(K, ncols, need_x);
+      PcgBatchResult r = run_batch_k(K, ncols, need_x, bb);
       accumulate(stats, r, ncols);
       const int ge = grid_for((int64_t)ncols * (ngather + 1));
       if (need_x) {

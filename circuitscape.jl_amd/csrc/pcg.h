@@ -241,6 +241,10 @@ struct PcgParams {
   // true: the caller wrote the right-hand side straight into PcgWork::r (W.b is not valid); only with need_x == false
   // (nothing after the set-up of r0 = b reads b on that path)
   bool rhs_in_r = false;
+  // with rhs_in_r: the caller also wrote the preconditioner-precision copy (PcgWork::rp) and knows ||b||^2 of every
+  // column (pair right-hand sides: 2, or 0 when src == dst) -- saves a conversion pass and a reduction pass over n x K
+  bool rp_ready = false;
+  const double* bb_host = nullptr;  // kMaxK values, valid until pcg_solve returns
   // Block-diagonal systems (K = 1, one PCG over many components): component label per node and the number of
   // components. When set, the post-check is the WORST component's ||A x - b|| / ||b|| (the reference checks every
   // component's solve separately, advanced.jl:186-312 -> core.jl:640).
@@ -425,7 +429,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_REQUIRE(!(pp.rhs_in_r && need_x), CSGPU_INTERNAL, "rhs_in_r needs the focal-node path");
   if (!pp.rhs_in_r) CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
-  if (MIXED)
+  if (MIXED && !(pp.rhs_in_r && pp.rp_ready))
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
   vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
@@ -433,8 +437,14 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   if (grounded)
     hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
                        (const int*)nullptr);
-  hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
-                     (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+  int rr_rows = gv;  // rows of r'r partials currently in pb
+  if (pp.rhs_in_r && pp.bb_host) {
+    CS_HIP(hipMemcpyAsync(pb, pp.bb_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
+    rr_rows = 1;
+  } else {
+    hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
+                       (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+  }
   // partial rows of the big SpMM-shaped launches are collapsed before the single-workgroup scalar kernels read them
   double* pac = dptr<double>(W.part_ca);
   double* pcc = dptr<double>(W.part_cc);
@@ -449,7 +459,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   };
   {
     auto rz = collapsed(pa, spmv_gp, pac);
-    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, gv,
+    hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, rr_rows,
                        pp.criterion, pp.rtol, atol, 1, ncols_active);
   }
   // the first iteration runs p = z + beta p with beta = 0 (set by the init call above) on a zeroed p
@@ -515,9 +525,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     // r -= alpha Ap (+ x += alpha p when the whole solution is wanted), fused with the TP copy of r, the level-0 first
     // pre-smoothing sweep xa = omega D^-1 r and (when the true residual is monitored) the partials of r'r
     if (recompute) {
-      const bool rr = criterion == CSGPU_CRIT_TRUE_RESIDUAL;
-      dia_residual_update<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, x,
-                                    rr ? pb : (double*)nullptr, st);
+      // (the partials of r'r come for free here; the focal path's post-check reads the last ones instead of making
+      // another pass over r)
+      dia_residual_update<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, x, pb, st);
     } else {
       TP* rpo = MIXED ? rp : (TP*)nullptr;
       TP* xao = fuse_xa ? xa0 : (TP*)nullptr;
@@ -659,9 +669,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       }
     } else {
       // fp64 recurrence residual against ||b|| recorded at start-up
-      hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa,
-                         (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
-      hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)nullptr, 0);
+      if (recompute && it > 0 && !grounded) {
+        // ||r||^2 partials of the last residual update that ran (surplus launches exit before writing)
+        auto rr = collapsed(pb, spmv_g, pcc);
+        hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, rr.first, rr.second, (const double*)nullptr, 0);
+      } else {
+        hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa,
+                           (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)nullptr,
+                           0);
+      }
       CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
       CS_HIP(hipStreamSynchronize(st));
       return;
