@@ -184,7 +184,10 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
  * Cells with conductance <= 0 are NODATA (no node), as in construct_node_map.
  * cond: host pointer, nrows*ncols values (row-major, the orientation of the reference's cellmap[i,j]),
  * all > 0; node numbering is column-major like construct_node_map (raster/pairwise.jl:273-275).
- * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). */
+ * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). On a raster with several
+ * connected components the norm is taken over the WHOLE raster's nonzeros (one handle serves all components), where
+ * the reference shifts each component's matrix with that component's own norm (core.jl:158-161): the shifts differ by
+ * O(eps), far below the solve tolerance, but the matrices are not bit-identical to the reference's per-component ones. */
 int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_bytes, int four_neighbors,
                        int avg_resistances, int reg, const csgpu_opts* opts, csgpu_handle** out);
 

@@ -969,3 +969,33 @@ def test_every_raster_pairwise_golden_with_device_built_graph(emu_lib, name):
     exp = np.array(case["expected"])
     assert np.array_equal(exp[1:, 0], got[1:, 0])
     compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+
+
+def test_degenerate_pairs_and_single_precision_maps(emu_lib):
+    """(a) a pair with src == dst is a zero right-hand side with R = 0 (the reference skips it, core.jl:210)
+    instead of an inconsistent +1-only system; (b) a pair across two connected components is refused (BAD_ARGS) once
+    the components are known, instead of iterating to itmax; (c) cumulative / maximum current maps on a float32 handle
+    (node_cum / node_max take the handle's value type)."""
+    rng = np.random.default_rng(8)
+    g = np.exp(rng.standard_normal((30, 41)))
+    g[:, 20] = 0.0                                  # NODATA wall: two components
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=4))
+    nm = h.raster_nodemap()
+    a, b, c = int(nm[3, 3]) - 1, int(nm[25, 10]) - 1, int(nm[5, 30]) - 1
+    R, _, _, st = h.solve_pairs([a, a, b], [b, a, b])
+    assert st["not_converged"] == 0 and R[0] > 0 and R[1] == 0.0 and R[2] == 0.0
+    labels, nc = h.components()
+    assert nc == 2 and labels[a] != labels[c]
+    with pytest.raises(emu_lib.CsgpuError) as e:
+        h.solve_pairs([a], [c])
+    assert e.value.code == emu_lib.CSGPU_BAD_ARGS and "components" in str(e.value)
+    h.close()
+    g32 = np.exp(rng.standard_normal((24, 24))).astype(np.float32)
+    h = emu_lib.raster_setup(g32, emu_lib.default_opts(batch=2, rtol=1e-5, atol=0.0))
+    n = h.info["n"]
+    cum = np.zeros(n, dtype=np.float32)
+    mx = np.zeros(n, dtype=np.float32)
+    R, _, cur, st = h.solve_pairs_currents([0, 5], [n - 1, n - 7], cum=cum, mx=mx)
+    assert cur.dtype == np.float32 and st["not_converged"] == 0
+    assert np.allclose(cum, cur[:, 0] + cur[:, 1], rtol=1e-5) and np.allclose(mx, np.maximum(cur[:, 0], cur[:, 1]))
+    h.close()
