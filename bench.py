@@ -58,7 +58,7 @@ def focal_pairs(size, npts=15, seed=67890):
     return cells, pairs
 
 
-def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16):
+def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16, single=False):
     """Oracle (CPU restatement of the reference CG+AMG path) on a bounded sample of the same workload: one thread, and
     all host cores the way the reference parallelises (one pair per task, src/core.jl:262-272). Also returns the
     TIGHT oracle's resistances (true-residual rtol 1e-12) of the first `ntight` pairs: the parity reference the GPU
@@ -66,7 +66,10 @@ def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16):
     from oracle import refgraph as rg, refsolve as rs
     g = make_raster(sample_size)
     G = rg.raster_laplacian_from_conductance(g)
-    A = rs.regularize(G)
+    # (single precision: the reference's shift eps(Float32) * norm(nzval) of EVERY stored entry, core.jl:161, is part of
+    # the problem definition -- at n = 1e8 it is 4e-3 per entry and turns the Laplacian into a strongly grounded system;
+    # the oracle solves that same matrix, in double)
+    A = rs.regularize(G, dtype=np.float32).astype(np.float64) if single else rs.regularize(G)
     t0 = time.time()
     S = rs.OracleAMG(A)
     t_setup = time.time() - t0
@@ -190,8 +193,8 @@ def main():
                          "side can take the GPU line down)")
     args = ap.parse_args()
     if args.cpu_baseline_only > 0:
-        print(json.dumps(cpu_baseline_entry(cpu_baseline(args.cpu_sample), args.cpu_baseline_only, args.size,
-                                            args.cpu_sample)), flush=True)
+        print(json.dumps(cpu_baseline_entry(cpu_baseline(args.cpu_sample, single=args.precision == "single"),
+                                            args.cpu_baseline_only, args.size, args.cpu_sample)), flush=True)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -377,7 +380,8 @@ def main():
             try:
                 import subprocess
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(info["n"]),
-                                        "--cpu-sample", str(args.cpu_sample), "--size", str(size)],
+                                        "--cpu-sample", str(args.cpu_sample), "--size", str(size), "--precision",
+                                        args.precision],
                                        capture_output=True, text=True, timeout=900)
                 cb = json.loads(child.stdout.strip().splitlines()[-1])
                 tight = cb.pop("_tight", None)
