@@ -1002,7 +1002,7 @@ struct Solver : ISolver {
     if (sq && dots) {
       int g = 1;
       CS_DISPATCH_K(k, g = sq_lattice ? dia_grid<TP, TP, KK>(L.Sdia)
-                             : (KK > 1 && spmv_wave_enabled()) ? spmv_wave_grid<TP, KK>(M.nrows) : spmv_grid<TP, KK>(M.nrows));
+                             : spmv_grid<TP, KK>(M.nrows));
       std::vector<double> ph((size_t)g * k);
       CS_HIP(hipMemcpy(ph.data(), part.p, ph.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int c = 0; c < k; ++c) {

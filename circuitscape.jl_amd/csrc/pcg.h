@@ -402,13 +402,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_HIP(hipEventRecord(e0, st));
 
   // rows of dot partials the CG product / the last product of the V-cycle write (one per workgroup)
-  const bool wave = K > 1 && spmv_wave_enabled();
   const bool two_product = H.levels.size() > 1 && L0.two_product() && pp.nu_pre == 1 && pp.nu_post == 1 &&
                            W.tail >= H.levels[1].A.nrows;
-  const int spmv_g = use_dia ? dia_grid<T, TP, K>(*dia) : (wave ? spmv_wave_grid<T, K>((int)n) : spmv_grid<T, K>((int)n));
+  const int spmv_g = use_dia ? dia_grid<T, TP, K>(*dia) : spmv_grid<T, K>((int)n);
   const int spmv_gp = (two_product && L0.lattice_two_product()) ? dia_grid<TP, TP, K>(L0.Sdia)
-                      : (wave && two_product)        ? spmv_wave_grid<TP, K>((int)n)
-                                                     : spmv_grid<TP, K>((int)n);
+                                                                : spmv_grid<TP, K>((int)n);
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
   const bool grounded = pp.gptr && pp.gtotal > 0;

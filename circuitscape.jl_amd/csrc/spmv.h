@@ -327,176 +327,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
     if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
   }
 }
-// ---- single-wave variant of the two hot products (EXPERIMENTAL, off by default: CSGPU_WAVE_SPMM=1) ------------------
-// Same algorithm as spmv_kernel for y = A x with the fused x.y partials (EPI_PLAIN + DOT, K > 1), but a workgroup is
-// ONE wave owning 64 rows (32 at K = 16): the three block-wide barriers per 256-row block, which stall all four waves
-// of a workgroup on the slowest one, become wave-local. Per-lane state (rows per lane, gathers in flight) is the same
-// as in spmv_kernel, the row blocks are the 256-row blocks of the traversal order cut into 4 (8) consecutive pieces,
-// and the summation order inside a row is unchanged (bit-identical y; the dot partials are per 64-row piece).
-// Not yet measured on the device: see DESIGN.md section 9.
-template <class T, int K, class XT, int TPL>
-__global__ __launch_bounds__(64) void spmv_wave_kernel(SpmvArgs<T, XT> a) {
-  static_assert(K > 1, "multi-column products only");
-  constexpr int ROWS = K >= 16 ? 32 : 64;
-  constexpr int SUB = kSpmvRows / ROWS;  // pieces per 256-row block of the traversal order
-  constexpr int TILE = ROWS * TPL;
-  static_assert(TILE % 64 == 0, "every lane streams TILE / 64 nonzeros per tile");
-  __shared__ int s_rp[ROWS + 1];
-  __shared__ T s_val[TILE];
-  __shared__ int s_col[TILE];
-  if (a.skip && *a.skip) return;
-  const int tid = threadIdx.x;
-  constexpr int VEC = 16 / (int)sizeof(XT);
-  constexpr int CPL = K < VEC ? K : VEC;
-  constexpr int LPR = K / CPL;
-  constexpr int RPP = 64 / LPR;
-  constexpr int NPASS = ROWS / RPP;
-  typedef SpmvVec<XT, CPL> XV;
-  typedef SpmvVec<T, CPL> YV;
-  const int c0 = (tid % LPR) * CPL;
-  double dot_acc[CPL];
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
-
-  const int nblocks = SUB * ((a.nrows + kSpmvRows - 1) / kSpmvRows);
-  int rb_first = blockIdx.x, rb_last = nblocks, rb_step = gridDim.x;
-  if ((gridDim.x & 7) == 0) {
-    const int xcd = blockIdx.x & 7, chunk = (nblocks + 7) >> 3;
-    rb_first = xcd * chunk + (blockIdx.x >> 3);
-    rb_last = min(nblocks, (xcd + 1) * chunk);
-    rb_step = gridDim.x >> 3;
-  }
-  for (int pos = rb_first; pos < rb_last; pos += rb_step) {
-    const int rb = a.order ? a.order[pos / SUB] * SUB + (pos % SUB) : pos;
-    const int row0 = rb * ROWS;
-    if (row0 >= a.nrows) continue;
-    const int nr = min(ROWS, a.nrows - row0);
-    __syncthreads();  // one wave: orders this wave's LDS traffic only
-    for (int t = tid; t <= nr; t += 64) s_rp[t] = a.rowptr[row0 + t];
-    __syncthreads();
-    const int kbeg = s_rp[0], kend = s_rp[nr];
-    T acc[NPASS][CPL];
-    XV xself[NPASS];
-    bool have_self[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      have_self[p] = false;
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        acc[p][q] = T(0);
-        xself[p].e[q] = XT(0);
-      }
-    }
-    for (int ts = kbeg; ts < kend; ts += TILE) {
-      const int te = min(kend, ts + TILE);
-      if (ts != kbeg) __syncthreads();
-      {
-        constexpr int U = TILE / 64;
-        T vv[U];
-        int cc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = ts + tid + u * 64;
-          vv[u] = k < te ? stream_load(a.val + k) : T(0);
-          cc[u] = k < te ? stream_load(a.col + k) : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (ts + tid + u * 64 < te) {
-            s_val[tid + u * 64] = vv[u];
-            s_col[tid + u * 64] = cc[u];
-          }
-      }
-      __syncthreads();
-      int lo[NPASS], len[NPASS];
-      int maxlen = 0;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int r = tid / LPR + p * RPP;
-        lo[p] = 0;
-        len[p] = 0;
-        if (r < nr) {
-          const int l = max(s_rp[r], ts), h = min(s_rp[r + 1], te);
-          lo[p] = l - ts;
-          len[p] = h - l;
-        }
-        maxlen = max(maxlen, len[p]);
-      }
-      constexpr int JU = NPASS >= 8 ? 1 : (8 / NPASS);
-      for (int j = 0; j < maxlen; j += JU) {
-        XV xv[JU][NPASS];
-        T vv[JU][NPASS];
-#pragma unroll
-        for (int u = 0; u < JU; ++u) {
-#pragma unroll
-          for (int p = 0; p < NPASS; ++p) {
-            const bool on = j + u < len[p];
-            const int i = on ? lo[p] + j + u : 0;
-            vv[u][p] = on ? s_val[i] : T(0);
-            if (on) {
-              const int col = s_col[i];
-              xv[u][p] = *reinterpret_cast<const XV*>(a.x + (size_t)col * K + c0);
-              if (col == row0 + tid / LPR + p * RPP) {
-                xself[p] = xv[u][p];
-                have_self[p] = true;
-              }
-            } else {
-#pragma unroll
-              for (int q = 0; q < CPL; ++q) xv[u][p].e[q] = XT(0);
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < JU; ++u) {
-#pragma unroll
-          for (int p = 0; p < NPASS; ++p)
-            if (j + u < len[p]) {
-#pragma unroll
-              for (int q = 0; q < CPL; ++q) acc[p][q] += vv[u][p] * (T)xv[u][p].e[q];
-            }
-        }
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int r = tid / LPR + p * RPP;
-      if (r < nr) {
-        const size_t e0 = (size_t)(row0 + r) * K + c0;
-        YV out, dw;
-        if (a.dotw) {
-          dw = *reinterpret_cast<const YV*>(a.dotw + e0);
-        } else {
-          XV xs;
-          if (have_self[p])
-            xs = xself[p];
-          else
-            xs = *reinterpret_cast<const XV*>(a.x + e0);
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) dw.e[q] = (T)xs.e[q];
-        }
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          out.e[q] = acc[p][q];
-          dot_acc[q] += (double)dw.e[q] * (double)acc[p][q];
-        }
-        stream_store(reinterpret_cast<YV*>(a.y + e0), out);
-      }
-    }
-  }
-  // lanes owning the same columns sit LPR apart: one shuffle reduction, one partial row per workgroup (= wave)
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    double v = dot_acc[q];
-#pragma unroll
-    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (tid < LPR) a.partials[(size_t)blockIdx.x * K + tid * CPL + q] = v;
-  }
-}
-
-inline bool spmv_wave_enabled() {
-  static const bool on = getenv("CSGPU_WAVE_SPMM") != nullptr;
-  return on;
-}
+// (A single-wave variant of this kernel -- one 64-lane workgroup per 64 / 32 rows, no block-wide barriers -- was written
+// at the end of round 1 and measured in round 2: 2-5 % slower at K = 8 and 16, profiles/r2_wave_spmm_ab.json. Removed.)
 
 // ---- long rows (restriction: R = P^T has ~25 nonzeros per row on rasters, Q^T ~49) --------------------------------
 // The kernel above gives every row one lane group for the whole 256-row block; with rows of 25-50 nonzeros a block
@@ -674,7 +506,7 @@ inline size_t spmv_grid_upper(int64_t nrows) {
   const int cap = spmv_grid_cap();
   const size_t nb = (size_t)(2 * ((nrows + kSpmvRows - 1) / kSpmvRows) + 8);
   const size_t g = cap > 0 ? std::min<size_t>(nb, (size_t)cap) : nb;
-  return spmv_wave_enabled() ? 4 * std::max<size_t>(g, 1024) + 8 : g;
+  return g;
 }
 
 template <class T, int K>
@@ -691,16 +523,6 @@ inline int spmv_grid(int nrows) {
   return nb;
 }
 
-// workgroups (= waves) of the single-wave variant: four times the 256-thread grid, same XCD-aware multiple of 8
-template <class T, int K>
-inline int spmv_wave_grid(int nrows) {
-  int nb = ceil_div(nrows, kSpmvRows) * (K >= 16 ? 8 : 4);
-  const int cap = 4 * std::max(1024, spmv_grid_cap());
-  if (nb > cap) nb = cap;
-  if (nb >= 64) nb &= ~7;
-  return std::max(nb, 1);
-}
-
 template <class T, int K, int EPI, bool DOT, class XT = T>
 inline void spmv_launch_t(const SpmvArgs<T, XT>& a, hipStream_t st) {
   hipLaunchKernelGGL((spmv_kernel<T, K, EPI, DOT, XT>), dim3(spmv_grid<T, K>(a.nrows)), dim3(256), 0, st, a);
@@ -710,12 +532,6 @@ inline void spmv_launch_t(const SpmvArgs<T, XT>& a, hipStream_t st) {
 template <class T, int K, class XT>
 inline void spmv_launch_cg(const SpmvArgs<T, XT>& a, hipStream_t st) {
   if (a.nrows <= 0) return;
-  if constexpr (K > 1) {
-    if (spmv_wave_enabled()) {
-      hipLaunchKernelGGL((spmv_wave_kernel<T, K, XT, 10>), dim3(spmv_wave_grid<T, K>(a.nrows)), dim3(64), 0, st, a);
-      return;
-    }
-  }
   spmv_launch_t<T, K, EPI_PLAIN, true, XT>(a, st);
 }
 
@@ -750,16 +566,6 @@ inline void spmv_launch_wide(const SpmvArgs<T>& a, bool dot, hipStream_t st) {
   if (a.nrows <= 0) return;
   static const bool narrow = getenv("CSGPU_NARROW_TILE") != nullptr;
   const bool wide = !narrow && a.nnz > 11 * (long long)a.nrows;
-  if constexpr (K > 1) {
-    if (dot && spmv_wave_enabled()) {  // experimental single-wave variant (partials: spmv_wave_grid rows)
-      const dim3 gw(spmv_wave_grid<T, K>(a.nrows));
-      if (wide)
-        hipLaunchKernelGGL((spmv_wave_kernel<T, K, T, 16>), gw, dim3(64), 0, st, a);
-      else
-        hipLaunchKernelGGL((spmv_wave_kernel<T, K, T, 10>), gw, dim3(64), 0, st, a);
-      return;
-    }
-  }
   const dim3 g(spmv_grid<T, K>(a.nrows));
   if (wide) {
     if (dot)

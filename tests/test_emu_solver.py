@@ -843,23 +843,6 @@ def test_onetoall_on_device_built_graph(emu_lib, name):
     assert check_onetoall_against_golden(case, res, cum, pts) > 0
 
 
-def test_experimental_single_wave_spmm_variant():
-    """CSGPU_WAVE_SPMM=1 switches the CG product and the [S Q] product to the single-wave kernel (one 64-lane workgroup
-    per 64 / 32 rows, no block-wide barriers; off by default until it has been measured on the device). The switch is
-    read once per process, so the checks run in a child: every level operator at every batch width, and the
-    two-product level against the classic V-cycle."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CSGPU_WAVE_SPMM="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_emu_solver.py"), "-q", "-x", "-k",
-                        "level_products_all_operators or two_product_level_matches or graph_replay_is_bitwise"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
 def test_closed_form_circuits(emu_lib):
     """Known-answer circuits (series, cycle, complete graph, star, parallel chains) and the metric properties of the
     effective resistance -- checks that do not go through the oracle at all."""
