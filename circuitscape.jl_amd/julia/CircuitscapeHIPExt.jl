@@ -194,6 +194,82 @@ function components(factor::HIPFactor, n::Int)
     lab, Int(nc[])
 end
 
+"""
+One-to-all / all-to-one on ONE hierarchy (scope row N2): column c of `rhs` is solved with the nodes `grounds[c]`
+(0-based) tied directly to ground -- what `multiple_solver` does per focal point by deleting rows / columns and
+factorising again (raster/onetoall.jl:106-151, raster/advanced.jl:282-312). Returns voltages (n x nrhs) and, optionally,
+node currents.
+"""
+function solve_grounded(factor::HIPFactor, rhs::Matrix{T}, grounds::Vector{Vector{Int64}}; want_currents = false) where {T}
+    n, nrhs = size(rhs)
+    gptr = Int64[0; cumsum(length.(grounds))]
+    gidx = isempty(grounds) ? Int64[] : reduce(vcat, grounds)
+    isempty(gidx) && (gidx = Int64[0])
+    x = similar(rhs)
+    cur = want_currents ? similar(rhs) : Matrix{T}(undef, 0, 0)
+    st = CsgpuStats()
+    rc = GC.@preserve rhs gptr gidx x cur ccall((:csgpu_solve_grounded, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, rhs, nrhs, gptr, gidx, x, want_currents ? pointer(cur) : C_NULL, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_grounded failed: $(csgpu_error())")
+    x, cur, st
+end
+
+"""
+Raster with short-circuit polygons, graph layer on the device (construct_node_map with a polymap,
+raster/pairwise.jl:276-301): `polymap` > 0 names the polygon of a cell.
+"""
+function raster_factor(cellmap::Matrix{T}, polymap::Matrix{<:Integer}, s::HIPAMGSolver; four_neighbors = false,
+                       avg_res = false) where {T}
+    o = default_opts(s.bs)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rm = permutedims(cellmap); pm = Matrix{Int32}(permutedims(polymap))
+    rc = GC.@preserve rm pm ccall((:csgpu_raster_setup_poly, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int32}, Int64, Int64, Cint, Cint, Cint, Cint, Ref{CsgpuOpts}, Ref{Ptr{Cvoid}}),
+              rm, pm, size(cellmap, 1), size(cellmap, 2), sizeof(T), four_neighbors, avg_res, 1, o, h)
+    rc == 0 || error("csgpu_raster_setup_poly failed: $(csgpu_error())")
+    HIPFactor(h[])
+end
+
+"""
+All GPUs of the node behind one handle (csgpu_multi_*): replaces the Threads.@spawn fan-out and the serial merge of
+core.jl:262-285 by ONE call; results land in `res` / `gat` directly.
+"""
+mutable struct HIPMultiFactor
+    ptr::Ptr{Cvoid}
+    function HIPMultiFactor(ptr)
+        f = new(ptr)
+        finalizer(x -> (x.ptr != C_NULL && ccall((:csgpu_multi_free, LIBCSGPU), Cvoid, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), f)
+        f
+    end
+end
+
+function construct_multi_factor(matrix::SparseMatrixCSC{T,V}, s::HIPAMGSolver; ndevices::Int = 0) where {T,V}
+    o = default_opts(s.bs)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = GC.@preserve matrix ccall((:csgpu_multi_setup, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Ref{CsgpuOpts}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+              matrix.colptr, matrix.rowval, matrix.nzval, size(matrix, 1), nnz(matrix), sizeof(V), sizeof(T), 1, o,
+              C_NULL, ndevices, h)
+    rc == 0 || error("csgpu_multi_setup failed: $(csgpu_error())")
+    HIPMultiFactor(h[])
+end
+
+function solve_pairs(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst::Vector{Int64};
+                     gather::Vector{Int64} = Int64[]) where {T}
+    np = length(src)
+    res = Vector{T}(undef, np)
+    gat = Matrix{T}(undef, length(gather), np)
+    st = CsgpuStats()
+    rc = GC.@preserve src dst gather res gat ccall((:csgpu_multi_solve_pairs, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, src, dst, np, gather, length(gather), isempty(gather) ? C_NULL : pointer(gat), res, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_multi_solve_pairs failed: $(csgpu_error())")
+    res, gat, st
+end
+
 # solve(prob, ::HIPAMGSolver, flags, cfg, log): identical bookkeeping to solve(prob, ::AMGSolver, ...) (core.jl:96-305)
 # except that per connected component the pair list is handed to `solve_pairs` in ONE call (no Threads.@spawn fan-out
 # over blocking ccalls) -- the Python mirror of exactly this method is circuitscape.jl_amd/solver.py::solve and is what
