@@ -911,15 +911,24 @@ struct Solver : ISolver {
     info->device_bytes = bytes;
     info->spmv_bytes_fine = spmv_bytes(cg_matrix(), 1);
     // B_iter = B_spmv(A0) + 10 n sizeof(T) + sum_l [(nu1+nu2+1) B_spmv(A_l) + B_spmv(P_l) + B_spmv(R_l) + 4 n_l sizeof(TP)]
-    int64_t bi = spmv_bytes(cg_matrix(), 1) + 10 * n * (int64_t)sizeof(T);
-    for (size_t l = 0; l + 1 < H.levels.size(); ++l) {
+    // for the CSR path; on a lattice level 0 the four marching kernels of DESIGN.md 4a (batch width 1):
+    //   CG product n(5T + 3P), residual update n(5T + 2T + 2P), restriction n(9P + P) + n_c P, second product
+    //   n(5P + 9P + 2P) + n_c P          (T, P = sizeof of the CG / preconditioner precision)
+    const int64_t sT = (int64_t)sizeof(T), sP = (int64_t)sizeof(TP);
+    const bool lat = dia.n > 0 && !H.levels.empty() && H.levels[0].lattice_two_product();
+    int64_t bi = spmv_bytes(cg_matrix(), 1) + 10 * n * sT;
+    if (lat) {
+      const int64_t nc = H.levels.size() > 1 ? H.levels[1].A.nrows : 0;
+      bi = n * (5 * sT + 3 * sP) + n * (7 * sT + 2 * sP) + (n * 10 * sP + nc * sP) + (n * 16 * sP + nc * sP);
+    }
+    for (size_t l = lat ? 1 : 0; l + 1 < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
-      // first pre-sweep from a zero guess needs no product: (nu_pre - 1) + nu_post Jacobi products + 1 residual
-      const int nup = l == 0 ? opts.nu_pre : opts.nu_coarse, nuq = l == 0 ? opts.nu_post : opts.nu_coarse;
-      // products with A: (nu_pre - 1) pre-sweeps after the free first one, 1 residual, (nu_post - 1) post-sweeps after
-      // the first one, which is fused with the prolongation into one product with Q = P - omega D^-1 A P
+      // sweeps: nu_pre / nu_post on level 0, nu_coarse on level 1, nu_coarse + 1 below; the first pre-sweep from a zero
+      // guess needs no product, the first post-sweep is fused with the prolongation into one product with Q
+      const int nuc = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
+      const int nup = l == 0 ? opts.nu_pre : (l == 1 ? nuc : nuc + 1), nuq = l == 0 ? opts.nu_post : (l == 1 ? nuc : nuc + 1);
       const int prods = std::max(nup - 1, 0) + 1 + std::max(nuq - 1, 0);
-      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.Q, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * (int64_t)sizeof(TP);
+      bi += prods * spmv_bytes(L.A, 1) + spmv_bytes(L.Q, 1) + spmv_bytes(L.R, 1) + 4 * (int64_t)L.A.nrows * sP;
     }
     info->bytes_per_iteration = bi;
   }
@@ -1104,7 +1113,7 @@ using csgpu::g_last_error;
 
 extern "C" {
 
-const char* csgpu_version(void) { return "csgpu 0.1 (gfx950)"; }
+const char* csgpu_version(void) { return "csgpu 0.2 (gfx950)"; }
 const char* csgpu_last_error(void) { return g_last_error.c_str(); }
 
 int csgpu_device_count(void) {
