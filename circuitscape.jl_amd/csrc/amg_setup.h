@@ -452,6 +452,77 @@ inline void spgemm_lds(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t 
   CS_HIP(hipStreamSynchronize(st));
 }
 
+// ---- A * T for a tentative prolongator T with exactly one entry per row (column agg[j], value tva[j]) -------------
+// Row i of A*T is row i of A with every column j replaced by agg[j] and equal columns merged: no second matrix to walk,
+// so one thread per row with a sorted list of at most MAXL aggregates in registers does it (rows of a raster level touch
+// <= 9 columns, i.e. <= 4 aggregates). Entries are added in A's column order (deterministic). FILL = false: counts only.
+template <class T, int MAXL, bool FILL>
+__global__ __launch_bounds__(256) void spgemm_tentative_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                               const T* __restrict__ va, const int* __restrict__ agg,
+                                                               const T* __restrict__ tva, int* __restrict__ count,
+                                                               const int* __restrict__ crp, int* __restrict__ cci,
+                                                               T* __restrict__ cva) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int cols[MAXL];
+    T vals[MAXL];
+    int m = 0;
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int j = ci[k];
+      const int a = agg[j];
+      const T v = FILL ? va[k] * tva[j] : T(0);
+      int q = 0;
+      while (q < m && cols[q] < a) ++q;
+      if (q < m && cols[q] == a) {
+        vals[q] += v;
+      } else {
+        for (int s2 = m; s2 > q; --s2) {
+          cols[s2] = cols[s2 - 1];
+          vals[s2] = vals[s2 - 1];
+        }
+        cols[q] = a;
+        vals[q] = v;
+        ++m;
+      }
+    }
+    if (!FILL) {
+      count[i] = m;
+    } else {
+      const int o = crp[i];
+      for (int q = 0; q < m; ++q) {
+        cci[o + q] = cols[q];
+        cva[o + q] = vals[q];
+      }
+    }
+  }
+}
+
+template <class T>
+inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st);
+
+// C = A * T (see above); falls back to the general SpGEMM when a row of A is longer than the register list
+template <class T>
+inline void spgemm_tentative(const Csr<T>& A, const Csr<T>& Tm, const int* agg, Csr<T>& C, hipStream_t st) {
+  constexpr int MAXL = 16;
+  static const bool off = getenv("CSGPU_NO_DIRECT_AT") != nullptr;  // A/B knob
+  if (off || max_row_len(A, st) > MAXL) return spgemm(A, Tm, C, st);
+  const int n = A.nrows;
+  C.nrows = n;
+  C.ncols = Tm.ncols;
+  C.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+  CS_HIP(hipMemsetAsync(C.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+  const int g = grid_for(n);
+  hipLaunchKernelGGL((spgemm_tentative_kernel<T, MAXL, false>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), agg,
+                     Tm.va(), C.rp(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(C.rp(), (int64_t)n + 1, st, dptr<int>(total));
+  C.nnz = read_int(dptr<int>(total), st);
+  C.col.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(int));
+  C.val.alloc((size_t)std::max<int64_t>(C.nnz, 1) * sizeof(T));
+  hipLaunchKernelGGL((spgemm_tentative_kernel<T, MAXL, true>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), agg,
+                     Tm.va(), (int*)nullptr, (const int*)C.rp(), C.ci(), C.va());
+  check_launch("A * T");
+}
+
 template <class T>
 inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st) {
   // fast path when every row of A fits a lane group and every row of B fits its LDS slot
@@ -922,7 +993,7 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
                        (const long long*)size_prev.p, dptr<unsigned long long>(size_c), Tm.rp(), Tm.ci(), Tm.va());
     check_launch("tentative");
     // P = T - omega_p Dl^-1 A T
-    spgemm(L.A, Tm, L.P, st);
+    spgemm_tentative(L.A, Tm, (const int*)dptr<int>(agg), L.P, st);
     if ((double)L.P.nnz > 0.75 * (double)L.A.nnz) {
       // (nearly) every neighbour of every node lies in a different aggregate: the graph has no locality for
       // aggregation to exploit (expander-like networks, e.g. random graphs; rasters sit at 0.3). The Galerkin

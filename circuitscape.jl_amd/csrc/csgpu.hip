@@ -140,7 +140,7 @@ struct Solver : ISolver {
     dia = Dia<T>();
     if (off || opts.stencil < 0 || known_period < 0) return;
     if (known_period > 0) {
-      dia_from_csr(A, known_period, dia, st);
+      dia_from_csr(A, known_period, dia, st, /*trusted=*/true);
       return;
     }
     // node 0 of a lattice is coupled to 1, R and (8 neighbours) R+1: its last column gives the period

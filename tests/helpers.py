@@ -489,3 +489,62 @@ def run_fixture_device_graph(case, solver):
     r[1:, 0] = pts
     r[1:, 1:] = res
     return r
+
+
+def check_direct_tentative_product(libpath, shape=(61, 47), seed=3):
+    """amg_setup.h spgemm_tentative (one thread per row, aggregates merged in registers) against the general SpGEMM it
+    replaces for A * T: the knob is read once per process, so both hierarchies are built in child processes and the
+    prolongators / Galerkin operators of every level compared here. Same sparsity bit for bit; values to rounding (the
+    general kernel adds in hash order). A network graph with a hub of degree > 16 covers the fallback."""
+    import json, os, subprocess, sys, tempfile, textwrap
+    import scipy.sparse as sp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, numpy as np, scipy.sparse as sp
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        lib.load(%r)
+        rng = np.random.default_rng(%d)
+        out = {}
+        g = np.exp(rng.standard_normal(%r))
+        g[rng.random(g.shape) < 0.15] = 0.0       # holes: ragged rows, MIS-2 rather than tile aggregation in places
+        def dump(h, tag):
+            for lvl in range(h.info["levels"] - 1):
+                for w in ("P", "A"):
+                    M = h.level_matrix(lvl + (w == "A"), w)
+                    out["%%s_%%s%%d_p" %% (tag, w, lvl)] = M.indptr; out["%%s_%%s%%d_i" %% (tag, w, lvl)] = M.indices
+                    out["%%s_%%s%%d_v" %% (tag, w, lvl)] = M.data
+            out[tag + "_levels"] = np.array([h.info["levels"]])
+        with lib.raster_setup(g, lib.default_opts(batch=4, precond_bytes=0)) as h:
+            dump(h, "raster")
+        n = 400
+        i = rng.integers(0, n, 1500); j = rng.integers(0, n, 1500)
+        i = np.concatenate([i, np.zeros(60, int), np.arange(n - 1)]); j = np.concatenate([j, rng.integers(1, n, 60), np.arange(1, n)])
+        keep = i != j
+        W = sp.coo_matrix((rng.random(keep.sum()) + 0.1, (i[keep], j[keep])), shape=(n, n)).tocsr()
+        W = W + W.T
+        A = (sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W).tocsr()
+        A = A + sp.diags(np.full(n, 1e-6))
+        with lib.setup(A, lib.default_opts(batch=4, precond_bytes=0)) as h:
+            dump(h, "hub")
+        np.savez(sys.argv[1], **out)
+    ''') % (root, libpath, seed, tuple(shape))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("direct", {}), ("general", {"CSGPU_NO_DIRECT_AT": "1"})):
+            path = os.path.join(td, tag + ".npz")
+            env = dict(os.environ, **extra)
+            env.pop("CSGPU_NO_DIRECT_AT", None) if not extra else None
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900,
+                               cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = dict(np.load(path))
+    a, b = res["direct"], res["general"]
+    assert set(a) == set(b) and int(a["raster_levels"][0]) >= 3 and int(a["hub_levels"][0]) >= 2
+    for k in a:
+        if k.endswith("_v"):
+            assert a[k].shape == b[k].shape, k
+            assert np.max(np.abs(a[k] - b[k])) <= 1e-13 * np.max(np.abs(b[k])), k
+        else:
+            assert np.array_equal(a[k], b[k]), k

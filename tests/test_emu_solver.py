@@ -929,6 +929,12 @@ def test_multi_device_handle_matches_single_device(emu_lib, oracle):
     assert np.max(np.abs(np.array(d["R"]) - Ro) / Ro) < 1e-6
 
 
+def test_direct_tentative_product_matches_general_spgemm(emu_lib):
+    """setup: A * T by the one-thread-per-row kernel == the general SpGEMM (see helpers.check_direct_tentative_product)."""
+    from helpers import check_direct_tentative_product
+    check_direct_tentative_product(emu_lib.loaded_path())
+
+
 def test_grounded_solves_share_one_hierarchy(emu_lib):
     """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
     from helpers import check_grounded_solves

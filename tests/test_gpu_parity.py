@@ -266,6 +266,13 @@ def test_lattice_transfer_products(gpu_lib):
     check_lattice_transfer_products(gpu_lib, shapes=((1000, 700), (1201, 334)), ks=(16,), pbs=(4, 0))
 
 
+def test_direct_tentative_product_matches_general_spgemm(gpu_lib):
+    """setup: A * T by the one-thread-per-row kernel == the general SpGEMM, on the device (see the emulator twin)."""
+    from helpers import check_direct_tentative_product
+    check_direct_tentative_product(gpu_lib.loaded_path())
+    check_direct_tentative_product(gpu_lib.loaded_path(), shape=(700, 400), seed=11)
+
+
 def test_grounded_solves_share_one_hierarchy(gpu_lib):
     """scope row N2: csgpu_solve_grounded on the device (see the emulator twin), also with a full batch of 16 columns."""
     from helpers import check_grounded_solves
