@@ -468,7 +468,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
 
-  const int max_timed = 512;
+  static const int max_timed = getenv("CSGPU_TIMED_LAUNCHES") ? atoi(getenv("CSGPU_TIMED_LAUNCHES")) : 512;  // per solve
   int timed = 0;
   int it = 0;
   int graph_launches = 0;

@@ -31,6 +31,38 @@
 
 namespace csgpu {
 
+// Streams that are written once / read once per launch can bypass cache allocation (-DCSGPU_DIA_NT=1: the stores,
+// =2: also the loads of r and z). A/B: profiles/r2_nontemporal_ab.json.
+#ifndef CSGPU_DIA_NT
+#define CSGPU_DIA_NT 0
+#endif
+template <class T, int N>
+__device__ __forceinline__ void dia_store(SpmvVec<T, N>* p, const SpmvVec<T, N>& v) {
+#if CSGPU_DIA_NT >= 1 && defined(__HIPCC__)
+  typedef T VT __attribute__((ext_vector_type(N)));
+  VT t;
+#pragma unroll
+  for (int q = 0; q < N; ++q) t[q] = v.e[q];
+  __builtin_nontemporal_store(t, reinterpret_cast<VT*>(p));
+#else
+  *p = v;
+#endif
+}
+template <class T, int N>
+__device__ __forceinline__ SpmvVec<T, N> dia_load(const SpmvVec<T, N>* p) {
+#if CSGPU_DIA_NT >= 2 && defined(__HIPCC__)
+  typedef T VT __attribute__((ext_vector_type(N)));
+  const VT t = __builtin_nontemporal_load(reinterpret_cast<const VT*>(p));
+  SpmvVec<T, N> v;
+#pragma unroll
+  for (int q = 0; q < N; ++q) v.e[q] = t[q];
+  return v;
+#else
+  return *p;
+#endif
+}
+
+
 // slot of a diagonal offset (0 = main diagonal), -1 when the offset is not one of the lattice's
 __device__ __forceinline__ int dia_slot(int64_t d, int R) {
   if (d == 0) return 0;
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
         if (id >= 0 && id < a.n) {
           const size_t e = (size_t)id * K + c0;
           xr = *reinterpret_cast<const XV*>(a.pin + e);
-          if (FUSE) zr = *reinterpret_cast<const XV*>(a.z + e);
+          if (FUSE) zr = dia_load(reinterpret_cast<const XV*>(a.z + e));
         }
       }
       if (tid < 2 * LPR) {  // halo rows: tile row -1 (lanes 0..LPR-1) and tile row TI (lanes LPR..2LPR-1)
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
 #pragma unroll
         for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)xr.e[q], (T)zr.e[q]);
         const int64_t id = (int64_t)jc * a.R + i0 + t;
-        if (jc >= j0 && jc < j1 && row_on && id < a.n) *reinterpret_cast<XV*>(a.pout + (size_t)id * K + c0) = v;
+        if (jc >= j0 && jc < j1 && row_on && id < a.n) dia_store(reinterpret_cast<XV*>(a.pout + (size_t)id * K + c0), v);
         xr = v;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) xh.e[q] = (XT)fma(beta[q], (T)xh.e[q], (T)zh.e[q]);
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
         if (MODE == DIA_RUPD) {
           // r -= alpha * (A p): same arithmetic as cg_update_r_kernel on a stored A p
           const size_t e = (size_t)id * K + c0;
-          const YV rv = *reinterpret_cast<const YV*>(a.r + e);
+          const YV rv = dia_load(reinterpret_cast<const YV*>(a.r + e));
           YV rn;
           XV rq;
 #pragma unroll
@@ -400,8 +432,8 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
             rq.e[q] = (XT)rn.e[q];
             if (a.partials) dot_acc[q] += (double)rn.e[q] * (double)rn.e[q];
           }
-          *reinterpret_cast<YV*>(a.r + e) = rn;
-          if (a.rp) *reinterpret_cast<XV*>(a.rp + e) = rq;
+          dia_store(reinterpret_cast<YV*>(a.r + e), rn);
+          if (a.rp) dia_store(reinterpret_cast<XV*>(a.rp + e), rq);
           if (a.xsol) {
             const YV xv = *reinterpret_cast<const YV*>(a.xsol + e);
             YV xn;
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
         } else {
 #pragma unroll
           for (int q = 0; q < CPL; ++q) dot_acc[q] += (double)(T)xw[1][1].e[q] * (double)out.e[q];
-          if (a.y) stream_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
+          if (a.y) dia_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
         }
       }
     }
