@@ -707,8 +707,50 @@ __global__ __launch_bounds__(256) void dinv_kernel(int n, const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// Near-kernel of the coarsest operator of an fp32 hierarchy. The Galerkin chain keeps the candidate vector
+// v = sqrt(number of fine nodes under a coarse node) (tentative_kernel) in the near-kernel of every level: A_c v is the
+// regularisation shift only. In fp32 the chain's rounding errors replace that eigenvalue by noise of either sign which
+// GROWS relative to lambda_max from level to level (the stiffness shrinks ~10x per level, the errors do not): measured
+// 2e-6 lambda_max after four coarsenings, 7e-4 after seven -- sometimes above, sometimes below the pseudo-inverse's
+// cutoff, and when the mode is kept its huge gain feeds the rounding noise of the residual back into z (300 x 300
+// raster: 14.4 instead of 10.0 iterations, 3e-10 instead of 5e-13 agreement with the fp64 hierarchy; 2000 x 2000:
+// 13.8 instead of 10.6 iterations). The candidate is known, so the pseudo-inverse treats as null space every eigenpair
+// below `thr` * lambda_max whose eigenvector lies (>= 80 % of its norm) in the span of the candidate restricted to the
+// connected components of the coarsest graph. Dropping a direction of the preconditioner costs CG at most one
+// iteration; keeping a noisy one costs many. Returns the orthonormal per-component candidates, one per row.
+inline std::vector<std::vector<double>> component_candidates(const std::vector<double>& M, int n,
+                                                             const std::vector<double>& cand) {
+  std::vector<std::vector<double>> out;
+  std::vector<int> comp(n, -1), stack;
+  for (int s0 = 0; s0 < n; ++s0) {
+    if (comp[s0] >= 0) continue;
+    std::vector<double> v((size_t)n, 0.0);
+    double nrm = 0;
+    comp[s0] = s0;
+    stack.push_back(s0);
+    while (!stack.empty()) {
+      const int i = stack.back();
+      stack.pop_back();
+      v[i] = cand[i];
+      nrm += cand[i] * cand[i];
+      for (int j = 0; j < n; ++j)
+        if (comp[j] < 0 && (M[(size_t)i * n + j] != 0 || M[(size_t)j * n + i] != 0)) {
+          comp[j] = s0;
+          stack.push_back(j);
+        }
+    }
+    if (!(nrm > 0)) continue;
+    const double inv = 1.0 / std::sqrt(nrm);
+    for (double& x : v) x *= inv;
+    out.push_back(std::move(v));
+  }
+  return out;
+}
+
 // Dense symmetric pseudo-inverse (cyclic Jacobi eigen-solver); n is at most a few hundred.
-inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double eps) {
+inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double eps,
+                                          const std::vector<std::vector<double>>* kernel_cand = nullptr,
+                                          double kernel_thr = 0.0, int* kernel_dropped = nullptr) {
   std::vector<double> V((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j) {
@@ -751,12 +793,48 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   double smax = 0;
   for (int i = 0; i < n; ++i) smax = std::max(smax, std::fabs(M[(size_t)i * n + i]));
   // eigenvalues below n*eps(T)*lambda_max are treated as the null space (Julia pinv's default rtol)
-  const double cut = eps * (double)n * smax;
+  double cut = eps * (double)n * smax;
+  if (getenv("CSGPU_PINV_CUT")) cut = atof(getenv("CSGPU_PINV_CUT")) * smax;  // experiment knob
+  if (getenv("CSGPU_VERBOSE")) {
+    std::vector<double> ev(n);
+    for (int i = 0; i < n; ++i) ev[i] = M[(size_t)i * n + i];
+    std::sort(ev.begin(), ev.end());
+    fprintf(stderr, "csgpu: coarsest level n=%d eigenvalues/lambda_max: %.3e %.3e %.3e ... cut %.3e\n", n, ev[0] / smax,
+            n > 1 ? ev[1] / smax : 0.0, n > 2 ? ev[2] / smax : 0.0, cut / smax);
+  }
   std::vector<double> Pinv((size_t)n * n, 0.0);
+  std::vector<int> kind((size_t)n, 0);  // 0: null space (below the cutoff), 1: near-kernel eigenpair, 2: kept
+  double lam_ref = 0;                   // smallest kept eigenvalue
   for (int e = 0; e < n; ++e) {
     const double lam = M[(size_t)e * n + e];
     if (!(std::fabs(lam) > cut)) continue;
-    const double inv = 1.0 / lam;
+    kind[e] = 2;
+    if (kernel_cand && std::fabs(lam) < kernel_thr * smax) {  // near-kernel eigenpair of an fp32 hierarchy (see above)
+      double overlap = 0;
+      for (const auto& v : *kernel_cand) {
+        double d = 0;
+        for (int i = 0; i < n; ++i) d += v[i] * V[(size_t)i * n + e];
+        overlap += d * d;
+      }
+      if (overlap >= 0.8) {
+        kind[e] = 1;
+        if (kernel_dropped) ++*kernel_dropped;
+      }
+    }
+    if (kind[e] == 2 && lam > 0 && (lam_ref == 0 || lam < lam_ref)) lam_ref = lam;
+  }
+  // A near-kernel eigenpair gets NO gain: the coarsest problem is solved in the orthogonal complement of the candidate.
+  // (Giving it the gain of the smoothest kept mode instead -- a non-singular preconditioner -- was measured too,
+  // CSGPU_KERNEL_GAIN_REF=1: fine up to 5000^2, but at 10000^2 the fp32 restriction chain of eight levels has put so much
+  // spurious weight on the candidate that any gain feeds it back: 13.3 iterations instead of 11.1.)
+  static const bool kernel_ref = getenv("CSGPU_KERNEL_GAIN_REF") != nullptr;  // A/B knob
+  for (int e = 0; e < n; ++e) {
+    if (kind[e] == 0) continue;
+    double inv = 1.0 / M[(size_t)e * n + e];
+    if (kind[e] == 1) {
+      if (!kernel_ref || !(lam_ref > 0)) continue;
+      inv = 1.0 / lam_ref;
+    }
     for (int i = 0; i < n; ++i) {
       const double vi = V[(size_t)i * n + e] * inv;
       for (int j = 0; j < n; ++j) Pinv[(size_t)i * n + j] += vi * V[(size_t)j * n + e];
@@ -794,6 +872,12 @@ struct Hierarchy {
   bool coarse_dense = false;
   double setup_ms = 0;
   int work_k = 0;       // batch width the work vectors are allocated for
+  // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
+  // per-column scratch area and the batch width it is allocated for
+  int tail_first = -2;
+  DBuf tail_ws;
+  int64_t tail_stride = 0;
+  int tail_k = 0;
 };
 
 struct SetupParams {
@@ -1064,7 +1148,23 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       std::vector<double> M((size_t)n * n, 0.0);
       for (int i = 0; i < n; ++i)
         for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + ci[k]] += (double)va[k];
-      std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon());
+      std::vector<std::vector<double>> kc;
+      const bool deflate = sizeof(T) == 4 && !getenv("CSGPU_NO_DEFLATION");
+      if (deflate) {
+        std::vector<double> cand((size_t)n, 1.0);
+        if (size_prev.p) {
+          std::vector<long long> sz((size_t)n);
+          CS_HIP(hipMemcpyAsync(sz.data(), size_prev.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, st));
+          CS_HIP(hipStreamSynchronize(st));
+          for (int i = 0; i < n; ++i) cand[i] = std::sqrt((double)sz[i]);
+        }
+        kc = component_candidates(M, n, cand);
+      }
+      int dropped = 0;
+      std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon(),
+                                              deflate ? &kc : nullptr, 1e-2, &dropped);
+      if (deflate && getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: coarsest level: %d near-kernel eigenpair(s) of %zu candidate(s) dropped\n", dropped, kc.size());
       std::vector<T> Pt((size_t)n * n);
       for (size_t i = 0; i < Pt.size(); ++i) Pt[i] = (T)Pi[i];
       H.coarse_inv.alloc(std::max<size_t>(Pt.size(), 1) * sizeof(T));

@@ -15,6 +15,7 @@
 #include "spmv.h"
 #include "stencil.h"
 #include "lattice.h"
+#include "tail.h"
 #include "raster.h"
 
 namespace csgpu {
@@ -47,6 +48,68 @@ struct VcycleFuse {
                                // two-product form out = [S Q][b; x_c] can be used (needs L.M and V(1,1))
 };
 
+// Levels from `first` down run in one launch (tail.h) when they are small: the first level l >= 1 with at most
+// 4096 rows (measured: above that one workgroup per column is slower than the launches it replaces), provided at least two
+// levels are left. CSGPU_TAIL_ROWS=0 switches the tail off (A/B knob).
+template <class T>
+inline int tail_first_level(Hierarchy<T>& H) {
+  if (H.tail_first != -2) return H.tail_first;
+  const int rows = getenv("CSGPU_TAIL_ROWS") ? atoi(getenv("CSGPU_TAIL_ROWS")) : 4096;  // (read once per hierarchy)
+  H.tail_first = -1;
+  const int nl = (int)H.levels.size();
+  for (int l = 1; l + 1 < nl; ++l) {
+    if (H.levels[l].A.nrows <= rows && nl - l <= kTailMaxLevels) {
+      H.tail_first = l;
+      if (getenv("CSGPU_TAIL_DEBUG")) fprintf(stderr, "csgpu: coarse tail from level %d (%d rows) of %d\n", l, H.levels[l].A.nrows, nl);
+      break;
+    }
+  }
+  return H.tail_first;
+}
+
+template <class T, int K>
+inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_first, int nu_deep, const int* skip,
+                        hipStream_t st) {
+  const int nl = (int)H.levels.size();
+  TailArgs<T> a;
+  a.nlev = nl - first;
+  a.dense = H.coarse_dense ? 1 : 0;
+  a.inv = dptr<T>(H.coarse_inv);
+  int64_t off = 0;
+  for (int t = 0; t < a.nlev; ++t) {
+    Level<T>& L = H.levels[first + t];
+    TailLevel<T>& tl = a.lev[t];
+    tl.n = L.A.nrows;
+    tl.nu = (first + t == 1) ? nu_first : nu_deep;
+    tl.omega = (T)L.omega;
+    tl.arp = L.A.rp();
+    tl.aci = L.A.ci();
+    tl.ava = L.A.va();
+    tl.dinv = dptr<T>(L.dinv);
+    tl.rrp = L.R.rp();
+    tl.rci = L.R.ci();
+    tl.rva = L.R.va();
+    tl.has_q = L.Q.nnz > 0 ? 1 : 0;
+    const Csr<T>& PQ = tl.has_q ? L.Q : L.P;
+    tl.qrp = PQ.rp();
+    tl.qci = PQ.ci();
+    tl.qva = PQ.va();
+    tl.off = off;
+    off += 4 * (int64_t)tl.n;
+  }
+  if (H.tail_k != K || H.tail_stride != off) {
+    H.tail_ws.alloc((size_t)off * K * sizeof(T));
+    H.tail_stride = off;
+    H.tail_k = K;
+  }
+  a.scratch = dptr<T>(H.tail_ws);
+  a.stride = off;
+  a.bin = b;
+  a.xout = out;
+  a.skip = skip;
+  hipLaunchKernelGGL((coarse_tail_kernel<T, K>), dim3(K), dim3(kTailThreads), 0, st, a);
+}
+
 template <class T>
 inline SpmvArgs<T> level_args(const Level<T>& L, const T* x, T* y, const int* skip = nullptr) {
   SpmvArgs<T> a = spmv_args(L.A, x, y);
@@ -74,6 +137,11 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   const int nu_pre = l == 0 ? nu_pre0 : nu_lvl, nu_post = l == 0 ? nu_post0 : nu_lvl;
   const bool want_dot = fuse && fuse->dotw && l == 0;
   const int* skip = fuse ? fuse->skip : nullptr;
+  if (l >= 1 && l == tail_first_level(H)) {
+    const int nu1 = nu_l1 > 0 ? nu_l1 : nu_coarse, nud = nu_deep > 0 ? nu_deep : nu_coarse + 1;
+    launch_tail<T, K>(H, l, b, out, nu1, nud, skip, st);
+    return;
+  }
   if (last && H.coarse_dense) {
     hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n, dptr<T>(H.coarse_inv), b, out, skip);
     if (want_dot)

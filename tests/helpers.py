@@ -548,3 +548,59 @@ def check_direct_tentative_product(libpath, shape=(61, 47), seed=3):
             assert np.max(np.abs(a[k] - b[k])) <= 1e-13 * np.max(np.abs(b[k])), k
         else:
             assert np.array_equal(a[k], b[k]), k
+
+
+def check_coarse_tail(L, shapes=((150, 131),), batches=(1, 4, 16), pbs=(0, 4), monkeypatch=None):
+    """csrc/tail.h: the levels below 16384 rows in one launch (one workgroup per right-hand side) against the
+    launch-per-product V-cycle on the same hierarchy (CSGPU_TAIL_ROWS=0, read when a hierarchy runs its first cycle):
+    same iteration counts, resistances equal to rounding (rows are summed in a different order)."""
+    import os
+    for shape in shapes:
+        rng = np.random.default_rng(shape[0])
+        g = np.exp(rng.standard_normal(shape))
+        g[rng.random(shape) < 0.1] = 0.0          # holes: MIS-2 aggregates, ragged coarse rows
+        n = int((g > 0).sum())
+        for batch in batches:
+            for pb in pbs:
+                ids = rng.choice(n, size=2 * batch, replace=False)
+                src, dst = [int(v) for v in ids[:batch]], [int(v) for v in ids[batch:]]
+                res = {}
+                for tag, rows in (("tail", None), ("classic", "0")):
+                    if rows is None:
+                        os.environ.pop("CSGPU_TAIL_ROWS", None)
+                    else:
+                        os.environ["CSGPU_TAIL_ROWS"] = rows
+                    try:
+                        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+                            assert h.info["levels"] >= 3
+                            R, _, _, st = h.solve_pairs(src, dst)
+                            R2, _, _, st2 = h.solve_pairs(dst, src)      # second solve on the same scratch area
+                            res[tag] = (R, st["total_iters"], R2, st["not_converged"])
+                    finally:
+                        os.environ.pop("CSGPU_TAIL_ROWS", None)
+                a, b = res["tail"], res["classic"]
+                assert a[3] == 0 and b[3] == 0
+                # (fp32 hierarchies on rasters with islands are sensitive to the summation order: a few iterations either way)
+                assert abs(a[1] - b[1]) <= batch + 0.2 * b[1], (shape, batch, pb, a[1], b[1])
+                assert np.max(np.abs(a[0] - b[0]) / b[0]) < 2e-6, (shape, batch, pb)
+                assert np.max(np.abs(a[0] - a[2]) / a[0]) < 2e-6     # R(s, d) == R(d, s)
+
+
+def check_fp32_hierarchy_near_kernel(L, sizes=(200, 300), batch=8, max_extra_iters=1.0, tol=2e-11):
+    """amg_setup.h deflate_candidates: the coarsest operator of an fp32 hierarchy has its near-kernel candidate projected
+    out, so the fp32 preconditioner needs the same number of iterations as the fp64 one (300 x 300 took 14.4 against
+    10.0 before) and the resistances agree to ~1e-12 instead of ~1e-10."""
+    import bench
+    for N in sizes:
+        g = bench.make_raster(N)
+        _, pairs = bench.focal_pairs(N)
+        src = [p[0] for p in pairs[:batch]]
+        dst = [p[1] for p in pairs[:batch]]
+        out = {}
+        for pb in (0, 4):
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+                R, _, _, st = h.solve_pairs(src, dst)
+                out[pb] = (R, st["total_iters"] / batch, st["not_converged"])
+        assert out[0][2] == 0 and out[4][2] == 0
+        assert out[4][1] <= out[0][1] + max_extra_iters, (N, out[0][1], out[4][1])
+        assert np.max(np.abs(out[4][0] - out[0][0]) / out[0][0]) < tol, N

@@ -935,6 +935,18 @@ def test_direct_tentative_product_matches_general_spgemm(emu_lib):
     check_direct_tentative_product(emu_lib.loaded_path())
 
 
+def test_coarse_tail_matches_launch_per_product_vcycle(emu_lib):
+    """csrc/tail.h (see helpers.check_coarse_tail)."""
+    from helpers import check_coarse_tail
+    check_coarse_tail(emu_lib, shapes=((60, 53),), batches=(1, 4), pbs=(0, 4))
+
+
+def test_fp32_hierarchy_near_kernel_is_projected_out(emu_lib):
+    """see helpers.check_fp32_hierarchy_near_kernel"""
+    from helpers import check_fp32_hierarchy_near_kernel
+    check_fp32_hierarchy_near_kernel(emu_lib, sizes=(150, 300))
+
+
 def test_grounded_solves_share_one_hierarchy(emu_lib):
     """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
     from helpers import check_grounded_solves

@@ -273,6 +273,18 @@ def test_direct_tentative_product_matches_general_spgemm(gpu_lib):
     check_direct_tentative_product(gpu_lib.loaded_path(), shape=(700, 400), seed=11)
 
 
+def test_coarse_tail_matches_launch_per_product_vcycle(gpu_lib):
+    """csrc/tail.h on the device (see the emulator twin): a raster whose tail holds three levels."""
+    from helpers import check_coarse_tail
+    check_coarse_tail(gpu_lib, shapes=((150, 131), (700, 500)))
+
+
+def test_fp32_hierarchy_near_kernel_is_projected_out(gpu_lib):
+    """fp32 hierarchies of every depth from 4 to 7 levels need the fp64 hierarchy's iteration count (see the emulator twin)"""
+    from helpers import check_fp32_hierarchy_near_kernel
+    check_fp32_hierarchy_near_kernel(gpu_lib, sizes=(200, 300, 700, 1000, 2500), batch=16, max_extra_iters=1.5)
+
+
 def test_grounded_solves_share_one_hierarchy(gpu_lib):
     """scope row N2: csgpu_solve_grounded on the device (see the emulator twin), also with a full batch of 16 columns."""
     from helpers import check_grounded_solves
