@@ -1138,7 +1138,7 @@ void csgpu_default_opts(csgpu_opts* o) {
   o->nu_coarse = 2;
   o->theta = 0.0;
   o->omega_p = 1.6;
-  o->omega_s = 1.5;
+  o->omega_s = 1.7;
   o->rtol = 1e-6;
   o->atol = -1.0;
   o->node_row = nullptr;
