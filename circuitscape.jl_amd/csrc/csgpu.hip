@@ -114,6 +114,12 @@ struct Solver : ISolver {
     sp.omega_s = opts.omega_s;
     static const bool no_two_product = getenv("CSGPU_NO_TWO_PRODUCT") != nullptr;  // tuning / A-B knob
     sp.two_product = opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0 && !no_two_product;
+    // coarse levels: Chebyshev weights for the sweep counts the solve phase will run (CSGPU_COARSE_JACOBI=1: the damped
+    // Jacobi of round 1, A/B knob)
+    const int nuc = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
+    sp.nu_l1 = getenv("CSGPU_NU_L1") ? atoi(getenv("CSGPU_NU_L1")) : nuc;
+    sp.nu_deep = getenv("CSGPU_NU_DEEP") ? atoi(getenv("CSGPU_NU_DEEP")) : nuc + 1;
+    sp.coarse_chebyshev = getenv("CSGPU_COARSE_JACOBI") == nullptr;
     return sp;
   }
   PcgParams pcg_params(int K = 1) const {
@@ -235,6 +241,13 @@ struct Solver : ISolver {
     }
     static const bool no_lattice_s = getenv("CSGPU_NO_LATTICE_S") != nullptr;  // A/B knob
     sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
+    // Chebyshev weights on the coarse levels need a clean restriction chain: measured on MI355X they save 4-17 % of the
+    // iterations on rasters up to 5000^2 (7 levels) with an fp32 hierarchy and at 10000^2 (8 levels) with an fp64 one,
+    // but the fp32 hierarchy of a 10000^2 raster loses with them (11.8 / 21 instead of 10.9 / 11 iterations, mean /
+    // slowest column): the large weights of the polynomial amplify the spurious near-kernel component that eight fp32
+    // restrictions put on the coarse right-hand sides (amg_setup.h, component_candidates). Until that component is
+    // projected out, fp32 hierarchies above 3e7 rows (an eighth level) keep the damped Jacobi of round 1 there.
+    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;
     if constexpr (MIXED) {
       Csr<TP> Ap;
       convert_csr(A, Ap, st);

@@ -81,6 +81,9 @@ inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_f
     TailLevel<T>& tl = a.lev[t];
     tl.n = L.A.nrows;
     tl.nu = (first + t == 1) ? nu_first : nu_deep;
+    if (!L.weights.empty()) tl.nu = (int)L.weights.size();
+    CS_REQUIRE(tl.nu <= kTailMaxSweeps, CSGPU_BAD_ARGS, "more sweeps per coarse level than the tail kernel holds weights for");
+    for (int s = 0; s < kTailMaxSweeps; ++s) tl.w[s] = L.weights.empty() ? (T)L.omega : (T)L.weights[std::min<size_t>(s, L.weights.size() - 1)];
     tl.omega = (T)L.omega;
     tl.arp = L.A.rp();
     tl.aci = L.A.ci();
@@ -134,7 +137,11 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   static const int nu_l1 = getenv("CSGPU_NU_L1") ? atoi(getenv("CSGPU_NU_L1")) : 0;
   static const int nu_deep = getenv("CSGPU_NU_DEEP") ? atoi(getenv("CSGPU_NU_DEEP")) : 0;
   const int nu_lvl = l == 1 ? (nu_l1 > 0 ? nu_l1 : nu_coarse) : (nu_deep > 0 ? nu_deep : nu_coarse + 1);
-  const int nu_pre = l == 0 ? nu_pre0 : nu_lvl, nu_post = l == 0 ? nu_post0 : nu_lvl;
+  // Chebyshev levels (amg_setup.h): one weight per sweep, fixed at setup; the sweep count is the polynomial's degree
+  const bool cheb = l >= 1 && !L.weights.empty();
+  const int nu_pre = l == 0 ? nu_pre0 : (cheb ? (int)L.weights.size() : nu_lvl);
+  const int nu_post = l == 0 ? nu_post0 : (cheb ? (int)L.weights.size() : nu_lvl);
+  auto weight = [&](int sweep) { return cheb ? (T)L.weights[sweep] : (T)L.omega; };
   const bool want_dot = fuse && fuse->dotw && l == 0;
   const int* skip = fuse ? fuse->skip : nullptr;
   if (l >= 1 && l == tail_first_level(H)) {
@@ -152,11 +159,11 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   T* cur = dptr<T>(L.xa);
   T* oth = dptr<T>(L.rb);
   const T omega = (T)L.omega;
-  auto jacobi_sweep = [&](const T* xin, T* xout, bool dot) {
+  auto jacobi_sweep = [&](const T* xin, T* xout, bool dot, int sweep = 0) {
     SpmvArgs<T> a = level_args(L, xin, xout, skip);
     a.b = b;
     a.dinv = dptr<T>(L.dinv);
-    a.omega = omega;
+    a.omega = weight(sweep);
     if (dot) {
       a.dotw = fuse->dotw;
       a.partials = fuse->partials;
@@ -211,7 +218,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     if (!(fuse && fuse->xa_ready && l == 0))
       hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega, skip);
     for (int s = 1; s < nu_pre; ++s) {
-      jacobi_sweep(cur, oth, false);
+      jacobi_sweep(cur, oth, false, s);
       std::swap(cur, oth);
     }
   } else {
@@ -263,7 +270,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
       for (int s2 = 1; s2 < nu_post; ++s2) {
         const bool last_sweep = (s2 + 1 == nu_post);
         T* d2 = last_sweep ? out : spare;
-        jacobi_sweep(src, d2, last_sweep && want_dot);
+        jacobi_sweep(src, d2, last_sweep && want_dot, s2);
         spare = src;
         src = d2;
       }
@@ -281,7 +288,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   if (nu_post >= 1) {
     for (int s = 0; s < nu_post; ++s) {
       const bool fin = (s + 1 == nu_post);
-      jacobi_sweep(cur, fin ? out : oth, fin && want_dot);
+      jacobi_sweep(cur, fin ? out : oth, fin && want_dot, s);
       std::swap(cur, oth);
     }
   } else {

@@ -18,11 +18,13 @@ namespace csgpu {
 
 static const int kTailMaxLevels = 10;
 static const int kTailThreads = 1024;
+static const int kTailMaxSweeps = 8;
 
 template <class T>
 struct TailLevel {
   int n, nu, has_q;
-  T omega;
+  T omega;               // weight of the coarsest level's Jacobi sweeps (no dense inverse)
+  T w[kTailMaxSweeps];   // weight of sweep s (damped Jacobi: all equal; Chebyshev levels: amg_setup.h)
   const int *arp, *aci;
   const T* ava;
   const T* dinv;
@@ -127,11 +129,12 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
       __syncthreads();
       break;
     }
-    for (int i = tid; i < n; i += kTailThreads) x[i] = L.omega * L.dinv[i] * b[i];
+    for (int i = tid; i < n; i += kTailThreads) x[i] = L.w[0] * L.dinv[i] * b[i];
     __syncthreads();
     for (int s = 1; s < L.nu; ++s) {
+      const T ws = L.w[s];
       for (int i = tid; i < n; i += kTailThreads)
-        y[i] = x[i] + L.omega * L.dinv[i] * (b[i] - tail_row(L.arp, L.aci, L.ava, x, i));
+        y[i] = x[i] + ws * L.dinv[i] * (b[i] - tail_row(L.arp, L.aci, L.ava, x, i));
       __syncthreads();
       T* t = x;
       x = y;
@@ -156,11 +159,11 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
     T* y = (x == b + n) ? b + 2 * n : b + n;
     T* r = b + 3 * n;
     const T* xc = s_x[l + 1];
-    int sweeps = L.nu;
-    if (L.has_q) {  // x' = x + w D^-1 r + Q x_c : prolongation and first post-sweep in one product
+    int first = 0;
+    if (L.has_q) {  // x' = x + w_0 D^-1 r + Q x_c : prolongation and first post-sweep in one product
       for (int i = tid; i < n; i += kTailThreads)
-        y[i] = x[i] + L.omega * L.dinv[i] * r[i] + tail_row(L.qrp, L.qci, L.qva, xc, i);
-      --sweeps;
+        y[i] = x[i] + L.w[0] * L.dinv[i] * r[i] + tail_row(L.qrp, L.qci, L.qva, xc, i);
+      first = 1;
     } else {
       for (int i = tid; i < n; i += kTailThreads) y[i] = x[i] + tail_row(L.qrp, L.qci, L.qva, xc, i);
     }
@@ -170,9 +173,10 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
       x = y;
       y = t;
     }
-    for (int s = 0; s < sweeps; ++s) {
+    for (int s = first; s < L.nu; ++s) {
+      const T ws = L.w[s];
       for (int i = tid; i < n; i += kTailThreads)
-        y[i] = x[i] + L.omega * L.dinv[i] * (b[i] - tail_row(L.arp, L.aci, L.ava, x, i));
+        y[i] = x[i] + ws * L.dinv[i] * (b[i] - tail_row(L.arp, L.aci, L.ava, x, i));
       __syncthreads();
       T* t = x;
       x = y;

@@ -947,6 +947,12 @@ def test_fp32_hierarchy_near_kernel_is_projected_out(emu_lib):
     check_fp32_hierarchy_near_kernel(emu_lib, sizes=(150, 300))
 
 
+def test_coarse_levels_smooth_with_chebyshev_weights(emu_lib, oracle):
+    """see helpers.check_coarse_chebyshev"""
+    from helpers import check_coarse_chebyshev
+    check_coarse_chebyshev(emu_lib, oracle, N=150, gain=0.97)
+
+
 def test_grounded_solves_share_one_hierarchy(emu_lib):
     """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
     from helpers import check_grounded_solves

@@ -285,6 +285,12 @@ def test_fp32_hierarchy_near_kernel_is_projected_out(gpu_lib):
     check_fp32_hierarchy_near_kernel(gpu_lib, sizes=(200, 300, 700, 1000, 2500), batch=16, max_extra_iters=1.5)
 
 
+def test_coarse_levels_smooth_with_chebyshev_weights(gpu_lib, oracle):
+    """Chebyshev weights on the coarse levels on the device (see the emulator twin), 6-level hierarchy"""
+    from helpers import check_coarse_chebyshev
+    check_coarse_chebyshev(gpu_lib, oracle, N=900, batch=8, gain=0.95)
+
+
 def test_grounded_solves_share_one_hierarchy(gpu_lib):
     """scope row N2: csgpu_solve_grounded on the device (see the emulator twin), also with a full batch of 16 columns."""
     from helpers import check_grounded_solves
