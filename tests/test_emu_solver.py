@@ -944,13 +944,13 @@ def test_coarse_tail_matches_launch_per_product_vcycle(emu_lib):
 def test_fp32_hierarchy_near_kernel_is_projected_out(emu_lib):
     """see helpers.check_fp32_hierarchy_near_kernel"""
     from helpers import check_fp32_hierarchy_near_kernel
-    check_fp32_hierarchy_near_kernel(emu_lib, sizes=(150, 300))
+    check_fp32_hierarchy_near_kernel(emu_lib, sizes=(300,), batch=4)
 
 
 def test_coarse_levels_smooth_with_chebyshev_weights(emu_lib, oracle):
     """see helpers.check_coarse_chebyshev"""
     from helpers import check_coarse_chebyshev
-    check_coarse_chebyshev(emu_lib, oracle, N=150, gain=0.97)
+    check_coarse_chebyshev(emu_lib, oracle, N=150, sigmas=(2.5,), gain=0.97)
 
 
 def test_grounded_solves_share_one_hierarchy(emu_lib):
