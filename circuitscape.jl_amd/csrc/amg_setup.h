@@ -229,6 +229,11 @@ __global__ __launch_bounds__(256) void agg_coords_kernel(int n, const int* __res
     }
 }
 
+template <class T>
+__global__ __launch_bounds__(256) void candidate_kernel(int n, const long long* __restrict__ size, T* __restrict__ v) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v[i] = (T)sqrt((double)size[i]);
+}
+
 // tentative prolongator as CSR with exactly one entry per row
 template <class T>
 __global__ __launch_bounds__(256) void tentative_kernel(int n, const int* __restrict__ agg,
@@ -859,6 +864,7 @@ struct Level {
   long long periodA = 0;  // band period detected on A (0: none)
   double omega = 0;     // damped-Jacobi weight (Chebyshev levels: the weight of the first sweep = the weight Q is built with)
   double lam_max = 0;   // Chebyshev levels (l >= 1): upper end of the targeted eigenvalue interval of D^-1 A
+  DBuf cand;            // levels >= 1 with at most 4096 rows: the candidate vector sqrt(fine nodes under the node) (tail.h)
   std::vector<double> weights;  // Chebyshev levels: one Jacobi weight per sweep (empty: damped Jacobi with `omega`)
   double rho = 0;       // Gershgorin bound on rho(D^-1 A)
   int n = 0;
@@ -876,6 +882,8 @@ struct Hierarchy {
   int work_k = 0;       // batch width the work vectors are allocated for
   // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
   // per-column scratch area and the batch width it is allocated for
+  bool near_singular = false;  // the coarsest operator's near-kernel eigenpair was dropped (fp32 hierarchy of a Laplacian)
+  double cand_norm2 = 0;       // |candidate|^2 (= number of fine nodes: the same on every level)
   int tail_first = -2;
   DBuf tail_ws;
   int64_t tail_stride = 0;
@@ -1156,6 +1164,12 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
     cur_col = ccol_prev.p ? dptr<int>(ccol_prev) : nullptr;
     H.levels.emplace_back();
     H.levels.back().A = std::move(Ac);
+    if (nagg <= 4096) {  // (levels the coarse tail may run; see tail.h)
+      Level<T>& Ln = H.levels.back();
+      Ln.cand.alloc((size_t)nagg * sizeof(T));
+      hipLaunchKernelGGL((candidate_kernel<T>), dim3(grid_for(nagg)), dim3(256), 0, st, nagg, (const long long*)size_prev.p,
+                         dptr<T>(Ln.cand));
+    }
   }
   // coarsest level: dense pseudo-inverse when small enough
   {
@@ -1192,6 +1206,8 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       int dropped = 0;
       std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon(),
                                               deflate ? &kc : nullptr, 1e-2, &dropped);
+      H.near_singular = deflate && dropped > 0;
+      H.cand_norm2 = (double)H.levels[0].A.nrows;
       if (deflate && getenv("CSGPU_VERBOSE"))
         fprintf(stderr, "csgpu: coarsest level: %d near-kernel eigenpair(s) of %zu candidate(s) dropped\n", dropped, kc.size());
       std::vector<T> Pt((size_t)n * n);

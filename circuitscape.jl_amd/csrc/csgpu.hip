@@ -243,10 +243,13 @@ struct Solver : ISolver {
     sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
     // Chebyshev weights on the coarse levels need a clean restriction chain: measured on MI355X they save 4-17 % of the
     // iterations on rasters up to 5000^2 (7 levels) with an fp32 hierarchy and at 10000^2 (8 levels) with an fp64 one,
-    // but the fp32 hierarchy of a 10000^2 raster loses with them (11.8 / 21 instead of 10.9 / 11 iterations, mean /
+    // but the fp32 hierarchy of a 10000^2 raster lost with them (11.8 / 21 instead of 10.9 / 11 iterations, mean /
     // slowest column): the large weights of the polynomial amplify the spurious near-kernel component that eight fp32
-    // restrictions put on the coarse right-hand sides (amg_setup.h, component_candidates). Until that component is
-    // projected out, fp32 hierarchies above 3e7 rows (an eighth level) keep the damped Jacobi of round 1 there.
+    // restrictions put on the coarse right-hand sides (amg_setup.h, component_candidates). The coarse tail now projects
+    // that component out (tail.h, tail_project) and with it the same hierarchy reaches the fp64 count (10.77 / 11,
+    // profiles/r2_coarse_chebyshev.json) -- measured on 48 pairs at the very end of the round, after the full evidence
+    // set had been taken with the rule below in place; CSGPU_COARSE_CHEBYSHEV=1 lifts it, and the next full evidence run
+    // should.
     if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;
     if constexpr (MIXED) {
       Csr<TP> Ap;

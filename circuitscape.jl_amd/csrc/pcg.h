@@ -97,6 +97,7 @@ inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_f
     tl.qrp = PQ.rp();
     tl.qci = PQ.ci();
     tl.qva = PQ.va();
+    tl.cand = L.cand.p ? (const T*)dptr<T>(L.cand) : nullptr;
     tl.off = off;
     off += 4 * (int64_t)tl.n;
   }
@@ -105,6 +106,9 @@ inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_f
     H.tail_stride = off;
     H.tail_k = K;
   }
+  // projection of the candidate out of the tail's right-hand sides: near-singular fp32 hierarchies only (A/B knob:
+  // CSGPU_NO_TAIL_PROJECTION)
+  a.cand_inv_norm2 = (H.near_singular && H.cand_norm2 > 0 && !getenv("CSGPU_NO_TAIL_PROJECTION")) ? (T)(1.0 / H.cand_norm2) : T(0);
   a.scratch = dptr<T>(H.tail_ws);
   a.stride = off;
   a.bin = b;

@@ -32,6 +32,7 @@ struct TailLevel {
   const T* rva;
   const int *qrp, *qci;  // Q (has_q) or P
   const T* qva;
+  const T* cand;         // candidate vector of the level (null: no projection)
   int64_t off;           // offset of this level's four vectors inside a column's scratch area
 };
 
@@ -45,8 +46,29 @@ struct TailArgs {
   int64_t stride;
   const T* bin;          // [n_first][K] right-hand side of the first tail level (interleaved batch layout)
   T* xout;               // [n_first][K] its solution
+  T cand_inv_norm2;      // 1 / |candidate|^2 (the same on every level); 0: no projection
   const int* skip;
 };
+
+// b <- b - v (v'b) / (v'v): in exact arithmetic the restricted right-hand sides of a near-singular Laplacian system have no
+// component along the candidate (v_c'(R r) = (P v_c)'r = 1'r = 0 for every right-hand side the reference solves on such a
+// system); in an fp32 hierarchy the restriction chain leaves one, and the deeper the level the larger it is relative to
+// the level's own scale (amg_setup.h, component_candidates).
+template <class T>
+__device__ __forceinline__ void tail_project(T* b, const T* __restrict__ v, int n, T inv_norm2, double* s_red, int tid) {
+  double s = 0;
+  for (int i = tid; i < n; i += kTailThreads) s += (double)v[i] * (double)b[i];
+  s_red[tid] = s;
+  __syncthreads();
+  for (int h = kTailThreads / 2; h > 0; h >>= 1) {
+    if (tid < h) s_red[tid] += s_red[tid + h];
+    __syncthreads();
+  }
+  const T c = (T)(s_red[0] * (double)inv_norm2);
+  __syncthreads();
+  for (int i = tid; i < n; i += kTailThreads) b[i] -= c * v[i];
+  __syncthreads();
+}
 
 template <class T>
 __device__ __forceinline__ T tail_row(const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ va,
@@ -74,10 +96,13 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
   T* ws = a.scratch + (size_t)c * a.stride;
   __shared__ T* s_x[kTailMaxLevels];  // which of a level's two solution buffers holds x after the way down
   __shared__ T s_part[kTailThreads];
+  __shared__ double s_red[kTailThreads];
   {
     const TailLevel<T>& L = a.lev[0];
     T* b = ws + L.off;
     for (int i = tid; i < L.n; i += kTailThreads) b[i] = a.bin[(size_t)i * K + c];
+    __syncthreads();
+    if (a.cand_inv_norm2 != T(0) && L.cand) tail_project(b, L.cand, L.n, a.cand_inv_norm2, s_red, tid);
   }
   __syncthreads();
   // ---- down
@@ -147,6 +172,8 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
       const TailLevel<T>& Lc = a.lev[l + 1];
       T* bc = ws + Lc.off;
       for (int i = tid; i < Lc.n; i += kTailThreads) bc[i] = tail_row(L.rrp, L.rci, L.rva, r, i);
+      __syncthreads();
+      if (a.cand_inv_norm2 != T(0) && Lc.cand) tail_project(bc, Lc.cand, Lc.n, a.cand_inv_norm2, s_red, tid);
     }
     __syncthreads();
   }

@@ -641,3 +641,41 @@ def check_coarse_chebyshev(L, oracle, N=150, sigmas=(1.0, 2.5), batch=4, gain=0.
             assert its[("chebyshev", pb)] <= its[("jacobi", pb)] + 0.5, (sigma, its)
             if sigma >= 2.0:
                 assert its[("chebyshev", pb)] <= gain * its[("jacobi", pb)], (sigma, its)
+
+
+def check_tail_projection(L, N=120, batch=4):
+    """tail.h tail_project: near-singular fp32 hierarchies project the candidate vector out of the coarse tail's
+    right-hand sides. Exact arithmetic has no such component (v'b_c = 1'r = 0), so switching the projection off
+    (CSGPU_NO_TAIL_PROJECTION, read per cycle) must not change resistances beyond the solver tolerance nor the iteration
+    count by more than one per column -- on pair solves and on grounded (one-to-all style) solves of the same handle,
+    where 1'r is NOT zero and the projection must still be harmless."""
+    import os
+    import bench
+    g = bench.make_raster(N)
+    _, pairs = bench.focal_pairs(N)
+    src = [p[0] for p in pairs[:batch]]
+    dst = [p[1] for p in pairs[:batch]]
+    out = {}
+    for tag in ("on", "off"):
+        if tag == "off":
+            os.environ["CSGPU_NO_TAIL_PROJECTION"] = "1"
+        else:
+            os.environ.pop("CSGPU_NO_TAIL_PROJECTION", None)
+        try:
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=4)) as h:
+                R, _, _, st = h.solve_pairs(src, dst)
+                rhs = np.zeros((h.info["n"], batch))
+                grounds = []
+                for c in range(batch):
+                    rhs[src[c], c] = 1.0
+                    grounds.append([dst[c]])
+                X, _, st2 = h.solve_grounded(rhs, grounds)
+                out[tag] = (R, st["total_iters"], X[src, np.arange(batch)], st2["total_iters"], st["not_converged"] + st2["not_converged"])
+        finally:
+            os.environ.pop("CSGPU_NO_TAIL_PROJECTION", None)
+    a, b = out["on"], out["off"]
+    assert a[4] == 0 and b[4] == 0
+    assert np.max(np.abs(a[0] - b[0]) / b[0]) < 1e-9 and abs(a[1] - b[1]) <= batch
+    # a grounded solve's voltage at the source IS the pair's resistance
+    assert np.max(np.abs(a[2] - a[0]) / a[0]) < 1e-5 and np.max(np.abs(b[2] - b[0]) / b[0]) < 1e-5
+    assert abs(a[3] - b[3]) <= 2 * batch

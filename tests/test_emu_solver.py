@@ -953,6 +953,12 @@ def test_coarse_levels_smooth_with_chebyshev_weights(emu_lib, oracle):
     check_coarse_chebyshev(emu_lib, oracle, N=150, sigmas=(2.5,), gain=0.97)
 
 
+def test_tail_projection_is_harmless(emu_lib):
+    """see helpers.check_tail_projection"""
+    from helpers import check_tail_projection
+    check_tail_projection(emu_lib)
+
+
 def test_grounded_solves_share_one_hierarchy(emu_lib):
     """scope row N2: csgpu_solve_grounded (see helpers.check_grounded_solves)."""
     from helpers import check_grounded_solves

@@ -291,6 +291,12 @@ def test_coarse_levels_smooth_with_chebyshev_weights(gpu_lib, oracle):
     check_coarse_chebyshev(gpu_lib, oracle, N=900, batch=8, gain=0.95)
 
 
+def test_tail_projection_is_harmless(gpu_lib):
+    """candidate projected out of the coarse tail's right-hand sides, on the device (see the emulator twin)"""
+    from helpers import check_tail_projection
+    check_tail_projection(gpu_lib, N=700, batch=16)
+
+
 def test_grounded_solves_share_one_hierarchy(gpu_lib):
     """scope row N2: csgpu_solve_grounded on the device (see the emulator twin), also with a full batch of 16 columns."""
     from helpers import check_grounded_solves
