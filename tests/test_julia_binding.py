@@ -1,0 +1,86 @@
+"""Static consistency of the reference-side Julia binding (circuitscape.jl_amd/julia/CircuitscapeHIPExt.jl) with the C ABI.
+
+Julia is not installed in the build image, so the binding cannot be executed here. What CAN be checked
+without Julia: every struct mirrored in the .jl file has the same fields, in the same order and of the same width as
+the C struct in include/csgpu.h (through the ctypes mirror, which the GPU tests do execute), and every `ccall` names an
+exported symbol and passes exactly as many arguments as the C prototype declares.
+"""
+import ctypes
+import os
+import re
+
+import circuitscape_jl_amd  # noqa: F401
+from circuitscape_jl_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = open(os.path.join(ROOT, "circuitscape.jl_amd", "julia", "CircuitscapeHIPExt.jl")).read()
+HDR = open(os.path.join(ROOT, "include", "csgpu.h")).read()
+
+JL_SIZES = {"Int32": 4, "Int64": 8, "Float64": 8, "Float32": 4, "Cint": 4}
+
+
+def jl_struct(name):
+    m = re.search(r"mutable struct %s\n(.*?)\n\s*%s\(\)" % (name, name), JL, re.S)
+    assert m, name
+    fields = []
+    for part in re.split(r"[;\n]", m.group(1)):
+        part = part.split("#")[0].strip()
+        if not part:
+            continue
+        fname, ftype = [x.strip() for x in part.split("::")]
+        fields.append((fname, 8 if ftype.startswith("Ptr{") else JL_SIZES[ftype]))
+    return fields
+
+
+def test_structs_match_field_by_field():
+    for jl_name, ct in (("CsgpuOpts", lib.Opts), ("CsgpuStats", lib.Stats)):
+        jl = jl_struct(jl_name)
+        c = [(k, ctypes.sizeof(t)) for k, t in ct._fields_]
+        assert jl == c, (jl_name, jl, c)
+
+
+def c_prototypes():
+    protos = {}
+    for m in re.finditer(r"^(?:int|void|const char\*|int64_t|csgpu_handle\*)\s+(csgpu_\w+)\(([^;]*?)\);", HDR, re.S | re.M):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+    return protos
+
+
+def split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def test_every_ccall_names_an_export_with_the_right_arity():
+    protos = c_prototypes()
+    assert set(lib.EXPORTS) <= set(protos), sorted(set(lib.EXPORTS) - set(protos))
+    seen = set()
+    for m in re.finditer(r"ccall\(\(:(csgpu_\w+), LIBCSGPU\),\s*(\w+),\s*\(", JL):
+        name = m.group(1)
+        seen.add(name)
+        assert name in protos, name
+        # the argument-type tuple starts at the parenthesis the pattern ends with
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(JL[i], 0)
+            i += 1
+        types = [t for t in split_top(JL[m.end():i - 1]) if t.strip()]
+        assert len(types) == protos[name], (name, len(types), protos[name], types)
+    # the binding covers the whole solve surface a Julia host needs
+    for needed in ("csgpu_setup", "csgpu_solve_rhs", "csgpu_solve_pairs", "csgpu_free", "csgpu_last_error",
+                   "csgpu_default_opts", "csgpu_solve_grounded", "csgpu_raster_setup_poly", "csgpu_multi_setup",
+                   "csgpu_multi_solve_pairs", "csgpu_multi_free"):
+        assert needed in seen, needed
