@@ -693,3 +693,139 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
 
 
 
+
+
+def focal_regions_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, avg_res=False, exclude_pairs=(),
+                                     stats=None, polymap=None):
+    """Pairwise mode when focal points are REGIONS (several cells share an id): the reference short-circuits the two
+    regions of every pair and builds a fresh graph + AMG hierarchy per pair (`_pt_file_polygons_path`,
+    src/raster/pairwise.jl:72-135 -> create_new_polymap :369-442 -> construct_node_map). Here ONE graph (user polygons
+    merged on the device, csgpu_raster_setup[_poly]) and ONE hierarchy serve all pairs: a short-circuited set is an
+    equipotential, so the effective resistance between the sets I and J is 1 / (total current leaving I when I is held at
+    potential 1 and J at 0) -- a Dirichlet problem on the graph in which they are NOT merged,
+        A_ff x_f = -A_fI 1,   x = 1 on I, 0 on J,   R = 1 / sum_{i in I} (A x)_i = 1 / x'Ax,
+    which is exactly what csgpu_solve_grounded solves (rows / columns of I u J masked, one column per pair, batches of
+    `solver.bs` pairs per PCG). Edges inside a set carry no current at equal potential (the merged graph drops them as
+    self-loops); parallel edges from a set to an outside cell add up in the sum (the merged graph sums them). Sets that
+    reach several components behave like the merged graph: only components both sets touch carry current.
+
+    Which nodes form a region's set follows create_new_polymap to the letter: a single-cell region is its cell's node; a
+    region none of whose cells lies in a user polygon is all of its cells (:401-411); a region with cells in user
+    polygons merges THOSE POLYGONS and nothing else (:426-433), the pair being measured from the region's first cell
+    (:154-157) -- if that cell lies outside the merged polygons the short-circuit is a floating one, which a Dirichlet
+    mask cannot express: such a pair takes the reference's own route (its polygon map built, csgpu_raster_setup_poly and
+    csgpu_solve_pairs for that pair alone). Returns the reference's padded resistance matrix over the region ids in order
+    of first appearance (-1: not connected or excluded, 0: sets sharing a node)."""
+    rows = np.asarray(points_rc[0], dtype=np.int64) - 1
+    cols = np.asarray(points_rc[1], dtype=np.int64) - 1
+    ids = [int(v) for v in points_rc[2]]
+    pts = []
+    for v in ids:
+        if v not in pts:
+            pts.append(v)
+    pm = None if polymap is None or np.size(polymap) == 0 else np.asarray(polymap, dtype=np.int64)
+    excl = {(int(a), int(b)) for a, b in exclude_pairs} | {(int(b), int(a)) for a, b in exclude_pairs}
+    res = -np.ones((len(pts), len(pts)))
+    np.fill_diagonal(res, 0.0)
+    fallback = []
+    try:
+        with lib.raster_setup(np.asarray(cellmap), _opts_for(solver), four_neighbors=four_neighbors,
+                              avg_resistances=avg_res, reg=True, polymap=pm) as h:
+            nodemap = h.raster_nodemap()
+            n = h.info["n"]
+            labels, _ = h.components()
+            cell_node = nodemap[rows, cols].astype(np.int64) - 1        # -1: the cell is NODATA
+            region, floating = {}, set()
+            for p in pts:
+                cells = [k for k in range(len(ids)) if ids[k] == p]
+                in_poly = [k for k in cells if pm is not None and pm[rows[k], cols[k]] != 0]
+                if len(cells) == 1 or not in_poly:
+                    nodes = {int(cell_node[k]) for k in cells if cell_node[k] >= 0}
+                else:
+                    if len(in_poly) == 1:
+                        raise ValueError("focal region %d has exactly one cell inside a polygon: the reference itself "
+                                         "fails on this input (undefined variable at src/raster/pairwise.jl:424)" % p)
+                    vals = {int(pm[rows[k], cols[k]]) for k in in_poly}
+                    sel = np.isin(pm, list(vals)) & (nodemap > 0)
+                    nodes = {int(v) - 1 for v in np.unique(nodemap[sel])}
+                    if int(cell_node[cells[0]]) not in nodes:
+                        floating.add(p)
+                region[p] = sorted(nodes)
+            jobs = []
+            for a in range(len(pts)):
+                for b in range(a + 1, len(pts)):
+                    if (pts[a], pts[b]) in excl:
+                        continue
+                    if pts[a] in floating or pts[b] in floating:
+                        fallback.append((a, b))
+                        continue
+                    I, J = region[pts[a]], region[pts[b]]
+                    common = {int(labels[v]) for v in I} & {int(labels[v]) for v in J}
+                    if not common:
+                        continue                                       # stays -1
+                    if set(I) & set(J):
+                        res[a, b] = res[b, a] = 0.0
+                        continue
+                    jobs.append((a, b, [v for v in I if int(labels[v]) in common],
+                                 [v for v in J if int(labels[v]) in common]))
+            width = max(1, min(16, int(solver.bs)))
+            for c0 in range(0, len(jobs), width):
+                chunk = jobs[c0:c0 + width]
+                k = 1
+                while k < len(chunk):
+                    k *= 2                                             # csgpu_spmv_host takes 1, 2, 4, 8 or 16 columns
+                ind = np.zeros((n, k))
+                for c, (_, _, I, _) in enumerate(chunk):
+                    ind[I, c] = 1.0
+                rhs = -h.spmv(ind)                                     # -A 1_I
+                grounds = []
+                for c, (_, _, I, J) in enumerate(chunk):
+                    grounds.append(I + J)
+                    rhs[I + J, c] = 0.0
+                X, _, st = h.solve_grounded(np.asfortranarray(rhs[:, :len(chunk)]), grounds)
+                if stats is not None:
+                    for key in ("total_iters", "nrhs"):
+                        stats[key] = stats.get(key, 0) + st[key]
+                    stats["max_relres"] = max(stats.get("max_relres", 0.0), st["max_relres"])
+                volt = ind.copy()
+                volt[:, :len(chunk)] += X.reshape(n, -1)
+                av = h.spmv(volt)
+                # total current = sum_{i in I} (A v)_i = v'Av for the exact v; the energy form is used because its error is
+                # second order in the error of the iterate (the same reason pair resistances b'x come out at 1e-11)
+                energy = np.sum(volt * av, axis=0)
+                for c, (a, b, _, _) in enumerate(chunk):
+                    cur = float(energy[c])
+                    res[a, b] = res[b, a] = (1.0 / cur) if cur > 0 else -1.0
+    except lib.CsgpuError as e:
+        if e.code == lib.CSGPU_NOT_CONVERGED:
+            _raise_not_converged(e)
+        raise
+    if fallback:
+        if stats is not None:
+            stats["per_pair_graphs"] = len(fallback)
+        for a, b in fallback:
+            # the pair's polygon map as create_new_polymap builds it (pt1 / pt2 branch, pairwise.jl:406-440): a region
+            # clear of user polygons becomes a new polygon, a region with cells in user polygons merges those polygons
+            newpoly = pm.copy()
+            nxt = int(pm.max())
+            for p in (pts[a], pts[b]):
+                cells = [k for k in range(len(ids)) if ids[k] == p]
+                if len(cells) == 1:
+                    continue
+                in_poly = [k for k in cells if pm[rows[k], cols[k]] != 0]
+                nxt += 1
+                if not in_poly:
+                    for k in cells:
+                        newpoly[rows[k], cols[k]] = nxt
+                else:
+                    newpoly[np.isin(pm, [int(pm[rows[k], cols[k]]) for k in in_poly])] = nxt
+            first = [ids.index(pts[a]), ids.index(pts[b])]
+            pair_pts = ([int(rows[k]) + 1 for k in first], [int(cols[k]) + 1 for k in first], [pts[a], pts[b]])
+            r2 = raster_pairwise_on_device(cellmap, pair_pts, solver, four_neighbors=four_neighbors, avg_res=avg_res,
+                                           polymap=newpoly)
+            res[a, b] = res[b, a] = r2[1, 2]
+    out = np.zeros((len(pts) + 1, len(pts) + 1))
+    out[0, 1:] = pts
+    out[1:, 0] = pts
+    out[1:, 1:] = res
+    return out

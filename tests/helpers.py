@@ -679,3 +679,85 @@ def check_tail_projection(L, N=120, batch=4):
     # a grounded solve's voltage at the source IS the pair's resistance
     assert np.max(np.abs(a[2] - a[0]) / a[0]) < 1e-5 and np.max(np.abs(b[2] - b[0]) / b[0]) < 1e-5
     assert abs(a[3] - b[3]) <= 2 * batch
+
+
+FOCAL_REGION_GOLDENS = ("sgVerify3", "sgVerify5", "sgVerify6", "sgVerify8", "sgVerify9", "sgVerify10", "sgVerify11")
+
+
+def run_fixture_focal_regions_on_device(case, solver):
+    """A pairwise fixture whose focal points are regions, through solver.focal_regions_pairwise_on_device: ONE device-built
+    graph and ONE hierarchy for all pairs (the reference builds a graph and a hierarchy per pair,
+    src/raster/pairwise.jl:72-135)."""
+    from circuitscape_jl_amd import solver as ps
+    o = case["options"]
+    gmap = np.array(case["cellmap"], dtype=np.float64)
+    polymap = np.array(case["polymap"], dtype=np.int64) if case["polymap"] is not None else None
+    points_rc = tuple(list(x) for x in case["points_rc"])
+    exclude = ()
+    if case["included_pairs"] is not None:
+        exclude, points_rc = rg.generate_exclude_pairs(points_rc, case["included_pairs"])
+    return ps.focal_regions_pairwise_on_device(gmap, points_rc, solver, four_neighbors=o["connect_four_neighbors_only"],
+                                               avg_res=o["connect_using_avg_resistances"], exclude_pairs=exclude,
+                                               polymap=polymap)
+
+
+def check_focal_regions_synthetic(L, oracle, shape=(40, 33), nregions=5, seed=3):
+    """Focal regions on a raster with NODATA and user polygons, some regions reaching into polygons, one region split over
+    two places: the single-hierarchy Dirichlet formulation against the reference's procedure restated by the oracle
+    (merge the two regions of a pair into nodes, build that pair's graph, solve it directly)."""
+    from circuitscape_jl_amd import solver as ps
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(seed)
+    g = np.exp(rng.standard_normal(shape))
+    g[rng.random(shape) < 0.08] = 0.0
+    polymap = np.zeros(shape, dtype=np.int64)
+    polymap[5:9, 4:7] = 1
+    polymap[20:22, 10:20] = 2
+    rows, cols, ids = [], [], []
+    for r in range(nregions):
+        r0, c0 = int(rng.integers(1, shape[0] - 6)), int(rng.integers(1, shape[1] - 6))
+        for _ in range(int(rng.integers(2, 7))):
+            rr, cc = r0 + int(rng.integers(0, 4)), c0 + int(rng.integers(0, 4))
+            if polymap[rr, cc] != 0:
+                continue                                  # (the random regions stay clear of the user polygons)
+            rows.append(rr + 1)
+            cols.append(cc + 1)
+            ids.append(r + 1)
+    # region 1: two cells inside polygon 1 listed FIRST (the merged polygon is the measured node: Dirichlet route);
+    # region 2: two cells inside polygon 2 listed LAST (measured from a cell outside it: floating short-circuit, the
+    # pair takes the per-pair graph); region nregions + 1: a single cell
+    g[5:9, 4:7] = np.maximum(g[5:9, 4:7], 0.3)
+    g[20:22, 10:20] = np.maximum(g[20:22, 10:20], 0.3)
+    rows = [6, 7] + rows + [21, 22, 30]
+    cols = [5, 6] + cols + [12, 15, 3]
+    ids = [1, 1] + ids + [2, 2, nregions + 1]
+    g[29, 2] = max(g[29, 2], 0.5)
+    points_rc = (rows, cols, ids)
+    sv = ps.HIPAMGSolver(bs=4, opts={"precond_bytes": 0})
+    st = {}
+    got = ps.focal_regions_pairwise_on_device(g, points_rc, sv, polymap=polymap, stats=st)
+    pts = list(got[0, 1:].astype(int))
+    assert st.get("per_pair_graphs", 0) == len(pts) - 1          # every pair with region 2, and only those
+    for a in range(len(pts)):
+        for b in range(a + 1, len(pts)):
+            ref = rg.compute_graph_data_polygons(g, polymap, points_rc, pts[a], pts[b], False, False)
+            A = ref.G
+            c1, c2 = int(ref.points[0]) - 1, int(ref.points[1]) - 1      # nodes of the two merged regions (0-based)
+            comp_of = {}
+            for idx, comp in enumerate(ref.cc):
+                for v in comp:
+                    comp_of[int(v) - 1] = idx
+            if comp_of[c1] != comp_of[c2]:
+                assert got[a + 1, b + 1] == -1
+                continue
+            if c1 == c2:
+                assert got[a + 1, b + 1] == 0
+                continue
+            keep = np.asarray(ref.cc[comp_of[c1]], dtype=np.int64) - 1
+            keep = keep[keep != c2]                      # ground the second region's node
+            Ak = A.tocsr()[keep][:, keep].tocsc()
+            rhs = np.zeros(len(keep))
+            rhs[np.flatnonzero(keep == c1)[0]] = 1.0
+            v = spl.spsolve(Ak, rhs)
+            R = v[np.flatnonzero(keep == c1)[0]]
+            assert abs(got[a + 1, b + 1] - R) <= 1e-6 * R, (pts[a], pts[b], got[a + 1, b + 1], R)
