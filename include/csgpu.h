@@ -96,8 +96,11 @@ typedef struct csgpu_opts {
   int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
                              every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
-  int32_t nu_coarse;      /* damped-Jacobi sweeps (pre and post) on level 1; the levels below it (1/81 of the fine level's
-                             work) run one more (profiles/r2_sweeps_per_level.json); default 2 (measured
+  int32_t nu_coarse;      /* Jacobi sweeps (pre and post) on level 1; the levels below it (1/81 of the fine level's
+                             work) run one more (profiles/r2_sweeps_per_level.json). On these levels the sweeps of a
+                             level carry Chebyshev weights (the reciprocal roots of the Chebyshev polynomial of degree
+                             = sweeps on [rho/10, rho], rho = Gershgorin bound; profiles/r2_coarse_chebyshev.json) unless
+                             the hierarchy is fp32 above 3e7 rows, which keeps one damped weight. Default 2 (measured
                              on the 10000^2 raster: 3 -> 324.7 ms per batch of 16 at 12.8 iterations, 2 -> 309.2 ms at
                              12.9, 1 -> 327.4 ms at 14.9; profiles/r2_polling_graph_nucoarse.json) */
   double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
