@@ -24,6 +24,8 @@ struct ISolver {
   virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
   virtual void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
                               void* curr_out, csgpu_stats* stats) = 0;
+  virtual void solve_region_pairs(const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets, const int64_t* src_set,
+                                  const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
   virtual double spmv_bench(int k, int reps) = 0;
   virtual void spmv_host(const void* x, void* y, int k) = 0;
@@ -69,6 +71,24 @@ inline void convert_csr(const Csr<T>& A, Csr<TP>& B, hipStream_t st) {
   if (A.nnz > 0)
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(grid_for(A.nnz)), dim3(256), 0, st, A.nnz, A.va(), B.va());
   CS_HIP(hipStreamSynchronize(st));
+}
+
+// ---- csgpu_solve_region_pairs helpers --------------------------------------------------------------------------------
+// v[node, c] = 1 for the nodes of column c's source set (lists in the layout of mask_grounds_kernel: ptr[K+1], idx[])
+template <class T, int K>
+__global__ __launch_bounds__(256) void scatter_ones_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                           T* __restrict__ v) {
+  const int total = ptr[K];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int c = 0;
+    while (c + 1 < K && e >= ptr[c + 1]) ++c;
+    v[(size_t)idx[e] * K + c] = T(1);
+  }
+}
+// v -= y
+template <class T>
+__global__ __launch_bounds__(256) void subtract_kernel(int64_t total, T* __restrict__ v, const T* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) v[e] -= y[e];
 }
 
 // T: precision of the CG iteration and of the C-ABI's vectors; TP: precision of the AMG preconditioner.
@@ -891,6 +911,106 @@ struct Solver : ISolver {
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
+  // Effective resistance between short-circuited node sets on ONE hierarchy (see csgpu_solve_region_pairs in csgpu.h):
+  // column c solves A_ff y = A_fI 1 with the rows / columns of I u J masked; v = 1_I - y is the potential with I at 1 and
+  // J at 0, and R = 1 / v'Av (the energy form: its error is second order in the error of the iterate).
+  void solve_region_pairs(const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets, const int64_t* src_set,
+                          const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) override {
+    std::lock_guard<std::mutex> lk(mu);
+    CS_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (int64_t q = 0; q < nsets; ++q) {
+      CS_REQUIRE(set_ptr[q] <= set_ptr[q + 1], CSGPU_BAD_ARGS, "set_ptr must be non-decreasing");
+      for (int64_t e = set_ptr[q]; e < set_ptr[q + 1]; ++e)
+        CS_REQUIRE(set_nodes[e] >= 0 && set_nodes[e] < n, CSGPU_BAD_ARGS, "set node id out of range");
+    }
+    for (int64_t p = 0; p < npairs; ++p)
+      CS_REQUIRE(src_set[p] >= 0 && src_set[p] < nsets && dst_set[p] >= 0 && dst_set[p] < nsets && src_set[p] != dst_set[p],
+                 CSGPU_BAD_ARGS, "pair refers to a set that does not exist (or to the same set twice)");
+    const int K = pick_k(npairs);
+    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
+    W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
+    if (stats) {
+      stats->nrhs = (int)npairs;
+      stats->batch = K;
+    }
+    const Csr<T>& A = cg_matrix();
+    DBuf volt((size_t)n * K * sizeof(T)), av((size_t)n * K * sizeof(T));
+    DBuf dgp = dalloc<int>(K + 1), dsp = dalloc<int>(K + 1), dgi, dsi;
+    int sg = 1;
+    CS_DISPATCH_K(K, sg = (spmv_grid<T, KK>((int)n)));
+    DBuf part = dalloc<double>((size_t)sg * K);
+    std::vector<double> hpart((size_t)sg * K);
+    std::vector<int> gp(K + 1), sp(K + 1), gi, si;
+    for (int64_t p0 = 0; p0 < npairs; p0 += K) {
+      const int ncols = (int)std::min<int64_t>(K, npairs - p0);
+      gi.clear();
+      si.clear();
+      for (int c = 0; c < K; ++c) {
+        gp[c] = (int)gi.size();
+        sp[c] = (int)si.size();
+        if (c < ncols) {
+          const int64_t a = src_set[p0 + c], b = dst_set[p0 + c];
+          for (int64_t e = set_ptr[a]; e < set_ptr[a + 1]; ++e) {
+            si.push_back((int)set_nodes[e]);
+            gi.push_back((int)set_nodes[e]);
+          }
+          for (int64_t e = set_ptr[b]; e < set_ptr[b + 1]; ++e) gi.push_back((int)set_nodes[e]);
+        }
+      }
+      gp[K] = (int)gi.size();
+      sp[K] = (int)si.size();
+      CS_REQUIRE(!si.empty(), CSGPU_BAD_ARGS, "empty source set");
+      if (dgi.bytes < gi.size() * sizeof(int)) dgi.alloc(gi.size() * sizeof(int));
+      if (dsi.bytes < si.size() * sizeof(int)) dsi.alloc(si.size() * sizeof(int));
+      CS_HIP(hipMemcpyAsync(dgp.p, gp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dsp.p, sp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dgi.p, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dsi.p, si.data(), si.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemsetAsync(volt.p, 0, volt.bytes, st));
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((scatter_ones_kernel<T, KK>), dim3(ceil_div((int64_t)si.size(), 256)), dim3(256), 0,
+                                           st, (const int*)dptr<int>(dsp), (const int*)dptr<int>(dsi), dptr<T>(volt)));
+      {  // b = A 1_I, masked on I u J
+        SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(volt), dptr<T>(W.b));
+        a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
+        CS_DISPATCH_K(K, (spmv_launch<T, KK>(a, EPI_PLAIN, false, st)));
+      }
+      CS_DISPATCH_K(K, hipLaunchKernelGGL((mask_grounds_kernel<T, T, KK>), dim3(ceil_div((int64_t)gi.size(), 256)), dim3(256),
+                                           0, st, (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), dptr<T>(W.b),
+                                           (T*)nullptr, (const int*)nullptr));
+      CS_HIP(hipStreamSynchronize(st));  // the host lists are reused by the next batch
+      PcgBatchResult r;
+      {
+        PcgParams pp = pcg_params(K);
+        pp.need_x = true;
+        pp.gptr = dptr<int>(dgp);
+        pp.gidx = dptr<int>(dgi);
+        pp.gtotal = (int)gi.size();
+        CS_DISPATCH_K(K, r = (pcg_solve<T, TP, KK>(A, H, W, pp, ncols, st, dia_ptr())));
+      }
+      accumulate(stats, r, ncols);
+      hipLaunchKernelGGL((subtract_kernel<T>), dim3(grid_for(n * K)), dim3(256), 0, st, (int64_t)n * K, dptr<T>(volt),
+                         (const T*)dptr<T>(W.x));
+      {  // v'Av per column: the product's fused dot with its own input
+        SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(volt), dptr<T>(av));
+        a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
+        a.dotw = nullptr;
+        a.partials = dptr<double>(part);
+        CS_DISPATCH_K(K, (spmv_launch<T, KK>(a, EPI_PLAIN, true, st)));
+      }
+      CS_HIP(hipMemcpyAsync(hpart.data(), part.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      check_launch("solve_region_pairs batch");
+      CS_HIP(hipStreamSynchronize(st));
+      for (int c = 0; c < ncols; ++c) {
+        double e = 0;
+        for (int b = 0; b < sg; ++b) e += hpart[(size_t)b * K + c];
+        resistances[p0 + c] = e > 0 ? 1.0 / e : -1.0;
+      }
+    }
+    if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
   template <class U>
   static int64_t spmv_bytes(const Csr<U>& A, int k) {
     return A.nnz * (int64_t)(sizeof(U) + 4) + ((int64_t)A.nrows + 1) * 4 +
@@ -1412,6 +1532,30 @@ int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out,
   memset(s, 0, sizeof(*s));
   if (nrhs == 0) return CSGPU_OK;
   h->solver->solve_rhs(rhs, nrhs, x_out, s);
+  if (s->not_converged > 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
+             s->max_relres, s->not_converged, s->nrhs);
+    g_last_error = buf;
+    return CSGPU_NOT_CONVERGED;
+  }
+  return CSGPU_OK;
+  CS_API_END
+}
+
+int csgpu_solve_region_pairs(csgpu_handle* h, const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets,
+                             const int64_t* src_set, const int64_t* dst_set, int64_t npairs, double* resistances,
+                             csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!h || nsets < 0 || npairs < 0 || (npairs > 0 && (!set_ptr || !set_nodes || !src_set || !dst_set || !resistances))) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  if (npairs == 0) return CSGPU_OK;
+  h->solver->solve_region_pairs(set_ptr, set_nodes, nsets, src_set, dst_set, npairs, resistances, s);
   if (s->not_converged > 0) {
     char buf[256];
     snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",

@@ -217,6 +217,27 @@ function solve_grounded(factor::HIPFactor, rhs::Matrix{T}, grounds::Vector{Vecto
 end
 
 """
+Effective resistance between short-circuited node sets on ONE hierarchy (csgpu_solve_region_pairs): what
+`_pt_file_polygons_path` (raster/pairwise.jl:72-135) obtains with a fresh graph and hierarchy per pair of focal regions.
+`sets` hold 1-based node ids of the graph in which the regions are NOT merged; `pairs[p] = (i, j)` indexes into `sets`.
+Returns R (-1: no current flows between the two sets).
+"""
+function solve_region_pairs(factor::HIPFactor, sets::Vector{Vector{Int64}}, pairs::Vector{Tuple{Int,Int}})
+    sptr = Int64[0; cumsum(length.(sets))]
+    snodes = reduce(vcat, sets) .- 1
+    a = Int64[p[1] - 1 for p in pairs]
+    b = Int64[p[2] - 1 for p in pairs]
+    R = zeros(Float64, length(pairs))
+    st = CsgpuStats()
+    rc = GC.@preserve sptr snodes a b R ccall((:csgpu_solve_region_pairs, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}, Ref{CsgpuStats}),
+              factor.ptr, sptr, snodes, length(sets), a, b, length(pairs), R, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_region_pairs failed: $(csgpu_error())")
+    R, st
+end
+
+"""
 Raster with short-circuit polygons, graph layer on the device (construct_node_map with a polymap,
 raster/pairwise.jl:276-301): `polymap` > 0 names the polygon of a cell.
 """

@@ -21,7 +21,7 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
-    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
+    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_solve_region_pairs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
     "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
@@ -91,6 +91,7 @@ def _bind(L):
     L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_grounded.argtypes = [vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_region_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
     L.csgpu_level_spmv_host.argtypes = [vp, i32, i32, vp, vp, i32, vp]
@@ -284,6 +285,22 @@ class Handle:
         if one:
             return X[:, 0], (C[:, 0] if C is not None else None), st.as_dict()
         return X, C, st.as_dict()
+
+    def solve_region_pairs(self, sets, src_set, dst_set):
+        """csgpu_solve_region_pairs: `sets` = list of lists of 0-based node ids; effective resistance between the
+        short-circuited sets sets[src_set[p]] and sets[dst_set[p]] for every p (-1: no current flows). Returns
+        (resistances, stats)."""
+        sptr = np.zeros(len(sets) + 1, dtype=np.int64)
+        sptr[1:] = np.cumsum([len(q) for q in sets])
+        snodes = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.int64) for q in sets])
+                                      if sptr[-1] > 0 else np.zeros(1, dtype=np.int64))
+        a = np.ascontiguousarray(src_set, dtype=np.int64)
+        b = np.ascontiguousarray(dst_set, dtype=np.int64)
+        R = np.zeros(len(a), dtype=np.float64)
+        st = Stats()
+        _check(lib().csgpu_solve_region_pairs(self._p, sptr.ctypes.data, snodes.ctypes.data, len(sets), a.ctypes.data,
+                                              b.ctypes.data, len(a), R.ctypes.data, ctypes.byref(st)))
+        return R, st.as_dict()
 
     def spmv_bench(self, k=1, reps=20):
         ms = ctypes.c_double(0)

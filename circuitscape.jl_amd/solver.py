@@ -704,8 +704,8 @@ def focal_regions_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=
     equipotential, so the effective resistance between the sets I and J is 1 / (total current leaving I when I is held at
     potential 1 and J at 0) -- a Dirichlet problem on the graph in which they are NOT merged,
         A_ff x_f = -A_fI 1,   x = 1 on I, 0 on J,   R = 1 / sum_{i in I} (A x)_i = 1 / x'Ax,
-    which is exactly what csgpu_solve_grounded solves (rows / columns of I u J masked, one column per pair, batches of
-    `solver.bs` pairs per PCG). Edges inside a set carry no current at equal potential (the merged graph drops them as
+    which csgpu_solve_region_pairs solves on the device (rows / columns of I u J masked as in csgpu_solve_grounded, one
+    column per pair, batches of `solver.bs` pairs per PCG; no n-sized array crosses the boundary). Edges inside a set carry no current at equal potential (the merged graph drops them as
     self-loops); parallel edges from a set to an outside cell add up in the sum (the merged graph sums them). Sets that
     reach several components behave like the merged graph: only components both sets touch carry current.
 
@@ -768,34 +768,19 @@ def focal_regions_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=
                         continue
                     jobs.append((a, b, [v for v in I if int(labels[v]) in common],
                                  [v for v in J if int(labels[v]) in common]))
-            width = max(1, min(16, int(solver.bs)))
-            for c0 in range(0, len(jobs), width):
-                chunk = jobs[c0:c0 + width]
-                k = 1
-                while k < len(chunk):
-                    k *= 2                                             # csgpu_spmv_host takes 1, 2, 4, 8 or 16 columns
-                ind = np.zeros((n, k))
-                for c, (_, _, I, _) in enumerate(chunk):
-                    ind[I, c] = 1.0
-                rhs = -h.spmv(ind)                                     # -A 1_I
-                grounds = []
-                for c, (_, _, I, J) in enumerate(chunk):
-                    grounds.append(I + J)
-                    rhs[I + J, c] = 0.0
-                X, _, st = h.solve_grounded(np.asfortranarray(rhs[:, :len(chunk)]), grounds)
+            if jobs:
+                # the sets of every job go down once; indicator, right-hand side, masked solve and energy stay on the device
+                sets, src_set, dst_set = [], [], []
+                for (_, _, I, J) in jobs:
+                    src_set.append(len(sets))
+                    sets.append(I)
+                    dst_set.append(len(sets))
+                    sets.append(J)
+                R, st = h.solve_region_pairs(sets, src_set, dst_set)
                 if stats is not None:
-                    for key in ("total_iters", "nrhs"):
-                        stats[key] = stats.get(key, 0) + st[key]
-                    stats["max_relres"] = max(stats.get("max_relres", 0.0), st["max_relres"])
-                volt = ind.copy()
-                volt[:, :len(chunk)] += X.reshape(n, -1)
-                av = h.spmv(volt)
-                # total current = sum_{i in I} (A v)_i = v'Av for the exact v; the energy form is used because its error is
-                # second order in the error of the iterate (the same reason pair resistances b'x come out at 1e-11)
-                energy = np.sum(volt * av, axis=0)
-                for c, (a, b, _, _) in enumerate(chunk):
-                    cur = float(energy[c])
-                    res[a, b] = res[b, a] = (1.0 / cur) if cur > 0 else -1.0
+                    stats.update({k: st[k] for k in ("total_iters", "nrhs", "max_relres")})
+                for (a, b, _, _), r in zip(jobs, R):
+                    res[a, b] = res[b, a] = float(r)
     except lib.CsgpuError as e:
         if e.code == lib.CSGPU_NOT_CONVERGED:
             _raise_not_converged(e)

@@ -18,6 +18,7 @@
  *                              RHS -1/+1 (core.jl:224-226), solve (:229), grounding shift and resistance
  *                              (:231-232), focal-voltage gather for the shortcut (update_voltmatrix! :685-703);
  *                              batched like the direct-solver driver (core.jl:448-493)
+ *   csgpu_solve_region_pairs <-> the per-pair graph + hierarchy of _pt_file_polygons_path (src/raster/pairwise.jl:72-135)
  *   csgpu_solve_grounded   <-> multiple_solver with infinite grounds (src/raster/advanced.jl:274-305) as the one-to-all /
  *                              all-to-one drivers call it per focal point (src/raster/onetoall.jl:106-151): many
  *                              ground sets, one hierarchy
@@ -275,6 +276,21 @@ int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const i
 
 /* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
  * library's stream; returns the average milliseconds per launch. Used by bench.py for the roofline line. */
+/* Scope row N2 / missing item "focal regions" -- effective resistance between SHORT-CIRCUITED NODE SETS on one
+ * hierarchy. With focal regions (several cells per focal id) the reference merges the two regions of every pair into
+ * one node each and builds a fresh graph and a fresh hierarchy per pair (_pt_file_polygons_path,
+ * src/raster/pairwise.jl:72-135; create_new_polymap :369-442). A merged set is an equipotential, so on the graph in
+ * which the sets are NOT merged
+ *     R(I, J) = 1 / v'Av,   v = 1 on I, 0 on J,  (A v)_f = 0 on every other node,
+ * one masked solve per pair (rows / columns of I u J, as in csgpu_solve_grounded), in batches of opts.batch pairs.
+ *   set_ptr[nsets + 1], set_nodes:  the sets as lists of 0-based node ids
+ *   src_set, dst_set [npairs]:      the two sets of every pair (indices into set_ptr)
+ *   resistances [npairs] (double):  R, or -1 when no current flows (the sets share no component)
+ * Sets sharing a node (R = 0) are the caller's to filter, like src == dst pairs of csgpu_solve_pairs. */
+int csgpu_solve_region_pairs(csgpu_handle* h, const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets,
+                             const int64_t* src_set, const int64_t* dst_set, int64_t npairs, double* resistances,
+                             csgpu_stats* stats);
+
 int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms);
 
 /* y = A x on the device for host vectors (tests: parity of the SpMV kernel itself). */

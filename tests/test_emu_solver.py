@@ -1032,3 +1032,33 @@ def test_focal_regions_synthetic_against_merged_graphs(emu_lib, oracle):
     """see helpers.check_focal_regions_synthetic"""
     from helpers import check_focal_regions_synthetic
     check_focal_regions_synthetic(emu_lib, oracle)
+
+
+@pytest.mark.parametrize("holes", [False, True])
+def test_region_pairs_of_single_nodes_are_plain_pair_resistances(emu_lib, holes):
+    """csgpu_solve_region_pairs with one node per set must reproduce csgpu_solve_pairs (R(I, J) = 1 / v'Av is the
+    effective resistance); on a lattice handle and on a CSR handle, fp32 and fp64 hierarchy, plus the argument checks."""
+    rng = np.random.default_rng(9)
+    g = np.exp(rng.standard_normal((48, 41)))
+    if holes:
+        g[rng.random(g.shape) < 0.1] = 0.0
+    for pb in (0, 4):
+        with emu_lib.raster_setup(g, emu_lib.default_opts(batch=4, precond_bytes=pb)) as h:
+            n = h.info["n"]
+            assert (h.info["lattice_period"] > 0) == (not holes)
+            labels, _ = h.components()
+            big = np.flatnonzero(labels == np.bincount(labels).argmax())
+            ids = rng.choice(big, size=10, replace=False)
+            src, dst = [int(v) for v in ids[:5]], [int(v) for v in ids[5:]]
+            R, _, _, _ = h.solve_pairs(src, dst)
+            sets = [[v] for v in src] + [[v] for v in dst]
+            Rr, st = h.solve_region_pairs(sets, list(range(5)), list(range(5, 10)))
+            assert st["not_converged"] == 0 and st["nrhs"] == 5
+            assert np.max(np.abs(Rr - R) / R) < 1e-6          # (observed 1e-8: both stop on the reference rule)
+            # a two-node source set can only lower the resistance to the same sink
+            R2, _ = h.solve_region_pairs([[src[0], src[1]], [dst[0]]], [0], [1])
+            assert 0 < R2[0] <= min(R[0], h.solve_pairs([src[1]], [dst[0]])[0][0]) * (1 + 1e-9)
+            with pytest.raises(emu_lib.CsgpuError):
+                h.solve_region_pairs([[src[0]], [dst[0]]], [0], [0])
+            with pytest.raises(emu_lib.CsgpuError):
+                h.solve_region_pairs([[n + 5], [dst[0]]], [0], [1])
