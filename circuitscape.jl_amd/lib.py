@@ -22,7 +22,7 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_solve_region_pairs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
-    "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded",
+    "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded", "csgpu_raster_setup_poly",
     "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
     "csgpu_multi_handle", "csgpu_multi_last_busy", "csgpu_multi_free",
