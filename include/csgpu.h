@@ -285,8 +285,11 @@ int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const i
  * one masked solve per pair (rows / columns of I u J, as in csgpu_solve_grounded), in batches of opts.batch pairs.
  *   set_ptr[nsets + 1], set_nodes:  the sets as lists of 0-based node ids
  *   src_set, dst_set [npairs]:      the two sets of every pair (indices into set_ptr)
- *   resistances [npairs] (double):  R, or -1 when no current flows (the sets share no component)
- * Sets sharing a node (R = 0) are the caller's to filter, like src == dst pairs of csgpu_solve_pairs. */
+ *   resistances [npairs] (double):  R (-1 if the energy comes out non-positive)
+ * The caller filters what the reference's bookkeeping filters: sets sharing a node (R = 0), pairs whose sets share no
+ * component (-1; csgpu_components), and the nodes of a set that lie in components the other set does not reach (they
+ * carry no current in the merged graph either, but held at potential 1 on a regularised matrix they would add a
+ * spurious eps-sized term to the energy). solver.py::focal_regions_pairwise_on_device is that caller. */
 int csgpu_solve_region_pairs(csgpu_handle* h, const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets,
                              const int64_t* src_set, const int64_t* dst_set, int64_t npairs, double* resistances,
                              csgpu_stats* stats);
