@@ -52,45 +52,106 @@ static std::atomic<int64_t> g_live_bytes{0};  // bookkeeping only (handles of a 
 // the next handle's buffers costs 3.5-4.5 s of driver time (page-table teardown / set-up), an order of magnitude more
 // than the whole AMG setup -- and the reference's workloads do exactly that (one factorisation per component, per
 // focal region, per one-to-all source: src/core.jl:146-167, src/raster/onetoall.jl:106-151). Released blocks are
-// therefore kept in a per-device pool and handed out again on an exact size match (the sizes of "the same problem
-// again" repeat exactly); csgpu_trim_memory() / a failed hipMalloc return the pooled blocks to the driver.
-// A block is pooled only after the device has drained (hipDeviceSynchronize -- the implicit synchronisation hipFree has
-// always provided), so a block can never be handed to another stream while kernels of its previous owner still run.
+// therefore kept in a per-device pool and handed out again for requests they fit with at most 1/8 of slack (the sizes
+// of "the same problem again" repeat exactly; temporaries whose size follows a list length vary a little).
+//   * A released block first sits in a PENDING list: kernels of its previous owner may still be running. It becomes
+//     reusable at the next point the pool drains the device -- once per group of releases (when an allocation finds
+//     nothing ready), not once per block.
+//   * The pool is capped (CSGPU_POOL_MAX_GB, default 60 % of the device's memory): beyond the cap the blocks released
+//     longest ago go back to the driver, so buffer sizes that never repeat cannot strand memory without bound.
+//   * csgpu_trim_memory() / a failed hipMalloc return everything to the driver. CSGPU_NO_POOL=1 disables pooling.
+// Handles are NOT trimmed when the last one of a device is freed: "free the factorisation, build the next one" is the
+// very pattern the pool exists for.
 struct DevicePool {
   static const int kMaxDev = 64;
-  std::mutex mu;
-  std::multimap<size_t, void*> blocks[kMaxDev];
-  size_t pooled[kMaxDev] = {0};
+  struct Blk {
+    void* p;
+    size_t cap;
+    uint64_t seq;  // release order (eviction: oldest first)
+  };
+  std::mutex mu[kMaxDev];
+  std::multimap<size_t, Blk> ready[kMaxDev];  // capacity -> block, device drained since the release
+  std::vector<Blk> pending[kMaxDev];          // released, device not drained yet
+  size_t pooled[kMaxDev] = {0};               // bytes in ready + pending
+  size_t limit[kMaxDev] = {0};                // cap in bytes (0: not initialised yet)
+  uint64_t seq = 0;
   bool enabled = getenv("CSGPU_NO_POOL") == nullptr;
-  void* take(int dev, size_t b) {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = blocks[dev].find(b);
-    if (it == blocks[dev].end()) return nullptr;
-    void* p = it->second;
-    blocks[dev].erase(it);
-    pooled[dev] -= b;
-    return p;
+  // (caller holds mu[dev] and has `dev` current) drain the device and make the pending blocks reusable
+  void promote(int dev) {
+    if (pending[dev].empty()) return;
+    (void)hipDeviceSynchronize();
+    for (const Blk& b : pending[dev]) ready[dev].emplace(b.cap, b);
+    pending[dev].clear();
   }
-  void give(int dev, size_t b, void* p) {
-    std::lock_guard<std::mutex> lk(mu);
-    blocks[dev].emplace(b, p);
-    pooled[dev] += b;
+  // a block of at least b bytes with at most b/8 of slack; *cap = its capacity. The current device must be `dev`.
+  void* take(int dev, size_t b, size_t* cap) {
+    std::lock_guard<std::mutex> lk(mu[dev]);
+    for (int pass = 0; pass < 2; ++pass) {
+      auto it = ready[dev].lower_bound(b);
+      if (it != ready[dev].end() && it->first <= b + b / 8) {
+        void* p = it->second.p;
+        *cap = it->second.cap;
+        ready[dev].erase(it);
+        pooled[dev] -= *cap;
+        return p;
+      }
+      if (pass == 0) {
+        bool fits = false;
+        for (const Blk& q : pending[dev]) fits = fits || (q.cap >= b && q.cap <= b + b / 8);
+        if (!fits) break;
+        promote(dev);
+      }
+    }
+    return nullptr;
+  }
+  void give(int dev, size_t cap, void* p) {
+    std::vector<void*> victims;
+    {
+      std::lock_guard<std::mutex> lk(mu[dev]);
+      if (limit[dev] == 0) {
+        size_t fr = 0, tot = 0;
+        const char* e = getenv("CSGPU_POOL_MAX_GB");
+        if (e) limit[dev] = (size_t)(atof(e) * 1073741824.0) + 1;
+        else if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) limit[dev] = tot / 10 * 6;
+        else limit[dev] = (size_t)64 << 30;
+      }
+      pending[dev].push_back(Blk{p, cap, ++seq});
+      pooled[dev] += cap;
+      if (pooled[dev] > limit[dev]) {
+        int cur = dev;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        promote(dev);
+        if (cur != dev) (void)hipSetDevice(cur);
+        while (pooled[dev] > limit[dev] && !ready[dev].empty()) {
+          auto oldest = ready[dev].begin();
+          for (auto it = ready[dev].begin(); it != ready[dev].end(); ++it)
+            if (it->second.seq < oldest->second.seq) oldest = it;
+          victims.push_back(oldest->second.p);
+          pooled[dev] -= oldest->second.cap;
+          ready[dev].erase(oldest);
+        }
+      }
+    }
+    for (void* v : victims) hipFree(v);
   }
   // return the pooled blocks of one device (dev < 0: of every device) to the driver; bytes released
   size_t trim(int dev) {
-    std::vector<void*> victims;
     size_t freed = 0;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      for (int d = 0; d < kMaxDev; ++d) {
-        if (dev >= 0 && d != dev) continue;
-        for (auto& kv : blocks[d]) victims.push_back(kv.second);
+    for (int d = 0; d < kMaxDev; ++d) {
+      if (dev >= 0 && d != dev) continue;
+      std::vector<void*> victims;
+      {
+        std::lock_guard<std::mutex> lk(mu[d]);
+        for (auto& kv : ready[d]) victims.push_back(kv.second.p);
+        for (const Blk& b : pending[d]) victims.push_back(b.p);
         freed += pooled[d];
-        blocks[d].clear();
+        ready[d].clear();
+        pending[d].clear();
         pooled[d] = 0;
       }
+      for (void* p : victims) hipFree(p);  // (hipFree waits for the device: pending blocks are safe to free)
     }
-    for (void* p : victims) hipFree(p);
     return freed;
   }
 };
@@ -102,24 +163,28 @@ inline DevicePool& device_pool() {
 // Owning device allocation (pooled, see above).
 struct DBuf {
   void* p = nullptr;
-  size_t bytes = 0;
-  int dev = -1;  // device the block lives on
+  size_t bytes = 0;  // bytes asked for
+  size_t cap = 0;    // capacity of the underlying block (>= bytes: a pooled block may be slightly larger)
+  int dev = -1;      // device the block lives on
   DBuf() {}
   explicit DBuf(size_t b) { alloc(b); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes), dev(o.dev) {
+  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), dev(o.dev) {
     o.p = nullptr;
     o.bytes = 0;
+    o.cap = 0;
   }
   DBuf& operator=(DBuf&& o) noexcept {
     if (this != &o) {
       release();
       p = o.p;
       bytes = o.bytes;
+      cap = o.cap;
       dev = o.dev;
       o.p = nullptr;
       o.bytes = 0;
+      o.cap = 0;
     }
     return *this;
   }
@@ -130,8 +195,10 @@ struct DBuf {
     CS_HIP(hipGetDevice(&dev));
     DevicePool& pool = device_pool();
     const bool poolable = pool.enabled && dev >= 0 && dev < DevicePool::kMaxDev;
-    if (poolable) p = pool.take(dev, b);
+    cap = b;
+    if (poolable) p = pool.take(dev, b, &cap);
     if (!p) {
+      cap = b;
       hipError_t e = hipMalloc(&p, b);
       if (e != hipSuccess && poolable && pool.trim(dev) > 0) {  // the pool may be what fills the device
         (void)hipGetLastError();
@@ -139,6 +206,7 @@ struct DBuf {
       }
       if (e != hipSuccess) {
         p = nullptr;
+        cap = 0;
         CS_HIP(e);
       }
     }
@@ -148,20 +216,15 @@ struct DBuf {
   void release() {
     if (p) {
       DevicePool& pool = device_pool();
-      if (pool.enabled && dev >= 0 && dev < DevicePool::kMaxDev) {
-        int cur = dev;
-        (void)hipGetDevice(&cur);
-        if (cur != dev) (void)hipSetDevice(dev);
-        (void)hipDeviceSynchronize();  // what hipFree did implicitly: no kernel of the old owner is still running
-        if (cur != dev) (void)hipSetDevice(cur);
-        pool.give(dev, bytes, p);
-      } else {
+      if (pool.enabled && dev >= 0 && dev < DevicePool::kMaxDev)
+        pool.give(dev, cap, p);
+      else
         hipFree(p);
-      }
       g_live_bytes -= (int64_t)bytes;
     }
     p = nullptr;
     bytes = 0;
+    cap = 0;
   }
   template <class U>
   U* as() const {

@@ -928,16 +928,66 @@ struct Solver : ISolver {
     for (int64_t p = 0; p < npairs; ++p)
       CS_REQUIRE(src_set[p] >= 0 && src_set[p] < nsets && dst_set[p] >= 0 && dst_set[p] < nsets && src_set[p] != dst_set[p],
                  CSGPU_BAD_ARGS, "pair refers to a set that does not exist (or to the same set twice)");
+    // Two sets that share a node are one equipotential: R = 0 without a solve (the reference's bookkeeping does the same
+    // for focal points on one node, core.jl:189,209-211). The remaining pairs are solved; `slot` maps them back.
+    std::vector<int64_t> act_src, act_dst, slot;
+    {
+      std::vector<std::vector<int64_t>> sorted_sets((size_t)nsets);
+      auto sorted = [&](int64_t q) -> const std::vector<int64_t>& {
+        std::vector<int64_t>& v = sorted_sets[(size_t)q];
+        if (v.empty() && set_ptr[q + 1] > set_ptr[q]) {
+          v.assign(set_nodes + set_ptr[q], set_nodes + set_ptr[q + 1]);
+          std::sort(v.begin(), v.end());
+        }
+        return v;
+      };
+      for (int64_t p = 0; p < npairs; ++p) {
+        const std::vector<int64_t>&a = sorted(src_set[p]), &b = sorted(dst_set[p]);
+        CS_REQUIRE(!a.empty() && !b.empty(), CSGPU_BAD_ARGS, "pair with an empty source or destination set");
+        bool shared = false;
+        for (size_t i = 0, j = 0; i < a.size() && j < b.size() && !shared;) {
+          if (a[i] == b[j]) shared = true;
+          else if (a[i] < b[j]) ++i;
+          else ++j;
+        }
+        if (shared) {
+          resistances[p] = 0.0;
+        } else {
+          act_src.push_back(src_set[p]);
+          act_dst.push_back(dst_set[p]);
+          slot.push_back(p);
+        }
+      }
+    }
+    if (stats) stats->nrhs = (int)npairs;
+    if (slot.empty()) return;
+    double* const res_all = resistances;
+    src_set = act_src.data();
+    dst_set = act_dst.data();
+    npairs = (int64_t)slot.size();
     const int K = pick_k(npairs);
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
-    if (stats) {
-      stats->nrhs = (int)npairs;
-      stats->batch = K;
-    }
+    if (stats) stats->batch = K;
     const Csr<T>& A = cg_matrix();
     DBuf volt((size_t)n * K * sizeof(T)), av((size_t)n * K * sizeof(T));
-    DBuf dgp = dalloc<int>(K + 1), dsp = dalloc<int>(K + 1), dgi, dsi;
+    // the set lists of the largest batch, allocated once: a captured PCG chunk bakes the list pointers in, so they must
+    // not move between the batches of a call (a re-allocation here let a later batch replay a chunk that
+    // masked the residual at the nodes of an earlier one)
+    size_t maxg = 1, maxs = 1;
+    for (int64_t p0 = 0; p0 < npairs; p0 += K) {
+      size_t g = 0, s = 0;
+      for (int64_t p = p0; p < std::min<int64_t>(npairs, p0 + K); ++p) {
+        const size_t la = (size_t)(set_ptr[src_set[p] + 1] - set_ptr[src_set[p]]);
+        const size_t lb = (size_t)(set_ptr[dst_set[p] + 1] - set_ptr[dst_set[p]]);
+        g += la + lb;
+        s += la;
+      }
+      maxg = std::max(maxg, g);
+      maxs = std::max(maxs, s);
+    }
+    CS_REQUIRE(maxg < ((size_t)1 << 31), CSGPU_BAD_ARGS, "set lists of one batch exceed 2^31 entries");
+    DBuf dgp = dalloc<int>(K + 1), dsp = dalloc<int>(K + 1), dgi = dalloc<int>(maxg), dsi = dalloc<int>(maxs);
     int sg = 1;
     CS_DISPATCH_K(K, sg = (spmv_grid<T, KK>((int)n)));
     DBuf part = dalloc<double>((size_t)sg * K);
@@ -961,9 +1011,6 @@ struct Solver : ISolver {
       }
       gp[K] = (int)gi.size();
       sp[K] = (int)si.size();
-      CS_REQUIRE(!si.empty(), CSGPU_BAD_ARGS, "empty source set");
-      if (dgi.bytes < gi.size() * sizeof(int)) dgi.alloc(gi.size() * sizeof(int));
-      if (dsi.bytes < si.size() * sizeof(int)) dsi.alloc(si.size() * sizeof(int));
       CS_HIP(hipMemcpyAsync(dgp.p, gp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipMemcpyAsync(dsp.p, sp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipMemcpyAsync(dgi.p, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -1005,7 +1052,7 @@ struct Solver : ISolver {
       for (int c = 0; c < ncols; ++c) {
         double e = 0;
         for (int b = 0; b < sg; ++b) e += hpart[(size_t)b * K + c];
-        resistances[p0 + c] = e > 0 ? 1.0 / e : -1.0;
+        res_all[slot[(size_t)(p0 + c)]] = e > 0 ? 1.0 / e : -1.0;
       }
     }
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

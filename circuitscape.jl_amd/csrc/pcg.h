@@ -345,10 +345,15 @@ struct PcgGraphKey {
   double rtol = 0, atol = 0;
   const void* matrix = nullptr;
   int need_x = 0, nf = 0, parity = 0;
+  // Dirichlet sets of the batch: the list pointers and the launch geometry of the mask kernels are baked into a chunk
+  const void* gptr = nullptr;
+  const void* gidx = nullptr;
+  int gtotal = 0;
   bool operator==(const PcgGraphKey& o) const {
     return K == o.K && ncols_active == o.ncols_active && criterion == o.criterion && nu_pre == o.nu_pre &&
            nu_post == o.nu_post && nu_coarse == o.nu_coarse && iters == o.iters && rtol == o.rtol && atol == o.atol &&
-           matrix == o.matrix && need_x == o.need_x && nf == o.nf && parity == o.parity;
+           matrix == o.matrix && need_x == o.need_x && nf == o.nf && parity == o.parity && gptr == o.gptr &&
+           gidx == o.gidx && gtotal == o.gtotal;
   }
 };
 
@@ -619,9 +624,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       else CS_UPD_R(false, false);
 #undef CS_UPD_R
     }
-    if (grounded)  // the update put (A p) at the grounded rows into r: back to zero, in both precisions
+    const bool rr_after_mask = grounded && criterion == CSGPU_CRIT_TRUE_RESIDUAL;
+    if (grounded) {  // the update put (A p) at the grounded rows into r: back to zero, in both precisions
       hipLaunchKernelGGL((mask_grounds_kernel<T, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, r,
                          MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done);
+      // the partials of r'r the update wrote include alpha (A p) at the Dirichlet rows, which are not equations of the
+      // reduced system: when the true residual is monitored, take the norm of the masked r instead
+      if (rr_after_mask)
+        hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
+                           (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+    }
     if (nf > 0)
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
@@ -634,7 +646,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       // r'r partials (true-residual criterion): one row per workgroup of whichever kernel updated r
       const double* prr = pb;
       int nrr = gv;
-      if (recompute && criterion == CSGPU_CRIT_TRUE_RESIDUAL) {
+      if (recompute && criterion == CSGPU_CRIT_TRUE_RESIDUAL && !rr_after_mask) {
         auto rr = collapsed(pb, spmv_g, pcc);
         prr = rr.first;
         nrr = rr.second;
@@ -663,7 +675,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   gkey.atol = atol;
   gkey.matrix = (const void*)A.val.p;
   gkey.need_x = need_x ? 1 : 0;
-  gkey.nf = nf + 100000 * pp.gtotal;  // (launch geometry of the mask kernels is baked into a captured chunk)
+  gkey.nf = nf;
+  gkey.gptr = grounded ? (const void*)pp.gptr : nullptr;
+  gkey.gidx = grounded ? (const void*)pp.gidx : nullptr;
+  gkey.gtotal = grounded ? pp.gtotal : 0;
   auto chunk_graph = [&]() -> hipGraphExec_t {
     for (auto& g : W.graphs)
       if (g.first == gkey) return g.second;

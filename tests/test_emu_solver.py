@@ -1062,3 +1062,34 @@ def test_region_pairs_of_single_nodes_are_plain_pair_resistances(emu_lib, holes)
                 h.solve_region_pairs([[src[0]], [dst[0]]], [0], [0])
             with pytest.raises(emu_lib.CsgpuError):
                 h.solve_region_pairs([[n + 5], [dst[0]]], [0], [1])
+
+
+def test_region_pairs_graph_replay_survives_growing_and_repeating_set_lists(emu_lib):
+    """batch totals 4 / 64 / 4 with hipGraph replay on. The set lists used to be re-allocated when a
+    batch's lists grew, and the third batch then replayed the first batch's captured chunk, which masked the residual at
+    the first batch's nodes (no convergence). Lists are now sized once per call and the graph key carries the list
+    pointers and totals. Also: sets that share a node are one equipotential (R = 0, no solve)."""
+    rng = np.random.default_rng(11)
+    g = np.exp(rng.standard_normal((40, 37)))
+    with emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, use_graph=1, check_every=2, itmax=400)) as h:
+        n = h.info["n"]
+        ids = [int(v) for v in rng.choice(n, size=80, replace=False)]
+        small = [[ids[0]], [ids[1]], [ids[2]], [ids[3]]]
+        large = [ids[8:24], ids[24:40], ids[40:56], ids[56:72]]
+        small2 = [[ids[4]], [ids[5]], [ids[6]], [ids[7]]]
+        sets = small + large + small2
+        src = [0, 2, 4, 6, 8, 10]
+        dst = [1, 3, 5, 7, 9, 11]
+        Rg, st = h.solve_region_pairs(sets, src, dst)
+        assert st["not_converged"] == 0
+    with emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, use_graph=-1)) as h:
+        Rd, st = h.solve_region_pairs(sets, src, dst)
+        assert st["not_converged"] == 0
+        assert np.max(np.abs(Rg - Rd) / Rd) < 1e-9
+        # overlapping sets: R = 0 for that pair, the others unaffected
+        sets2 = sets + [[ids[0], ids[30]]]
+        Ro, st = h.solve_region_pairs(sets2, [0, 12, 2], [1, 5, 3])
+        assert Ro[1] == 0.0 and st["nrhs"] == 3
+        assert abs(Ro[0] - Rd[0]) < 1e-9 * Rd[0] and abs(Ro[2] - Rd[1]) < 1e-9 * Rd[1]
+        with pytest.raises(emu_lib.CsgpuError):
+            h.solve_region_pairs([[ids[0]], []], [0], [1])
