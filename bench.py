@@ -31,15 +31,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def pmc_traffic(size, batch, vb, lattice=False):
+def pmc_traffic(size, batch, vb, lattice=False, pb=4):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh -> profiles/),
     collected with rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md prescribes. None when no
-    profile matches the current workload."""
+    profile matches the current workload. (PMC passes cannot run inside this process; the key names size, batch width,
+    CG precision, matrix form and -- for the all-fp64 path -- the preconditioner precision.)"""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        key = "%d_k%d_f%d%s" % (size, batch, vb * 8, "_lattice" if lattice else "")
+        key = "%d_k%d_f%d%s%s" % (size, batch, vb * 8, "_lattice" if lattice else "",
+                                  "_fp64precond" if (vb == 8 and pb == 8) else "")
         return d.get(key, {}).get("traffic_bytes_per_launch")
     except Exception:
         return None
@@ -168,16 +170,19 @@ def main():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="raster edge of the CPU-baseline / parity sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
-    ap.add_argument("--precond", default="fp32", choices=["same", "fp32"],
-                    help="precision of the AMG preconditioner: fp32 under the fp64 CG iteration (default), or the same "
-                         "precision as the CG iteration")
+    ap.add_argument("--precond", default="same", choices=["same", "fp32"],
+                    help="precision of the AMG preconditioner (hierarchy, V-cycle, stored search direction) of the path "
+                         "`value` is measured on: the same precision as the CG iteration (default: the reference computes "
+                         "everything in T = Float64, src/run.jl:29, src/core.jl:639), or fp32 under the fp64 CG iteration. "
+                         "The other one is timed beside it over --compare-steps steps")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--opt", action="append", default=[], help="extra csgpu_opts override key=value (tuning)")
     ap.add_argument("--compare-steps", type=int, default=-1,
-                    help="N=1 only: also time this many steps with the preconditioner in fp64 (the all-fp64 path) and "
-                         "report them as value_fp64; -1 = the same number as --steps, 0 = skip")
+                    help="N=1 only: also time this many steps on the OTHER preconditioner precision (see --precond) and "
+                         "report them as value_mixed / value_fp64 with their own roofline; -1 = the same number as "
+                         "--steps, 0 = skip")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, what the driver runs): every rank solves --steps batches. strong: the config's "
                          "FIXED pair list (--pairs, default 100 = BASELINE configs[2]) is dealt over the ranks at pair "
@@ -258,7 +263,8 @@ def main():
     g = make_raster(size, dtype=dtype)
     # untimed warm-up of the setup path on a small raster (first launch of every kernel loads its code object; a fresh
     # process pays ~1 s for that once -- the solve path is warmed by the --warmup batches below)
-    for precond in ((args.precond, "same") if (vb == 8 and args.precond == "fp32") else (args.precond,)):
+    other = {"same": "fp32", "fp32": "same"}[args.precond] if vb == 8 else None
+    for precond in ((args.precond, other) if other else (args.precond,)):
         wn = min(768, size)
         hw = lib.raster_setup(np.ascontiguousarray(g[:wn, :wn]), make_opts(precond))
         hw.solve_pairs([0] * B, [wn * wn - 1] * B)
@@ -291,16 +297,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    def roofline_of(info_p, agg_p):
+        """roofline object of the fine-level CG product of one path: algorithmic bytes per launch (reported by the
+        library) / mean HIP-event duration of those launches on the library's stream, measured live in this run"""
+        avg_ms = agg_p["cg_spmv_ms"] / max(agg_p["cg_spmv_calls"], 1)
+        nbytes = agg_p["cg_spmv_bytes"]
+        ach = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": cg_product_name(info_p, B, vb), "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(size, B, vb, info_p["lattice_period"] > 0, info_p["precond_bytes"] or vb),
+                "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms, "launches_timed": agg_p["cg_spmv_calls"]}
+
     if rank == 0:
         pairs_done = K * B * world
         setup_s = (info["setup_ms"] + info["upload_ms"]) / 1e3
         # setup is per GPU and amortised over the config's 100 pairs per matrix
         value = pairs_done / (elapsed + setup_s * (K * B) / 100.0)
-        spmv_avg_ms = agg["cg_spmv_ms"] / max(agg["cg_spmv_calls"], 1)
-        spmm_bytes, kname = agg["cg_spmv_bytes"], cg_product_name(info, B, vb)
-        achieved = spmm_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         spmv1_ms = h.spmv_bench(1, 10)
         mixed = vb == 8 and info["precond_bytes"] == 4
+        path_name = "mixed" if mixed else ("fp64" if vb == 8 else "fp32")
+        roof = roofline_of(info, agg)
+        roof.update({"spmv_k1_avg_ms": spmv1_ms,
+                     "spmv_k1_GBs": info["spmv_bytes_fine"] / (spmv1_ms * 1e-3) / 1e9 if spmv1_ms > 0 else 0.0})
         out = {
             "metric": "pair-solves/sec (AMG-PCG, setup amortised over 100 pairs) on %dx%d raster pairwise" % (size, size),
             "value": value,
@@ -312,11 +330,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if dtype == np.float64 else "f32",
-            "dtype_note": ("`value` = value_mixed: CG iteration (x, r, A p, every dot product, the residual check) in f64; "
-                           "AMG preconditioner (hierarchy + V-cycle) and the stored search direction in f32. value_fp64 = "
-                           "the same workload and step count with everything in f64 (the reference's arithmetic)"
-                           if mixed else "uniform precision"),
+            "dtype": "f64/f32-mixed" if mixed else ("f64" if dtype == np.float64 else "f32"),
+            "dtype_note": ("`value` is timed on the %s path. fp64 path: every operation in f64 -- the reference's arithmetic "
+                           "(T = Float64, src/run.jl:29, src/core.jl:639). mixed path: CG iteration (x, r, A p, every dot "
+                           "product, the residual check) in f64, AMG preconditioner (hierarchy + V-cycle) and the stored "
+                           "search direction in f32. The other path runs the same workload, warm-up and step count and is "
+                           "reported as value_%s with its own roofline" % (path_name, "fp64" if mixed else "mixed")
+                           if vb == 8 else "uniform precision"),
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic raster, 8-neighbour, %d pairs/GPU in batches of %d, %s"
                                    % (size, size, K * B, B, "fp64" if vb == 8 else "fp32"),
@@ -333,41 +353,35 @@ def main():
             "iters_mean": agg["total_iters"] / float(K * B), "iters_max": agg["max_iters"],
             "max_relres": agg["max_relres"], "not_converged": agg["not_converged"],
             "pcg_device_ms_per_step": agg["device_ms"] / K,   # HIP-event time of the PCG loops (rest of ms_per_step: host side)
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(size, B, vb, info["lattice_period"] > 0),
-                         "algorithmic_bytes_per_launch": spmm_bytes, "avg_ms": spmv_avg_ms,
-                         "launches_timed": agg["cg_spmv_calls"],
-                         "spmv_k1_avg_ms": spmv1_ms,
-                         "spmv_k1_GBs": info["spmv_bytes_fine"] / (spmv1_ms * 1e-3) / 1e9 if spmv1_ms > 0 else 0.0},
+            "roofline": roof,
         }
-        if mixed:
-            out["value_mixed"] = value
-        elif vb == 8:
-            out["value_fp64"] = value
+        out["value_" + path_name] = value
         h.close()
         h = None
         csteps = K if args.compare_steps < 0 else args.compare_steps
-        if world == 1 and csteps > 0 and mixed:
-            # the same workload, same warm-up and step count, with the preconditioner (and the search direction) in fp64
-            h2 = lib.raster_setup(g, make_opts("same"))      # cold for the block sizes of this precision, see above
+        if world == 1 and csteps > 0 and other:
+            # the same workload, same warm-up and step count on the other preconditioner precision
+            oname = "fp64" if other == "same" else "mixed"
+            h2 = lib.raster_setup(g, make_opts(other))      # cold for the block sizes of this precision, see above
             cold2 = h2.info
             h2.solve_pairs(*batch_pairs(0))
             h2.close()
-            h2 = lib.raster_setup(g, make_opts("same"))
+            h2 = lib.raster_setup(g, make_opts(other))
             el2, res2, agg2 = run_pairs(h2, batch_pairs, csteps, Wm, sync)
             i2 = h2.info
             s2 = (i2["setup_ms"] + i2["upload_ms"]) / 1e3
-            out["value_fp64"] = csteps * B / (el2 + s2 * csteps * B / 100.0)
+            out["value_" + oname] = csteps * B / (el2 + s2 * csteps * B / 100.0)
             ncmp = min(csteps, K)
-            out["fp64_path"] = {
-                "value": out["value_fp64"], "solve_only_pairs_per_s": csteps * B / el2, "steps": csteps,
+            out[oname + "_path"] = {
+                "value": out["value_" + oname], "solve_only_pairs_per_s": csteps * B / el2, "steps": csteps,
                 "ms_per_step": el2 / csteps * 1e3, "setup_s": s2, "setup_cold_s": (cold2["setup_ms"] + cold2["upload_ms"]) / 1e3,
                 "setup_device_s": i2["setup_ms"] / 1e3,
                 "upload_s": i2["upload_ms"] / 1e3, "iters_mean": agg2["total_iters"] / float(csteps * B),
-                "max_relres": agg2["max_relres"],
-                "max_rel_diff_R_vs_mixed_path": float(max(np.max(np.abs(res2[k] - results[k]) / np.abs(res2[k]))
-                                                          for k in range(ncmp)))}
+                "iters_max": agg2["max_iters"], "max_relres": agg2["max_relres"], "not_converged": agg2["not_converged"],
+                "pcg_device_ms_per_step": agg2["device_ms"] / csteps,
+                "roofline": roofline_of(i2, agg2),
+                "max_rel_diff_R_vs_%s_path" % path_name: float(max(np.max(np.abs(res2[k] - results[k]) / np.abs(res2[k]))
+                                                                   for k in range(ncmp)))}
             h2.close()
         if world == 1 and args.host_csr:
             try:
@@ -387,7 +401,7 @@ def main():
                 tight = cb.pop("_tight", None)
                 out["cpu_baseline"] = cb
                 if tight:
-                    out["parity"] = gpu_parity(lib, args.cpu_sample, tight, make_opts, dtype, mixed)
+                    out["parity"] = gpu_parity(lib, args.cpu_sample, tight, make_opts, dtype, vb == 8)
             except Exception as e:  # the GPU line must be printed whatever happens to the host-side leg
                 out.setdefault("cpu_baseline", {"value": None, "unit": "pair-solves/s", "cores": 0, "kind": "port",
                                                 "sample": "failed: %r" % (e,)})
@@ -401,8 +415,8 @@ def main():
         dist.destroy_process_group()
 
 
-def gpu_parity(lib, sample_size, tight, make_opts, dtype, mixed):
-    """The GPU path, with exactly the options the timed run used, on the CPU leg's sample raster against the TIGHT
+def gpu_parity(lib, sample_size, tight, make_opts, dtype, both):
+    """The GPU paths, with exactly the options the timed runs used, on the CPU leg's sample raster against the TIGHT
     oracle's resistances of the same pairs (a parity figure accompanies every number)."""
     g = make_raster(sample_size, dtype=dtype)
     cells, pairs = focal_pairs(sample_size)
@@ -414,7 +428,7 @@ def gpu_parity(lib, sample_size, tight, make_opts, dtype, mixed):
     # single-precision tolerance is 1e-2 absolute, test/test_utils.jl:72-73)
     out = {"n": sample_size * sample_size, "pairs": nt, "oracle": "tight (true-residual rtol 1e-12)",
            "oracle_max_true_relres": tight["max_true_relres"], "tolerance": 1e-6 if dtype == np.float64 else 1e-3}
-    for name, precond in ((("mixed", "fp32"), ("fp64", "same")) if mixed else (("uniform", "same"),)):
+    for name, precond in ((("fp64", "same"), ("mixed", "fp32")) if both else (("uniform", "same"),)):
         h = lib.raster_setup(g, make_opts(precond))
         R, _, _, st = h.solve_pairs(src, dst)
         h.close()

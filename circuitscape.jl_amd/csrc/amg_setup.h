@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void tentative_kernel(int n, const int* __rest
       const int a = agg[i];
       tci[i] = a;
       const double sf = size_f ? (double)size_f[i] : 1.0;
-      tva[i] = (T)sqrt(sf / (double)size_c[a]);
+      const double sc = (double)size_c[a];
+      tva[i] = sc > 0.0 ? (T)sqrt(sf / sc) : T(0);  // (an aggregate of weightless nodes -- NODATA cells of a cell-space raster)
     }
   }
 }
@@ -904,6 +905,10 @@ struct SetupParams {
   int nu_l1 = 2, nu_deep = 3;    // sweeps (= polynomial degree) on level 1 / on the levels below it
   bool lattice_s = false;    // the caller builds the lattice forms of the two-product level (Level::Sdia, Level::Ql) from
                              // the aggregates kept in Level::agg0; Q^T and [S Q] are not built here
+  // Cell-space rasters (csgpu.hip): weight of every level-0 row in its aggregate (device, long long, 1 = a real node,
+  // 0 = the isolated row of a NODATA cell) and the number of real nodes; null / 0 = every row is a node
+  const long long* size0 = nullptr;
+  int64_t n_real = 0;
 };
 
 // Q^T (with its traversal order) of the two-product form in CSR
@@ -1054,6 +1059,10 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
   const int* cur_row = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_row;
   const int* cur_col = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_col;
   DBuf size_prev;  // long long fine sizes of the current level (null on level 0 => all ones)
+  if (sp.size0) {
+    size_prev.alloc((size_t)H.levels[0].A.nrows * sizeof(long long));
+    CS_HIP(hipMemcpyAsync(size_prev.p, sp.size0, size_prev.bytes, hipMemcpyDeviceToDevice, st));
+  }
   int gridR = cur_row ? sp.grid_rows : 0, gridC = cur_row ? sp.grid_cols : 0;  // raster extent of the current level
   for (;;) {
     Level<T>& L = H.levels.back();
@@ -1207,7 +1216,7 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon(),
                                               deflate ? &kc : nullptr, 1e-2, &dropped);
       H.near_singular = deflate && dropped > 0;
-      H.cand_norm2 = (double)H.levels[0].A.nrows;
+      H.cand_norm2 = sp.n_real > 0 ? (double)sp.n_real : (double)H.levels[0].A.nrows;
       if (deflate && getenv("CSGPU_VERBOSE"))
         fprintf(stderr, "csgpu: coarsest level: %d near-kernel eigenpair(s) of %zu candidate(s) dropped\n", dropped, kc.size());
       std::vector<T> Pt((size_t)n * n);

@@ -103,7 +103,20 @@ struct Solver : ISolver {
   Dia<T> dia;         // lattice form of the CG matrix (all-valid rasters; empty otherwise)
   PcgWork<T, TP> W;
   double upload_ms = 0;
-  int64_t n = 0, nnz = 0;
+  int64_t n = 0, nnz = 0;             // dimension / stored entries of the matrix the device solves with
+  // Cell space. A raster with NODATA cells (construct_node_map drops every cell with conductance <= 0,
+  // src/raster/pairwise.jl:271-301 -- nearly every real landscape has them) is solved on the FULL R x C lattice: every
+  // cell keeps a row, a NODATA cell's row is an isolated unknown (diagonal 1, no couplings, right-hand side always 0, so
+  // x, r, z, p stay exactly 0 there and every dot product is that of the real graph). The matrix is then a lattice
+  // again and the index-free marching kernels (stencil.h, lattice.h) apply; NODATA cells weigh 0 in the aggregates, so
+  // the transfer operators and every Galerkin operator are those of the real graph. The C ABI keeps speaking the
+  // reference's node numbering: ids and n-vectors are translated at the boundary (node2cell / cell2node).
+  bool cellspace = false;
+  int64_t n_api = 0, nnz_api = 0;     // what the caller sees (reference numbering); == n, nnz unless cellspace
+  DBuf node2cell, cell2node;          // cellspace: [n_api] column-major cell id of a node; [n] 1-based node id of a cell, 0 = none
+  DBuf cellmap;                       // cellspace: row-major [rows][cols], 1-based ROW id of the cell, 0 = no node
+  DBuf comp_label_api;                // cellspace: component label per NODE in the reference's terms (csgpu_components)
+  int64_t ncomp_api = -1;
   DBuf nodemap;                       // csgpu_raster_setup: row-major [rows][cols], 1-based node id, 0 = no node
   DBuf ground_node;                   // csgpu_raster_setup_grounded: finite ground conductance per node (T)
   DBuf comp_label;                    // connected-component label per node (computed on first use)
@@ -159,6 +172,54 @@ struct Solver : ISolver {
   }
   const Dia<T>* dia_ptr() const { return dia.n > 0 ? &dia : nullptr; }
 
+  // ---- boundary translation (no-ops unless cellspace) ----------------------------------------------------------------
+  // node ids of the caller -> row ids of the device matrix
+  struct Ids {
+    const int64_t* p = nullptr;
+    std::vector<int64_t> own;
+    const int64_t& operator[](int64_t k) const { return p[k]; }
+  };
+  Ids rows_of(const int64_t* ids, int64_t cnt) {
+    Ids r;
+    r.p = ids;
+    if (!cellspace || cnt <= 0) return r;
+    DBuf in = dalloc<int64_t>((size_t)cnt), out = dalloc<int64_t>((size_t)cnt);
+    CS_HIP(hipMemcpyAsync(in.p, ids, (size_t)cnt * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(map_ids_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, cnt, (const int64_t*)dptr<int64_t>(in),
+                       (const int*)dptr<int>(node2cell), dptr<int64_t>(out));
+    r.own.resize((size_t)cnt);
+    CS_HIP(hipMemcpyAsync(r.own.data(), out.p, (size_t)cnt * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    r.p = r.own.data();
+    return r;
+  }
+  // host column-major n_api x ncols  ->  device column-major n x ncols (zeros at the NODATA rows)
+  void upload_cols(const T* host, int64_t ncols, T* dev) {
+    if (!cellspace) {
+      CS_HIP(hipMemcpyAsync(dev, host, (size_t)n * ncols * sizeof(T), hipMemcpyHostToDevice, st));
+      return;
+    }
+    DBuf tmp((size_t)n_api * ncols * sizeof(T));
+    CS_HIP(hipMemcpyAsync(tmp.p, host, tmp.bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((cells_from_nodes_kernel<T>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n, n_api,
+                       (const int*)dptr<int>(cell2node), (const T*)dptr<T>(tmp), (int)ncols, dev);
+    CS_HIP(hipStreamSynchronize(st));  // tmp is released on return
+  }
+  // device column-major n x ncols  ->  host column-major n_api x ncols; blocks until the copy has landed
+  void download_cols(const T* dev, int64_t ncols, T* host) {
+    if (!cellspace) {
+      CS_HIP(hipMemcpyAsync(host, dev, (size_t)n * ncols * sizeof(T), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      return;
+    }
+    DBuf tmp((size_t)n_api * ncols * sizeof(T));
+    hipLaunchKernelGGL((nodes_from_cells_kernel<T>), dim3(grid_for(n_api * ncols)), dim3(256), 0, st, n, n_api,
+                       (const int*)dptr<int>(node2cell), dev, (int)ncols, dptr<T>(tmp));
+    CS_HIP(hipMemcpyAsync(host, tmp.p, tmp.bytes, hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+  }
+  const int* raster_rowmap() const { return cellspace ? (const int*)dptr<int>(cellmap) : (const int*)dptr<int>(nodemap); }
+
   // Lattice form of the CG matrix: period known (raster built here, every cell valid) or detected from the band
   // structure of a host-built matrix (candidates around the dominant band offset found by spmv_block_order).
   void detect_lattice(const Csr<T>& A, int known_period) {
@@ -181,8 +242,8 @@ struct Solver : ISolver {
   void setup_from_host(const void* rowptr, const void* colidx, const void* vals, int64_t n_, int64_t nnz_,
                        int idx_bytes, int index_base) {
     auto t0 = std::chrono::steady_clock::now();
-    n = n_;
-    nnz = nnz_;
+    n = n_api = n_;
+    nnz = nnz_api = nnz_;
     Csr<T> A;
     A.nrows = A.ncols = (int)n;
     A.nnz = nnz;
@@ -241,7 +302,7 @@ struct Solver : ISolver {
   }
 
   // known_period: raster height when the matrix was built here from an all-valid raster, 0 = detect, -1 = no lattice
-  void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period) {
+  void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period, const long long* size0 = nullptr) {
     detect_lattice(A, known_period);
     DBuf lrow, lcol;
     if (dia.n > 0 && !prow && !pcol) {
@@ -252,6 +313,8 @@ struct Solver : ISolver {
       pcol = dptr<int>(lcol);
     }
     SetupParams sp = setup_params();
+    sp.size0 = size0;
+    sp.n_real = size0 ? n_api : 0;
     if (dia.n > 0) {  // raster extent known: left-over cells stay with their own 3x3 tile (agg_pass2_kernel)
       sp.grid_rows = dia.R;
       sp.grid_cols = (int)(n / dia.R);
@@ -310,6 +373,19 @@ struct Solver : ISolver {
     }
   }
 
+  // Cell space is chosen for rasters WITH NODATA cells when the index-free fine level applies (two-product V(1,1) level,
+  // lattice product not switched off) and most cells are valid: the marching kernels stream every cell, so below
+  // ~half-full rasters the compact CSR path moves fewer bytes (CSGPU_CELLSPACE_MIN_FRAC, default 0.5; CSGPU_NO_CELLSPACE=1
+  // keeps the compact numbering of round 2).
+  bool want_cellspace(int64_t nvalid, int64_t ncells, int64_t R, int64_t C) const {
+    if (getenv("CSGPU_NO_CELLSPACE") || getenv("CSGPU_NO_STENCIL") || opts.stencil < 0) return false;
+    if (nvalid == ncells || R < 6 || C < 6) return false;
+    if (!(opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0) || getenv("CSGPU_NO_TWO_PRODUCT")) return false;
+    if (opts.aggregation == CSGPU_AGG_MIS2 || opts.theta != 0.0) return false;
+    const double minfrac = getenv("CSGPU_CELLSPACE_MIN_FRAC") ? atof(getenv("CSGPU_CELLSPACE_MIN_FRAC")) : 0.5;
+    return (double)nvalid >= minfrac * (double)ncells;
+  }
+
   void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg,
                          const void* ground = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
@@ -328,19 +404,29 @@ struct Solver : ISolver {
     hipLaunchKernelGGL((raster_valid_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, dptr<T>(dcond), dptr<int>(node));
     DBuf total = dalloc<int>(1);
     exclusive_scan_i32(dptr<int>(node), ncells + 1, st, dptr<int>(total));
-    n = read_int(dptr<int>(total), st);
-    CS_REQUIRE(n > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
+    n_api = read_int(dptr<int>(total), st);
+    CS_REQUIRE(n_api > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
+    cellspace = want_cellspace(n_api, ncells, R, C);
+    n = cellspace ? ncells : n_api;
     raster_rows = R;
     raster_cols = C;
     nodemap.alloc((size_t)ncells * sizeof(int));
+    if (cellspace) {
+      cellmap.alloc((size_t)ncells * sizeof(int));
+      node2cell.alloc((size_t)n_api * sizeof(int));
+      cell2node.alloc((size_t)ncells * sizeof(int));
+    }
     Csr<T> A;
     A.nrows = A.ncols = (int)n;
     A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
     CS_HIP(hipMemsetAsync(A.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
     hipLaunchKernelGGL((raster_count_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, dptr<T>(dcond),
-                       dptr<int>(node), A.rp(), dptr<int>(nodemap));
+                       dptr<int>(node), A.rp(), dptr<int>(nodemap), cellspace ? 1 : 0,
+                       cellspace ? dptr<int>(cellmap) : (int*)nullptr, cellspace ? dptr<int>(node2cell) : (int*)nullptr,
+                       cellspace ? dptr<int>(cell2node) : (int*)nullptr);
     exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
     nnz = read_int(dptr<int>(total), st);
+    nnz_api = nnz - (n - n_api);  // (the NODATA rows hold one entry each)
     A.nnz = nnz;
     A.col.alloc((size_t)nnz * sizeof(int));
     A.val.alloc((size_t)nnz * sizeof(T));
@@ -349,8 +435,10 @@ struct Solver : ISolver {
     hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
                        dptr<T>(dcond), dptr<int>(node), A.rp(), A.ci(), A.va(), dptr<int>(drow), dptr<int>(dcol),
                        ground ? (const T*)dptr<T>(dground) : (const T*)nullptr,
-                       ground ? dptr<T>(ground_node) : (T*)nullptr);
+                       ground ? dptr<T>(ground_node) : (T*)nullptr, cellspace ? 1 : 0);
     if (reg) {
+      // (cell space: the NODATA diagonals are still 0 here, so the norm is that of the real graph's entries; the shift
+      // they receive is overwritten below)
       const int g = grid_for(nnz);
       DBuf part = dalloc<double>(g);
       hipLaunchKernelGGL((dot_kernel<T, 1, false>), dim3(g), dim3(256), 0, st, nnz, (const T*)A.va(), (const T*)A.va(),
@@ -359,13 +447,22 @@ struct Solver : ISolver {
                          (double)std::numeric_limits<T>::epsilon());
       CS_HIP(hipStreamSynchronize(st));
     }
+    DBuf size0;
+    if (cellspace) {
+      size0.alloc((size_t)n * sizeof(long long));
+      hipLaunchKernelGGL((raster_identity_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                         (const int*)A.rp(), A.va(), dptr<long long>(size0));
+    }
     check_launch("raster build");
     CS_HIP(hipStreamSynchronize(st));
     dcond.release();
     node.release();
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    // every cell valid: node i couples to i+-1, i+-(R-1), i+-R, i+-(R+1) -> lattice form (stencil.h)
-    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), n == ncells ? (int)R : -1);
+    // every cell a row: row i couples to i+-1, i+-(R-1), i+-R, i+-(R+1) -> lattice form (stencil.h)
+    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), n == ncells ? (int)R : -1,
+                 cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr);
+    if (cellspace && !(dia.n > 0 && H.levels[0].lattice_two_product()) && getenv("CSGPU_VERBOSE"))
+      fprintf(stderr, "csgpu: cell-space raster without the index-free fine level (CSR kernels on %lld rows)\n", (long long)n);
   }
 
   // csgpu_raster_setup_poly: raster with short-circuit polygons, graph built on the device (raster.h, second half)
@@ -393,7 +490,7 @@ struct Solver : ISolver {
     hipLaunchKernelGGL((poly_label_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
                        (const int*)dpoly.p, (const int*)dptr<int>(rep), dptr<int>(label), dptr<int>(flag));
     exclusive_scan_i32(dptr<int>(flag), ncells + 1, st, dptr<int>(total));
-    n = read_int(dptr<int>(total), st);
+    n = n_api = read_int(dptr<int>(total), st);
     CS_REQUIRE(n > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
     hipLaunchKernelGGL(poly_present_kernel, dim3(grid_for(maxid + 1)), dim3(256), 0, st, maxid, (const int*)dptr<int>(rep),
                        dptr<int>(present));
@@ -452,7 +549,7 @@ struct Solver : ISolver {
                          (int*)nullptr, (T*)nullptr);
     }
     exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
-    nnz = read_int(dptr<int>(total), st);
+    nnz = nnz_api = read_int(dptr<int>(total), st);
     A.nnz = nnz;
     A.col.alloc((size_t)nnz * sizeof(int));
     A.val.alloc((size_t)nnz * sizeof(T));
@@ -498,8 +595,27 @@ struct Solver : ISolver {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     ensure_components();
-    if (out) CS_HIP(hipMemcpy(out, comp_label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    return ncomp;
+    if (!cellspace) {
+      if (out) CS_HIP(hipMemcpy(out, comp_label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      return ncomp;
+    }
+    // cell space: every NODATA row is a component of its own in comp_label; the caller sees the components of the real
+    // graph, numbered by their smallest node id (the order of the surviving labels is already that order)
+    if (ncomp_api < 0) {
+      DBuf keep = dalloc<int>((size_t)ncomp + 1), total = dalloc<int>(1);
+      CS_HIP(hipMemsetAsync(keep.p, 0, keep.bytes, st));
+      hipLaunchKernelGGL(comp_keep_kernel, dim3(grid_for(n_api)), dim3(256), 0, st, n_api, (const int*)dptr<int>(node2cell),
+                         (const int*)dptr<int>(comp_label), dptr<int>(keep));
+      exclusive_scan_i32(dptr<int>(keep), ncomp + 1, st, dptr<int>(total));
+      ncomp_api = read_int(dptr<int>(total), st);
+      comp_label_api.alloc((size_t)n_api * sizeof(int));
+      hipLaunchKernelGGL(comp_compact_kernel, dim3(grid_for(n_api)), dim3(256), 0, st, n_api, (const int*)dptr<int>(node2cell),
+                         (const int*)dptr<int>(comp_label), (const int*)dptr<int>(keep), dptr<int>(comp_label_api));
+      check_launch("components (cell space)");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    if (out) CS_HIP(hipMemcpy(out, comp_label_api.p, (size_t)n_api * sizeof(int), hipMemcpyDeviceToHost));
+    return ncomp_api;
   }
 
   // Advanced-mode solve on a raster-built handle, rasters in and out (compute_omniscape_current, utils.jl:145-257, for
@@ -524,7 +640,7 @@ struct Solver : ISolver {
     CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * sizeof(T), st));
     const T* gnode = ground_node.p ? (const T*)dptr<T>(ground_node) : (const T*)nullptr;
     hipLaunchKernelGGL((raster_rhs_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
-                       (const int*)dptr<int>(nodemap), (const T*)dptr<T>(dsrc), gnode, (const int*)dptr<int>(comp_label),
+                       raster_rowmap(), (const T*)dptr<T>(dsrc), gnode, (const int*)dptr<int>(comp_label),
                        dptr<T>(W.b), dptr<int>(has));
     hipLaunchKernelGGL((raster_rhs_mask_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
                        (const int*)dptr<int>(comp_label), (const int*)dptr<int>(has), dptr<T>(W.b));
@@ -548,7 +664,7 @@ struct Solver : ISolver {
     DBuf draster((size_t)ncells * sizeof(T));
     if (volt_out) {
       hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
-                         (const int*)dptr<int>(nodemap), (const T*)dptr<T>(W.x), dptr<T>(draster));
+                         raster_rowmap(), (const T*)dptr<T>(W.x), dptr<T>(draster));
       CS_HIP(hipMemcpyAsync(volt_out, draster.p, (size_t)ncells * sizeof(T), hipMemcpyDeviceToHost, st));
       CS_HIP(hipStreamSynchronize(st));
     }
@@ -565,7 +681,7 @@ struct Solver : ISolver {
                          (const T*)dptr<T>(W.x), (const double*)nullptr, dptr<T>(dcurr), gnode,
                          (const int*)dptr<int>(comp_label), (const unsigned long long*)dptr<unsigned long long>(cmax));
       hipLaunchKernelGGL((raster_scatter_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
-                         (const int*)dptr<int>(nodemap), (const T*)dptr<T>(dcurr), dptr<T>(draster));
+                         raster_rowmap(), (const T*)dptr<T>(dcurr), dptr<T>(draster));
       CS_HIP(hipMemcpyAsync(curr_out, draster.p, (size_t)ncells * sizeof(T), hipMemcpyDeviceToHost, st));
       CS_HIP(hipStreamSynchronize(st));
     }
@@ -635,16 +751,30 @@ struct Solver : ISolver {
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t p = 0; p < npairs; ++p)
-      CS_REQUIRE(src[p] >= 0 && src[p] < n && dst[p] >= 0 && dst[p] < n, CSGPU_BAD_ARGS, "pair node id out of range");
+      CS_REQUIRE(src[p] >= 0 && src[p] < n_api && dst[p] >= 0 && dst[p] < n_api, CSGPU_BAD_ARGS, "pair node id out of range");
     for (int64_t g = 0; g < ngather; ++g)
-      CS_REQUIRE(gather[g] >= 0 && gather[g] < n, CSGPU_BAD_ARGS, "gather node id out of range");
+      CS_REQUIRE(gather[g] >= 0 && gather[g] < n_api, CSGPU_BAD_ARGS, "gather node id out of range");
+    CS_REQUIRE(!(cellspace && branch_out), CSGPU_BAD_ARGS,
+               "branch currents are indexed by the stored entries of a network's matrix (out.jl:209-290); this handle was "
+               "built from a raster");
+    // from here on: row ids of the device matrix (cell space: the cells of the nodes)
+    const Ids src_r = rows_of(src, npairs), dst_r = rows_of(dst, npairs), gather_r = rows_of(gather, ngather);
+    src = src_r.p;
+    dst = dst_r.p;
+    gather = gather_r.p;
     if (ncomp > 1) {
       // a pair across two components is an inconsistent singular system (the reference only pairs points of one
       // component, core.jl:146-153): refuse it instead of iterating to itmax
-      std::vector<int> lab((size_t)n);
-      CS_HIP(hipMemcpy(lab.data(), comp_label.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      DBuf ids = dalloc<int64_t>((size_t)2 * npairs), labs = dalloc<int>((size_t)2 * npairs);
+      CS_HIP(hipMemcpyAsync(ids.p, src, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dptr<int64_t>(ids) + npairs, dst, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(gather_int_kernel, dim3(grid_for(2 * npairs)), dim3(256), 0, st, 2 * npairs,
+                         (const int64_t*)dptr<int64_t>(ids), (const int*)dptr<int>(comp_label), dptr<int>(labs));
+      std::vector<int> lab((size_t)2 * npairs);
+      CS_HIP(hipMemcpyAsync(lab.data(), labs.p, lab.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
       for (int64_t p = 0; p < npairs; ++p)
-        CS_REQUIRE(lab[src[p]] == lab[dst[p]], CSGPU_BAD_ARGS, "pair spans two connected components");
+        CS_REQUIRE(lab[p] == lab[npairs + p], CSGPU_BAD_ARGS, "pair spans two connected components");
     }
     const int K = pick_k(npairs);
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
@@ -738,8 +868,7 @@ struct Solver : ISolver {
       if (volt_out) {
         CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_volt_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                              (const T*)dptr<T>(W.x), dptr<int>(dsrc), ncols, dptr<T>(dvolt)));
-        CS_HIP(hipMemcpyAsync((T*)volt_out + (size_t)p0 * n, dvolt.p, (size_t)n * ncols * sizeof(T),
-                              hipMemcpyDeviceToHost, st));
+        download_cols((const T*)dptr<T>(dvolt), ncols, (T*)volt_out + (size_t)p0 * n_api);
       }
       if (want_curr) {
         const Csr<T>& A = cg_matrix();
@@ -764,8 +893,7 @@ struct Solver : ISolver {
         if (curr_out) {
           CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                               (const T*)dptr<T>(dcurr), ncols, dptr<T>(dvolt)));
-          CS_HIP(hipMemcpyAsync((T*)curr_out + (size_t)p0 * n, dvolt.p, (size_t)n * ncols * sizeof(T),
-                                hipMemcpyDeviceToHost, st));
+          download_cols((const T*)dptr<T>(dvolt), ncols, (T*)curr_out + (size_t)p0 * n_api);
         }
         if (cum_inout || max_inout) {
           for (int c = 0; c < K; ++c) w32[c] = c < ncols ? (weights ? weights[p0 + c] : 1) : 0;
@@ -779,16 +907,16 @@ struct Solver : ISolver {
       CS_HIP(hipStreamSynchronize(st));
     }
     if (cum_inout || max_inout) {
-      std::vector<T> tmp((size_t)n);
+      std::vector<T> tmp((size_t)n_api);
       if (cum_inout) {
-        CS_HIP(hipMemcpy(tmp.data(), dcum.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+        download_cols((const T*)dptr<T>(dcum), 1, tmp.data());
         T* h = (T*)cum_inout;
-        for (int64_t i = 0; i < n; ++i) h[i] += tmp[i];
+        for (int64_t i = 0; i < n_api; ++i) h[i] += tmp[i];
       }
       if (max_inout) {
-        CS_HIP(hipMemcpy(tmp.data(), dmax.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+        download_cols((const T*)dptr<T>(dmax), 1, tmp.data());
         T* h = (T*)max_inout;
-        for (int64_t i = 0; i < n; ++i) h[i] = tmp[i] > h[i] ? tmp[i] : h[i];
+        for (int64_t i = 0; i < n_api; ++i) h[i] = tmp[i] > h[i] ? tmp[i] : h[i];
       }
     }
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -808,18 +936,15 @@ struct Solver : ISolver {
     DBuf stage((size_t)n * K * sizeof(T));
     for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
       const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
-      CS_HIP(hipMemcpyAsync(stage.p, (const T*)rhs + (size_t)p0 * n, (size_t)n * ncols * sizeof(T),
-                            hipMemcpyHostToDevice, st));
+      upload_cols((const T*)rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
                                            (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
       PcgBatchResult r = run_batch_k(K, ncols);
       accumulate(stats, r, ncols);
       CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                            (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
-      CS_HIP(hipMemcpyAsync((T*)x_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T), hipMemcpyDeviceToHost,
-                            st));
       check_launch("solve_rhs batch");
-      CS_HIP(hipStreamSynchronize(st));
+      download_cols((const T*)dptr<T>(stage), ncols, (T*)x_out + (size_t)p0 * n_api);
     }
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -834,8 +959,10 @@ struct Solver : ISolver {
     for (int64_t c = 0; c < nrhs; ++c) {
       CS_REQUIRE(gptr[c] <= gptr[c + 1], CSGPU_BAD_ARGS, "ground_ptr must be non-decreasing");
       for (int64_t e = gptr[c]; e < gptr[c + 1]; ++e)
-        CS_REQUIRE(gidx[e] >= 0 && gidx[e] < n, CSGPU_BAD_ARGS, "ground node id out of range");
+        CS_REQUIRE(gidx[e] >= 0 && gidx[e] < n_api, CSGPU_BAD_ARGS, "ground node id out of range");
     }
+    const Ids gidx_r = rows_of(gidx + gptr[0], gptr[nrhs] - gptr[0]);  // row ids of the device matrix (cell space)
+    gidx = gidx_r.p - gptr[0];
     const int K = pick_k(nrhs);
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
@@ -864,8 +991,7 @@ struct Solver : ISolver {
       hp[K] = (int)hi.size();
       CS_HIP(hipMemcpyAsync(dgp.p, hp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
       if (!hi.empty()) CS_HIP(hipMemcpyAsync(dgi.p, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      CS_HIP(hipMemcpyAsync(stage.p, (const T*)rhs + (size_t)p0 * n, (size_t)n * ncols * sizeof(T),
-                            hipMemcpyHostToDevice, st));
+      upload_cols((const T*)rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
                                            (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
       const int gtotal = (int)hi.size();
@@ -886,8 +1012,7 @@ struct Solver : ISolver {
       accumulate(stats, r, ncols);
       CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                            (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
-      CS_HIP(hipMemcpyAsync((T*)x_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T), hipMemcpyDeviceToHost,
-                            st));
+      download_cols((const T*)dptr<T>(stage), ncols, (T*)x_out + (size_t)p0 * n_api);
       if (curr_out) {
         const Csr<T>& A = cg_matrix();
         const int gc = grid_for(n * K);
@@ -902,8 +1027,7 @@ struct Solver : ISolver {
         CS_HIP(hipStreamSynchronize(st));  // stage still feeds the copy of x
         CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
                                             (const T*)dptr<T>(dcurr), ncols, dptr<T>(stage)));
-        CS_HIP(hipMemcpyAsync((T*)curr_out + (size_t)p0 * n, stage.p, (size_t)n * ncols * sizeof(T),
-                              hipMemcpyDeviceToHost, st));
+        download_cols((const T*)dptr<T>(stage), ncols, (T*)curr_out + (size_t)p0 * n_api);
       }
       check_launch("solve_grounded batch");
       CS_HIP(hipStreamSynchronize(st));
@@ -923,8 +1047,10 @@ struct Solver : ISolver {
     for (int64_t q = 0; q < nsets; ++q) {
       CS_REQUIRE(set_ptr[q] <= set_ptr[q + 1], CSGPU_BAD_ARGS, "set_ptr must be non-decreasing");
       for (int64_t e = set_ptr[q]; e < set_ptr[q + 1]; ++e)
-        CS_REQUIRE(set_nodes[e] >= 0 && set_nodes[e] < n, CSGPU_BAD_ARGS, "set node id out of range");
+        CS_REQUIRE(set_nodes[e] >= 0 && set_nodes[e] < n_api, CSGPU_BAD_ARGS, "set node id out of range");
     }
+    const Ids set_r = rows_of(set_nodes + set_ptr[0], set_ptr[nsets] - set_ptr[0]);  // row ids of the device matrix
+    set_nodes = set_r.p - set_ptr[0];
     for (int64_t p = 0; p < npairs; ++p)
       CS_REQUIRE(src_set[p] >= 0 && src_set[p] < nsets && dst_set[p] >= 0 && dst_set[p] < nsets && src_set[p] != dst_set[p],
                  CSGPU_BAD_ARGS, "pair refers to a set that does not exist (or to the same set twice)");
@@ -1066,8 +1192,8 @@ struct Solver : ISolver {
 
   void get_info(csgpu_info* info) const override {
     memset(info, 0, sizeof(*info));
-    info->n = n;
-    info->nnz = nnz;
+    info->n = n_api;      // (cell space: the caller's node count; level_n[0] / level_nnz[0] are the device matrix's)
+    info->nnz = nnz_api;
     info->levels = (int)H.levels.size();
     info->val_bytes = (int)sizeof(T);
     info->precond_bytes = (int)sizeof(TP);
@@ -1148,6 +1274,31 @@ struct Solver : ISolver {
     CS_HIP(hipSetDevice(device));
     const Csr<T>& A = cg_matrix();
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
+    if (cellspace) {
+      // host vectors are interleaved [n_api][k] in the caller's numbering: (node, column) pairs are "columns" of length k
+      // for the translation kernels when the roles of the two indices are swapped -- simplest: go through column-major
+      DBuf xc((size_t)n * k * sizeof(T)), t((size_t)n_api * k * sizeof(T)), t2((size_t)n_api * k * sizeof(T));
+      CS_HIP(hipMemcpyAsync(t.p, xh, t.bytes, hipMemcpyHostToDevice, st));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n_api * k)), dim3(256), 0, st, n_api,
+                                           (const T*)dptr<T>(t), k, dptr<T>(t2)));
+      hipLaunchKernelGGL((cells_from_nodes_kernel<T>), dim3(grid_for(n * k)), dim3(256), 0, st, n, n_api,
+                         (const int*)dptr<int>(cell2node), (const T*)dptr<T>(t2), k, dptr<T>(xc));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * k)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(xc), k, dptr<T>(x)));
+      SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
+      a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
+      CS_DISPATCH_K(k, spmv_launch<T, KK>(a, EPI_PLAIN, false, st));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * k)), dim3(256), 0, st, n,
+                                           (const T*)dptr<T>(y), k, dptr<T>(xc)));
+      hipLaunchKernelGGL((nodes_from_cells_kernel<T>), dim3(grid_for(n_api * k)), dim3(256), 0, st, n, n_api,
+                         (const int*)dptr<int>(node2cell), (const T*)dptr<T>(xc), k, dptr<T>(t2));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n_api * k)), dim3(256), 0, st, n_api,
+                                           (const T*)dptr<T>(t2), k, dptr<T>(t)));
+      check_launch("spmv_host (cell space)");
+      CS_HIP(hipMemcpyAsync(yh, t.p, t.bytes, hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      return;
+    }
     CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
     SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(x), dptr<T>(y));
     a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
@@ -1209,6 +1360,33 @@ struct Solver : ISolver {
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     const Level<TP>& L = H.levels[lvl];
+    if (cellspace && lvl == 0 && which == 0) {
+      // the matrix of the real graph in the reference's node numbering: the NODATA rows dropped, columns renumbered
+      // (test / measurement hook: compacted on the host)
+      const Csr<T>& A = cg_matrix();
+      if (nrows) *nrows = n_api;
+      if (ncols) *ncols = n_api;
+      if (nnz_out) *nnz_out = nnz_api;
+      if (!rowptr && !colidx && !vals) return;
+      std::vector<int> rp((size_t)n + 1), ci((size_t)nnz), c2n((size_t)n);
+      std::vector<T> va((size_t)nnz);
+      CS_HIP(hipMemcpy(rp.data(), A.rp(), rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+      CS_HIP(hipMemcpy(ci.data(), A.ci(), ci.size() * sizeof(int), hipMemcpyDeviceToHost));
+      CS_HIP(hipMemcpy(va.data(), A.va(), va.size() * sizeof(T), hipMemcpyDeviceToHost));
+      CS_HIP(hipMemcpy(c2n.data(), cell2node.p, c2n.size() * sizeof(int), hipMemcpyDeviceToHost));
+      int64_t o = 0;
+      for (int64_t cell = 0; cell < n; ++cell) {
+        const int nd = c2n[(size_t)cell] - 1;
+        if (nd < 0) continue;
+        if (rowptr) rowptr[nd] = (int32_t)o;
+        for (int k = rp[(size_t)cell]; k < rp[(size_t)cell + 1]; ++k, ++o) {
+          if (colidx) colidx[o] = c2n[(size_t)ci[(size_t)k]] - 1;
+          if (vals) ((T*)vals)[o] = va[(size_t)k];
+        }
+      }
+      if (rowptr) rowptr[n_api] = (int32_t)o;
+      return;
+    }
     if (L.lattice_two_product() && ((which == 5 && L.M.nnz == 0) || (which == 4 && L.QT.nnz == 0))) {
       // lattice level: the CSR forms of Q^T / [S Q] are not kept; build them (independent CSR builders) for inspection
       if (which == 5) build_sq_matrix(const_cast<Level<TP>&>(L), st);

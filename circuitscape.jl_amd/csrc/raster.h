@@ -31,16 +31,29 @@ __global__ __launch_bounds__(256) void raster_valid_kernel(int R, int C, const T
 
 // node[id] = exclusive scan of the valid flags (the node index of a valid cell). counts[node] = stored entries of
 // the node's Laplacian row (itself + its valid neighbours); nodemap (row-major, 1-based, 0 = no node) for the host.
+// cellspace != 0 ("cell space", see csgpu.hip): the matrix keeps one row per CELL of the raster (row id = j*R + i); a
+// NODATA cell gets a row holding its diagonal entry only (an isolated unknown whose right-hand side is always zero), so
+// the matrix of a raster with holes is still a lattice. cellmap (may be null): row-major, 1-based ROW id of every cell
+// with a node, 0 elsewhere (= nodemap when cellspace == 0).
 template <class T>
 __global__ __launch_bounds__(256) void raster_count_kernel(int R, int C, int four, const T* __restrict__ cond,
                                                            const int* __restrict__ node, int* __restrict__ counts,
-                                                           int* __restrict__ nodemap) {
+                                                           int* __restrict__ nodemap, int cellspace = 0,
+                                                           int* __restrict__ cellmap = nullptr,
+                                                           int* __restrict__ node2cell = nullptr,
+                                                           int* __restrict__ cell2node = nullptr) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
     const int i = (int)(id % R), j = (int)(id / R);
     const bool valid = cond[(size_t)i * C + j] > T(0);
     nodemap[(size_t)i * C + j] = valid ? node[id] + 1 : 0;
-    if (!valid) continue;
+    if (cellmap) cellmap[(size_t)i * C + j] = valid ? (int)id + 1 : 0;
+    if (node2cell && valid) node2cell[node[id]] = (int)id;
+    if (cell2node) cell2node[id] = valid ? node[id] + 1 : 0;  // (column-major cell id -> 1-based node id, 0 = no node)
+    if (!valid) {
+      if (cellspace) counts[id] = 1;
+      continue;
+    }
     int cnt = 1;
     for (int dj = -1; dj <= 1; ++dj) {
       const int jj = j + dj;
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(256) void raster_count_kernel(int R, int C, int fou
         cnt += cond[(size_t)ii * C + jj] > T(0) ? 1 : 0;
       }
     }
-    counts[node[id]] = cnt;
+    counts[cellspace ? (int)id : node[id]] = cnt;
   }
 }
 
@@ -64,13 +77,22 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
                                                           const int* __restrict__ rp, int* __restrict__ ci,
                                                           T* __restrict__ va, int* __restrict__ nrow,
                                                           int* __restrict__ ncol, const T* __restrict__ ground,
-                                                          T* __restrict__ ground_node) {
+                                                          T* __restrict__ ground_node, int cellspace = 0) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
     const int i = (int)(id % R), j = (int)(id / R);
     const double g0 = (double)cond[(size_t)i * C + j];
-    if (!(g0 > 0.0)) continue;
-    const int me = node[id];
+    if (!(g0 > 0.0)) {
+      if (cellspace) {  // NODATA cell: a row of its own holding the diagonal only (value set by raster_identity_kernel)
+        ci[rp[id]] = (int)id;
+        va[rp[id]] = T(0);
+        nrow[id] = i;
+        ncol[id] = j;
+        if (ground_node) ground_node[id] = T(0);
+      }
+      continue;
+    }
+    const int me = cellspace ? (int)id : node[id];
     nrow[me] = i;
     ncol[me] = j;
     int k = rp[me];
@@ -91,7 +113,7 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(int R, int C, int four
         } else {
           const double g1 = (double)cond[(size_t)ii * C + jj];
           if (!(g1 > 0.0)) continue;
-          ci[k] = node[(int64_t)jj * R + ii];
+          ci[k] = cellspace ? (int)((int64_t)jj * R + ii) : node[(int64_t)jj * R + ii];
           const double w = raster_edge(g0, g1, diag, avg_res != 0);
           va[k] = (T)(-w);
           deg += w;
@@ -282,6 +304,64 @@ __global__ __launch_bounds__(256) void add_scalar_kernel(int64_t nnz, T* __restr
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256) va[k] += shift;
 }
 
+// cell space: diagonal of the NODATA rows = 1 (after the regularisation shift, which must see 0 there: the reference's
+// norm runs over the entries of the real graph only); size0[cell] = 1 for a cell with a node, 0 otherwise -- the
+// weight of the cell in the aggregates (amg_setup.h: a NODATA cell carries no part of the near-null-space candidate)
+template <class T>
+__global__ __launch_bounds__(256) void raster_identity_kernel(int R, int C, const T* __restrict__ cond,
+                                                              const int* __restrict__ rp, T* __restrict__ va,
+                                                              long long* __restrict__ size0) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
+    const bool valid = cond[(size_t)i * C + j] > T(0);
+    size0[id] = valid ? 1 : 0;
+    if (!valid) va[rp[id]] = T(1);
+  }
+}
+
+// cell space <-> node numbering of the reference, column-major n x ncols arrays
+template <class T>
+__global__ __launch_bounds__(256) void cells_from_nodes_kernel(int64_t ncell, int64_t nnode, const int* __restrict__ cell2node,
+                                                               const T* __restrict__ in, int ncols, T* __restrict__ out) {
+  const int64_t total = ncell * ncols;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t c = t / ncell, cell = t % ncell;
+    const int nd = cell2node[cell] - 1;
+    out[t] = nd >= 0 ? in[c * nnode + nd] : T(0);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void nodes_from_cells_kernel(int64_t ncell, int64_t nnode, const int* __restrict__ node2cell,
+                                                               const T* __restrict__ in, int ncols, T* __restrict__ out) {
+  const int64_t total = nnode * ncols;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t c = t / nnode, nd = t % nnode;
+    out[t] = in[c * ncell + node2cell[nd]];
+  }
+}
+// out[k] = map[ids[k]] (64-bit ids in, 64-bit out)
+__global__ __launch_bounds__(256) void map_ids_kernel(int64_t cnt, const int64_t* __restrict__ ids,
+                                                      const int* __restrict__ map, int64_t* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * 256) out[k] = map[ids[k]];
+}
+// out[k] = v[idx[k]]
+__global__ __launch_bounds__(256) void gather_int_kernel(int64_t cnt, const int64_t* __restrict__ idx,
+                                                         const int* __restrict__ v, int* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * 256) out[k] = v[idx[k]];
+}
+// components of a cell-space graph in the reference's terms: keep[label] = 1 for the labels that own a real node
+__global__ __launch_bounds__(256) void comp_keep_kernel(int64_t nnode, const int* __restrict__ node2cell,
+                                                        const int* __restrict__ label, int* __restrict__ keep) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnode; k += (int64_t)gridDim.x * 256)
+    keep[label[node2cell[k]]] = 1;
+}
+__global__ __launch_bounds__(256) void comp_compact_kernel(int64_t nnode, const int* __restrict__ node2cell,
+                                                           const int* __restrict__ label, const int* __restrict__ dense,
+                                                           int* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnode; k += (int64_t)gridDim.x * 256)
+    out[k] = dense[label[node2cell[k]]];
+}
 
 // =====================================================================================================================
 // Rasters WITH short-circuit polygons (construct_node_map with a polymap, src/raster/pairwise.jl:276-301): every cell
