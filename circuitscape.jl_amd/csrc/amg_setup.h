@@ -88,8 +88,13 @@ static const unsigned long long kKeyOut = 0ull;
 
 // Undecided nodes carry their priority: [class:8][hash:24][node id:32]; class 2 = raster 3x3 tile centre.
 __global__ __launch_bounds__(256) void mis_init_kernel(int n, unsigned long long* __restrict__ key,
-                                                       const int* __restrict__ nrow, const int* __restrict__ ncol) {
+                                                       const int* __restrict__ nrow, const int* __restrict__ ncol,
+                                                       const long long* __restrict__ size_f) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (size_f && size_f[i] == 0) {  // a weightless row (empty tile of a cell-space raster) seeds no aggregate
+      key[i] = kKeyOut;
+      continue;
+    }
     unsigned long long cls = 1;
     if (nrow && (nrow[i] % 3 == 1) && (ncol[i] % 3 == 1)) cls = 2;
     key[i] = (cls << 56) | ((unsigned long long)(hash32((unsigned)i) & 0xffffffu) << 32) | (unsigned)i;
@@ -172,10 +177,15 @@ __global__ __launch_bounds__(256) void agg_pass2_kernel(int n, const int* __rest
                                                         double theta2, const int* __restrict__ agg1,
                                                         int* __restrict__ agg, int* __restrict__ orphan_flag,
                                                         const int* __restrict__ nrow, const int* __restrict__ ncol,
-                                                        int gridR, int gridC) {
+                                                        int gridR, int gridC, const long long* __restrict__ size_f) {
   const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     int a = agg1[i];
+    if (a < 0 && size_f && size_f[i] == 0) {  // weightless and uncoupled: belongs nowhere (column 0 with weight 0)
+      agg[i] = 0;
+      orphan_flag[i] = 0;
+      continue;
+    }
     if (a < 0) {
       double best = -1.0;
       bool same_tile = false;
@@ -954,27 +964,158 @@ __global__ __launch_bounds__(256) void tile_aggregate_kernel(int n, const int* _
   }
 }
 
+// ---- regular tiles on a cell-space raster (rows of NODATA cells carry weight 0) -------------------------------------
+// A 3x3 tile may hold cells that are NOT connected inside the tile (two banks of a NODATA line, the rims of two windows
+// of a stacked raster, ...). One aggregate over disconnected pieces gives a coarse basis function that cannot tell the
+// pieces apart -- and couples connected components the graph does not couple. So per tile (one thread, <= 4 x 4 cells):
+//   pass 1: label the pieces the tile's cells form under the couplings stored in A; the largest piece (ties: the one
+//           holding the smallest cell id) is the tile's MAIN piece and keeps the tile's aggregate;
+//   pass 2: every other piece joins, as a whole, the aggregate of a neighbouring tile it is coupled to through a cell of
+//           that tile's main piece (first such coupling in cell / CSR order); a piece without such a coupling weighs 0
+//           (it is interpolated from its neighbours by the prolongator smoothing, like the F-points of classical AMG).
+// An aggregate thus reaches at most one cell into the next tile, which keeps every entry of Q = P - w D^-1 A P inside
+// the 3 x 3 block of tiles around a row's own tile: the index-free form (lattice.h) survives.
+__device__ __forceinline__ void tile_extent(int t, int nt, int len, int& lo, int& hi) {
+  lo = 3 * t;
+  hi = t == nt - 1 ? len : 3 * t + 3;
+}
+
+template <class T, int PASS>
+__global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, int Cc, const int* __restrict__ rp,
+                                                          const int* __restrict__ ci, const T* __restrict__ va,
+                                                          long long* __restrict__ size_f, signed char* __restrict__ piece,
+                                                          signed char* __restrict__ mainlab, int* __restrict__ agg) {
+  const int ntiles = Rc * Cc;
+  for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
+    const int I = tile % Rc, J = tile / Rc;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const int h = r1 - r0, w = c1 - c0;  // <= 4 each
+    if (PASS == 1) {
+      int lab[16];
+      int nvalid = 0;
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) {
+          const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+          const bool valid = size_f[cell] != 0;
+          lab[kc * h + kr] = valid ? kc * h + kr : -1;
+          nvalid += valid ? 1 : 0;
+        }
+      if (nvalid > 0 && nvalid < h * w) {  // (a full tile is connected: adjacent valid cells are always coupled)
+        for (int sweep = 0; sweep < 16; ++sweep) {
+          bool changed = false;
+          for (int kc = 0; kc < w; ++kc)
+            for (int kr = 0; kr < h; ++kr) {
+              int& me = lab[kc * h + kr];
+              if (me < 0) continue;
+              const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+              for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
+                const int nb = ci[e];
+                if (nb == cell || va[e] == T(0)) continue;
+                const int ni = nb % R - r0, nj = nb / R - c0;
+                if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+                const int l2 = lab[nj * h + ni];
+                if (l2 >= 0 && l2 < me) {
+                  me = l2;
+                  changed = true;
+                }
+              }
+            }
+          if (!changed) break;
+        }
+      } else if (nvalid == h * w) {
+        for (int k = 0; k < h * w; ++k) lab[k] = 0;
+      }
+      // main piece: most cells, ties to the smaller label
+      int best = -1, bestcnt = 0;
+      for (int q = 0; q < h * w; ++q) {
+        int cnt = 0;
+        for (int k = 0; k < h * w; ++k) cnt += lab[k] == q ? 1 : 0;
+        if (cnt > bestcnt) {
+          bestcnt = cnt;
+          best = q;
+        }
+      }
+      mainlab[tile] = (signed char)best;
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) piece[(int64_t)(c0 + kc) * R + r0 + kr] = (signed char)lab[kc * h + kr];
+    } else {
+      const int mainq = mainlab[tile];
+      for (int q = 0; q < h * w; ++q) {
+        if (q == mainq) continue;
+        bool any = false;
+        int target = -1;
+        for (int kc = 0; kc < w && target < 0; ++kc)
+          for (int kr = 0; kr < h && target < 0; ++kr) {
+            const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+            if (piece[cell] != q) continue;
+            any = true;
+            for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
+              const int nb = ci[e];
+              if (nb == cell || va[e] == T(0)) continue;
+              const int ni = nb % R, nj = nb / R;
+              if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
+              const int tI = min(ni / 3, Rc - 1), tJ = min(nj / 3, Cc - 1);
+              const int nt = tJ * Rc + tI;
+              if (piece[nb] >= 0 && piece[nb] == mainlab[nt]) {
+                target = nt;
+                break;
+              }
+            }
+          }
+        if (!any) continue;
+        for (int kc = 0; kc < w; ++kc)
+          for (int kr = 0; kr < h; ++kr) {
+            const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+            if (piece[cell] != q) continue;
+            if (target >= 0) agg[cell] = target;
+            else size_f[cell] = 0;
+          }
+      }
+    }
+  }
+}
+
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
+// size_f (may be null): weight of every row (cell-space rasters: 0 for the rows of NODATA cells / empty tiles). With
+// weights the regular tiles are used on the raster's own level only (`cell_level`: rows are the cells in column-major
+// order), refined by the piece analysis above (which may zero further weights); deeper levels take the MIS(2) path,
+// where weightless rows seed and join nothing.
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
-                     DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0) {
+                     DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0, long long* size_f = nullptr,
+                     bool cell_level = false) {
   const int n = A.nrows;
   const double theta2 = theta * theta;
   static const bool no_direct_tiles = getenv("CSGPU_NO_DIRECT_TILES") != nullptr;  // A/B knob
-  if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n) {
+  if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n &&
+      (!size_f || cell_level)) {
     const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
     agg.alloc((size_t)n * sizeof(int));
     crow.alloc((size_t)Rc * Cc * sizeof(int));
     ccol.alloc((size_t)Rc * Cc * sizeof(int));
     hipLaunchKernelGGL(tile_aggregate_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, nrow, ncol, Rc, Cc, dptr<int>(agg),
                        dptr<int>(crow), dptr<int>(ccol));
+    static const bool no_pieces = getenv("CSGPU_NO_TILE_PIECES") != nullptr;  // A/B knob
+    if (size_f && !no_pieces) {
+      DBuf piece((size_t)n), mainlab((size_t)Rc * Cc);
+      const int gt = grid_for((int64_t)Rc * Cc);
+      hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+      hipLaunchKernelGGL((tile_pieces_kernel<T, 2>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+      check_launch("tile pieces");
+      CS_HIP(hipStreamSynchronize(st));  // piece / mainlab are released on return
+    }
     check_launch("tile aggregation");
     return Rc * Cc;
   }
   DBuf key = dalloc<unsigned long long>(n), k1 = dalloc<unsigned long long>(n), k2 = dalloc<unsigned long long>(n);
   DBuf counter = dalloc<int>(1);
   const int g = grid_for(n);
-  hipLaunchKernelGGL(mis_init_kernel, dim3(g), dim3(256), 0, st, n, dptr<unsigned long long>(key), nrow, ncol);
+  hipLaunchKernelGGL(mis_init_kernel, dim3(g), dim3(256), 0, st, n, dptr<unsigned long long>(key), nrow, ncol,
+                     (const long long*)size_f);
   for (int round = 0; round < 1000; ++round) {
     CS_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), st));
     hipLaunchKernelGGL((mis_prop_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
@@ -1000,7 +1141,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
   hipLaunchKernelGGL((agg_pass1_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
                      dptr<unsigned long long>(key), dptr<int>(root_id), dptr<int>(agg1));
   hipLaunchKernelGGL((agg_pass2_kernel<T>), dim3(g), dim3(256), 0, st, n, A.rp(), A.ci(), A.va(), diag, theta2,
-                     dptr<int>(agg1), dptr<int>(agg), dptr<int>(orphan), nrow, ncol, gridR, gridC);
+                     dptr<int>(agg1), dptr<int>(agg), dptr<int>(orphan), nrow, ncol, gridR, gridC, (const long long*)size_f);
   // nodes that could not be attached (cannot happen for a symmetric strength graph; kept as a safety net)
   DBuf orphan_flag = dalloc<int>((size_t)n + 1);
   CS_HIP(hipMemcpyAsync(orphan_flag.p, orphan.p, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -1089,10 +1230,12 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       }
     }
     DBuf agg, crow, ccol;
-    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC);
+    long long* wts = (sp.size0 && size_prev.p) ? dptr<long long>(size_prev) : (long long*)nullptr;
+    const bool cell_level = sp.size0 && H.levels.size() == 1;
+    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level);
     if (sp.theta > 0.0 && (double)nagg > 0.5 * (double)n) {
       // the strength filter left too few strong couplings to coarsen this level: aggregate on the full pattern
-      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC);
+      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level);
     }
     // coarse raster extent (tile counts), valid while the aggregates are the regular tiles
     gridR = gridR > 0 ? (gridR + 1) / 3 : 0;

@@ -23,7 +23,7 @@ __device__ __forceinline__ int lat_tile(int i, int nc) {  // tile index of fine 
   return t < nc ? t : nc - 1;
 }
 
-// agg[node] must be the regular tile numbering; every Q entry must lie in the 3x3 tile block of its row
+// agg[node] must be the row's own tile or one next to it; every Q entry must lie in the 3x3 tile block of its row
 template <class T>
 __global__ __launch_bounds__(256) void lattice_q_fill_kernel(int64_t n, int R, int Rc, int Cc, const int* __restrict__ agg,
                                                              const int* __restrict__ qrp, const int* __restrict__ qci,
@@ -32,9 +32,13 @@ __global__ __launch_bounds__(256) void lattice_q_fill_kernel(int64_t n, int R, i
   for (int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x; node < n; node += (int64_t)gridDim.x * 256) {
     const int i = (int)(node % R), j = (int)(node / R);
     const int I = lat_tile(i, Rc), J = lat_tile(j, Cc);
-    if (agg[node] != J * Rc + I) {
-      atomicOr(bad, 1);
-      continue;
+    {  // the row's aggregate: its own tile, or (cell-space rasters, amg_setup.h tile_pieces_kernel) a neighbouring one
+      const int a = agg[node];
+      const int dI = a % Rc - I, dJ = a / Rc - J;
+      if (dI < -1 || dI > 1 || dJ < -1 || dJ > 1) {
+        atomicOr(bad, 1);
+        continue;
+      }
     }
     T row[9];
 #pragma unroll

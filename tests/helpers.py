@@ -302,11 +302,19 @@ def check_lattice_product(L, shapes=((70, 40), (64, 64), (130, 9), (33, 100)), k
         h = L.setup(A, L.default_opts(batch=8, precond_bytes=4))
         one(h, R, C, 8, 4)
         h.close()
-    # not a lattice: NODATA holes, and an explicit opt-out
+    # NODATA holes: cell space keeps the lattice (round 3; the caller still sees the reference's node count); a host-built
+    # matrix of the same raster is not a lattice; and an explicit opt-out
     g = np.exp(rng.standard_normal((40, 40)))
     g[5, 7] = 0.0
     h = L.raster_setup(g, L.default_opts(batch=8))
-    assert h.info["lattice_period"] == 0
+    assert h.info["lattice_period"] == 40 and h.info["n"] == 1599 and h.info["level_n"][0] == 1600
+    Ac = h.level_matrix(0, "A")          # the real graph's matrix in the reference's numbering (NODATA row dropped)
+    h.close()
+    nm = rg.construct_node_map(g, None)
+    Aref = rs.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+    assert Ac.shape == (1599, 1599) and abs(Ac - Aref).max() < 1e-14
+    h = L.setup(Ac, L.default_opts(batch=8))
+    assert h.info["lattice_period"] == 0 and h.info["n"] == 1599
     h.close()
     g[5, 7] = 1.0
     h = L.raster_setup(g, L.default_opts(batch=8, stencil=-1))
@@ -761,3 +769,96 @@ def check_focal_regions_synthetic(L, oracle, shape=(40, 33), nregions=5, seed=3)
             v = spl.spsolve(Ak, rhs)
             R = v[np.flatnonzero(keep == c1)[0]]
             assert abs(got[a + 1, b + 1] - R) <= 1e-6 * R, (pts[a], pts[b], got[a + 1, b + 1], R)
+
+
+def _nodata_raster(shape, seed, frac=0.15, wall=True):
+    """log-normal raster with `frac` random NODATA cells and (wall) a one-cell NODATA line with a two-cell gap: 3x3
+    tiles straddling the line hold cells of both banks (amg_setup.h, tile_pieces_kernel)"""
+    rng = np.random.default_rng(seed)
+    g = np.exp(rng.standard_normal(shape))
+    g[rng.random(shape) < frac] = 0.0
+    if wall:
+        j = shape[1] // 2 + 1
+        g[:, j] = 0.0
+        g[shape[0] // 3:shape[0] // 3 + 2, j] = 1.0
+    return g
+
+
+def check_cellspace(L, oracle, shape=(70, 61), batch=4, monkeypatch=None):
+    """Rasters with NODATA cells on the full lattice ("cell space", csgpu.hip; construct_node_map drops cells with
+    conductance <= 0, src/raster/pairwise.jl:271-301). The handle must be indistinguishable from the compact-numbering
+    handle of round 2 (CSGPU_NO_CELLSPACE=1) at the C ABI -- node count, node map, components, the matrix itself, pair
+    resistances, focal voltages, voltage / current / cumulative maps, general and grounded right-hand sides, products --
+    while running the lattice kernels; resistances also against the tight oracle on the reference's own graph; the
+    iteration count must stay within 1.3x of the compact hierarchy's (MIS(2) aggregates on the real graph)."""
+    import os
+    for four in (False, True):
+        g = _nodata_raster(shape, 7 + four)
+        nm_ref = rg.construct_node_map(g, None)
+        Aref = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm_ref, False, four)))
+        n = int(nm_ref.max())
+        out = {}
+        for mode in ("cell", "compact"):
+            if mode == "compact":
+                monkeypatch.setenv("CSGPU_NO_CELLSPACE", "1")
+            else:
+                monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+            for pb in (0, 4):
+                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), four_neighbors=four) as h:
+                    info = h.info
+                    # (a valid cell without a valid neighbour keeps its -- zero -- diagonal entry in the device-built matrix)
+                    assert info["n"] == n and info["nnz"] == Aref.nnz + int(np.sum(np.diff(Aref.indptr) == 0))
+                    assert (info["lattice_period"] == shape[0]) == (mode == "cell")
+                    assert info["level_n"][0] == (shape[0] * shape[1] if mode == "cell" else n)
+                    assert np.array_equal(h.raster_nodemap(), nm_ref)
+                    labels, nc = h.components()
+                    A = h.level_matrix(0, "A")
+                    assert A.shape == Aref.shape and abs(A - Aref).max() < 1e-12   # (the shift eps * norm(nzval) itself is ~1e-13)
+                    big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                    ids = np.random.default_rng(5).choice(big, size=2 * batch + 2, replace=False)
+                    src = [int(v) for v in ids[:batch + 1]]
+                    dst = [int(v) for v in ids[batch + 1:]]
+                    R, gath, volt, st = h.solve_pairs(src, dst, gather=ids[:5], want_voltages=True)
+                    R2, _, _, st2 = h.solve_pairs(src, dst)                      # focal path (resistances only)
+                    cum = np.zeros(n)
+                    mx = np.zeros(n)
+                    Rc, _, cur, _ = h.solve_pairs_currents(src[:3], dst[:3], cum=cum, mx=mx)
+                    rng = np.random.default_rng(9)
+                    B = rng.standard_normal((n, 3))
+                    B -= B.mean(axis=0)                      # consistent with the (regularised, near-singular) system
+                    for c in range(nc):                      # ... on every component
+                        m = labels == c
+                        B[m] -= B[m].mean(axis=0)
+                    X, st3 = h.solve_rhs(B)
+                    Xg, Cg, st4 = h.solve_grounded(B[:, :2], [[src[0], dst[0]], [src[1]]], want_currents=True)
+                    y = h.spmv(B[:, 0].copy())
+                    assert st["not_converged"] == st2["not_converged"] == st3["not_converged"] == st4["not_converged"] == 0
+                    out[(mode, pb)] = dict(labels=labels, nc=nc, R=R, R2=R2, gath=gath, volt=volt, cur=cur, cum=cum, mx=mx,
+                                           X=X, Xg=Xg, Cg=Cg, y=y, iters=st2["total_iters"], B=B, src=src, dst=dst)
+        monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+        Ro, _, _ = oracle.OracleAMG(Aref).solve_pairs(out[("cell", 0)]["src"], out[("cell", 0)]["dst"], rtol=1e-12, atol=0.0,
+                                                     criterion=1)
+        for pb in (0, 4):
+            a, b = out[("cell", pb)], out[("compact", pb)]
+            assert a["nc"] == b["nc"] and np.array_equal(a["labels"], b["labels"])
+            assert np.max(np.abs(a["R"] - Ro) / Ro) < 1e-6 and np.max(np.abs(a["R2"] - Ro) / Ro) < 1e-6
+            assert np.max(np.abs(a["R"] - b["R"]) / b["R"]) < 1e-6
+            # voltages v - v[src] inside the pairs' component (elsewhere they are minus the arbitrary additive constant of
+            # the singular system -- the reference extracts the component's submatrix and never sees those nodes)
+            inside = a["labels"] == a["labels"][a["src"][0]]
+            vs = np.max(np.abs(b["volt"][inside]))
+            assert np.max(np.abs(a["volt"][inside] - b["volt"][inside])) < 2e-5 * vs
+            assert np.max(np.abs(a["gath"] - b["gath"])) < 2e-5 * vs
+            for key, tol in (("cur", 5e-5), ("cum", 5e-5), ("mx", 5e-5), ("Cg", 1e-4)):
+                assert np.max(np.abs(a[key] - b[key])) < tol * max(1.0, np.max(np.abs(b[key]))), key
+            assert np.allclose(a["y"], Aref @ a["B"][:, 0], rtol=1e-12, atol=1e-12)
+            for key in ("X", "Xg"):
+                # solutions of the near-singular system are compared through what the reference checks: the residual
+                Bk = a["B"] if key == "X" else a["B"][:, :2]
+                ra = Aref @ a[key] - Bk
+                if key == "Xg":
+                    ra[[a["src"][0], a["dst"][0]], 0] = 0
+                    ra[a["src"][1], 1] = 0
+                    assert a[key][a["src"][0], 0] == 0 and a[key][a["src"][1], 1] == 0
+                assert np.max(np.linalg.norm(ra, axis=0) / np.linalg.norm(Bk, axis=0)) < 1e-4
+            assert a["iters"] <= 1.3 * b["iters"] + batch, (a["iters"], b["iters"])

@@ -1037,7 +1037,8 @@ def test_focal_regions_synthetic_against_merged_graphs(emu_lib, oracle):
 @pytest.mark.parametrize("holes", [False, True])
 def test_region_pairs_of_single_nodes_are_plain_pair_resistances(emu_lib, holes):
     """csgpu_solve_region_pairs with one node per set must reproduce csgpu_solve_pairs (R(I, J) = 1 / v'Av is the
-    effective resistance); on a lattice handle and on a CSR handle, fp32 and fp64 hierarchy, plus the argument checks."""
+    effective resistance); on an all-valid raster and on one with NODATA holes (cell space), fp32 and fp64 hierarchy, plus
+    the argument checks."""
     rng = np.random.default_rng(9)
     g = np.exp(rng.standard_normal((48, 41)))
     if holes:
@@ -1045,7 +1046,7 @@ def test_region_pairs_of_single_nodes_are_plain_pair_resistances(emu_lib, holes)
     for pb in (0, 4):
         with emu_lib.raster_setup(g, emu_lib.default_opts(batch=4, precond_bytes=pb)) as h:
             n = h.info["n"]
-            assert (h.info["lattice_period"] > 0) == (not holes)
+            assert h.info["lattice_period"] == 48          # (holes: cell space keeps the lattice kernels)
             labels, _ = h.components()
             big = np.flatnonzero(labels == np.bincount(labels).argmax())
             ids = rng.choice(big, size=10, replace=False)
@@ -1093,3 +1094,9 @@ def test_region_pairs_graph_replay_survives_growing_and_repeating_set_lists(emu_
         assert abs(Ro[0] - Rd[0]) < 1e-9 * Rd[0] and abs(Ro[2] - Rd[1]) < 1e-9 * Rd[1]
         with pytest.raises(emu_lib.CsgpuError):
             h.solve_region_pairs([[ids[0]], []], [0], [1])
+
+
+def test_cellspace_raster_is_indistinguishable_at_the_boundary(emu_lib, oracle, monkeypatch):
+    """lattice kernels for rasters with NODATA (see helpers.check_cellspace)"""
+    from helpers import check_cellspace
+    check_cellspace(emu_lib, oracle, shape=(46, 43), batch=4, monkeypatch=monkeypatch)

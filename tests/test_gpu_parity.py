@@ -412,3 +412,53 @@ def test_bench_strong_scaling_code_path_on_one_gpu(gpu_lib):
     d = json.loads(res.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["all_pairs_gathered"] and d["max_relres"] < 1e-4
     assert d["value"] > 0 and d["config"]["n"] == 1000 * 1000
+
+
+def test_cellspace_raster_is_indistinguishable_at_the_boundary_gpu(gpu_lib, oracle, monkeypatch):
+    """Rasters with NODATA on the full lattice (cell space): see helpers.check_cellspace"""
+    from helpers import check_cellspace
+    check_cellspace(gpu_lib, oracle, shape=(310, 287), batch=8, monkeypatch=monkeypatch)
+
+
+def test_nodata_raster_2000_lattice_kernels_vs_tight_oracle(gpu_lib, oracle, monkeypatch):
+    """a 2000 x 2000 raster with 15 % NODATA cells (construct_node_map drops them,
+    src/raster/pairwise.jl:271-301) runs the marching kernels (lattice_period > 0), resistances within 1e-6 of the tight
+    oracle on the reference's own graph (compact numbering), iteration count within 1.3x of the all-valid raster of the
+    same generator and no worse than the compact-numbering hierarchy of round 2."""
+    from oracle import refgraph as rg
+    N = 2000
+    rng = np.random.default_rng(11)
+    base = np.exp(rng.standard_normal((N, N)))
+    g = np.where(rng.random((N, N)) < 0.15, 0.0, base)
+    nm = rg.construct_node_map(g, None)
+    A = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+    res = {}
+    for mode in ("cell", "compact", "all-valid"):
+        if mode == "compact":
+            monkeypatch.setenv("CSGPU_NO_CELLSPACE", "1")
+        else:
+            monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+        for pb in (0, 4):
+            with gpu_lib.raster_setup(base if mode == "all-valid" else g, gpu_lib.default_opts(batch=16, precond_bytes=pb)) as h:
+                info = h.info
+                assert (info["lattice_period"] == N) == (mode != "compact")
+                if mode == "all-valid":
+                    ids = np.random.default_rng(5).choice(N * N, size=32, replace=False)
+                else:
+                    assert info["n"] == A.shape[0]
+                    labels, _ = h.components()
+                    big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                    ids = np.random.default_rng(5).choice(big, size=32, replace=False)
+                src, dst = [int(v) for v in ids[:16]], [int(v) for v in ids[16:]]
+                R, _, _, st = h.solve_pairs(src, dst)
+                assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+                res[(mode, pb)] = (R, st["total_iters"] / 16.0, src, dst)
+    monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+    src, dst = res[("cell", 0)][2], res[("cell", 0)][3]
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src[:8], dst[:8], rtol=1e-12, atol=0.0, criterion=1, nthreads=8)
+    for pb in (0, 4):
+        Rc, itc = res[("cell", pb)][:2]
+        assert np.max(np.abs(Rc[:8] - Ro) / Ro) < 1e-6
+        assert np.max(np.abs(Rc - res[("compact", pb)][0]) / Rc) < 1e-6
+        assert itc <= 1.3 * res[("all-valid", pb)][1] + 0.5, (itc, res[("all-valid", pb)][1])
+        assert itc <= res[("compact", pb)][1] + 0.5, (itc, res[("compact", pb)][1])
