@@ -970,11 +970,13 @@ __global__ __launch_bounds__(256) void tile_aggregate_kernel(int n, const int* _
 // pieces apart -- and couples connected components the graph does not couple. So per tile (one thread, <= 4 x 4 cells):
 //   pass 1: label the pieces the tile's cells form under the couplings stored in A; the largest piece (ties: the one
 //           holding the smallest cell id) is the tile's MAIN piece and keeps the tile's aggregate;
-//   pass 2: every other piece joins, as a whole, the aggregate of a neighbouring tile it is coupled to through a cell of
-//           that tile's main piece (first such coupling in cell / CSR order); a piece without such a coupling weighs 0
-//           (it is interpolated from its neighbours by the prolongator smoothing, like the F-points of classical AMG).
-// An aggregate thus reaches at most one cell into the next tile, which keeps every entry of Q = P - w D^-1 A P inside
-// the 3 x 3 block of tiles around a row's own tile: the index-free form (lattice.h) survives.
+//   pass 2: every cell of another piece joins the aggregate of the neighbouring tile whose main piece it is most strongly
+//           coupled to DIRECTLY; a cell without such a coupling weighs 0 (it is interpolated from its neighbours by the
+//           prolongator smoothing, like the F-points of classical AMG).
+// An aggregate thus reaches exactly one cell into the next tile: a row of Q = P - w D^-1 A P sees the aggregates of the
+// cells within distance 2, each of which holds a cell within distance 3 of the row's cell -- inside the 3 x 3 block of
+// tiles around the row's own tile, so the index-free form (lattice.h) survives. (Moving a piece as a whole does not:
+// its far end can be three cells from the tile it joins.)
 __device__ __forceinline__ void tile_extent(int t, int nt, int len, int& lo, int& hi) {
   lo = 3 * t;
   hi = t == nt - 1 ? len : 3 * t + 3;
@@ -1041,38 +1043,31 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
       for (int kc = 0; kc < w; ++kc)
         for (int kr = 0; kr < h; ++kr) piece[(int64_t)(c0 + kc) * R + r0 + kr] = (signed char)lab[kc * h + kr];
     } else {
+      // every cell outside the tile's main piece joins the tile of the main-piece cell it is most strongly coupled to
+      // (ties: the first in CSR order); without such a coupling it weighs 0
       const int mainq = mainlab[tile];
-      for (int q = 0; q < h * w; ++q) {
-        if (q == mainq) continue;
-        bool any = false;
-        int target = -1;
-        for (int kc = 0; kc < w && target < 0; ++kc)
-          for (int kr = 0; kr < h && target < 0; ++kr) {
-            const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
-            if (piece[cell] != q) continue;
-            any = true;
-            for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
-              const int nb = ci[e];
-              if (nb == cell || va[e] == T(0)) continue;
-              const int ni = nb % R, nj = nb / R;
-              if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
-              const int tI = min(ni / 3, Rc - 1), tJ = min(nj / 3, Cc - 1);
-              const int nt = tJ * Rc + tI;
-              if (piece[nb] >= 0 && piece[nb] == mainlab[nt]) {
-                target = nt;
-                break;
-              }
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) {
+          const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+          if (piece[cell] < 0 || piece[cell] == mainq) continue;
+          int target = -1;
+          double best = 0.0;
+          for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
+            const int nb = ci[e];
+            if (nb == cell || va[e] == T(0)) continue;
+            const int ni = nb % R, nj = nb / R;
+            if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
+            const int nt = min(nj / 3, Cc - 1) * Rc + min(ni / 3, Rc - 1);
+            if (piece[nb] < 0 || piece[nb] != mainlab[nt]) continue;
+            const double a = fabs((double)va[e]);
+            if (a > best) {
+              best = a;
+              target = nt;
             }
           }
-        if (!any) continue;
-        for (int kc = 0; kc < w; ++kc)
-          for (int kr = 0; kr < h; ++kr) {
-            const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
-            if (piece[cell] != q) continue;
-            if (target >= 0) agg[cell] = target;
-            else size_f[cell] = 0;
-          }
-      }
+          if (target >= 0) agg[cell] = target;
+          else size_f[cell] = 0;
+        }
     }
   }
 }
@@ -1185,6 +1180,18 @@ inline void level_stats(Level<T>& L, DBuf& diag, DBuf& labs, double omega_s, hip
   spmv_block_order(L.A, L.orderA, st, &L.periodA);
 }
 
+// State the level loop carries from one level to the next (also the hand-over from lattice_setup.h, which builds level 0
+// of a raster without a CSR matrix and enters the loop at level 1).
+struct SetupCarry {
+  DBuf crow, ccol;   // raster coordinates of the current level's nodes (may be empty)
+  DBuf size;         // long long: fine nodes under every node of the current level (empty: all ones)
+  int gridR = 0, gridC = 0;  // raster extent of the current level while the aggregates are the regular tiles (0: unknown)
+};
+
+template <class T>
+inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* cur_row, const int* cur_col,
+                             SetupCarry& carry, hipStream_t st);
+
 // Build the hierarchy. A0 is moved into level 0. node_row/node_col (device, may be null) are raster coordinates.
 template <class T>
 inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const int* node_row, const int* node_col,
@@ -1196,15 +1203,38 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
   H.levels.clear();
   H.levels.emplace_back();
   H.levels.back().A = std::move(A0);
-  DBuf crow_prev, ccol_prev;  // coarse coordinates of the current level (owned here)
+  SetupCarry carry;
   const int* cur_row = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_row;
   const int* cur_col = (sp.aggregation == CSGPU_AGG_MIS2) ? nullptr : node_col;
-  DBuf size_prev;  // long long fine sizes of the current level (null on level 0 => all ones)
   if (sp.size0) {
-    size_prev.alloc((size_t)H.levels[0].A.nrows * sizeof(long long));
-    CS_HIP(hipMemcpyAsync(size_prev.p, sp.size0, size_prev.bytes, hipMemcpyDeviceToDevice, st));
+    carry.size.alloc((size_t)H.levels[0].A.nrows * sizeof(long long));
+    CS_HIP(hipMemcpyAsync(carry.size.p, sp.size0, carry.size.bytes, hipMemcpyDeviceToDevice, st));
   }
-  int gridR = cur_row ? sp.grid_rows : 0, gridC = cur_row ? sp.grid_cols : 0;  // raster extent of the current level
+  carry.gridR = cur_row ? sp.grid_rows : 0;
+  carry.gridC = cur_row ? sp.grid_cols : 0;
+  amg_setup_levels(H, sp, cur_row, cur_col, carry, st);
+  CS_HIP(hipEventRecord(e1, st));
+  CS_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  H.setup_ms = ms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+}
+
+// The level loop: coarsens H.levels.back() until the coarsest level is reached, then builds the coarse solver.
+// cur_row / cur_col: raster coordinates of the nodes of H.levels.back() (device; null = none; carry.crow / carry.ccol
+// take over from the next level on).
+template <class T>
+inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* cur_row, const int* cur_col,
+                             SetupCarry& carry, hipStream_t st) {
+  DBuf crow_prev = std::move(carry.crow), ccol_prev = std::move(carry.ccol);  // coarse coordinates of the current level
+  if (!cur_row && crow_prev.p && sp.aggregation != CSGPU_AGG_MIS2) {
+    cur_row = dptr<int>(crow_prev);
+    cur_col = dptr<int>(ccol_prev);
+  }
+  DBuf size_prev = std::move(carry.size);  // long long fine sizes of the current level (null => all ones)
+  int gridR = cur_row ? carry.gridR : 0, gridC = cur_row ? carry.gridC : 0;  // raster extent of the current level
   for (;;) {
     Level<T>& L = H.levels.back();
     DBuf diag, labs;
@@ -1369,13 +1399,6 @@ inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const
       CS_HIP(hipStreamSynchronize(st));
     }
   }
-  CS_HIP(hipEventRecord(e1, st));
-  CS_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  CS_HIP(hipEventElapsedTime(&ms, e0, e1));
-  H.setup_ms = ms;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
 }
 
 }  // namespace csgpu

@@ -10,6 +10,7 @@
 #include "pairs.h"
 #include "pcg.h"
 #include "raster.h"
+#include "lattice_setup.h"
 
 namespace csgpu {
 
@@ -55,6 +56,12 @@ __global__ __launch_bounds__(256) void lattice_coords_kernel(int64_t n, int R, i
     row[i] = (int)(i % R);
     col[i] = (int)(i / R);
   }
+}
+
+// weight of every row of a cell-space matrix from the cell -> node map (1 = a real node, 0 = NODATA row)
+__global__ __launch_bounds__(256) void weights_from_map_kernel(int64_t n, const int* __restrict__ cell2node,
+                                                               long long* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) w[i] = cell2node[i] != 0 ? 1 : 0;
 }
 
 // element-wise precision conversion of a CSR matrix (pattern copied)
@@ -112,6 +119,14 @@ struct Solver : ISolver {
   // the transfer operators and every Galerkin operator are those of the real graph. The C ABI keeps speaking the
   // reference's node numbering: ids and n-vectors are translated at the boundary (node2cell / cell2node).
   bool cellspace = false;
+  // Rasters set up through the lattice pipeline (lattice_setup.h) hold NO CSR form of the fine-level matrix: resistance-
+  // only pair solves never touch one. Entry points that do (current maps, explicit residual checks of full solutions,
+  // region pairs, components, the product hooks) build it from the lattice form on first use (ensure_csr).
+  bool csr_ready = true;
+  // Test hooks only: level 0 rebuilt by the CSR pipeline of amg_setup.h (A, P, R, Q, Q^T, [S Q] in CSR) for a handle
+  // whose level 0 came from the lattice pipeline -- csgpu_get_level_matrix / csgpu_level_spmv_host then compare the two
+  // pipelines with each other.
+  std::unique_ptr<Hierarchy<TP>> Href;
   int64_t n_api = 0, nnz_api = 0;     // what the caller sees (reference numbering); == n, nnz unless cellspace
   DBuf node2cell, cell2node;          // cellspace: [n_api] column-major cell id of a node; [n] 1-based node id of a cell, 0 = none
   DBuf cellmap;                       // cellspace: row-major [rows][cols], 1-based ROW id of the cell, 0 = no node
@@ -300,6 +315,22 @@ struct Solver : ISolver {
       return H.levels[0].A;
     }
   }
+  // CSR form of the fine-level matrix, built from the lattice form when the handle was set up without one
+  void ensure_csr() {
+    if (csr_ready) return;
+    CS_REQUIRE(nnz < ((int64_t)1 << 31), CSGPU_BAD_ARGS,
+               "this call needs the CSR form of the matrix, which a raster of this size does not have (2^31 stored "
+               "entries); resistance-only csgpu_solve_pairs works without it");
+    Csr<T> A;
+    dia_to_csr(dia, A, st);
+    CS_HIP(hipStreamSynchronize(st));
+    if constexpr (MIXED) {
+      Aouter = std::move(A);
+    } else {
+      H.levels[0].A = std::move(A);
+    }
+    csr_ready = true;
+  }
 
   // known_period: raster height when the matrix was built here from an all-valid raster, 0 = detect, -1 = no lattice
   void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period, const long long* size0 = nullptr) {
@@ -386,6 +417,96 @@ struct Solver : ISolver {
     return (double)nvalid >= minfrac * (double)ncells;
   }
 
+  // The index-free pipeline needs what the lattice two-product level needs (and its A/B knobs off).
+  bool want_lattice_pipeline(int64_t R, int64_t C) const {
+    if (getenv("CSGPU_NO_DIRECT_LATTICE") || getenv("CSGPU_NO_STENCIL") || getenv("CSGPU_NO_LATTICE_S") ||
+        getenv("CSGPU_NO_LATTICE_Q") || getenv("CSGPU_NO_TWO_PRODUCT") || getenv("CSGPU_NO_DIRECT_TILES"))
+      return false;
+    if (opts.stencil < 0 || !(opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0)) return false;
+    if (opts.aggregation == CSGPU_AGG_MIS2 || opts.theta != 0.0) return false;
+    return R >= 6 && C >= 6 && R * C > opts.max_coarse && opts.max_levels >= 2;
+  }
+
+  // Raster -> lattice form -> hierarchy, no CSR (lattice_setup.h). dcond / dground: device rasters (row-major); node: the
+  // exclusive scan of the valid flags (column-major). Returns false when the pipeline declined (the caller falls back).
+  bool setup_lattice_direct(DBuf& dcond, DBuf& dground, DBuf& node, int64_t R, int64_t C, int four, int avg_res, int reg,
+                            std::chrono::steady_clock::time_point t0) {
+    const int64_t ncells = R * C;
+    const int gc = grid_for(ncells);
+    if (cellspace) {
+      cellmap.alloc((size_t)ncells * sizeof(int));
+      node2cell.alloc((size_t)n_api * sizeof(int));
+      cell2node.alloc((size_t)ncells * sizeof(int));
+    }
+    hipLaunchKernelGGL((raster_maps_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       (const int*)dptr<int>(node), dptr<int>(nodemap), cellspace ? dptr<int>(cellmap) : (int*)nullptr,
+                       cellspace ? dptr<int>(node2cell) : (int*)nullptr, cellspace ? dptr<int>(cell2node) : (int*)nullptr);
+    dia.n = ncells;
+    dia.R = (int)R;
+    dia.rows.alloc((size_t)ncells * 5 * sizeof(T));
+    if (dground.p) ground_node.alloc((size_t)ncells * sizeof(T));
+    DBuf part = dalloc<double>(gc), cnt = dalloc<unsigned long long>(gc), size0;
+    hipLaunchKernelGGL((raster_dia_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       (const T*)dptr<T>(dcond), dground.p ? (const T*)dptr<T>(dground) : (const T*)nullptr, dptr<T>(dia.rows),
+                       dground.p ? dptr<T>(ground_node) : (T*)nullptr, dptr<double>(part), dptr<unsigned long long>(cnt));
+    if (cellspace) size0.alloc((size_t)ncells * sizeof(long long));
+    hipLaunchKernelGGL((raster_dia_finish_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       dptr<T>(dia.rows), (const double*)dptr<double>(part), gc,
+                       reg ? (double)std::numeric_limits<T>::epsilon() : 0.0,
+                       cellspace ? dptr<long long>(size0) : (long long*)nullptr);
+    std::vector<unsigned long long> hc((size_t)gc);
+    CS_HIP(hipMemcpyAsync(hc.data(), cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    check_launch("raster -> lattice form");
+    CS_HIP(hipStreamSynchronize(st));
+    nnz_api = 0;
+    for (unsigned long long v : hc) nnz_api += (int64_t)v;
+    nnz = nnz_api + (n - n_api);  // entries a CSR form of the device matrix would hold (NODATA rows: their diagonal)
+    dcond.release();
+    dground.release();
+    node.release();
+    upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    hipEvent_t e0, e1;
+    CS_HIP(hipEventCreate(&e0));
+    CS_HIP(hipEventCreate(&e1));
+    CS_HIP(hipEventRecord(e0, st));
+    SetupParams sp = setup_params();
+    sp.grid_rows = (int)R;
+    sp.grid_cols = (int)C;
+    sp.lattice_s = true;
+    sp.size0 = cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr;
+    sp.n_real = cellspace ? n_api : 0;
+    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;  // (see finish_setup)
+    SetupCarry carry;
+    const bool ok = lattice_level0_setup<T, TP>(H, dia, (int)R, (int)C, cellspace ? dptr<long long>(size0) : (long long*)nullptr,
+                                                sp, carry, st);
+    if (ok) {
+      amg_setup_levels(H, sp, nullptr, nullptr, carry, st);
+      CS_HIP(hipEventRecord(e1, st));
+      CS_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+      H.setup_ms = ms;
+      if constexpr (MIXED) Aouter.nrows = Aouter.ncols = (int)n;
+      csr_ready = false;
+      if (getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: %lld x %lld raster through the index-free pipeline (%lld rows, %lld nodes, %d levels)\n",
+                (long long)R, (long long)C, (long long)n, (long long)n_api, (int)H.levels.size());
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (ok) return true;
+    // declined (cannot happen for tile aggregates): CSR pipeline on the CSR form of the same matrix
+    CS_REQUIRE(nnz < ((int64_t)1 << 31), CSGPU_BAD_ARGS, "raster too large for the CSR pipeline");
+    Csr<T> A;
+    dia_to_csr(dia, A, st);
+    DBuf drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int));
+    hipLaunchKernelGGL(lattice_coords_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, (int)R, dptr<int>(drow), dptr<int>(dcol));
+    dia = Dia<T>();
+    finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), (int)R,
+                 cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr);
+    return true;
+  }
+
   void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg,
                          const void* ground = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
@@ -411,6 +532,13 @@ struct Solver : ISolver {
     raster_rows = R;
     raster_cols = C;
     nodemap.alloc((size_t)ncells * sizeof(int));
+    if (n == ncells && want_lattice_pipeline(R, C)) {
+      // every cell a row: the whole level 0 is built from the lattice form, without a CSR matrix (lattice_setup.h)
+      if (setup_lattice_direct(dcond, dground, node, R, C, four, avg_res, reg, t0)) return;
+    }
+    CS_REQUIRE(ncells * 9 < ((int64_t)1 << 31), CSGPU_BAD_ARGS,
+               "raster too large for the CSR pipeline (int32 entry offsets); only all-valid / mostly-valid rasters without "
+               "polygons, with the default two-product fine level, go through the index-free pipeline");
     if (cellspace) {
       cellmap.alloc((size_t)ncells * sizeof(int));
       node2cell.alloc((size_t)n_api * sizeof(int));
@@ -586,6 +714,7 @@ struct Solver : ISolver {
 
   void ensure_components() {
     if (ncomp >= 0) return;
+    ensure_csr();
     const Csr<T>& A = cg_matrix();
     comp_label.alloc((size_t)n * sizeof(int));
     ncomp = connected_components((int)n, A.rp(), A.ci(), dptr<int>(comp_label), st);
@@ -628,6 +757,7 @@ struct Solver : ISolver {
     if (stats) memset(stats, 0, sizeof(*stats));
     CS_REQUIRE(nodemap.p != nullptr, CSGPU_BAD_ARGS, "handle was not built by csgpu_raster_setup");
     const int64_t ncells = raster_rows * raster_cols;
+    ensure_csr();
     ensure_components();
     W.ensure(n, 1, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
@@ -637,21 +767,21 @@ struct Solver : ISolver {
     DBuf dsrc((size_t)ncells * sizeof(T)), has = dalloc<int>((size_t)2 * ncomp);
     CS_HIP(hipMemcpyAsync(dsrc.p, source, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
     CS_HIP(hipMemsetAsync(has.p, 0, (size_t)2 * ncomp * sizeof(int), st));
-    CS_HIP(hipMemsetAsync(W.b.p, 0, (size_t)n * sizeof(T), st));
+    CS_HIP(hipMemsetAsync(W.rhs(), 0, (size_t)n * sizeof(T), st));
     const T* gnode = ground_node.p ? (const T*)dptr<T>(ground_node) : (const T*)nullptr;
     hipLaunchKernelGGL((raster_rhs_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells,
                        raster_rowmap(), (const T*)dptr<T>(dsrc), gnode, (const int*)dptr<int>(comp_label),
-                       dptr<T>(W.b), dptr<int>(has));
+                       W.rhs(), dptr<int>(has));
     hipLaunchKernelGGL((raster_rhs_mask_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
-                       (const int*)dptr<int>(comp_label), (const int*)dptr<int>(has), dptr<T>(W.b));
+                       (const int*)dptr<int>(comp_label), (const int*)dptr<int>(has), W.rhs());
     // every component weighs alike in the one stopping rule: exact power-of-two normalisation per component
     DBuf absmax = dalloc<unsigned long long>((size_t)ncomp);
     CS_HIP(hipMemsetAsync(absmax.p, 0, absmax.bytes, st));
     hipLaunchKernelGGL((comp_absmax_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
-                       (const int*)dptr<int>(comp_label), (const T*)dptr<T>(W.b), dptr<unsigned long long>(absmax));
+                       (const int*)dptr<int>(comp_label), (const T*)W.rhs(), dptr<unsigned long long>(absmax));
     hipLaunchKernelGGL((comp_scale_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
                        (const int*)dptr<int>(comp_label), (const unsigned long long*)dptr<unsigned long long>(absmax), 1,
-                       dptr<T>(W.b));
+                       W.rhs());
     PcgParams pp = pcg_params(1);
     pp.need_x = true;
     pp.comp_label = dptr<int>(comp_label);
@@ -798,6 +928,7 @@ struct Solver : ISolver {
     // resistance-only calls consume x at the pairs' nodes and the gathered focal nodes only (core.jl:231-232,
     // 685-703): accumulate just those entries instead of carrying the n x K solution through every iteration
     const bool need_x = volt_out || want_curr || opts.explicit_check > 0;
+    if (need_x) ensure_csr();  // (the explicit residual check and the current kernels walk the CSR form)
     std::vector<int> focal;
     if (!need_x) focal.resize((size_t)ngather + 2 * K);
     DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax, dbranch, dbranch2;
@@ -829,7 +960,7 @@ struct Solver : ISolver {
       CS_HIP(hipMemcpyAsync(dsrc.p, s32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipMemcpyAsync(ddst.p, d32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
       // right-hand side: into b, or -- focal path -- straight into the residual vector (r0 = b; nothing reads b later)
-      T* rhs = need_x ? dptr<T>(W.b) : dptr<T>(W.r);
+      T* rhs = need_x ? W.rhs() : dptr<T>(W.r);
       CS_HIP(hipMemsetAsync(rhs, 0, (size_t)n * K * sizeof(T), st));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, rhs, dptr<int>(dsrc),
                                            dptr<int>(ddst), ncols));
@@ -928,6 +1059,7 @@ struct Solver : ISolver {
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
     const int K = pick_k(nrhs);
+    ensure_csr();
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     if (stats) {
       stats->nrhs = (int)nrhs;
@@ -938,7 +1070,7 @@ struct Solver : ISolver {
       const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
       upload_cols((const T*)rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
-                                           (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
+                                           (const T*)dptr<T>(stage), ncols, W.rhs()));
       PcgBatchResult r = run_batch_k(K, ncols);
       accumulate(stats, r, ncols);
       CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
@@ -964,6 +1096,7 @@ struct Solver : ISolver {
     const Ids gidx_r = rows_of(gidx + gptr[0], gptr[nrhs] - gptr[0]);  // row ids of the device matrix (cell space)
     gidx = gidx_r.p - gptr[0];
     const int K = pick_k(nrhs);
+    ensure_csr();
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
     if (stats) {
@@ -993,11 +1126,11 @@ struct Solver : ISolver {
       if (!hi.empty()) CS_HIP(hipMemcpyAsync(dgi.p, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, st));
       upload_cols((const T*)rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
       CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
-                                           (const T*)dptr<T>(stage), ncols, dptr<T>(W.b)));
+                                           (const T*)dptr<T>(stage), ncols, W.rhs()));
       const int gtotal = (int)hi.size();
       if (gtotal > 0)
         CS_DISPATCH_K(K, hipLaunchKernelGGL((mask_grounds_kernel<T, T, KK>), dim3(ceil_div(gtotal, 256)), dim3(256), 0, st,
-                                             (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), dptr<T>(W.b),
+                                             (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), W.rhs(),
                                              (T*)nullptr, (const int*)nullptr));
       CS_HIP(hipStreamSynchronize(st));  // hp / hi are reused by the next batch
       PcgBatchResult r;
@@ -1092,6 +1225,7 @@ struct Solver : ISolver {
     dst_set = act_dst.data();
     npairs = (int64_t)slot.size();
     const int K = pick_k(npairs);
+    ensure_csr();
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
     if (stats) stats->batch = K;
@@ -1145,12 +1279,12 @@ struct Solver : ISolver {
       CS_DISPATCH_K(K, hipLaunchKernelGGL((scatter_ones_kernel<T, KK>), dim3(ceil_div((int64_t)si.size(), 256)), dim3(256), 0,
                                            st, (const int*)dptr<int>(dsp), (const int*)dptr<int>(dsi), dptr<T>(volt)));
       {  // b = A 1_I, masked on I u J
-        SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(volt), dptr<T>(W.b));
+        SpmvArgs<T> a = spmv_args(A, (const T*)dptr<T>(volt), W.rhs());
         a.order = H.levels[0].orderA.p ? dptr<int>(H.levels[0].orderA) : nullptr;
         CS_DISPATCH_K(K, (spmv_launch<T, KK>(a, EPI_PLAIN, false, st)));
       }
       CS_DISPATCH_K(K, hipLaunchKernelGGL((mask_grounds_kernel<T, T, KK>), dim3(ceil_div((int64_t)gi.size(), 256)), dim3(256),
-                                           0, st, (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), dptr<T>(W.b),
+                                           0, st, (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), W.rhs(),
                                            (T*)nullptr, (const int*)nullptr));
       CS_HIP(hipStreamSynchronize(st));  // the host lists are reused by the next batch
       PcgBatchResult r;
@@ -1202,30 +1336,32 @@ struct Solver : ISolver {
     int64_t bytes = (int64_t)(Aouter.device_bytes() + dia.device_bytes() + W.p2.bytes);
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
-      nnz_sum += (double)L.A.nnz;
+      const int64_t lnnz = l == 0 ? nnz : L.A.nnz;  // (level 0 may hold no CSR form: lattice pipeline)
+      nnz_sum += (double)lnnz;
       n_sum += (double)L.A.nrows;
       if (l < 32) {
         info->level_n[l] = L.A.nrows;
-        info->level_nnz[l] = L.A.nnz;
+        info->level_nnz[l] = lnnz;
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
                          L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
                          L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes() + L.Ql.device_bytes());
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
-    info->operator_complexity = nnz_sum / std::max(1.0, (double)H.levels[0].A.nnz);
+    info->operator_complexity = nnz_sum / std::max(1.0, (double)nnz);
     info->grid_complexity = n_sum / std::max(1.0, (double)H.levels[0].A.nrows);
     info->setup_ms = H.setup_ms;
     info->upload_ms = upload_ms;
     info->device_bytes = bytes;
-    info->spmv_bytes_fine = spmv_bytes(cg_matrix(), 1);
+    const int64_t csr_bytes_k1 = nnz * (int64_t)(sizeof(T) + 4) + (n + 1) * 4 + 2 * n * (int64_t)sizeof(T);
+    info->spmv_bytes_fine = csr_bytes_k1;
     // B_iter = B_spmv(A0) + 10 n sizeof(T) + sum_l [(nu1+nu2+1) B_spmv(A_l) + B_spmv(P_l) + B_spmv(R_l) + 4 n_l sizeof(TP)]
     // for the CSR path; on a lattice level 0 the four marching kernels of DESIGN.md 4a (batch width 1):
     //   CG product n(5T + 3P), residual update n(5T + 2T + 2P), restriction n(9P + P) + n_c P, second product
     //   n(5P + 9P + 2P) + n_c P          (T, P = sizeof of the CG / preconditioner precision)
     const int64_t sT = (int64_t)sizeof(T), sP = (int64_t)sizeof(TP);
     const bool lat = dia.n > 0 && !H.levels.empty() && H.levels[0].lattice_two_product();
-    int64_t bi = spmv_bytes(cg_matrix(), 1) + 10 * n * sT;
+    int64_t bi = csr_bytes_k1 + 10 * n * sT;
     if (lat) {
       const int64_t nc = H.levels.size() > 1 ? H.levels[1].A.nrows : 0;
       bi = n * (5 * sT + 3 * sP) + n * (7 * sT + 2 * sP) + (n * 10 * sP + nc * sP) + (n * 16 * sP + nc * sP);
@@ -1245,6 +1381,7 @@ struct Solver : ISolver {
   double spmv_bench(int k, int reps) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
+    ensure_csr();
     const Csr<T>& A = cg_matrix();
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
     fill<T>(dptr<T>(x), n * k, T(1), st);
@@ -1272,6 +1409,7 @@ struct Solver : ISolver {
   void spmv_host(const void* xh, void* yh, int k) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
+    ensure_csr();
     const Csr<T>& A = cg_matrix();
     DBuf x((size_t)n * k * sizeof(T)), y((size_t)n * k * sizeof(T));
     if (cellspace) {
@@ -1310,23 +1448,60 @@ struct Solver : ISolver {
 
   // y = (level matrix) x through the launcher the V-cycle uses for that operator (test hook). Host arrays in the
   // hierarchy's precision; for which == 5 ([S Q]) the fused dot x[0:n] . y is returned too.
+  // level whose CSR operators the test hooks read: H.levels[lvl], or -- level 0 of a lattice-pipeline handle -- level 0
+  // of a hierarchy built by the CSR pipeline from the CSR form of the same matrix (see Href)
+  Level<TP>& hook_level(int lvl) {
+    Level<TP>& L = H.levels[lvl];
+    if (lvl != 0 || csr_ready_at_setup()) return L;
+    if (!Href) {
+      ensure_csr();
+      Csr<TP> Ap;
+      if constexpr (MIXED) {
+        convert_csr(Aouter, Ap, st);
+      } else {
+        const Csr<T>& A = H.levels[0].A;  // copy: the hook hierarchy owns its matrix
+        convert_csr(A, Ap, st);
+      }
+      DBuf drow((size_t)n * sizeof(int)), dcol((size_t)n * sizeof(int)), w;
+      hipLaunchKernelGGL(lattice_coords_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, dia.R, dptr<int>(drow), dptr<int>(dcol));
+      SetupParams sp = setup_params();
+      sp.grid_rows = dia.R;
+      sp.grid_cols = (int)(n / dia.R);
+      sp.max_levels = 2;
+      sp.lattice_s = false;
+      if (cellspace) {
+        w.alloc((size_t)n * sizeof(long long));
+        hipLaunchKernelGGL(weights_from_map_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, (const int*)dptr<int>(cell2node),
+                           dptr<long long>(w));
+        sp.size0 = dptr<long long>(w);
+        sp.n_real = n_api;
+      }
+      Href.reset(new Hierarchy<TP>());
+      amg_setup(*Href, std::move(Ap), sp, dptr<int>(drow), dptr<int>(dcol), st);
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    return Href->levels[0];
+  }
+  bool csr_ready_at_setup() const { return H.levels[0].Q.nnz > 0 || !H.levels[0].lattice_two_product() || H.levels.size() < 2; }
+
   void level_spmv_host(int lvl, int which, const void* xh, void* yh, int k, double* dots) override {
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
-    Level<TP>& L = H.levels[lvl];
+    Level<TP>& L = H.levels[lvl];   // the forms the solve phase uses (lattice kernels)
+    Level<TP>& Lc = hook_level(lvl);  // the CSR operators
     // lattice level: the CSR forms of Q^T / [S Q] are not kept; build them for the size query only
-    if (which == 5 && L.M.nnz == 0 && L.lattice_two_product()) build_sq_matrix(L, st);
-    if (which == 4 && L.QT.nnz == 0 && L.lattice_two_product()) build_qt_matrix(L, st);
-    const Csr<TP>& M = which == 0 ? L.A : which == 1 ? L.P : which == 2 ? L.R : which == 3 ? L.Q : which == 4 ? L.QT : L.M;
+    if (which == 5 && Lc.M.nnz == 0 && L.lattice_two_product()) build_sq_matrix(Lc, st);
+    if (which == 4 && Lc.QT.nnz == 0 && L.lattice_two_product()) build_qt_matrix(Lc, st);
+    const Csr<TP>& M = which == 0 ? Lc.A : which == 1 ? Lc.P : which == 2 ? Lc.R : which == 3 ? Lc.Q : which == 4 ? Lc.QT : Lc.M;
     CS_REQUIRE(M.nnz > 0, CSGPU_BAD_ARGS, "level has no such operator");
     DBuf x((size_t)M.ncols * k * sizeof(TP)), y((size_t)M.nrows * k * sizeof(TP));
     DBuf part = dalloc<double>(std::max<size_t>(16384, spmv_grid_upper(M.nrows)) * kMaxK);
     CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
     SpmvArgs<TP> a = spmv_args(M, (const TP*)dptr<TP>(x), dptr<TP>(y));
     const bool sq = which == 5;
-    if (which == 0 || sq) a.order = L.orderA.p ? dptr<int>(L.orderA) : nullptr;
-    if (which == 4) a.order_lr = L.orderQT.p ? dptr<int>(L.orderQT) : nullptr;
+    if (which == 0 || sq) a.order = Lc.orderA.p ? dptr<int>(Lc.orderA) : nullptr;
+    if (which == 4) a.order_lr = Lc.orderQT.p ? dptr<int>(Lc.orderQT) : nullptr;
     if (sq) a.partials = dptr<double>(part);
     const bool sq_lattice = sq && L.lattice_two_product();
     if (sq_lattice) {  // the kernel the V-cycle runs on a lattice level: S b + Q x_c with x = [b; x_c]
@@ -1359,7 +1534,9 @@ struct Solver : ISolver {
   void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
                         int32_t* colidx, void* vals) const override {
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
-    const Level<TP>& L = H.levels[lvl];
+    auto* self = const_cast<Solver<T, TP>*>(this);  // (hooks may build the CSR forms they inspect)
+    if (lvl == 0 && which == 0) self->ensure_csr();
+    const Level<TP>& L = (lvl == 0 && which != 0) ? self->hook_level(0) : H.levels[lvl];
     if (cellspace && lvl == 0 && which == 0) {
       // the matrix of the real graph in the reference's node numbering: the NODATA rows dropped, columns renumbered
       // (test / measurement hook: compacted on the host)
@@ -1387,7 +1564,17 @@ struct Solver : ISolver {
       if (rowptr) rowptr[n_api] = (int32_t)o;
       return;
     }
-    if (L.lattice_two_product() && ((which == 5 && L.M.nnz == 0) || (which == 4 && L.QT.nnz == 0))) {
+    if (lvl == 0 && which == 0) {  // the CG matrix itself, in the handle's value type
+      const Csr<T>& A = cg_matrix();
+      if (nrows) *nrows = A.nrows;
+      if (ncols) *ncols = A.ncols;
+      if (nnz_out) *nnz_out = A.nnz;
+      if (rowptr && A.rowptr.p) CS_HIP(hipMemcpy(rowptr, A.rp(), (size_t)(A.nrows + 1) * sizeof(int), hipMemcpyDeviceToHost));
+      if (colidx && A.nnz > 0) CS_HIP(hipMemcpy(colidx, A.ci(), (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost));
+      if (vals && A.nnz > 0) CS_HIP(hipMemcpy(vals, A.va(), (size_t)A.nnz * sizeof(T), hipMemcpyDeviceToHost));
+      return;
+    }
+    if (H.levels[lvl].lattice_two_product() && ((which == 5 && L.M.nnz == 0) || (which == 4 && L.QT.nnz == 0))) {
       // lattice level: the CSR forms of Q^T / [S Q] are not kept; build them (independent CSR builders) for inspection
       if (which == 5) build_sq_matrix(const_cast<Level<TP>&>(L), st);
       if (which == 4) build_qt_matrix(const_cast<Level<TP>&>(L), st);
@@ -1400,14 +1587,10 @@ struct Solver : ISolver {
     if (rowptr && M.rowptr.p) CS_HIP(hipMemcpy(rowptr, M.rp(), (size_t)(M.nrows + 1) * sizeof(int), hipMemcpyDeviceToHost));
     if (colidx && M.nnz > 0) CS_HIP(hipMemcpy(colidx, M.ci(), (size_t)M.nnz * sizeof(int), hipMemcpyDeviceToHost));
     if (vals && M.nnz > 0) {
-      if (MIXED && lvl == 0 && which == 0) {
-        CS_HIP(hipMemcpy(vals, Aouter.va(), (size_t)M.nnz * sizeof(T), hipMemcpyDeviceToHost));
-      } else {
-        std::vector<TP> tmp((size_t)M.nnz);
-        CS_HIP(hipMemcpy(tmp.data(), M.va(), (size_t)M.nnz * sizeof(TP), hipMemcpyDeviceToHost));
-        T* out = (T*)vals;
-        for (size_t i = 0; i < tmp.size(); ++i) out[i] = (T)tmp[i];
-      }
+      std::vector<TP> tmp((size_t)M.nnz);
+      CS_HIP(hipMemcpy(tmp.data(), M.va(), (size_t)M.nnz * sizeof(TP), hipMemcpyDeviceToHost));
+      T* out = (T*)vals;
+      for (size_t i = 0; i < tmp.size(); ++i) out[i] = (T)tmp[i];
     }
   }
 
@@ -1572,10 +1755,8 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
   }
   int rc = check_common(nrows * ncols, 0, val_bytes, opts);
   if (rc) return rc;
-  if (nrows * ncols * 9 >= ((int64_t)1 << 31)) {
-    g_last_error = "raster too large for int32 device indexing";
-    return CSGPU_BAD_ARGS;
-  }
+  // (rasters of 2^31 / 9 = 238 M cells and more have no int32 CSR form; the index-free pipeline takes them when it
+  // applies -- checked inside)
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;

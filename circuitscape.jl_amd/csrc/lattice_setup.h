@@ -1,0 +1,644 @@
+// lattice_setup.h -- level 0 of the hierarchy of a raster built straight from the lattice form: no CSR matrix, no
+// SpGEMM, no transpose.
+//
+// GPU counterpart, for the matrices the reference's raster path produces (construct_graph, src/raster/pairwise.jl:
+// 316-362; laplacian!, src/core.jl:608-634), of the first coarsening step of `smoothed_aggregation(matrix; ...)`
+// (reference call site src/core.jl:164-167; algorithm restated in SURVEY.md section 2.3 and amg_setup.h):
+//
+//   raster -> A in lattice form (5 values per cell, stencil.h)                          raster_dia_kernel
+//   row statistics (diagonal, sum |a_ij|, Gershgorin bound)                             dia_stats_kernel
+//   aggregates = regular 3x3 tiles (+ piece analysis on rasters with NODATA cells)      lattice_tile_kernel, dia_pieces_kernel
+//   T (tentative prolongator), P = T - w_p Dl^-1 A T                                     lattice_p_kernel      [n][9]
+//   A P and Q = P - w D^-1 A P                                                           lattice_ap_q_kernel   [n][9]
+//   A_c = P^T (A P)  (Galerkin operator of level 1, CSR)                                 lattice_galerkin_kernel
+//
+// Every operator of the level is index-free: row (i, j) of P, A P and Q only reaches the 3 x 3 block of tiles around the
+// cell's own tile (LatticeQ in common.h), and A_c couples a tile to its neighbours within two tiles (one on all-valid
+// rasters). The general CSR pipeline of amg_setup.h produces the same operators (tests compare the two); it stays in
+// charge of matrices handed over in CSR form, of rasters with polygons and of every level below this one.
+//
+// Why: at 10000 x 10000 the CSR pipeline spends ~180 ms of device time and ~15 GB of transient memory on level 0 (CSR
+// build 45 ms, lattice detection 11 ms, A T / A P / R A P 95 ms, transpose 25 ms), the lattice one ~1/4 of that; and a
+// raster above 2^31 / 9 = 238 M cells has no int32 CSR form at all (the reference documents 437 M cells,
+// docs/src/compute.md:3).
+#pragma once
+#include "amg_setup.h"
+#include "lattice.h"
+#include "raster.h"
+
+namespace csgpu {
+
+// k-th entry (ascending column order, k = 0..8) of row i of a lattice matrix: column j (-1 when outside the matrix)
+// and value (0 where the entry is absent). U: storage precision, returned as double-convertible U.
+template <class U>
+__device__ __forceinline__ U dia_row_entry(const U* __restrict__ rows, int64_t n, int R, int64_t i, int k, int64_t& j) {
+  switch (k) {
+    case 0: j = i - R - 1; return j >= 0 ? rows[j * 5 + 4] : U(0);
+    case 1: j = i - R; return j >= 0 ? rows[j * 5 + 3] : U(0);
+    case 2: j = i - R + 1; return j >= 0 ? rows[j * 5 + 2] : U(0);
+    case 3: j = i - 1; return j >= 0 ? rows[j * 5 + 1] : U(0);
+    case 4: j = i; return rows[i * 5 + 0];
+    case 5: j = i + 1; return j < n ? rows[i * 5 + 1] : U(0);
+    case 6: j = i + R - 1; return j < n ? rows[i * 5 + 2] : U(0);
+    case 7: j = i + R; return j < n ? rows[i * 5 + 3] : U(0);
+    default: j = i + R + 1; return j < n ? rows[i * 5 + 4] : U(0);
+  }
+}
+
+// ---- raster -> lattice form ------------------------------------------------------------------------------------------
+// One thread per cell (column-major id = j*R + i). Same arithmetic as raster_fill_kernel (raster.h): weights in double,
+// diagonal = sum of the weights of the valid neighbours (+ finite ground), off-diagonals -w, rounded to T once.
+// NODATA cells (cell space): all five values 0 here; raster_dia_finish_kernel sets their diagonal to 1.
+// part[block] = sum of squares of the entries the CSR form would store (diagonal once, every coupling in both rows);
+// cnt[block] = number of those entries (the nnz the caller reports).
+template <class T>
+__global__ __launch_bounds__(256) void raster_dia_kernel(int R, int C, int four, int avg_res, const T* __restrict__ cond,
+                                                         const T* __restrict__ ground, T* __restrict__ rows,
+                                                         T* __restrict__ ground_node, double* __restrict__ part,
+                                                         unsigned long long* __restrict__ cnt) {
+  __shared__ double sm[4];
+  __shared__ unsigned long long smc[4];
+  const int64_t n = (int64_t)R * C;
+  double ss = 0.0;
+  unsigned long long c = 0;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
+    const double g0 = (double)cond[(size_t)i * C + j];
+    T out[5] = {T(0), T(0), T(0), T(0), T(0)};
+    if (g0 > 0.0) {
+      double deg = 0.0;
+      // neighbours in column-major order, like the CSR row (raster_fill_kernel): the degree is summed in that order
+      for (int dj = -1; dj <= 1; ++dj) {
+        const int jj = j + dj;
+        if (jj < 0 || jj >= C) continue;
+        for (int di = -1; di <= 1; ++di) {
+          const int ii = i + di;
+          if (ii < 0 || ii >= R || (di == 0 && dj == 0)) continue;
+          const bool diag = (di != 0 && dj != 0);
+          if (diag && four) continue;
+          const double g1 = (double)cond[(size_t)ii * C + jj];
+          if (!(g1 > 0.0)) continue;
+          const double w = raster_edge(g0, g1, diag, avg_res != 0);
+          deg += w;
+          const T v = (T)(-w);
+          ss += (double)v * (double)v;
+          ++c;
+          if (dj == 0 && di == 1) out[1] = v;
+          else if (dj == 1 && di == -1) out[2] = v;
+          else if (dj == 1 && di == 0) out[3] = v;
+          else if (dj == 1 && di == 1) out[4] = v;
+        }
+      }
+      const double gnd = ground ? (double)ground[(size_t)i * C + j] : 0.0;
+      out[0] = (T)(deg + gnd);
+      ss += (double)out[0] * (double)out[0];
+      ++c;
+      if (ground_node) ground_node[id] = (T)gnd;
+    } else if (ground_node) {
+      ground_node[id] = T(0);
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s) rows[id * 5 + s] = out[s];
+  }
+  ss = block_sum_256(ss, sm);
+  c = block_sum_256(c, smc);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = ss;
+    cnt[blockIdx.x] = c;
+  }
+}
+
+// regularisation nzval .+= eps(T) * norm(nzval) of the entries the CSR form stores (src/core.jl:161): the diagonal of
+// every valid cell and every coupling that exists (value != 0: conductances are positive); NODATA diagonal = 1;
+// size0[cell] = 1 for a cell with a node, 0 otherwise (may be null)
+template <class T>
+__global__ __launch_bounds__(256) void raster_dia_finish_kernel(int R, int C, const T* __restrict__ cond, T* __restrict__ rows,
+                                                                const double* __restrict__ part, int nparts, double eps,
+                                                                long long* __restrict__ size0) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = block_sum_256(s, sm);
+  const T shift = (T)(eps * sqrt(s));
+  const int64_t n = (int64_t)R * C;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
+    const bool valid = cond[(size_t)i * C + j] > T(0);
+    if (size0) size0[id] = valid ? 1 : 0;
+    if (!valid) {
+      rows[id * 5] = T(1);
+      continue;
+    }
+    if (eps != 0.0) {
+      rows[id * 5] += shift;
+#pragma unroll
+      for (int q = 1; q < 5; ++q)
+        if (rows[id * 5 + q] != T(0)) rows[id * 5 + q] += shift;
+    }
+  }
+}
+
+// node numbering of the reference for a cell-space / all-valid raster: nodemap (row-major, 1-based node id), cellmap
+// (row-major, 1-based row id of the device matrix), node2cell, cell2node (see Solver in csgpu.hip). node = exclusive scan
+// of the valid flags in column-major order.
+template <class T>
+__global__ __launch_bounds__(256) void raster_maps_kernel(int R, int C, const T* __restrict__ cond, const int* __restrict__ node,
+                                                          int* __restrict__ nodemap, int* __restrict__ cellmap,
+                                                          int* __restrict__ node2cell, int* __restrict__ cell2node) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
+    const bool valid = cond[(size_t)i * C + j] > T(0);
+    nodemap[(size_t)i * C + j] = valid ? node[id] + 1 : 0;
+    if (cellmap) cellmap[(size_t)i * C + j] = valid ? (int)id + 1 : 0;
+    if (node2cell && valid) node2cell[node[id]] = (int)id;
+    if (cell2node) cell2node[id] = valid ? node[id] + 1 : 0;
+  }
+}
+
+// ---- row statistics (row_stats_kernel + dinv_kernel of amg_setup.h on the lattice form) -------------------------------
+template <class U, class T>
+__global__ __launch_bounds__(256) void dia_stats_kernel(int64_t n, int R, const U* __restrict__ rows, T* __restrict__ labs,
+                                                        T* __restrict__ dinv, double* __restrict__ part_max) {
+  __shared__ double sm[4];
+  double mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T l = T(0), d = T(0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      const T v = (T)dia_row_entry(rows, n, R, i, k, j);
+      if (k == 4) d = v;
+      l += v < T(0) ? -v : v;
+    }
+    labs[i] = l;
+    dinv[i] = d != T(0) ? T(1) / d : T(0);
+    const double ad = d < T(0) ? -(double)d : (double)d;
+    if (ad > 0.0) {
+      const double q = (double)l / ad;
+      mx = q > mx ? q : mx;
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = sm[0];
+    for (int w = 1; w < 4; ++w) m = sm[w] > m ? sm[w] : m;
+    part_max[blockIdx.x] = m;
+  }
+}
+
+// ---- aggregates: the regular tiles -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lattice_tile_kernel(int64_t n, int R, int Rc, int Cc, int* __restrict__ agg,
+                                                           int* __restrict__ crow, int* __restrict__ ccol) {
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
+    const int i = (int)(id % R), j = (int)(id / R);
+    const int I = lat_tile(i, Rc), J = lat_tile(j, Cc);
+    const int a = J * Rc + I;
+    agg[id] = a;
+    if (i == 3 * I && j == 3 * J) {  // one writer per tile
+      crow[a] = I;
+      ccol[a] = J;
+    }
+  }
+}
+
+// piece analysis of amg_setup.h (tile_pieces_kernel) on the lattice form; see the comment there
+template <class U, int PASS>
+__global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
+                                                         long long* __restrict__ size_f, signed char* __restrict__ piece,
+                                                         signed char* __restrict__ mainlab, int* __restrict__ agg) {
+  const int ntiles = Rc * Cc;
+  const int64_t n = (int64_t)R * C;
+  for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
+    const int I = tile % Rc, J = tile / Rc;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const int h = r1 - r0, w = c1 - c0;  // <= 4 each
+    if (PASS == 1) {
+      int lab[16];
+      int nvalid = 0;
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) {
+          const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+          const bool valid = size_f[cell] != 0;
+          lab[kc * h + kr] = valid ? kc * h + kr : -1;
+          nvalid += valid ? 1 : 0;
+        }
+      if (nvalid > 0 && nvalid < h * w) {  // (a full tile is connected: adjacent valid cells are always coupled)
+        for (int sweep = 0; sweep < 16; ++sweep) {
+          bool changed = false;
+          for (int kc = 0; kc < w; ++kc)
+            for (int kr = 0; kr < h; ++kr) {
+              int& me = lab[kc * h + kr];
+              if (me < 0) continue;
+              const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+              for (int k = 0; k < 9; ++k) {
+                if (k == 4) continue;
+                int64_t nb;
+                if (dia_row_entry(rows, n, R, cell, k, nb) == U(0)) continue;
+                const int ni = (int)(nb % R) - r0, nj = (int)(nb / R) - c0;
+                if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+                const int l2 = lab[nj * h + ni];
+                if (l2 >= 0 && l2 < me) {
+                  me = l2;
+                  changed = true;
+                }
+              }
+            }
+          if (!changed) break;
+        }
+      } else if (nvalid == h * w) {
+        for (int k = 0; k < h * w; ++k) lab[k] = 0;
+      }
+      int best = -1, bestcnt = 0;
+      for (int q = 0; q < h * w; ++q) {
+        int cntq = 0;
+        for (int k = 0; k < h * w; ++k) cntq += lab[k] == q ? 1 : 0;
+        if (cntq > bestcnt) {
+          bestcnt = cntq;
+          best = q;
+        }
+      }
+      mainlab[tile] = (signed char)best;
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) piece[(int64_t)(c0 + kc) * R + r0 + kr] = (signed char)lab[kc * h + kr];
+    } else {
+      // every cell outside the tile's main piece joins the tile of the main-piece cell it is most strongly coupled to
+      // (ties: the first in column order); without such a coupling it weighs 0
+      const int mainq = mainlab[tile];
+      for (int kc = 0; kc < w; ++kc)
+        for (int kr = 0; kr < h; ++kr) {
+          const int64_t cell = (int64_t)(c0 + kc) * R + r0 + kr;
+          if (piece[cell] < 0 || piece[cell] == mainq) continue;
+          int target = -1;
+          double best = 0.0;
+          for (int k = 0; k < 9; ++k) {
+            if (k == 4) continue;
+            int64_t nb;
+            const U v = dia_row_entry(rows, n, R, cell, k, nb);
+            if (v == U(0)) continue;
+            const int ni = (int)(nb % R), nj = (int)(nb / R);
+            if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
+            const int nt = lat_tile(nj, Cc) * Rc + lat_tile(ni, Rc);
+            if (piece[nb] < 0 || piece[nb] != mainlab[nt]) continue;
+            const double a = fabs((double)v);
+            if (a > best) {
+              best = a;
+              target = nt;
+            }
+          }
+          if (target >= 0) agg[cell] = target;
+          else size_f[cell] = 0;
+        }
+    }
+  }
+}
+
+// t[i] = sqrt(size_f[i] / size_c[agg[i]])   (tentative_kernel of amg_setup.h; size_f null = all ones)
+template <class T>
+__global__ __launch_bounds__(256) void lattice_tentative_kernel(int64_t n, const int* __restrict__ agg,
+                                                                const long long* __restrict__ size_f,
+                                                                const unsigned long long* __restrict__ size_c,
+                                                                T* __restrict__ t) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double sf = size_f ? (double)size_f[i] : 1.0;
+    const double sc = (double)size_c[agg[i]];
+    t[i] = sc > 0.0 ? (T)sqrt(sf / sc) : T(0);
+  }
+}
+
+__global__ __launch_bounds__(256) void lattice_sizes_kernel(int64_t n, const int* __restrict__ agg,
+                                                            const long long* __restrict__ size_f,
+                                                            unsigned long long* __restrict__ size_c) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    atomicAdd(&size_c[agg[i]], (unsigned long long)(size_f ? size_f[i] : 1));
+}
+
+// slot (0..8) of aggregate a in the 3 x 3 block of tiles around tile (I, J); -1 when it lies outside
+__device__ __forceinline__ int lat_slot(int a, int Rc, int I, int J) {
+  const int dI = a % Rc - I, dJ = a / Rc - J;
+  if (dI < -1 || dI > 1 || dJ < -1 || dJ > 1) return -1;
+  return (dJ + 1) * 3 + (dI + 1);
+}
+
+// P = T - (w_p / labs) A T in index-free form: pl[i][slot] = P[i, aggregate at `slot` of the block around tile(i)].
+// Same arithmetic as spgemm_tentative_kernel + smooth_prolongator_kernel (amg_setup.h): products summed per aggregate in
+// column order in T, the smoothing step in double.
+template <class U, class T>
+__global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
+                                                        const int* __restrict__ agg, const T* __restrict__ t,
+                                                        const T* __restrict__ labs, double omega_p, T* __restrict__ pl,
+                                                        int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int I = lat_tile((int)(i % R), Rc), J = lat_tile((int)(i / R), Cc);
+    T acc[9];
+    bool has[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      acc[s] = T(0);
+      has[s] = false;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      const T a = (T)dia_row_entry(rows, n, R, i, k, j);
+      if (a == T(0) && k != 4) continue;  // (the diagonal is always a stored entry)
+      const int slot = lat_slot(agg[j], Rc, I, J);
+      if (slot < 0) {
+        atomicOr(bad, 1);
+        continue;
+      }
+      const T v = a * t[j];
+#pragma unroll
+      for (int s = 0; s < 9; ++s)
+        if (s == slot) {
+          acc[s] += v;
+          has[s] = true;
+        }
+    }
+    const double l = (double)labs[i];
+    const double w = l != 0.0 ? omega_p / l : 0.0;
+    const int own = lat_slot(agg[i], Rc, I, J);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      double v = 0.0;
+      if (has[s]) {
+        v = -w * (double)acc[s];
+        if (s == own) v += (double)t[i];
+      }
+      pl[i * 9 + s] = (T)v;
+    }
+  }
+}
+
+// A P and Q = P - w D^-1 A P, both index-free ([n][9]); ap may be null (only Q wanted)
+template <class U, class T>
+__global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
+                                                           const T* __restrict__ pl, const T* __restrict__ dinv, T omega,
+                                                           T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int I = lat_tile((int)(i % R), Rc), J = lat_tile((int)(i / R), Cc);
+    T acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) acc[s] = T(0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      const T a = (T)dia_row_entry(rows, n, R, i, k, j);
+      if (a == T(0)) continue;
+      const int Ij = lat_tile((int)(j % R), Rc), Jj = lat_tile((int)(j / R), Cc);
+      const int sI = Ij - I, sJ = Jj - J;  // tile of j relative to tile of i: -1, 0, 1
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const T pv = pl[j * 9 + s];
+        if (pv == T(0)) continue;
+        const int dI = s % 3 - 1 + sI, dJ = s / 3 - 1 + sJ;
+        if (dI < -1 || dI > 1 || dJ < -1 || dJ > 1) {
+          atomicOr(bad, 2);
+          continue;
+        }
+        const int so = (dJ + 1) * 3 + (dI + 1);
+#pragma unroll
+        for (int s2 = 0; s2 < 9; ++s2)
+          if (s2 == so) acc[s2] += a * pv;
+      }
+    }
+    const T w = omega * dinv[i];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      if (ap) ap[i * 9 + s] = acc[s];
+      q[i * 9 + s] = -w * acc[s] + pl[i * 9 + s];
+    }
+  }
+}
+
+// ---- Galerkin operator A_c = P^T (A P) ---------------------------------------------------------------------------------
+// One thread per coarse node a = (Ia, Ja): walks the cells of the 3 x 3 block of tiles around its tile in cell order
+// (deterministic), adds P[i, a] * (A P)[i, b] into a 5 x 5 window of coarse columns b around a (two tiles reach: see the
+// header), and writes the non-zero entries (the diagonal always) in ascending column order into a padded row of 25
+// slots; lattice_galerkin_compact_kernel packs the rows into CSR.
+template <class T>
+__global__ __launch_bounds__(128) void lattice_galerkin_kernel(int R, int C, int Rc, int Cc, const T* __restrict__ pl,
+                                                               const T* __restrict__ ap, int* __restrict__ count,
+                                                               int* __restrict__ pcol, T* __restrict__ pval) {
+  const int nc = Rc * Cc;
+  for (int a = blockIdx.x * 128 + threadIdx.x; a < nc; a += gridDim.x * 128) {
+    const int Ia = a % Rc, Ja = a / Rc;
+    T acc[25];
+#pragma unroll
+    for (int s = 0; s < 25; ++s) acc[s] = T(0);
+    for (int tJ = max(Ja - 1, 0); tJ <= min(Ja + 1, Cc - 1); ++tJ) {
+      int c0, c1;
+      tile_extent(tJ, Cc, C, c0, c1);
+      for (int jc = c0; jc < c1; ++jc)
+        for (int tI = max(Ia - 1, 0); tI <= min(Ia + 1, Rc - 1); ++tI) {
+          int r0, r1;
+          tile_extent(tI, Rc, R, r0, r1);
+          const int sa = (Ja - tJ + 1) * 3 + (Ia - tI + 1);  // slot of a in the block around tile (tI, tJ)
+          for (int ir = r0; ir < r1; ++ir) {
+            const int64_t i = (int64_t)jc * R + ir;
+            const T pv = pl[i * 9 + sa];
+            if (pv == T(0)) continue;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+              const T v = ap[i * 9 + s];
+              // coarse column b = tile (tI + s%3 - 1, tJ + s/3 - 1); window index relative to a
+              const int wI = tI + s % 3 - 1 - Ia + 2, wJ = tJ + s / 3 - 1 - Ja + 2;  // 0..4
+              const int wi = wJ * 5 + wI;
+#pragma unroll
+              for (int s2 = 0; s2 < 25; ++s2)
+                if (s2 == wi) acc[s2] += pv * v;
+            }
+          }
+        }
+    }
+    int m = 0;
+#pragma unroll
+    for (int s = 0; s < 25; ++s) {
+      const int bI = Ia + s % 5 - 2, bJ = Ja + s / 5 - 2;
+      if (bI < 0 || bI >= Rc || bJ < 0 || bJ >= Cc) continue;
+      if (acc[s] == T(0) && s != 12) continue;
+      pcol[(size_t)a * 25 + m] = bJ * Rc + bI;
+      pval[(size_t)a * 25 + m] = acc[s];
+      ++m;
+    }
+    count[a] = m;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void lattice_galerkin_compact_kernel(int nc, const int* __restrict__ rp,
+                                                                       const int* __restrict__ pcol, const T* __restrict__ pval,
+                                                                       int* __restrict__ ci, T* __restrict__ va) {
+  for (int a = blockIdx.x * 256 + threadIdx.x; a < nc; a += gridDim.x * 256) {
+    const int b = rp[a], m = rp[a + 1] - b;
+    for (int e = 0; e < m; ++e) {
+      ci[b + e] = pcol[(size_t)a * 25 + e];
+      va[b + e] = pval[(size_t)a * 25 + e];
+    }
+  }
+}
+
+// ---- the lattice form back to CSR (on demand: current maps, explicit residual checks, test hooks) ---------------------
+template <class T, bool FILL>
+__global__ __launch_bounds__(256) void dia_to_csr_kernel(int64_t n, int R, const T* __restrict__ rows, int* __restrict__ rp,
+                                                         int* __restrict__ ci, T* __restrict__ va) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int m = 0;
+    const int o = FILL ? rp[i] : 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      const T a = dia_row_entry(rows, n, R, i, k, j);
+      if (a == T(0) && k != 4) continue;
+      if (FILL) {
+        ci[o + m] = (int)j;
+        va[o + m] = a;
+      }
+      ++m;
+    }
+    if (!FILL) rp[i] = m;
+  }
+}
+
+template <class T>
+inline void dia_to_csr(const Dia<T>& D, Csr<T>& A, hipStream_t st) {
+  const int64_t n = D.n;
+  A.nrows = A.ncols = (int)n;
+  A.rowptr.alloc((size_t)(n + 1) * sizeof(int));
+  CS_HIP(hipMemsetAsync(A.rp(), 0, (size_t)(n + 1) * sizeof(int), st));
+  hipLaunchKernelGGL((dia_to_csr_kernel<T, false>), dim3(grid_for(n)), dim3(256), 0, st, n, D.R, D.data(), A.rp(), (int*)nullptr,
+                     (T*)nullptr);
+  // the total may exceed int32 on rasters above 238 M cells: check in 64 bits before the scan
+  DBuf total = dalloc<int>(1);
+  exclusive_scan_i32(A.rp(), n + 1, st, dptr<int>(total));
+  const int nnz = read_int(dptr<int>(total), st);
+  CS_REQUIRE(nnz >= 0, CSGPU_BAD_ARGS, "raster too large for the CSR form this call needs (2^31 stored entries)");
+  A.nnz = nnz;
+  A.col.alloc((size_t)std::max(nnz, 1) * sizeof(int));
+  A.val.alloc((size_t)std::max(nnz, 1) * sizeof(T));
+  hipLaunchKernelGGL((dia_to_csr_kernel<T, true>), dim3(grid_for(n)), dim3(256), 0, st, n, D.R, D.data(), A.rp(), A.ci(), A.va());
+  check_launch("lattice form -> CSR");
+}
+
+// Level 0 of H from the lattice form A0 (storage precision U; the hierarchy computes in T on the rounded values) of an
+// R x C raster; weights `size0` (device, long long, may be null = every cell is a node; modified by the piece analysis).
+// Leaves H.levels = {level 0 (index-free: Ql, Sdia, dinv), level 1 (A = Galerkin operator in CSR)} and the carry for the
+// level loop. Returns false (H untouched) when the lattice pipeline does not apply.
+template <class U, class T>
+inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C, long long* size0, const SetupParams& sp,
+                                 SetupCarry& carry, hipStream_t st) {
+  const int64_t n = A0.n;
+  const int Rc = (R + 1) / 3, Cc = (C + 1) / 3;
+  if (!sp.two_product || sp.theta != 0.0 || sp.aggregation == CSGPU_AGG_MIS2 || R < 6 || C < 6 || n != (int64_t)R * C ||
+      n <= sp.max_coarse || sp.max_levels < 2)
+    return false;
+  const int64_t nc = (int64_t)Rc * Cc;
+  const int g = grid_for(n);
+  Level<T> L;
+  L.A.nrows = L.A.ncols = (int)n;  // (no CSR arrays: the level is index-free)
+  L.n = (int)n;
+  // row statistics
+  DBuf labs((size_t)n * sizeof(T)), part = dalloc<double>(g);
+  L.dinv.alloc((size_t)n * sizeof(T));
+  hipLaunchKernelGGL((dia_stats_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, A0.data(), dptr<T>(labs), dptr<T>(L.dinv),
+                     dptr<double>(part));
+  std::vector<double> hp(g);
+  CS_HIP(hipMemcpyAsync(hp.data(), part.p, (size_t)g * sizeof(double), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  double rho = 0;
+  for (double v : hp) rho = std::max(rho, v);
+  if (!(rho > 0)) rho = 1.0;
+  L.rho = rho;
+  L.omega = sp.omega_s / rho;
+  // aggregates
+  DBuf agg = dalloc<int>((size_t)n);
+  carry.crow.alloc((size_t)nc * sizeof(int));
+  carry.ccol.alloc((size_t)nc * sizeof(int));
+  hipLaunchKernelGGL(lattice_tile_kernel, dim3(g), dim3(256), 0, st, n, R, Rc, Cc, dptr<int>(agg), dptr<int>(carry.crow),
+                     dptr<int>(carry.ccol));
+  static const bool no_pieces = getenv("CSGPU_NO_TILE_PIECES") != nullptr;  // A/B knob
+  if (size0 && !no_pieces) {
+    DBuf piece((size_t)n), mainlab((size_t)nc);
+    const int gt = grid_for(nc);
+    hipLaunchKernelGGL((dia_pieces_kernel<U, 1>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                       (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+    hipLaunchKernelGGL((dia_pieces_kernel<U, 2>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                       (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+    check_launch("tile pieces (lattice)");
+    CS_HIP(hipStreamSynchronize(st));
+  }
+  DBuf size_c = dalloc<unsigned long long>((size_t)nc);
+  CS_HIP(hipMemsetAsync(size_c.p, 0, size_c.bytes, st));
+  hipLaunchKernelGGL(lattice_sizes_kernel, dim3(g), dim3(256), 0, st, n, (const int*)dptr<int>(agg), (const long long*)size0,
+                     dptr<unsigned long long>(size_c));
+  if (size0 && getenv("CSGPU_VERBOSE")) {
+    std::vector<unsigned long long> hs((size_t)nc);
+    CS_HIP(hipMemcpy(hs.data(), size_c.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long tot = 0, empty = 0;
+    for (unsigned long long v : hs) {
+      tot += v;
+      empty += v == 0 ? 1 : 0;
+    }
+    fprintf(stderr, "csgpu: cell space: %lld nodes, %lld of them without an aggregate (weight 0), %llu of %lld tiles empty\n",
+            (long long)sp.n_real, (long long)sp.n_real - (long long)tot, empty, (long long)nc);
+  }
+  DBuf tv((size_t)n * sizeof(T));
+  hipLaunchKernelGGL((lattice_tentative_kernel<T>), dim3(g), dim3(256), 0, st, n, (const int*)dptr<int>(agg),
+                     (const long long*)size0, (const unsigned long long*)dptr<unsigned long long>(size_c), dptr<T>(tv));
+  // P, A P, Q
+  DBuf pl((size_t)n * 9 * sizeof(T)), apl((size_t)n * 9 * sizeof(T)), ql((size_t)n * 9 * sizeof(T)), bad = dalloc<int>(1);
+  CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL((lattice_p_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const int*)dptr<int>(agg),
+                     (const T*)dptr<T>(tv), (const T*)dptr<T>(labs), sp.omega_p, dptr<T>(pl), dptr<int>(bad));
+  hipLaunchKernelGGL((lattice_ap_q_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const T*)dptr<T>(pl),
+                     (const T*)dptr<T>(L.dinv), (T)L.omega, dptr<T>(apl), dptr<T>(ql), dptr<int>(bad));
+  check_launch("lattice P / A P / Q");
+  if (read_int(dptr<int>(bad), st) != 0) return false;  // (cannot happen for tile aggregates; the CSR pipeline takes over)
+  tv.release();
+  labs.release();
+  agg.release();
+  // Galerkin operator of level 1
+  Csr<T> Ac;
+  Ac.nrows = Ac.ncols = (int)nc;
+  Ac.rowptr.alloc((size_t)(nc + 1) * sizeof(int));
+  CS_HIP(hipMemsetAsync(Ac.rp(), 0, (size_t)(nc + 1) * sizeof(int), st));
+  {
+    DBuf pcol = dalloc<int>((size_t)nc * 25), pval((size_t)nc * 25 * sizeof(T)), total = dalloc<int>(1);
+    int gg = ceil_div(nc, 128);
+    if (gg > 65536) gg = 65536;
+    hipLaunchKernelGGL((lattice_galerkin_kernel<T>), dim3(gg), dim3(128), 0, st, R, C, Rc, Cc, (const T*)dptr<T>(pl),
+                       (const T*)dptr<T>(apl), Ac.rp(), dptr<int>(pcol), dptr<T>(pval));
+    exclusive_scan_i32(Ac.rp(), nc + 1, st, dptr<int>(total));
+    Ac.nnz = read_int(dptr<int>(total), st);
+    Ac.col.alloc((size_t)std::max<int64_t>(Ac.nnz, 1) * sizeof(int));
+    Ac.val.alloc((size_t)std::max<int64_t>(Ac.nnz, 1) * sizeof(T));
+    hipLaunchKernelGGL((lattice_galerkin_compact_kernel<T>), dim3(grid_for(nc)), dim3(256), 0, st, (int)nc, (const int*)Ac.rp(),
+                       (const int*)dptr<int>(pcol), (const T*)dptr<T>(pval), Ac.ci(), Ac.va());
+    check_launch("lattice Galerkin");
+    CS_HIP(hipStreamSynchronize(st));
+  }
+  pl.release();
+  apl.release();
+  // the two-product level: index-free Q and S in lattice form
+  L.Ql.n = n;
+  L.Ql.R = R;
+  L.Ql.C = C;
+  L.Ql.Rc = Rc;
+  L.Ql.Cc = Cc;
+  L.Ql.q = std::move(ql);
+  dia_build_s(A0, (const T*)dptr<T>(L.dinv), L.omega, L.Sdia, st);
+  H.levels.clear();
+  H.levels.push_back(std::move(L));
+  H.levels.emplace_back();
+  H.levels.back().A = std::move(Ac);
+  carry.size = std::move(size_c);
+  carry.gridR = Rc;
+  carry.gridC = Cc;
+  return true;
+}
+
+}  // namespace csgpu

@@ -26,8 +26,15 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
   for (size_t l = 0; l < H.levels.size(); ++l) {
     Level<T>& L = H.levels[l];
     const size_t elems = (size_t)std::max(L.A.nrows, 1) * K;
-    L.xa.alloc(elems * sizeof(T));
-    L.rb.alloc(elems * sizeof(T));
+    if (l == 0 && L.lattice_two_product()) {
+      // the two marching products of an index-free level read b and write out directly (n x K x 2 vectors saved: 25.6 GB
+      // at 10000^2, K = 16, fp64); the generic branch of vcycle() allocates them should it ever run on this level
+      L.xa.release();
+      L.rb.release();
+    } else {
+      L.xa.alloc(elems * sizeof(T));
+      L.rb.alloc(elems * sizeof(T));
+    }
     L.qs.release();  // third buffer, allocated on demand by levels that run more than one post-smoothing sweep
     if (l > 0)
       L.b.alloc(2 * elems * sizeof(T));  // [0, elems): restricted rhs, [elems, 2*elems): this level's solution
@@ -159,6 +166,12 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
       hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
                          (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
     return;
+  }
+  if (!(l == 0 && fuse && fuse->b_has_tail && nu_pre == 1 && nu_post == 1 && L.two_product()) &&
+      (L.xa.bytes < (size_t)n * K * sizeof(T) || L.rb.bytes < (size_t)n * K * sizeof(T))) {
+    CS_REQUIRE(L.A.nnz > 0 || last, CSGPU_INTERNAL, "generic V-cycle branch on a level without a CSR matrix");
+    L.xa.alloc((size_t)n * K * sizeof(T));  // (level 0 of an index-free hierarchy running the generic branch)
+    L.rb.alloc((size_t)n * K * sizeof(T));
   }
   T* cur = dptr<T>(L.xa);
   T* oth = dptr<T>(L.rb);
@@ -396,8 +409,9 @@ struct PcgWork {
     p2.release();
     r.alloc(bytes + (SAME ? (size_t)tail * K * sizeof(T) : 0));
     p.alloc((size_t)n * K * sizeof(TP));
-    Ap.alloc(bytes);
-    b.alloc(bytes);
+    Ap.release();  // A p is stored only when the residual update does not recompute it, b only when the caller hands the
+    b.release();   // right-hand side over in it: both allocated on first need (need_vec) -- 2 x n x K x sizeof(T) saved on
+                   // the resistance-only lattice path
     z.alloc((size_t)n * K * sizeof(TP));
     if (!SAME) rp.alloc((size_t)(n + tail) * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
@@ -409,6 +423,16 @@ struct PcgWork {
     part_ca.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
     part_cc.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
   }
+  // b / Ap on demand (see ensure)
+  T* need_vec(DBuf& v) {
+    const size_t bytes = (size_t)n * K * sizeof(T);
+    if (v.bytes < bytes) {
+      drop_graphs();
+      v.alloc(bytes);
+    }
+    return (T*)v.p;
+  }
+  T* rhs() { return need_vec(b); }
   // focal nodes of the next solve (host ids); values land in xf[m*K + c]
   void set_focal(const std::vector<int>& nodes, hipStream_t st) {
     nf = (int)nodes.size();
@@ -465,8 +489,6 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   T* x = need_x ? dptr<T>(W.x) : nullptr;
   T* r = dptr<T>(W.r);
   TP* pbuf[2] = {dptr<TP>(W.p), use_dia ? dptr<TP>(W.p2) : dptr<TP>(W.p)};
-  T* Ap = dptr<T>(W.Ap);
-  const T* b = dptr<T>(W.b);
   TP* z = dptr<TP>(W.z);
   TP* rp = MIXED ? dptr<TP>(W.rp) : (TP*)r;
   CgScalars* S = dptr<CgScalars>(W.scalars);
@@ -500,6 +522,10 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // instead of the product kernel writing A p and the update reading it back (2 x sizeof(T) per vector element)
   static const bool no_recompute = getenv("CSGPU_NO_RECOMPUTE") != nullptr;  // A/B knob
   const bool recompute = use_dia && !fuse_xa && !no_recompute;
+  // A p is stored unless the residual update recomputes it; the explicit post-check of a carried solution uses the
+  // buffer too. b is read unless the caller wrote the right-hand side straight into r.
+  T* Ap = (!recompute || need_x) ? W.need_vec(W.Ap) : (T*)nullptr;
+  const T* b = pp.rhs_in_r ? (const T*)nullptr : (const T*)W.need_vec(W.b);
   VcycleFuse<TP> fuse;
   fuse.b_has_tail = two_product;
   fuse.dotw = rp;
