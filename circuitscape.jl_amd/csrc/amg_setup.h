@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256) void spgemm_tentative_kernel(int n, const int*
     int m = 0;
     for (int k = rp[i]; k < rp[i + 1]; ++k) {
       const int j = ci[k];
+      if (tva[j] == T(0)) continue;  // a weightless row (cell-space hierarchies) belongs to no aggregate: no entry
       const int a = agg[j];
       const T v = FILL ? va[k] * tva[j] : T(0);
       int q = 0;
@@ -518,7 +519,7 @@ inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st);
 // C = A * T (see above); falls back to the general SpGEMM when a row of A is longer than the register list
 template <class T>
 inline void spgemm_tentative(const Csr<T>& A, const Csr<T>& Tm, const int* agg, Csr<T>& C, hipStream_t st) {
-  constexpr int MAXL = 16;
+  constexpr int MAXL = 32;  // (rows of a cell-space level hold up to 25 entries)
   static const bool off = getenv("CSGPU_NO_DIRECT_AT") != nullptr;  // A/B knob
   if (off || max_row_len(A, st) > MAXL) return spgemm(A, Tm, C, st);
   const int n = A.nrows;
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(256) void smooth_prolongator_kernel(int n, const in
                                                                  const int* __restrict__ ci, T* __restrict__ va,
                                                                  const int* __restrict__ agg, const T* __restrict__ tva,
                                                                  const T* __restrict__ labs, double omega_p,
-                                                                 int* __restrict__ missing) {
+                                                                 int* __restrict__ missing,
+                                                                 const long long* __restrict__ size_f = nullptr) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const double l = (double)labs[i];
     const double w = l != 0.0 ? omega_p / l : 0.0;
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256) void smooth_prolongator_kernel(int n, const in
       }
       va[k] = (T)v;
     }
-    if (!found) atomicAdd(missing, 1);
+    if (!found && !(size_f && size_f[i] == 0)) atomicAdd(missing, 1);  // (a weightless row has no entry at all)
   }
 }
 
@@ -982,11 +984,15 @@ __device__ __forceinline__ void tile_extent(int t, int nt, int len, int& lo, int
   hi = t == nt - 1 ? len : 3 * t + 3;
 }
 
+// full_connected: a tile whose rows all carry weight is connected without looking (true on the raster's own level, where
+// adjacent valid cells are always coupled; NOT on coarser levels, where two non-empty tiles next to each other may lie on
+// the two sides of a NODATA line)
 template <class T, int PASS>
 __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, int Cc, const int* __restrict__ rp,
                                                           const int* __restrict__ ci, const T* __restrict__ va,
                                                           long long* __restrict__ size_f, signed char* __restrict__ piece,
-                                                          signed char* __restrict__ mainlab, int* __restrict__ agg) {
+                                                          signed char* __restrict__ mainlab, int* __restrict__ agg,
+                                                          int full_connected) {
   const int ntiles = Rc * Cc;
   for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
     const int I = tile % Rc, J = tile / Rc;
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
           lab[kc * h + kr] = valid ? kc * h + kr : -1;
           nvalid += valid ? 1 : 0;
         }
-      if (nvalid > 0 && nvalid < h * w) {  // (a full tile is connected: adjacent valid cells are always coupled)
+      if (nvalid > 0 && (nvalid < h * w || !full_connected)) {
         for (int sweep = 0; sweep < 16; ++sweep) {
           bool changed = false;
           for (int kc = 0; kc < w; ++kc)
@@ -1074,9 +1080,12 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
 
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
 // size_f (may be null): weight of every row (cell-space rasters: 0 for the rows of NODATA cells / empty tiles). With
-// weights the regular tiles are used on the raster's own level only (`cell_level`: rows are the cells in column-major
-// order), refined by the piece analysis above (which may zero further weights); deeper levels take the MIS(2) path,
-// where weightless rows seed and join nothing.
+// weights the regular tiles are refined by the piece analysis above (which may zero further weights) -- on EVERY level:
+// the tiles of level l are the rows of level l + 1 in column-major order again, so a cell-space hierarchy has the level
+// sizes of the all-valid raster's, empty tiles riding along as weightless rows (a diagonal entry, nothing else).
+// (Measured on MI355X, 15 % random NODATA: MIS(2) on the levels below the raster's own made the iteration count grow
+// with the raster, 17 at 3000^2 and 32 at 10000^2; profiles/r3_nodata_*.) In the MIS(2) path weightless rows seed and
+// join nothing.
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
                      DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0, long long* size_f = nullptr,
@@ -1084,8 +1093,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
   const int n = A.nrows;
   const double theta2 = theta * theta;
   static const bool no_direct_tiles = getenv("CSGPU_NO_DIRECT_TILES") != nullptr;  // A/B knob
-  if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n &&
-      (!size_f || cell_level)) {
+  if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n) {
     const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
     agg.alloc((size_t)n * sizeof(int));
     crow.alloc((size_t)Rc * Cc * sizeof(int));
@@ -1097,9 +1105,9 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
       DBuf piece((size_t)n), mainlab((size_t)Rc * Cc);
       const int gt = grid_for((int64_t)Rc * Cc);
       hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
       hipLaunchKernelGGL((tile_pieces_kernel<T, 2>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
       check_launch("tile pieces");
       CS_HIP(hipStreamSynchronize(st));  // piece / mainlab are released on return
     }
@@ -1309,7 +1317,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
     DBuf missing = dalloc<int>(1);
     CS_HIP(hipMemsetAsync(missing.p, 0, sizeof(int), st));
     hipLaunchKernelGGL((smooth_prolongator_kernel<T>), dim3(g), dim3(256), 0, st, n, L.P.rp(), L.P.ci(), L.P.va(),
-                       dptr<int>(agg), Tm.va(), dptr<T>(labs), sp.omega_p, dptr<int>(missing));
+                       dptr<int>(agg), Tm.va(), dptr<T>(labs), sp.omega_p, dptr<int>(missing), (const long long*)wts);
     check_launch("smooth prolongator");
     CS_REQUIRE(read_int(dptr<int>(missing), st) == 0, CSGPU_BAD_ARGS,
                "matrix has rows without a stored diagonal entry (not a graph Laplacian)");

@@ -502,7 +502,7 @@ def run_fixture_device_graph(case, solver):
 def check_direct_tentative_product(libpath, shape=(61, 47), seed=3):
     """amg_setup.h spgemm_tentative (one thread per row, aggregates merged in registers) against the general SpGEMM it
     replaces for A * T: the knob is read once per process, so both hierarchies are built in child processes and the
-    prolongators / Galerkin operators of every level compared here. Same sparsity bit for bit; values to rounding (the
+    prolongators / Galerkin operators of every level compared here. Same sparsity (stored zeros aside); values to rounding (the
     general kernel adds in hash order). A network graph with a hub of degree > 16 covers the fallback."""
     import json, os, subprocess, sys, tempfile, textwrap
     import scipy.sparse as sp
@@ -551,11 +551,21 @@ def check_direct_tentative_product(libpath, shape=(61, 47), seed=3):
     a, b = res["direct"], res["general"]
     assert set(a) == set(b) and int(a["raster_levels"][0]) >= 3 and int(a["hub_levels"][0]) >= 2
     for k in a:
-        if k.endswith("_v"):
-            assert a[k].shape == b[k].shape, k
-            assert np.max(np.abs(a[k] - b[k])) <= 1e-13 * np.max(np.abs(b[k])), k
-        else:
-            assert np.array_equal(a[k], b[k]), k
+        if not k.endswith("_p"):
+            continue
+        # compared as matrices without stored zeros: the direct kernel writes no entry for a weightless column (NODATA
+        # cell of a cell-space raster), the general SpGEMM keeps it as an explicit 0
+        def mat(d):
+            p_, i_, v_ = d[k], d[k[:-2] + "_i"], d[k[:-2] + "_v"]
+            ncol = int(i_.max()) + 1 if len(i_) else 1
+            M = sp.csr_matrix((v_, i_, p_), shape=(len(p_) - 1, ncol))
+            M.eliminate_zeros()
+            M.sort_indices()
+            return M
+        Ma, Mb = mat(a), mat(b)
+        assert Ma.shape == Mb.shape, k
+        assert np.array_equal(Ma.indptr, Mb.indptr) and np.array_equal(Ma.indices, Mb.indices), k
+        assert np.max(np.abs(Ma.data - Mb.data)) <= 1e-13 * np.max(np.abs(Mb.data)), k
 
 
 def check_coarse_tail(L, shapes=((150, 131),), batches=(1, 4, 16), pbs=(0, 4), monkeypatch=None):
@@ -866,3 +876,53 @@ def check_cellspace(L, oracle, shape=(70, 61), batch=4, monkeypatch=None):
             # (measured: fewer); 4-neighbour rasters with holes leave 3 x 3 tiles poorly connected inside (measured +20 %
             # iterations at 2-3x cheaper iterations)
             assert a["iters"] <= (1.45 if four else 1.3) * b["iters"] + batch, (a["iters"], b["iters"])
+
+
+def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))):
+    """lattice_setup.h (level 0 built from the raster without a CSR matrix) against the CSR pipeline of amg_setup.h
+    (CSGPU_NO_DIRECT_LATTICE=1) on the same rasters: all-valid and with NODATA (cell space), 8- and 4-neighbour, averaged
+    resistances, fp64 and fp32 hierarchy. Same level sizes, the same Galerkin operator on level 1 up to rounding (the
+    lattice pipeline drops entries that are numerically zero), the same resistances and iteration counts, the same
+    matrix and the same products through the boundary hooks (which build the CSR form on demand)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    for (R, C) in shapes:
+        for holes, four, avg in ((False, False, False), (True, False, False), (True, True, False), (False, True, True)):
+            g = _nodata_raster((R, C), R + C, wall=True) if holes else np.exp(rng.standard_normal((R, C)))
+            out = {}
+            for mode in ("lattice", "csr"):
+                if mode == "csr":
+                    monkeypatch.setenv("CSGPU_NO_DIRECT_LATTICE", "1")
+                else:
+                    monkeypatch.delenv("CSGPU_NO_DIRECT_LATTICE", raising=False)
+                for pb in (0, 4):
+                    with L.raster_setup(g, L.default_opts(batch=4, precond_bytes=pb), four_neighbors=four,
+                                        avg_resistances=avg) as h:
+                        info = h.info
+                        assert info["lattice_period"] == R and info["level_n"][0] == R * C
+                        labels, nc = h.components()
+                        big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                        ids = np.random.default_rng(5).choice(big, size=8, replace=False)
+                        src, dst = [int(v) for v in ids[:4]], [int(v) for v in ids[4:]]
+                        Rr, _, _, st = h.solve_pairs(src, dst)                       # resistance-only: no CSR form needed
+                        Rv, _, volt, st2 = h.solve_pairs(src[:2], dst[:2], want_voltages=True)   # builds it on demand
+                        A0 = h.level_matrix(0, "A")
+                        A1 = h.level_matrix(1, "A")
+                        x = rng.standard_normal(info["n"])
+                        y = h.spmv(x.copy())
+                        assert st["not_converged"] == 0 and st2["not_converged"] == 0
+                        out[(mode, pb)] = dict(info=info, R=Rr, Rv=Rv, volt=volt, A0=A0, A1=A1, x=x, y=y, it=st["total_iters"])
+            monkeypatch.delenv("CSGPU_NO_DIRECT_LATTICE", raising=False)
+            for pb in (0, 4):
+                a, b = out[("lattice", pb)], out[("csr", pb)]
+                for key in ("n", "nnz", "levels"):
+                    assert a["info"][key] == b["info"][key], key
+                assert a["info"]["level_n"] == b["info"]["level_n"]
+                assert abs(a["A0"] - b["A0"]).max() <= 4e-16 * abs(b["A0"]).max()     # (the regularisation shift's last bit)
+                tol = 1e-13 if pb == 0 else 2e-6
+                assert abs(a["A1"] - b["A1"]).max() <= tol * abs(b["A1"]).max()
+                assert a["A1"].nnz <= b["A1"].nnz
+                assert np.max(np.abs(a["R"] - b["R"]) / b["R"]) < (1e-10 if pb == 0 else 1e-6)
+                assert np.max(np.abs(a["Rv"] - a["R"][:2]) / a["R"][:2]) < 1e-6
+                assert abs(a["it"] - b["it"]) <= (0 if pb == 0 else 2)
+                assert np.allclose(a["y"], a["A0"] @ a["x"], rtol=1e-12, atol=1e-12)

@@ -1100,3 +1100,9 @@ def test_cellspace_raster_is_indistinguishable_at_the_boundary(emu_lib, oracle, 
     """lattice kernels for rasters with NODATA (see helpers.check_cellspace)"""
     from helpers import check_cellspace
     check_cellspace(emu_lib, oracle, shape=(46, 43), batch=4, monkeypatch=monkeypatch)
+
+
+def test_lattice_pipeline_matches_csr_pipeline(emu_lib, monkeypatch):
+    """see helpers.check_lattice_pipeline"""
+    from helpers import check_lattice_pipeline
+    check_lattice_pipeline(emu_lib, monkeypatch, shapes=((37, 41), (48, 36)))

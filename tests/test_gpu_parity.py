@@ -462,3 +462,9 @@ def test_nodata_raster_2000_lattice_kernels_vs_tight_oracle(gpu_lib, oracle, mon
         assert np.max(np.abs(Rc - res[("compact", pb)][0]) / Rc) < 1e-6
         assert itc <= 1.3 * res[("all-valid", pb)][1] + 0.5, (itc, res[("all-valid", pb)][1])
         assert itc <= res[("compact", pb)][1] + 0.5, (itc, res[("compact", pb)][1])
+
+
+def test_lattice_pipeline_matches_csr_pipeline_gpu(gpu_lib, monkeypatch):
+    """level 0 built from the raster without a CSR matrix (lattice_setup.h) == the CSR pipeline: helpers.check_lattice_pipeline"""
+    from helpers import check_lattice_pipeline
+    check_lattice_pipeline(gpu_lib, monkeypatch, shapes=((301, 250), (264, 370)))
