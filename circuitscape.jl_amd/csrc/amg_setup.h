@@ -973,12 +973,14 @@ __global__ __launch_bounds__(256) void tile_aggregate_kernel(int n, const int* _
 //   pass 1: label the pieces the tile's cells form under the couplings stored in A; the largest piece (ties: the one
 //           holding the smallest cell id) is the tile's MAIN piece and keeps the tile's aggregate;
 //   pass 2: every cell of another piece joins the aggregate of the neighbouring tile whose main piece it is most strongly
-//           coupled to DIRECTLY; a cell without such a coupling weighs 0 (it is interpolated from its neighbours by the
-//           prolongator smoothing, like the F-points of classical AMG).
+//           coupled to DIRECTLY;
+//   pass 3: what is left over joins the aggregate of an attached neighbour (tile_orphans_kernel below).
 // An aggregate thus reaches exactly one cell into the next tile: a row of Q = P - w D^-1 A P sees the aggregates of the
 // cells within distance 2, each of which holds a cell within distance 3 of the row's cell -- inside the 3 x 3 block of
 // tiles around the row's own tile, so the index-free form (lattice.h) survives. (Moving a piece as a whole does not:
 // its far end can be three cells from the tile it joins.)
+constexpr int kPieceAttached = 100;  // piece[] value of a cell attached to a neighbouring tile's aggregate (+ round of pass 3)
+constexpr int kOrphanRounds = 3;
 __device__ __forceinline__ void tile_extent(int t, int nt, int len, int& lo, int& hi) {
   lo = 3 * t;
   hi = t == nt - 1 ? len : 3 * t + 3;
@@ -1071,9 +1073,71 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
               target = nt;
             }
           }
-          if (target >= 0) agg[cell] = target;
-          else size_f[cell] = 0;
+          if (target >= 0) {
+            agg[cell] = target;
+            piece[cell] = kPieceAttached;  // (never equal to a main label: other tiles' threads still read it as "not main")
+          }
         }
+    }
+  }
+}
+
+// pass 3, rounds 1 .. kOrphanRounds: a cell pass 2 left over (an ORPHAN: outside its tile's main piece, not coupled to
+// the main piece of any neighbouring tile) adopts the aggregate of the attached cell it is most strongly coupled to --
+// attached by pass 2 or by an earlier round, so the result does not depend on the order the threads run in. After the
+// last round an orphan without any coupling (an island of one cell) weighs 0; a COUPLED one keeps its tile's aggregate:
+// a coupled row without weight is a row on which the coarse space cannot represent the constant, and every such row
+// costs the hierarchy its near-kernel (measured: ONE of them among 76 697 nodes lifts the smallest eigenvalue of the
+// level-1 operator from 6e-13 to 2e-7 of the largest, and a 1000 x 1000 raster with 15 % NODATA then needs 27 iterations
+// for distant pairs instead of 13).
+template <class T>
+__global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc, int Cc, const int* __restrict__ rp,
+                                                           const int* __restrict__ ci, const T* __restrict__ va,
+                                                           long long* __restrict__ size_f, signed char* __restrict__ piece,
+                                                           const signed char* __restrict__ mainlab, int* __restrict__ agg,
+                                                           int round, int last, int C, int constrain) {
+  for (int cell = blockIdx.x * 256 + threadIdx.x; cell < n; cell += gridDim.x * 256) {
+    const int pc = piece[cell];
+    if (pc < 0 || pc >= kPieceAttached) continue;
+    const int i = cell % R, j = cell / R;
+    const int I = min(i / 3, Rc - 1), J = min(j / 3, Cc - 1);
+    if (pc == mainlab[J * Rc + I]) continue;
+    // constrain (the raster's own level, whose Q is kept index-free): the adopted tile must lie within one tile of every
+    // row within two cells of this one (dia_orphans_kernel in lattice_setup.h is the same rule on the lattice form)
+    int Ilo = 0, Ihi = Rc - 1, Jlo = 0, Jhi = Cc - 1;
+    if (constrain) {
+      int r0, r1, c0, c1;
+      tile_extent(I, Rc, R, r0, r1);
+      tile_extent(J, Cc, C, c0, c1);
+      const bool up = i - r0 <= 1 && I > 0, dn = r1 - 1 - i <= 1 && I < Rc - 1;
+      const bool lf = j - c0 <= 1 && J > 0, rt = c1 - 1 - j <= 1 && J < Cc - 1;
+      Ilo = dn ? I : I - 1;
+      Ihi = up ? I : I + 1;
+      Jlo = rt ? J : J - 1;
+      Jhi = lf ? J : J + 1;
+    }
+    int target = -1;
+    double best = 0.0;
+    bool coupled = false;
+    for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
+      const int nb = ci[e];
+      if (nb == cell || va[e] == T(0)) continue;
+      coupled = true;
+      const int pn = piece[nb];
+      if (pn < kPieceAttached || pn >= kPieceAttached + round) continue;
+      const int ta = agg[nb], tI = ta % Rc, tJ = ta / Rc;
+      if (tI < Ilo || tI > Ihi || tJ < Jlo || tJ > Jhi) continue;
+      const double a = fabs((double)va[e]);
+      if (a > best) {
+        best = a;
+        target = ta;
+      }
+    }
+    if (target >= 0) {
+      agg[cell] = target;
+      piece[cell] = (signed char)(kPieceAttached + round);
+    } else if (last && !coupled) {
+      size_f[cell] = 0;
     }
   }
 }
@@ -1108,6 +1172,10 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
                          size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
       hipLaunchKernelGGL((tile_pieces_kernel<T, 2>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
                          size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
+      for (int round = 1; round <= kOrphanRounds; ++round)
+        hipLaunchKernelGGL((tile_orphans_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, n, gridR, Rc, Cc, A.rp(), A.ci(),
+                           A.va(), size_f, (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
+                           round == kOrphanRounds ? 1 : 0, gridC, cell_level ? 1 : 0);
       check_launch("tile pieces");
       CS_HIP(hipStreamSynchronize(st));  // piece / mainlab are released on return
     }

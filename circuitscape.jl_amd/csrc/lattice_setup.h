@@ -290,9 +290,61 @@ __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, i
               target = nt;
             }
           }
-          if (target >= 0) agg[cell] = target;
-          else size_f[cell] = 0;
+          if (target >= 0) {
+            agg[cell] = target;
+            piece[cell] = kPieceAttached;  // (never equal to a main label: other tiles' threads still read it as "not main")
+          }
         }
+    }
+  }
+}
+
+// pass 3 of the piece analysis (rounds 1, 2, ...; see tile_orphans_kernel in amg_setup.h) on the lattice form. An orphan
+// may only adopt an aggregate that keeps Q inside the 3 x 3 block of tiles of every row that sees it: rows within two
+// cells of the orphan lie in the tile above when the orphan sits in the first two rows of its tile, in the tile below
+// when it sits in the last two; the adopted tile must be within one tile of all of them (same for columns).
+template <class U>
+__global__ __launch_bounds__(256) void dia_orphans_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
+                                                          long long* __restrict__ size_f, signed char* __restrict__ piece,
+                                                          const signed char* __restrict__ mainlab, int* __restrict__ agg,
+                                                          int round, int last) {
+  const int64_t n = (int64_t)R * C;
+  for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < n; cell += (int64_t)gridDim.x * 256) {
+    const int pc = piece[cell];
+    if (pc < 0 || pc >= kPieceAttached) continue;
+    const int i = (int)(cell % R), j = (int)(cell / R);
+    const int I = lat_tile(i, Rc), J = lat_tile(j, Cc);
+    if (pc == mainlab[J * Rc + I]) continue;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const bool up = i - r0 <= 1 && I > 0, dn = r1 - 1 - i <= 1 && I < Rc - 1;
+    const bool lf = j - c0 <= 1 && J > 0, rt = c1 - 1 - j <= 1 && J < Cc - 1;
+    const int Ilo = dn ? I : I - 1, Ihi = up ? I : I + 1, Jlo = rt ? J : J - 1, Jhi = lf ? J : J + 1;
+    int target = -1;
+    double best = 0.0;
+    bool coupled = false;
+    for (int k = 0; k < 9; ++k) {
+      if (k == 4) continue;
+      int64_t nb;
+      const U v = dia_row_entry(rows, n, R, cell, k, nb);
+      if (v == U(0)) continue;
+      coupled = true;
+      const int pn = piece[nb];
+      if (pn < kPieceAttached || pn >= kPieceAttached + round) continue;  // attached in an EARLIER round (deterministic)
+      const int ta = agg[nb], tI = ta % Rc, tJ = ta / Rc;
+      if (tI < Ilo || tI > Ihi || tJ < Jlo || tJ > Jhi) continue;
+      const double a = fabs((double)v);
+      if (a > best) {
+        best = a;
+        target = ta;
+      }
+    }
+    if (target >= 0) {
+      agg[cell] = target;
+      piece[cell] = (signed char)(kPieceAttached + round);
+    } else if (last && !coupled) {
+      size_f[cell] = 0;  // an island of one cell: no aggregate (a COUPLED cell left over keeps its tile's)
     }
   }
 }
@@ -568,6 +620,10 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
                        (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
     hipLaunchKernelGGL((dia_pieces_kernel<U, 2>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
                        (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
+    for (int round = 1; round <= kOrphanRounds; ++round)
+      hipLaunchKernelGGL((dia_orphans_kernel<U>), dim3(g), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                         (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
+                         round == kOrphanRounds ? 1 : 0);
     check_launch("tile pieces (lattice)");
     CS_HIP(hipStreamSynchronize(st));
   }

@@ -468,3 +468,24 @@ def test_lattice_pipeline_matches_csr_pipeline_gpu(gpu_lib, monkeypatch):
     """level 0 built from the raster without a CSR matrix (lattice_setup.h) == the CSR pipeline: helpers.check_lattice_pipeline"""
     from helpers import check_lattice_pipeline
     check_lattice_pipeline(gpu_lib, monkeypatch, shapes=((301, 250), (264, 370)))
+
+
+def test_raster_above_2_31_stored_entries(gpu_lib):
+    """21000 x 21000 = 441 M cells (the reference documents 437 M as tested, docs/src/compute.md:3): 3.97e9 stored entries,
+    no int32 CSR form -- the index-free pipeline (lattice_setup.h) sets it up and the marching kernels solve on it with
+    64-bit element offsets. Size-independent properties: symmetry of independently solved reversed pairs, triangle
+    inequality, the reference's residual check (core.jl:640); then the same with 10 % NODATA cells (cell space)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from big_raster import run
+    for holes in (0.0, 0.1):
+        o = run(21000, 4, holes, 4, lib=gpu_lib)
+        assert o["cells"] == 441000000 and o["lattice_period"] == 21000
+        assert (o["n"] == o["cells"]) == (holes == 0.0)
+        assert o["stored_entries"] > 2 ** 31
+        assert o["not_converged"] == 0 and o["max_relres"] < 1e-4
+        assert all(r > 0 for r in o["R"])
+        assert o["symmetry_rel"] < 1e-6 and o["triangle_slack"] > -1e-9
+        assert o["iters_max"] <= (14 if holes == 0.0 else 20), o["iters_max"]
+        gpu_lib.trim_memory()
