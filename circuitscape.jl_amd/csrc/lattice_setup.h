@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void raster_maps_kernel(int R, int C, const T*
 // ---- row statistics (row_stats_kernel + dinv_kernel of amg_setup.h on the lattice form) -------------------------------
 template <class U, class T>
 __global__ __launch_bounds__(256) void dia_stats_kernel(int64_t n, int R, const U* __restrict__ rows, T* __restrict__ labs,
-                                                        T* __restrict__ dinv, double* __restrict__ part_max) {
-  __shared__ double sm[4];
-  double mx = 0.0;
+                                                        double* __restrict__ part_max, double* __restrict__ part_dmax) {
+  __shared__ double sm[4], smd[4];
+  double mx = 0.0, dmx = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T l = T(0), d = T(0);
 #pragma unroll
@@ -172,20 +172,39 @@ __global__ __launch_bounds__(256) void dia_stats_kernel(int64_t n, int R, const 
       l += v < T(0) ? -v : v;
     }
     labs[i] = l;
-    dinv[i] = d != T(0) ? T(1) / d : T(0);
     const double ad = d < T(0) ? -(double)d : (double)d;
     if (ad > 0.0) {
       const double q = (double)l / ad;
       mx = q > mx ? q : mx;
     }
+    dmx = ad > dmx ? ad : dmx;
   }
   mx = wave_max(mx);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  dmx = wave_max(dmx);
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6] = mx;
+    smd[threadIdx.x >> 6] = dmx;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double m = sm[0];
-    for (int w = 1; w < 4; ++w) m = sm[w] > m ? sm[w] : m;
+    double m = sm[0], md = smd[0];
+    for (int w = 1; w < 4; ++w) {
+      m = sm[w] > m ? sm[w] : m;
+      md = smd[w] > md ? smd[w] : md;
+    }
     part_max[blockIdx.x] = m;
+    part_dmax[blockIdx.x] = md;
+  }
+}
+
+// dinv_kernel of amg_setup.h (see there: no pivot on an isolated row below the floor) on the lattice form
+template <class U, class T>
+__global__ __launch_bounds__(256) void dia_dinv_kernel(int64_t n, const U* __restrict__ rows, const T* __restrict__ labs,
+                                                       double floor_, T* __restrict__ dinv) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const T d = (T)rows[i * 5];
+    const bool isolated = labs[i] <= (d < T(0) ? -d : d);
+    dinv[i] = (d > T(0) && !(isolated && (double)d <= floor_)) ? T(1) / d : T(0);
   }
 }
 
@@ -594,15 +613,20 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   L.A.nrows = L.A.ncols = (int)n;  // (no CSR arrays: the level is index-free)
   L.n = (int)n;
   // row statistics
-  DBuf labs((size_t)n * sizeof(T)), part = dalloc<double>(g);
+  DBuf labs((size_t)n * sizeof(T)), part = dalloc<double>(2 * (size_t)g);
   L.dinv.alloc((size_t)n * sizeof(T));
-  hipLaunchKernelGGL((dia_stats_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, A0.data(), dptr<T>(labs), dptr<T>(L.dinv),
-                     dptr<double>(part));
-  std::vector<double> hp(g);
-  CS_HIP(hipMemcpyAsync(hp.data(), part.p, (size_t)g * sizeof(double), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL((dia_stats_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, A0.data(), dptr<T>(labs), dptr<double>(part),
+                     dptr<double>(part) + g);
+  std::vector<double> hp(2 * (size_t)g);
+  CS_HIP(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
-  double rho = 0;
-  for (double v : hp) rho = std::max(rho, v);
+  double rho = 0, dmax = 0;
+  for (int b = 0; b < g; ++b) {
+    rho = std::max(rho, hp[b]);
+    dmax = std::max(dmax, hp[(size_t)g + b]);
+  }
+  hipLaunchKernelGGL((dia_dinv_kernel<U, T>), dim3(g), dim3(256), 0, st, n, A0.data(), (const T*)dptr<T>(labs),
+                     64.0 * (double)std::numeric_limits<T>::epsilon() * dmax, dptr<T>(L.dinv));
   if (!(rho > 0)) rho = 1.0;
   L.rho = rho;
   L.omega = sp.omega_s / rho;
