@@ -223,8 +223,9 @@ Effective resistance between short-circuited node sets on ONE hierarchy (csgpu_s
 Returns R (-1: no current flows between the two sets).
 """
 function solve_region_pairs(factor::HIPFactor, sets::Vector{Vector{Int64}}, pairs::Vector{Tuple{Int,Int}})
+    isempty(pairs) && return Float64[], CsgpuStats()
     sptr = Int64[0; cumsum(length.(sets))]
-    snodes = reduce(vcat, sets) .- 1
+    snodes = isempty(sets) ? Int64[] : reduce(vcat, sets) .- 1
     a = Int64[p[1] - 1 for p in pairs]
     b = Int64[p[2] - 1 for p in pairs]
     R = zeros(Float64, length(pairs))
@@ -291,7 +292,130 @@ function solve_pairs(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst:
     res, gat, st
 end
 
-# solve(prob, ::HIPAMGSolver, flags, cfg, log): identical bookkeeping to solve(prob, ::AMGSolver, ...) (core.jl:96-305)
-# except that per connected component the pair list is handed to `solve_pairs` in ONE call (no Threads.@spawn fan-out
-# over blocking ccalls) -- the Python mirror of exactly this method is circuitscape.jl_amd/solver.py::solve and is what
-# the parity tests exercise against the reference's golden files.
+"""
+0-based raster row / column of the first cell (column-major order) of every node of `comp` (sorted global node ids), or
+`nothing` when a node of the component has no cell in `nodemap`.
+"""
+function node_coords(nodemap::Matrix{V}, comp::Vector{V}) where {V}
+    rows = fill(Int32(-1), length(comp)); cols = fill(Int32(-1), length(comp))
+    for j in axes(nodemap, 2), i in axes(nodemap, 1)
+        id = nodemap[i, j]
+        id == 0 && continue
+        k = searchsortedfirst(comp, id)
+        (k <= length(comp) && comp[k] == id && rows[k] < 0) || continue
+        rows[k] = Int32(i - 1); cols[k] = Int32(j - 1)
+    end
+    any(<(0), rows) ? nothing : (rows, cols)
+end
+
+"""
+solve(prob, ::HIPAMGSolver, flags, cfg, log) -- the pairwise kernel behind `single_ground_all_pairs` (src/core.jl:81-83)
+for `solver = hip`. Same results and the same bookkeeping as solve(prob, ::AMGSolver, ...) (src/core.jl:96-305):
+-1 / 0 conventions, `smash_repeats!` for ids sharing a node, exclude pairs, the resistance shortcut (anchor point only,
+`update_voltmatrix!` / `update_shortcut_resistances!`), `postprocess` per id combination, `save_resistances`. What differs
+is the shape of the work: per connected component the hierarchy is built ONCE on the device and the component's whole
+pair list goes down in ONE `solve_pairs` call (batched `s.bs` right-hand sides per pass) instead of one
+`Threads.@spawn` task per source point each cloning the AMG workspace (core.jl:173-180, 262-285).
+`circuitscape.jl_amd/solver.py::solve` is the Python mirror of this method, line for line, and is what the parity
+tests run against the reference's golden files.
+"""
+function solve(prob::GraphProblem{T,V}, s::HIPAMGSolver, flags, cfg, log)::Matrix{T} where {T,V}
+    a = prob.G
+    cc = prob.cc
+    points = prob.points
+    exclude = prob.exclude_pairs
+    orig_pts = prob.user_points
+    of = flags.outputflags
+    numpoints = size(points, 1)
+    cum = prob.cum
+
+    @info("Graph has $(size(a,1)) nodes, $numpoints focal points and $(length(cc)) connected components")
+    num_pairs, _ = get_num_pairs(cc, points, exclude, orig_pts)
+    log && @info("Total number of pair solves = $num_pairs")
+
+    resistances = -1 * ones(T, numpoints, numpoints)
+    voltmatrix = zeros(T, numpoints, numpoints)
+    shortcut_res = deepcopy(resistances)
+
+    use_shortcut = flags.is_raster && !of.write_volt_maps && !of.write_cur_maps && !of.write_cum_cur_map_only &&
+                   !of.write_max_cur_maps && isempty(exclude)
+    if use_shortcut
+        @info("Triggering resistance calculation shortcut")
+        num_pairs, _ = get_num_pairs_shortcut(cc, points, exclude, orig_pts)
+        @info("Total number of pair solves has been reduced to $num_pairs ")
+    end
+    shortcut = Shortcut(use_shortcut, voltmatrix, shortcut_res)
+    want_maps = !use_shortcut && (of.write_volt_maps || of.write_cur_maps || of.write_cum_cur_map_only || of.write_max_cur_maps)
+
+    for comp in cc
+        csub = unique(filter(x -> x in comp, points))
+        isempty(csub) && continue
+
+        matrix = a[comp, comp]
+        matrix.nzval .+= eps(eltype(matrix)) * norm(matrix.nzval)            # core.jl:161
+        n = size(matrix, 1)
+        local_of = Dict{V,Int64}(node => Int64(findfirst(isequal(node), comp)) for node in csub)
+
+        # ---- pair list of the component: one right-hand side per distinct (src_node, dst_node)
+        src0 = Int64[]; dst0 = Int64[]                                       # 0-based local node ids for the device
+        fan = Vector{Vector{Tuple{Int,Int}}}()                               # id combinations served by each solve
+        nsrc = use_shortcut ? 1 : length(csub)                               # shortcut: the anchor point only (core.jl:256-260)
+        for pi in 1:nsrc
+            src_node = csub[pi]
+            src_idx = findall(isequal(src_node), points)
+            use_shortcut || smash_repeats!(resistances, src_idx)            # (the shortcut branch discards them, core.jl:259)
+            for pj in pi+1:length(csub)
+                dst_node = csub[pj]
+                dst_idx = findall(isequal(dst_node), points)
+                combos = [(ci, cj) for ci in src_idx for cj in dst_idx if (orig_pts[ci], orig_pts[cj]) ∉ exclude]
+                isempty(combos) && continue
+                push!(src0, local_of[src_node] - 1); push!(dst0, local_of[dst_node] - 1); push!(fan, combos)
+            end
+        end
+
+        if !isempty(src0)
+            # raster coordinates of the component's nodes seed the aggregation with 3 x 3 tiles (csgpu_opts.node_row/col)
+            coords = (flags.is_raster && !isempty(prob.nodemap)) ? node_coords(prob.nodemap, comp) : nothing
+            factor = @timeit CSTIMER "construct preconditioner" construct_cholesky_factor(matrix, s; coords = coords)
+            focal_in_comp = findall(x -> x in comp, points)
+            gather = use_shortcut ? Int64[findfirst(isequal(points[i]), comp) - 1 for i in focal_in_comp] : Int64[]
+            res, gat, volt, _ = @timeit CSTIMER "solve and accumulate pairs" solve_pairs(factor, T, n, src0, dst0;
+                                                  gather = gather, want_voltages = want_maps)
+            finalize(factor)
+
+            component_data = want_maps ?
+                ComponentData(comp, matrix, construct_local_node_map(prob.nodemap, comp, prob.polymap), prob.hbmeta, prob.cellmap) :
+                nothing
+            for (p, combos) in enumerate(fan)
+                r = res[p]
+                for (ci, cj) in combos
+                    resistances[ci, cj] = r
+                    resistances[cj, ci] = r
+                    if use_shortcut
+                        # update_voltmatrix! (core.jl:685-703) on the focal voltages the device gathered (v - v[src])
+                        for (g, i) in enumerate(focal_in_comp)
+                            i >= 2 && (voltmatrix[i, cj] = 1 - gat[g, p] / r)
+                        end
+                    elseif want_maps
+                        out = Output(points, volt[:, p], (orig_pts[ci], orig_pts[cj]),
+                                     (V(src0[p] + 1), V(dst0[p] + 1)), r, V(cj), cum)
+                        postprocess(out, component_data, flags, shortcut, cfg)
+                    end
+                end
+            end
+        end
+
+        if use_shortcut
+            anchor = findfirst(isequal(csub[1]), points)
+            update_shortcut_resistances!(anchor, shortcut, resistances, points, comp)
+        end
+    end
+
+    use_shortcut && (resistances = shortcut.shortcut_res)
+    for i in 1:numpoints
+        resistances[i, i] = 0
+    end
+    r = vcat(vcat(0, orig_pts)', hcat(orig_pts, resistances))
+    save_resistances(r, cfg)
+    r
+end

@@ -26,28 +26,40 @@ def pair_slice(npairs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_pairs(values, index, npairs, dist=None, device=None):
-    """Full per-pair vector on every rank from each rank's (index, value) list: ONE all_gather of fixed-size slots
-    (the path's only collective; RCCL over xGMI with backend nccl). dist=None: single process."""
+def batch_slot(npairs, batch, world):
+    """largest number of pairs shard_batches gives any rank"""
+    nb = (npairs + batch - 1) // batch
+    return (nb + world - 1) // world * batch
+
+
+def gather_pairs(values, index, npairs, dist=None, device=None, slot=None):
+    """Full per-pair vector on every rank from each rank's (index, value) list: ONE all_gather of fixed-size slots of
+    (index, value) rows padded with index -1 (the path's only collective; RCCL over xGMI with backend nccl).
+    dist=None: single process. Every pair must have been solved by exactly one rank. `slot` = the largest share a rank
+    can hold, known to every rank without communication: ceil(npairs / world) for the contiguous split (pair_slice, the
+    default), ceil(nbatches / world) * batch when whole batches are dealt (batch_slot)."""
     full = np.full(npairs, np.nan)
+    index = np.asarray(index, dtype=np.int64)
     if dist is None or dist.get_world_size() == 1:
-        full[np.asarray(index, dtype=np.int64)] = values
-        return full
-    import torch
-    world = dist.get_world_size()
-    slot = (npairs + world - 1) // world
-    buf = torch.full((slot, 2), -1.0, dtype=torch.float64)
-    if len(index):
-        buf[: len(index), 0] = torch.from_numpy(np.asarray(index, dtype=np.float64))
-        buf[: len(index), 1] = torch.from_numpy(np.asarray(values, dtype=np.float64))
-    if device is not None:
-        buf = buf.to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    for t in out:
-        a = t.cpu().numpy()
-        ok = a[:, 0] >= 0
-        full[a[ok, 0].astype(np.int64)] = a[ok, 1]
+        full[index] = values
+    else:
+        import torch
+        world = dist.get_world_size()
+        slot = max(slot if slot is not None else (npairs + world - 1) // world, 1)
+        assert len(index) <= slot, (len(index), slot)
+        buf = torch.full((slot, 2), -1.0, dtype=torch.float64)
+        if len(index):
+            buf[: len(index), 0] = torch.from_numpy(index.astype(np.float64))
+            buf[: len(index), 1] = torch.from_numpy(np.asarray(values, dtype=np.float64))
+        if device is not None:
+            buf = buf.to(device)
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        for t in out:
+            rows = t.cpu().numpy()
+            ok = rows[:, 0] >= 0
+            full[rows[ok, 0].astype(np.int64)] = rows[ok, 1]
+    assert not np.any(np.isnan(full)), "some pair was not solved by any rank"
     return full
 
 
@@ -60,54 +72,13 @@ def solve_pairs_sharded(handle, src, dst, batch, dist=None, device=None):
     if dist is None or dist.get_world_size() == 1:
         R, _, _, st = handle.solve_pairs(src, dst)
         return np.asarray(R, dtype=np.float64), [st]
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    mine = shard_batches(npairs, batch, rank, world)
+    mine = shard_batches(npairs, batch, dist.get_rank(), dist.get_world_size())
     stats = []
+    R = np.zeros(0)
     if len(mine):
         R, _, _, st = handle.solve_pairs(src[mine], dst[mine])
         stats.append(st)
-    else:
-        R = np.zeros(0)
-    # fixed-size slots so one all_gather moves everything: (index, value) pairs padded with index -1
-    slot = ((npairs + batch - 1) // batch + world - 1) // world * batch
-    buf = torch.full((slot, 2), -1.0, dtype=torch.float64)
-    if len(mine):
-        buf[: len(mine), 0] = torch.from_numpy(mine.astype(np.float64))
-        buf[: len(mine), 1] = torch.from_numpy(np.asarray(R, dtype=np.float64))
-    if device is not None:
-        buf = buf.to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    full = np.full(npairs, np.nan)
-    for t in out:
-        a = t.cpu().numpy()
-        ok = a[:, 0] >= 0
-        full[a[ok, 0].astype(np.int64)] = a[ok, 1]
-    assert not np.any(np.isnan(full)), "some pair was not solved by any rank"
-    return full, stats
-
-
-def _gather_pairs(values, mine, npairs, batch, dist, device):
-    """all_gather of per-pair scalars computed by this rank at global indices `mine` (fixed-size slots)."""
-    import torch
-    world = dist.get_world_size()
-    slot = ((npairs + batch - 1) // batch + world - 1) // world * batch
-    buf = torch.full((slot, 2), -1.0, dtype=torch.float64)
-    if len(mine):
-        buf[: len(mine), 0] = torch.from_numpy(mine.astype(np.float64))
-        buf[: len(mine), 1] = torch.from_numpy(np.asarray(values, dtype=np.float64))
-    if device is not None:
-        buf = buf.to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    full = np.full(npairs, np.nan)
-    for t in out:
-        a = t.cpu().numpy()
-        ok = a[:, 0] >= 0
-        full[a[ok, 0].astype(np.int64)] = a[ok, 1]
-    assert not np.any(np.isnan(full)), "some pair was not solved by any rank"
-    return full
+    return gather_pairs(R, mine, npairs, dist, device, slot=batch_slot(npairs, batch, dist.get_world_size())), stats
 
 
 def solve_pairs_currents_sharded(handle, src, dst, batch, dist=None, device=None, weights=None, want_max=False):
@@ -137,7 +108,7 @@ def solve_pairs_currents_sharded(handle, src, dst, batch, dist=None, device=None
         R, _, _, st = handle.solve_pairs_currents(src[mine], dst[mine], weights=None if w is None else w[mine],
                                                   want_currents=False, cum=cum, mx=mx)
         stats.append(st)
-    full = _gather_pairs(R, mine, npairs, batch, dist, device)
+    full = gather_pairs(R, mine, npairs, dist, device, slot=batch_slot(npairs, batch, world))
     tc = torch.from_numpy(cum)
     tc = tc.to(device) if device is not None else tc
     dist.all_reduce(tc, op=dist.ReduceOp.SUM)

@@ -140,18 +140,6 @@ def multiple_solve(solver, matrix, sources):
     return volt
 
 
-
-
-
-
-
-
-
-
-
-
-
-
 def _edge_weight(x, y, diag, avg_res):
     """construct_graph's edge conductance (raster/pairwise.jl:356-367): mean conductance or mean resistance, /sqrt(2)
     on diagonals."""
@@ -335,14 +323,26 @@ def _colmajor_nonzero(mask):
     return ii, jj
 
 
-
-
-
-
-
-
-
-
+def _construct_node_map(gmap, polymap):
+    """src/raster/pairwise.jl:271-314 (needed by construct_local_node_map when polygons are present)."""
+    gmap = np.asarray(gmap, dtype=np.float64)
+    nodemap = np.zeros(gmap.shape, dtype=np.int64)
+    ii, jj = _colmajor_nonzero(gmap > 0)
+    nodemap[ii, jj] = np.arange(1, len(ii) + 1)
+    if polymap is None or np.size(polymap) == 0:
+        return nodemap
+    polymap = np.asarray(polymap, dtype=np.int64)
+    pruned = np.where(gmap > 0, polymap, 0)
+    for polynum in np.unique(polymap):
+        if polynum == 0:
+            continue
+        i1, j1 = _colmajor_nonzero(pruned == polynum)
+        if len(i1) > 0:
+            nodemap[polymap == polynum] = nodemap[i1[0], j1[0]]
+    ii, jj = _colmajor_nonzero(nodemap != 0)
+    _, inv = np.unique(nodemap[ii, jj], return_inverse=True)
+    nodemap[ii, jj] = inv + 1
+    return nodemap
 
 
 def construct_local_node_map(nodemap, component, polymap):
@@ -356,7 +356,7 @@ def construct_local_node_map(nodemap, component, polymap):
         local = local.copy()
         local[ii, jj] = np.arange(1, len(ii) + 1)
         return local
-    from .hostmirror import _construct_node_map   # polygon case: the reference re-runs construct_node_map (utils.jl:24-29)
+    # polygon case: the reference re-runs construct_node_map (utils.jl:24-29)
     return _construct_node_map((local != 0).astype(float), np.where(local != 0, polymap, 0))
 
 
@@ -377,8 +377,6 @@ def _process_grid(cmap, cellmap, log_transform, set_null_to_nodata):
         cmap = cmap.copy()
         cmap[np.asarray(cellmap) == 0] = -9999.0
     return cmap
-
-
 
 
 def _node_coords(nodemap, comp):
@@ -546,7 +544,6 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
         stats["nsolves"] = stats.get("nsolves", 0) + nsolves
         stats["shortcut"] = bool(get_shortcut)
     if cfg is not None and cfg.get("output_file"):
-        from .hostmirror import save_resistances  # file output is the host side's business (harness only)
         save_resistances(r, cfg["output_file"])
     return r
 
@@ -691,10 +688,6 @@ def raster_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, 
     return out
 
 
-
-
-
-
 def focal_regions_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=False, avg_res=False, exclude_pairs=(),
                                      stats=None, polymap=None):
     """Pairwise mode when focal points are REGIONS (several cells share an id): the reference short-circuits the two
@@ -814,3 +807,23 @@ def focal_regions_pairwise_on_device(cellmap, points_rc, solver, four_neighbors=
     out[1:, 0] = pts
     out[1:, 1:] = res
     return out
+
+
+def compute_3col(r):
+    """out.jl:12-26."""
+    fp = r[1:, 0]
+    l = len(fp)
+    out = np.zeros((l * (l - 1) // 2, 3), dtype=r.dtype)
+    k = 0
+    for i in range(l):
+        for j in range(i + 1, l):
+            out[k] = (fp[i], fp[j], r[j + 1, i + 1])
+            k += 1
+    return out
+
+
+def save_resistances(r, output_file):
+    """out.jl:454-465: <prefix>_resistances.out and <prefix>_resistances_3columns.out."""
+    pref = output_file.split(".out")[0]
+    np.savetxt(pref + "_resistances.out", r, delimiter=" ", fmt="%.10g")
+    np.savetxt(pref + "_resistances_3columns.out", compute_3col(r), delimiter=" ", fmt="%.10g")

@@ -366,7 +366,7 @@ static void extend_hierarchy(Hierarchy<T>& H, Csr<T>& A, std::vector<T>& B, cons
   std::vector<double> scale(nagg);
   for (i64 j = 0; j < nagg; ++j) {
     const double nr = std::sqrt(nrm2[j]);
-    if (nr > 1e-10 * nr) {
+    if (nr > 0.0) {  // (an aggregate whose candidate entries are all zero gets no column)
       scale[j] = 1.0 / nr;
       Bc[j] = (T)nr;
     } else {

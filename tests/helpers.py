@@ -9,7 +9,7 @@ from oracle import refgraph as rg
 
 def to_product_problem(ref, solver, cellmap=None, cum=None):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     return ps.GraphProblem(G=ref.G, cc=ref.cc, points=ref.points, user_points=ref.user_points,
                            exclude_pairs=ref.exclude_pairs, nodemap=ref.nodemap, polymap=ref.polymap, solver=solver,
                            cellmap=cellmap, cum=cum)
@@ -17,7 +17,7 @@ def to_product_problem(ref, solver, cellmap=None, cum=None):
 
 def flags_from_case(case, is_raster):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     o = case.get("options", {})
     of = ps.OutputFlags(write_volt_maps=o.get("write_volt_maps", False), write_cur_maps=o.get("write_cur_maps", False),
                         write_cum_cur_map_only=o.get("write_cum_cur_map_only", False),
@@ -31,7 +31,7 @@ def flags_from_case(case, is_raster):
 def run_fixture(case, solver, stats=None):
     """Returns the padded resistance matrix computed by the product path for a tests/golden fixture."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     if case["kind"] == "network":
         ref = rg.compute_graph_data_network(case["edges_i"], case["edges_j"], case["edges_v"], case["focal"])
         prob = to_product_problem(ref, solver)
@@ -87,7 +87,7 @@ def run_network_advanced_fixture(case, solver):
     """network_advanced (src/network/advanced.jl:1-17) through the product's host mirror."""
     import scipy.sparse as sp
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     ei = np.asarray(case["edges_i"]); ej = np.asarray(case["edges_j"])
     m = int(max(ei.max(), ej.max()))
     A = sp.coo_matrix((np.asarray(case["edges_v"], dtype=np.float64), (ei - 1, ej - 1)), shape=(m, m)).tocsr()
@@ -116,7 +116,7 @@ def run_raster_advanced_fixture(case, solver):
     """raster_advanced (src/raster/advanced.jl:17-34) through the product's host mirror; graph construction is the
     oracle-side restatement (outside the hot-path boundary, stays in the reference)."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     o = case["options"]
     gmap = np.asarray(case["cellmap"], dtype=np.float64)
     polymap = np.asarray(case["polymap"], dtype=np.int64) if case.get("polymap") is not None else None
@@ -148,7 +148,7 @@ def run_onetoall_fixture(case, solver):
     """raster_one_to_all (src/raster/onetoall.jl:1-11) for a oneToAllVerify / allToOneVerify fixture through the
     product's host mirror. Returns (res, cum, per-point maps)."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     o = case["options"]
     flags = flags_from_case(case, True)
     flags.is_onetoall = case["kind"] == "one_to_all"

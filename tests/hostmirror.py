@@ -1,4 +1,4 @@
-"""Host-side harness: Python restatement of the reference's JULIA-SIDE host code around the solver boundary.
+"""TEST HARNESS (lives under tests/): Python restatement of the reference's JULIA-SIDE host code around the solver boundary.
 
 NOT part of the product path. In a real deployment everything in this module keeps running in Circuitscape.jl on its
 side of the C ABI (polygon handling, node maps, one-to-all / all-to-one drivers, the
@@ -20,8 +20,10 @@ from typing import List, Optional
 import numpy as np
 import scipy.sparse as sp
 
-from . import lib
-from .solver import (HIP, Flags, HIPAMGSolver, OutputFlags, _colmajor_nonzero, _process_grid, _scatter, construct_local_node_map, get_solver, initialize_cum_maps, multiple_solve)
+from circuitscape_jl_amd import lib
+from circuitscape_jl_amd.solver import (HIP, Flags, HIPAMGSolver, OutputFlags, _colmajor_nonzero, _construct_node_map,
+                                        _process_grid, _scatter, compute_3col, construct_local_node_map, get_solver,
+                                        initialize_cum_maps, multiple_solve, save_resistances)
 
 def resolve_conflicts(sources, grounds, policy):
     """src/raster/advanced.jl:118-149: finite grounds vector (or [-9999]), source/ground conflicts by policy,
@@ -326,27 +328,6 @@ def raster_advanced_kernel(prob, flags, cfg=None):
     return volt, outcurr, maps
 
 
-def _construct_node_map(gmap, polymap):
-    """src/raster/pairwise.jl:271-314 (needed by construct_local_node_map when polygons are present)."""
-    gmap = np.asarray(gmap, dtype=np.float64)
-    nodemap = np.zeros(gmap.shape, dtype=np.int64)
-    ii, jj = _colmajor_nonzero(gmap > 0)
-    nodemap[ii, jj] = np.arange(1, len(ii) + 1)
-    if polymap is None or np.size(polymap) == 0:
-        return nodemap
-    polymap = np.asarray(polymap, dtype=np.int64)
-    pruned = np.where(gmap > 0, polymap, 0)
-    for polynum in np.unique(polymap):
-        if polynum == 0:
-            continue
-        i1, j1 = _colmajor_nonzero(pruned == polynum)
-        if len(i1) > 0:
-            nodemap[polymap == polynum] = nodemap[i1[0], j1[0]]
-    ii, jj = _colmajor_nonzero(nodemap != 0)
-    _, inv = np.unique(nodemap[ii, jj], return_inverse=True)
-    nodemap[ii, jj] = inv + 1
-    return nodemap
-
 
 def write_cum_maps(cum):
     """postprocess_cum_curmap! (utils.jl:114-120) applied like write_cum_maps does (out.jl:467-481)."""
@@ -354,23 +335,3 @@ def write_cum_maps(cum):
     if cum.max_curr is not None:
         cum.max_curr[cum.max_curr < -9999] = -9999
     return cum
-
-
-def compute_3col(r):
-    """out.jl:12-26."""
-    fp = r[1:, 0]
-    l = len(fp)
-    out = np.zeros((l * (l - 1) // 2, 3), dtype=r.dtype)
-    k = 0
-    for i in range(l):
-        for j in range(i + 1, l):
-            out[k] = (fp[i], fp[j], r[j + 1, i + 1])
-            k += 1
-    return out
-
-
-def save_resistances(r, output_file):
-    """out.jl:454-465: <prefix>_resistances.out and <prefix>_resistances_3columns.out."""
-    pref = output_file.split(".out")[0]
-    np.savetxt(pref + "_resistances.out", r, delimiter=" ", fmt="%.10g")
-    np.savetxt(pref + "_resistances_3columns.out", compute_3col(r), delimiter=" ", fmt="%.10g")

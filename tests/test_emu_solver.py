@@ -12,7 +12,7 @@ from helpers import expected_ids, run_fixture
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden_fixtures_through_product_path(emu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     case = load_case(name)
     st = {}
     got = run_fixture(case, ps.HIPAMGSolver(bs=4), stats=st)
@@ -23,7 +23,7 @@ def test_golden_fixtures_through_product_path(emu_lib, name):
 
 def test_shortcut_and_solve_counts(emu_lib):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     st = {}
     run_fixture(load_case("sgVerify12"), ps.HIPAMGSolver(bs=8), stats=st)
     assert st["shortcut"] and st["nsolves"] == 12
@@ -235,7 +235,7 @@ def test_strength_threshold_does_not_stall_coarsening(emu_lib, oracle, theta):
 def test_network_advanced_through_product_path(emu_lib, name):
     """scope row N2: multiple_solver + multiple_solve(::HIPAMGSolver) on the reference's network advanced fixtures."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import run_network_advanced_fixture
     case = load_case(name)
     got = run_network_advanced_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
@@ -248,7 +248,7 @@ def _check_maps(case, st):
     """scope row N1: cumulative / maximum / per-pair current maps and voltage maps vs the reference's golden .asc files
     (reference criterion: sum(abs2, x - r) < 1e-6, test/test_utils.jl:196)."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     m = case["maps"]
     cum = hm.write_cum_maps(st["cum"])
     o = case["options"]
@@ -274,7 +274,7 @@ MAP_CASES = ["sgVerify1", "sgVerify3", "sgVerify4", "sgVerify5", "sgVerify9", "s
 @pytest.mark.parametrize("name", MAP_CASES)
 def test_current_and_voltage_maps_through_product_path(emu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     case = load_case(name)
     st = {}
     run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
@@ -320,7 +320,7 @@ def _check_network_tables(case, st):
 @pytest.mark.parametrize("name", ["sgNetworkVerify1", "sgNetworkVerify2", "sgNetworkVerify3"])
 def test_network_current_tables_through_product_path(emu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     case = load_case(name)
     st = {"want_tables": True}
     run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}), stats=st)
@@ -465,7 +465,7 @@ def test_raster_advanced_through_product_path(emu_lib, name):
     solves on the kernels, voltage and current maps -- against the reference's goldens (its own criterion) and
     against the oracle's maps."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from conftest import compare_aagrid
     from helpers import run_raster_advanced_fixture
     from oracle import refmaps
@@ -483,7 +483,7 @@ def test_onetoall_alltoone_through_product_path(emu_lib, name):
     ones) through the product's host mirror and the kernels: resistances, per-point voltage / current maps,
     cumulative and maximum current maps against the goldens."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import check_onetoall_against_golden, run_onetoall_fixture
     case = load_case(name)
     res, cum, pts = run_onetoall_fixture(case, ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}))
@@ -508,7 +508,7 @@ def test_compute_omniscape_current(emu_lib):
     """scope row N3 (entry point only): compute_omniscape_current on the reference's own 3x3 smoke input
     (test/internal.jl:6-43) and on a circular moving window, product path against the oracle's direct solve."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import _build_graph
     from oracle import refmaps
     cfg = {"connect_four_neighbors_only": "False", "solver": "hip", "cholmod_batch_size": "1"}
@@ -649,7 +649,7 @@ def test_raster_pairwise_with_device_built_graph(emu_lib, name):
     """scope row N4 end to end: the reference's pairwise cases that have NODATA, several components and no polygons
     (two of them with an included-pairs file), graph layer on the device, against the golden resistances."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from oracle import refgraph as rg
     case = load_case(name)
     o = case["options"]
@@ -716,7 +716,7 @@ def test_omniscape_batch_of_windows_as_one_block_diagonal_solve(emu_lib):
     device-built block-diagonal system; every window's current map against the oracle's per-window direct solve of
     compute_omniscape_current (which skips components lacking a source or a ground, advanced.jl:186-191)."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from oracle import refmaps
     wins = [_omniscape_window(n, s) for n, s in ((31, 3), (21, 4), (41, 5), (25, 6))]
     # window 1: a NODATA wall cuts it in two; the piece without the ground cell must come back all zero
@@ -743,7 +743,7 @@ def test_block_diagonal_solve_resolves_weak_windows_at_default_tolerances(emu_li
     (relative to its own scale) as when it is solved alone: the right-hand side is normalised per component by an exact
     power of two and the 1e-4 residual check is evaluated per component."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from oracle import refmaps
     base = [_omniscape_window(n, s) for n, s in ((31, 3), (27, 4), (35, 5))]
     for weak in (1e-5, 1e-8):
@@ -805,7 +805,7 @@ def test_raster_advanced_on_device_with_direct_grounds(emu_lib, name):
     device; the direct ground becomes a NODATA cell plus ground conductance on its neighbours. Golden voltage / current
     maps with the reference's criterion, and the host-mirror path of the same case."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from conftest import compare_aagrid
     from helpers import _float_map, flags_from_case, run_raster_advanced_fixture
     case = load_case(name)
@@ -829,7 +829,7 @@ def test_onetoall_on_device_built_graph(emu_lib, name):
     """scope rows N2 + N4: the polygon-free one-to-all / all-to-one cases with single-cell focal points, every per-point
     solve on the device-built graph (direct grounds at the other focal cells): golden resistances and maps."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import check_onetoall_against_golden, flags_from_case
     case = load_case(name)
     o = case["options"]

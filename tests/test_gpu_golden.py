@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden_fixture_on_gpu(gpu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     case = load_case(name)
     got = run_fixture(case, ps.HIPAMGSolver(bs=8))
     exp = np.array(case["expected"])
@@ -24,7 +24,7 @@ def test_golden_fixture_on_gpu(gpu_lib, name):
 @pytest.mark.parametrize("name", ["sgVerify12", "sgVerify4", "sgNetworkVerify1"])
 def test_golden_fixture_fp32_preconditioner(gpu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     case = load_case(name)
     got = run_fixture(case, ps.HIPAMGSolver(bs=4, opts={"precond_bytes": 4}))
     exp = np.array(case["expected"])
@@ -70,7 +70,7 @@ def test_not_converged_is_reported_like_the_reference(gpu_lib, oracle):
     """itmax exhausted -> status 1 and the reference's error wording (core.jl:641)."""
     from oracle import refgraph as rg
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     G, g = rg.synthetic_raster_problem(100, 100)
     h = gpu_lib.raster_setup(g, gpu_lib.default_opts(itmax=1, batch=1))
     with pytest.raises(gpu_lib.CsgpuError) as e:
@@ -82,7 +82,7 @@ def test_not_converged_is_reported_like_the_reference(gpu_lib, oracle):
 @pytest.mark.parametrize("name", __import__("conftest").advanced_cases())
 def test_network_advanced_on_gpu(gpu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import run_network_advanced_fixture
     case = load_case(name)
     got = run_network_advanced_fixture(case, ps.HIPAMGSolver(bs=1))
@@ -97,7 +97,7 @@ def test_current_and_voltage_maps_on_gpu(gpu_lib, name):
     """scope row N1 on the real device: node currents / cumulative / maximum maps computed by the HIP kernels in
     csrc/currents.h, compared with the reference's golden .asc maps (criterion sum(abs2, x - r) < 1e-6)."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from test_emu_solver import _check_maps
     case = load_case(name)
     st = {}
@@ -127,7 +127,7 @@ def test_node_currents_conserve_charge_large(gpu_lib):
 @pytest.mark.parametrize("name", ["sgNetworkVerify1", "sgNetworkVerify2", "sgNetworkVerify3"])
 def test_network_current_tables_on_gpu(gpu_lib, name):
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from test_emu_solver import _check_network_tables
     case = load_case(name)
     st = {"want_tables": True}
@@ -140,7 +140,7 @@ def test_raster_advanced_on_gpu(gpu_lib, name):
     """scope row N2: raster advanced mode (mgVerify1..6) on the device with the reference's stopping rule; maps
     against the goldens with the reference's criterion."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from conftest import compare_aagrid, load_case
     from helpers import run_raster_advanced_fixture
     case = load_case(name)
@@ -153,7 +153,7 @@ def test_raster_advanced_on_gpu(gpu_lib, name):
 def test_onetoall_alltoone_on_gpu(gpu_lib, name):
     """scope row N2: the 25 one-to-all / all-to-one cases on the device with the reference's stopping rule."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from conftest import load_case
     from helpers import check_onetoall_against_golden, run_onetoall_fixture
     case = load_case(name)
@@ -165,7 +165,7 @@ def test_compute_omniscape_current_on_gpu(gpu_lib):
     """scope row N3 (entry point only): a 201-cell-wide circular moving window through compute_omniscape_current on
     the device (reference stopping rule) against the oracle's direct solve of the same grounded system."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import _build_graph
     from oracle import refmaps
     from test_emu_solver import _omniscape_window
@@ -182,7 +182,7 @@ def test_raster_pairwise_with_device_built_graph_on_gpu(gpu_lib, name):
     """scope row N4 end to end on the device: graph layer (node map, Laplacian, regularisation, components) and all
     pair solves on one handle, reference stopping rule, against the golden resistances."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from oracle import refgraph as rg
     case = load_case(name)
     o = case["options"]
@@ -202,7 +202,7 @@ def test_omniscape_batch_on_gpu(gpu_lib):
     """scope row N3: 12 moving windows stacked into one raster, one block-diagonal PCG on the device (reference
     stopping rule + polishing); every window against the oracle's direct solve."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from oracle import refmaps
     from test_emu_solver import _omniscape_window
     wins = [_omniscape_window(61 + 10 * (k % 4), 100 + k) for k in range(12)]
@@ -219,7 +219,7 @@ def test_raster_advanced_on_device_with_direct_grounds_on_gpu(gpu_lib, name):
     """scope rows N2 + N4 on the device: polygon-free raster advanced cases (direct grounds) through
     csgpu_raster_setup_grounded + csgpu_solve_raster, reference stopping rule, golden maps."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from conftest import compare_aagrid
     from helpers import _float_map, flags_from_case
     case = load_case(name)
@@ -240,7 +240,7 @@ def test_onetoall_on_device_built_graph_on_gpu(gpu_lib, name):
     """scope rows N2 + N4 on the device: polygon-free one-to-all / all-to-one with single-cell focal points, every
     per-point solve on the device-built graph; golden resistances and maps."""
     from circuitscape_jl_amd import solver as ps
-    from circuitscape_jl_amd import hostmirror as hm
+    import hostmirror as hm
     from helpers import check_onetoall_against_golden, flags_from_case
     case = load_case(name)
     o = case["options"]
