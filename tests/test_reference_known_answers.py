@@ -5,7 +5,7 @@ import pytest
 
 import circuitscape_jl_amd  # noqa: F401
 from circuitscape_jl_amd import solver as ps
-from circuitscape_jl_amd import hostmirror as hm
+import hostmirror as hm
 from oracle import refgraph as rg
 from oracle import refonetoall, refsolve
 
