@@ -280,7 +280,7 @@ def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, 
     return np.column_stack([np.asarray(ids, dtype=np.float64), res]), cum, per_point
 
 
-def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
+def compute_omniscape_current_batch(windows, cs_cfg, solver=None, want_voltages=False):
     """Many moving-window solves of compute_omniscape_current (src/utils.jl:145-257) as ONE device job (scope row N3).
 
     windows: list of (conductance, source, ground) rasters (NODATA = conductance 0, ground = finite conductances to
@@ -310,12 +310,96 @@ def compute_omniscape_current_batch(windows, cs_cfg, solver=None):
     try:
         with lib.raster_setup(stack[0], _opts_for(solver, batch=1), four_neighbors=four, avg_resistances=False,
                               reg=False, ground=stack[2]) as h:
-            cur, _, st = h.solve_raster(stack[1], want_currents=True)
+            cur, vol, st = h.solve_raster(stack[1], want_currents=True, want_voltages=want_voltages)
     except lib.CsgpuError as e:
         if e.code == lib.CSGPU_NOT_CONVERGED:
             _raise_not_converged(e)
         raise
-    return [cur[o:o + hh, :ww].copy() for o, (hh, ww) in zip(offs, shapes)], st
+    maps = [cur[o:o + hh, :ww].copy() for o, (hh, ww) in zip(offs, shapes)]
+    if want_voltages:
+        return maps, st, [vol[o:o + hh, :ww].copy() for o, (hh, ww) in zip(offs, shapes)]
+    return maps, st
+
+
+def omniscape_windows(conductance, source_strength, radius, block_size=1):
+    """The moving windows of an Omniscape run, one per target block (Omniscape.jl's loop around the entry point
+    compute_omniscape_current, src/utils.jl:145-257; the loop itself lives in Omniscape.jl, McRae et al. 2016): targets are
+    the centres of the block_size x block_size blocks (block_size odd) whose summed source strength is positive and whose
+    centre cell has positive conductance; a window is the disc of `radius` cells around the centre, clipped at the
+    raster's edges. Per window: conductance (0 outside the disc), sources = the disc's source strengths with the
+    target's own block zeroed, rescaled so that the injected current equals the block's summed strength, and the centre
+    cell tied directly to ground (ground = inf). Yields (r0, c0, conductance, source, ground, disc) with r0, c0 the
+    window's origin in the raster."""
+    cond = np.asarray(conductance, dtype=np.float64)
+    strength = np.asarray(source_strength, dtype=np.float64)
+    assert block_size % 2 == 1 and cond.shape == strength.shape
+    R, C = cond.shape
+    half = block_size // 2
+    for ci in range(half, R, block_size):
+        for cj in range(half, C, block_size):
+            b0, b1, d0, d1 = max(ci - half, 0), min(ci + half + 1, R), max(cj - half, 0), min(cj + half + 1, C)
+            weight = float(np.sum(np.where(cond[b0:b1, d0:d1] > 0, strength[b0:b1, d0:d1], 0.0)))
+            if not (weight > 0 and cond[ci, cj] > 0):
+                continue
+            r0, r1, c0, c1 = max(ci - radius, 0), min(ci + radius + 1, R), max(cj - radius, 0), min(cj + radius + 1, C)
+            ii, jj = np.mgrid[r0:r1, c0:c1]
+            disc = (ii - ci) ** 2 + (jj - cj) ** 2 <= radius * radius
+            wc = np.where(disc, cond[r0:r1, c0:c1], 0.0)
+            ws = np.where(disc & (wc > 0), strength[r0:r1, c0:c1], 0.0)
+            ws[b0 - r0:b1 - r0, d0 - c0:d1 - c0] = 0.0
+            total = ws.sum()
+            if not total > 0:
+                continue
+            ws *= weight / total
+            wg = np.zeros(wc.shape)
+            wg[ci - r0, cj - c0] = np.inf
+            yield r0, c0, wc, ws, wg, disc
+
+
+def omniscape_moving_window(conductance, source_strength, radius, block_size=1, cs_cfg=None, solver=None,
+                            windows_per_solve=64):
+    """Cumulative current map of an Omniscape run with every window solved on the device (scope row N3): the windows of
+    omniscape_windows go down `windows_per_solve` at a time as ONE block-diagonal system (compute_omniscape_current_batch:
+    one graph build, one hierarchy, one PCG per chunk) and their current maps are added into the mosaic. The directly
+    grounded centre of a window becomes a NODATA cell whose edge conductances move onto its neighbours' ground
+    conductances -- the matrix the reference's row deletion leaves (multiple_solver, raster/advanced.jl:282-288) -- and
+    its own node current, the sum of what its neighbours send it, is evaluated from the voltage map for that one cell.
+    Returns (cumulative current map, number of windows solved)."""
+    cs_cfg = cs_cfg or {}
+    four = str(cs_cfg.get("connect_four_neighbors_only", "False")).lower() in ("true", "1")
+    nbrs = [(-1, 0), (1, 0), (0, -1), (0, 1)] + ([] if four else [(-1, -1), (-1, 1), (1, -1), (1, 1)])
+    cum = np.zeros(np.asarray(conductance).shape)
+    chunk, nsolved = [], 0
+
+    def flush():
+        nonlocal nsolved
+        if not chunk:
+            return
+        maps, _, volts = compute_omniscape_current_batch([(w[2], w[3], w[4]) for w in chunk], cs_cfg, solver=solver,
+                                                         want_voltages=True)
+        for (r0, c0, _, _, _, ti, tj, links), cur, vol in zip(chunk, maps, volts):
+            cur[ti, tj] = sum(w * vol[a, b] for a, b, w in links)     # everything the window injects sinks here
+            cum[r0:r0 + cur.shape[0], c0:c0 + cur.shape[1]] += cur
+        nsolved += len(chunk)
+        chunk.clear()
+
+    for r0, c0, wc, ws, wg, _ in omniscape_windows(conductance, source_strength, radius, block_size):
+        ti, tj = [int(v[0]) for v in np.nonzero(wg == np.inf)]
+        cond = wc.copy()
+        leak = np.zeros(wc.shape)
+        links = []
+        for a, b in nbrs:
+            ii, jj = ti + a, tj + b
+            if 0 <= ii < wc.shape[0] and 0 <= jj < wc.shape[1] and wc[ii, jj] > 0:
+                w = _edge_weight(wc[ti, tj], wc[ii, jj], a != 0 and b != 0, False)
+                leak[ii, jj] += w
+                links.append((ii, jj, w))
+        cond[ti, tj] = 0.0
+        chunk.append((r0, c0, cond, ws, leak, ti, tj, links))
+        if len(chunk) >= windows_per_solve:
+            flush()
+    flush()
+    return cum, nsolved
 
 
 def _colmajor_nonzero(mask):

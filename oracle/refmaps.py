@@ -293,12 +293,49 @@ def raster_advanced_from_fixture(case, mode="direct", solve=None):
     }
 
 
-def compute_omniscape_current(conductance, source, ground, four_neighbors=False, mode="direct", solve=None):
+def compute_omniscape_current(conductance, source, ground, four_neighbors=False, mode="direct", solve=None,
+                              avg_resistances=False, policy="rmvsrc", want="curmap"):
     """compute_omniscape_current (src/utils.jl:145-257): advanced mode on in-memory rasters -- no polygons, policy
-    :rmvsrc, avg_res = false (utils.jl:193-196) -- returning the raw accumulated current map."""
-    case = {"options": {"connect_using_avg_resistances": False, "connect_four_neighbors_only": four_neighbors,
-                        "remove_src_or_gnd": "rmvsrc", "set_null_voltages_to_nodata": False,
+    :rmvsrc, avg_res = false (utils.jl:193-196) -- returning the raw accumulated current map.
+    This IS raster_advanced_from_fixture with those options fixed, i.e. the code the reference's mgVerify goldens pin
+    (tests/test_oracle_golden.py); `avg_resistances` / `policy` / `want` exist so that the pinning test can drive this
+    very function with a fixture's own options (mgVerify2, mgVerify6: the reference cases without polygons)."""
+    case = {"options": {"connect_using_avg_resistances": avg_resistances, "connect_four_neighbors_only": four_neighbors,
+                        "remove_src_or_gnd": policy, "set_null_voltages_to_nodata": False,
                         "set_null_currents_to_nodata": False, "log_transform_maps": False},
             "cellmap": np.asarray(conductance, dtype=np.float64), "polymap": None,
             "source_map": np.asarray(source, dtype=np.float64), "ground_map": np.asarray(ground, dtype=np.float64)}
-    return raster_advanced_from_fixture(case, mode=mode, solve=solve)["curmap"]
+    return raster_advanced_from_fixture(case, mode=mode, solve=solve)[want]
+
+
+def omniscape_moving_window(conductance, source_strength, radius, block_size=1, four_neighbors=False, mode="direct"):
+    """CHECKER for solver.omniscape_moving_window: the same windows (restated here, so the product's window generator is
+    checked too), every window through compute_omniscape_current above with its centre tied directly to ground
+    (ground = inf: multiple_solver deletes the row, raster/advanced.jl:282-288), currents added into the mosaic."""
+    cond = np.asarray(conductance, dtype=np.float64)
+    strength = np.asarray(source_strength, dtype=np.float64)
+    R, C = cond.shape
+    half = block_size // 2
+    cum = np.zeros(cond.shape)
+    nwin = 0
+    for ci in range(half, R, block_size):
+        for cj in range(half, C, block_size):
+            blk = (slice(max(ci - half, 0), min(ci + half + 1, R)), slice(max(cj - half, 0), min(cj + half + 1, C)))
+            weight = float(np.where(cond[blk] > 0, strength[blk], 0.0).sum())
+            if weight <= 0 or cond[ci, cj] <= 0:
+                continue
+            win = (slice(max(ci - radius, 0), min(ci + radius + 1, R)), slice(max(cj - radius, 0), min(cj + radius + 1, C)))
+            ii, jj = np.mgrid[win]
+            disc = (ii - ci) ** 2 + (jj - cj) ** 2 <= radius ** 2
+            wc = np.where(disc, cond[win], 0.0)
+            full_src = np.where(cond > 0, strength, 0.0)
+            full_src[blk] = 0.0
+            ws = np.where(disc, full_src[win], 0.0)
+            if ws.sum() <= 0:
+                continue
+            ws = ws * (weight / ws.sum())
+            wg = np.zeros(wc.shape)
+            wg[ci - win[0].start, cj - win[1].start] = np.inf
+            cum[win] += compute_omniscape_current(wc, ws, wg, four_neighbors=four_neighbors, mode=mode)
+            nwin += 1
+    return cum, nwin

@@ -1106,3 +1106,30 @@ def test_lattice_pipeline_matches_csr_pipeline(emu_lib, monkeypatch):
     """see helpers.check_lattice_pipeline"""
     from helpers import check_lattice_pipeline
     check_lattice_pipeline(emu_lib, monkeypatch, shapes=((37, 41), (48, 36)))
+
+
+def _omniscape_landscape(shape, seed):
+    """conductance raster with NODATA cells and a sparse source-strength raster"""
+    rng = np.random.default_rng(seed)
+    cond = np.exp(0.5 * rng.standard_normal(shape))
+    cond[rng.random(shape) < 0.08] = 0.0
+    strength = np.where(rng.random(shape) < 0.3, rng.random(shape) + 0.2, 0.0)
+    return cond, strength
+
+
+def test_omniscape_moving_window_driver(emu_lib):
+    """scope row N3: the moving-window driver (windows -> block-diagonal device solves -> mosaic,
+    solver.omniscape_moving_window) against the checker that pushes every window through the oracle's
+    compute_omniscape_current (direct solves); windows per device solve must not matter."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    cond, strength = _omniscape_landscape((23, 19), 4)
+    tight = ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1})
+    ref, nref = refmaps.omniscape_moving_window(cond, strength, radius=6, block_size=3)
+    assert nref >= 20 and ref.max() > 0
+    for per_solve in (7, 64):
+        got, nwin = ps.omniscape_moving_window(cond, strength, radius=6, block_size=3, solver=tight,
+                                               windows_per_solve=per_solve)
+        assert nwin == nref
+        assert np.all(got[cond == 0] == 0)
+        assert np.max(np.abs(got - ref)) < 1e-7 * ref.max(), np.max(np.abs(got - ref)) / ref.max()

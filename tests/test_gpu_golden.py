@@ -269,3 +269,21 @@ def test_every_raster_pairwise_golden_with_device_built_graph(gpu_lib, name):
     exp = np.array(case["expected"])
     assert np.array_equal(exp[1:, 0], got[1:, 0])
     compare_resistances(exp[1:, 1:], got[1:, 1:], rtol=1e-6, atol=1e-9)
+
+
+def test_omniscape_moving_window_driver_on_gpu(gpu_lib):
+    """scope row N3: solver.omniscape_moving_window (windows -> block-diagonal device solves -> mosaic) on the device
+    against the checker (every window through the oracle's compute_omniscape_current, direct solves)."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    from test_emu_solver import _omniscape_landscape
+    cond, strength = _omniscape_landscape((64, 57), 9)
+    ref, nref = refmaps.omniscape_moving_window(cond, strength, radius=12, block_size=5)
+    tight = ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1})
+    got, nwin = ps.omniscape_moving_window(cond, strength, radius=12, block_size=5, solver=tight, windows_per_solve=48)
+    assert nwin == nref and nref > 100
+    assert np.all(got[cond == 0] == 0)
+    assert np.max(np.abs(got - ref)) < 1e-7 * ref.max()
+    # the reference's default tolerances (rtol 1e-6 on the M-norm, 1e-4 post-check per component)
+    got2, _ = ps.omniscape_moving_window(cond, strength, radius=12, block_size=5, solver=ps.HIPAMGSolver(bs=1))
+    assert np.max(np.abs(got2 - ref)) < 1e-3 * ref.max()

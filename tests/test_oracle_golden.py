@@ -84,3 +84,23 @@ def test_oracle_onetoall_alltoone_matches_golden(oracle, name, mode):
     r = refonetoall.onetoall_from_fixture(case, mode=mode)
     cum = SimpleNamespace(cum_curr=r["cum"], max_curr=r["max"])
     check_onetoall_against_golden(case, r["res"], cum, {int(k): v for k, v in r["points"].items()})
+
+
+@pytest.mark.parametrize("name,key", [("mgVerify2", "voltmap"), ("mgVerify6", "curmap")])
+def test_omniscape_checker_is_pinned_by_reference_vectors(oracle, name, key):
+    """scope row N3: the reference's own test of compute_omniscape_current is syntax-only (test/internal.jl:6-43), so the
+    CHECKER the N3 tests use (oracle/refmaps.py::compute_omniscape_current) is pinned here against the reference's
+    advanced-mode goldens that share its shape -- rasters in, no polygons (mgVerify2: voltage map, 4-neighbour; mgVerify6:
+    current map with the :rmvsrc policy) -- by driving that very function with the fixture's options. Criterion: the
+    reference's (sum of squared differences < 1e-6, test/test_utils.jl:196)."""
+    from conftest import compare_aagrid, load_case
+    from oracle import refmaps
+    case = load_case(name)
+    o = case["options"]
+    assert case.get("polymap") is None and key in case["expected"]
+    src, gnd = refmaps._maps_from_fixture(case)
+    got = refmaps.compute_omniscape_current(np.asarray(case["cellmap"], dtype=np.float64), src, gnd,
+                                            four_neighbors=o["connect_four_neighbors_only"], mode="direct",
+                                            avg_resistances=o["connect_using_avg_resistances"],
+                                            policy=o["remove_src_or_gnd"], want=key)
+    assert compare_aagrid(case["expected"][key], got)
