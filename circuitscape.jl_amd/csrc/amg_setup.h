@@ -891,7 +891,11 @@ struct Level {
   Dia<T> Sdia;          // ... or, when the fine matrix is a raster lattice with regular 3x3 aggregates: S in lattice form
   LatticeQ<T> Ql;       // (stencil.h) and Q in its index-free tile form (lattice.h); Q^T and [S Q] are not built then
   DBuf agg0;            // level 0 aggregate of every node (kept only until Ql has been built)
-  bool lattice_two_product() const { return Sdia.n > 0 && Ql.n > 0; }
+  Dia<T> Adia;          // level 1 of a raster hierarchy in lattice form (lattice_level1_setup, lattice_setup.h): with it
+                        // Sdia = the two-sweep smoother polynomial and Ql = (I - S A) P, and the level runs as four
+                        // marching products (vcycle in pcg.h) instead of seven CSR ones
+  bool lattice_v22() const { return Adia.n > 0 && Sdia.n > 0 && Ql.n > 0; }
+  bool lattice_two_product() const { return Adia.n == 0 && Sdia.n > 0 && Ql.n > 0; }
   bool two_product() const { return M.nnz > 0 || lattice_two_product(); }
   DBuf dinv;            // 1/a_ii
   DBuf orderA;          // band-aware row-block traversal order for products with A (may be empty)
@@ -1294,6 +1298,11 @@ template <class T>
 inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* cur_row, const int* cur_col,
                              SetupCarry& carry, hipStream_t st);
 
+// lattice_setup.h: lattice forms of level 1 (A, the two-sweep smoother, the transfer operator) when that level is an
+// R x C nine-point lattice with regular 3 x 3 aggregates `agg`; leaves the level untouched otherwise
+template <class T>
+inline void lattice_level1_setup(Level<T>& L, const int* agg, int R, int C, int nagg, hipStream_t st);
+
 // Build the hierarchy. A0 is moved into level 0. node_row/node_col (device, may be null) are raster coordinates.
 template <class T>
 inline void amg_setup(Hierarchy<T>& H, Csr<T>&& A0, const SetupParams& sp, const int* node_row, const int* node_col,
@@ -1369,6 +1378,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       // the strength filter left too few strong couplings to coarsen this level: aggregate on the full pattern
       nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level);
     }
+    const int lvlR = gridR, lvlC = gridC;  // raster extent of THIS level
     // coarse raster extent (tile counts), valid while the aggregates are the regular tiles
     gridR = gridR > 0 ? (gridR + 1) / 3 : 0;
     gridC = gridC > 0 ? (gridC + 1) / 3 : 0;
@@ -1428,6 +1438,9 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       CS_REQUIRE(read_int(dptr<int>(missing), st) == 0, CSGPU_INTERNAL, "pattern(P) is not contained in pattern(A*P)");
       L.Q = std::move(AP);
     }
+    if (H.levels.size() == 2 && sp.lattice_s && gridR > 0 && (int64_t)lvlR * lvlC == n && sp.nu_l1 == 2 &&
+        (L.weights.empty() || L.weights.size() == 2))
+      lattice_level1_setup(L, (const int*)dptr<int>(agg), lvlR, lvlC, nagg, st);
     if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
         (int64_t)n + nagg < 0x7fffffffLL) {
       if (sp.lattice_s) {

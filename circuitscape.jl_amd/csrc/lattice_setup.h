@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc
 template <class U, class T>
 __global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
                                                            const T* __restrict__ pl, const T* __restrict__ dinv, T omega,
-                                                           T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad) {
+                                                           T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad,
+                                                           const T* __restrict__ base = nullptr) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int I = lat_tile((int)(i % R), Rc), J = lat_tile((int)(i / R), Cc);
     T acc[9];
@@ -477,11 +478,13 @@ __global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int
           if (s2 == so) acc[s2] += a * pv;
       }
     }
-    const T w = omega * dinv[i];
+    // q = base - w (M pl) with w = omega * dinv (dinv null: w = omega) and base = pl unless given
+    const T w = dinv ? omega * dinv[i] : omega;
+    const T* bs = base ? base : pl;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
       if (ap) ap[i * 9 + s] = acc[s];
-      q[i * 9 + s] = -w * acc[s] + pl[i * 9 + s];
+      if (q) q[i * 9 + s] = -w * acc[s] + bs[i * 9 + s];
     }
   }
 }
@@ -675,7 +678,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   hipLaunchKernelGGL((lattice_p_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const int*)dptr<int>(agg),
                      (const T*)dptr<T>(tv), (const T*)dptr<T>(labs), sp.omega_p, dptr<T>(pl), dptr<int>(bad));
   hipLaunchKernelGGL((lattice_ap_q_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const T*)dptr<T>(pl),
-                     (const T*)dptr<T>(L.dinv), (T)L.omega, dptr<T>(apl), dptr<T>(ql), dptr<int>(bad));
+                     (const T*)dptr<T>(L.dinv), (T)L.omega, dptr<T>(apl), dptr<T>(ql), dptr<int>(bad), (const T*)nullptr);
   check_launch("lattice P / A P / Q");
   if (read_int(dptr<int>(bad), st) != 0) return false;  // (cannot happen for tile aggregates; the CSR pipeline takes over)
   tv.release();
@@ -719,6 +722,55 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   carry.gridR = Rc;
   carry.gridC = Cc;
   return true;
+}
+
+// ---- level 1 of a raster hierarchy in lattice form ---------------------------------------------------------------------
+// Level 1 of a full raster is again a nine-point lattice (R1 x C1 = the tiles of level 0) with regular 3 x 3 aggregates,
+// and it is where a V-cycle spends most of its time below the fine level (10000^2, K = 16, fp64: 6.1 of 34 ms -- seven
+// CSR products moving 15 vector passes). With w0, w1 the weights of its two Jacobi sweeps (Chebyshev or damped),
+//     S  = (w0 + w1) D^-1 - w0 w1 D^-1 A D^-1       two sweeps from a zero guess are x = S b; two sweeps from x are
+//                                                    x + S (b - A x)                      (nine-point, symmetric)
+//     Q2 = (I - S A) P                               restriction of the residual after pre-smoothing: R (b - A S b) = Q2' b
+// the level collapses to FOUR marching products without a column index (vcycle, pcg.h):
+//     x = S b ;  b_c = Q2' b ;  [levels below] ;  t = b - A x ;  out = x + S t + Q2 x_c
+// (out = [x + P x_c] + S (b - A [x + P x_c]), i.e. prolongation + the two post-sweeps). Q2 reaches three cells beyond a
+// row's own tile -- still inside the 3 x 3 block of tiles, so the index-free form of level 0's Q (LatticeQ) holds it.
+// Built from the CSR operators of the level (kept: test hooks, and the generic branch when the sweep count differs).
+// Declined (level untouched) when A is not a nine-point lattice of period R or P leaves the tile block -- cell-space
+// hierarchies whose tiles were refined by the piece analysis.
+template <class T>
+inline void lattice_level1_setup(Level<T>& L, const int* agg, int R, int C, int nagg, hipStream_t st) {
+  static const bool off = getenv("CSGPU_NO_LATTICE_L1") != nullptr;  // A/B knob
+  static const int min_rows = getenv("CSGPU_LATTICE_L1_MIN_ROWS") ? atoi(getenv("CSGPU_LATTICE_L1_MIN_ROWS")) : 16384;
+  const int64_t n = (int64_t)R * C;
+  const int Rc = (R + 1) / 3, Cc = (C + 1) / 3;
+  if (off || n < min_rows || L.A.nrows != n || (int64_t)Rc * Cc != nagg || R < 6 || C < 6) return;
+  Dia<T> Ad;
+  // (the Galerkin operator is symmetric up to rounding, not bit for bit: the lattice form keeps the upper triangle)
+  if (!dia_from_csr(L.A, R, Ad, st, true)) return;
+  LatticeQ<T> Pl;
+  if (!lattice_q_from_csr(L.P, agg, R, C, Pl, st)) return;
+  const double w0 = L.weights.empty() ? L.omega : L.weights[0], w1 = L.weights.empty() ? L.omega : L.weights[1];
+  Dia<T> Sd;
+  dia_build_s(Ad, (const T*)dptr<T>(L.dinv), w0, Sd, st, w1);
+  DBuf apl((size_t)n * 9 * sizeof(T)), ql((size_t)n * 9 * sizeof(T)), bad = dalloc<int>(1);
+  CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+  const int g = grid_for(n);
+  hipLaunchKernelGGL((lattice_ap_q_kernel<T, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, Ad.data(), Pl.data(),
+                     (const T*)nullptr, T(0), dptr<T>(apl), (T*)nullptr, dptr<int>(bad), (const T*)nullptr);      // A P
+  hipLaunchKernelGGL((lattice_ap_q_kernel<T, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, Sd.data(), (const T*)dptr<T>(apl),
+                     (const T*)nullptr, T(1), (T*)nullptr, dptr<T>(ql), dptr<int>(bad), Pl.data());                 // P - S (A P)
+  check_launch("lattice level 1");
+  if (read_int(dptr<int>(bad), st) != 0) return;
+  L.Adia = std::move(Ad);
+  L.Sdia = std::move(Sd);
+  L.Ql.n = n;
+  L.Ql.R = R;
+  L.Ql.C = C;
+  L.Ql.Rc = Rc;
+  L.Ql.Cc = Cc;
+  L.Ql.q = std::move(ql);
+  if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: level 1 (%d x %d) in lattice form\n", R, C);
 }
 
 }  // namespace csgpu

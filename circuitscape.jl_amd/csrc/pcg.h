@@ -230,6 +230,21 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     spmv_launch_wide<T, K>(a, want_dot, st);
     return;
   }
+  if (l >= 1 && L.lattice_v22() && nu_pre == 2 && nu_post == 2) {
+    // lattice form of the level (lattice_level1_setup, lattice_setup.h): four marching products, no column index
+    Level<T>& Lc = H.levels[l + 1];
+    const size_t celems = (size_t)std::max(Lc.A.nrows, 1) * K;
+    T* bc = dptr<T>(Lc.b);
+    T* xc = dptr<T>(Lc.b) + celems;
+    dia_apply<T, K>(L.Sdia, b, cur, (const T*)nullptr, skip, st);   // x = S b            (the two pre-sweeps)
+    lattice_restrict<T, K>(L.Ql, b, bc, skip, st);                  // b_c = Q2' b        (residual + restriction)
+    VcycleFuse<T> cf;
+    cf.skip = skip;
+    vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
+    dia_apply<T, K>(L.Adia, (const T*)cur, oth, b, skip, st);       // t = b - A x
+    dia_sq_product<T, K>(L.Sdia, L.Ql, (const T*)oth, (const T*)xc, out, (double*)nullptr, skip, st, (const T*)cur);
+    return;                                                         // out = x + S t + Q2 x_c (prolongation + post-sweeps)
+  }
   // pre-smoothing (first sweep from x = 0 is a scaling)
   if (nu_pre >= 1) {
     if (!(fuse && fuse->xa_ready && l == 0))

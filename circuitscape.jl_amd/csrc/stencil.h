@@ -166,6 +166,8 @@ struct DiaArgs {
   T* r;                    // DIA_RUPD: residual (in/out), interleaved [n][K]
   XT* rp;                  // DIA_RUPD: copy of the new residual in the preconditioner's precision (null when XT == T)
   T* xsol;                 // DIA_RUPD: optional whole solution vector, xsol += alpha x
+  const T* bsub = nullptr; // DIA_PLAIN: y = bsub - A x instead of A x (residual of a lattice level, pcg.h)
+  const T* xadd = nullptr; // DIA_SQ: y = xadd + S x + Q xc (second half of a lattice V(2,2) level, pcg.h)
 };
 
 template <class T, class XT, int K>
@@ -442,6 +444,16 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
             *reinterpret_cast<YV*>(a.xsol + e) = xn;
           }
         } else {
+          if (SQ && a.xadd) {
+            const YV av = *reinterpret_cast<const YV*>(a.xadd + (size_t)id * K + c0);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) out.e[q] += av.e[q];
+          }
+          if (MODE == DIA_PLAIN && a.bsub) {
+            const YV bv = *reinterpret_cast<const YV*>(a.bsub + (size_t)id * K + c0);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) out.e[q] = bv.e[q] - out.e[q];
+          }
 #pragma unroll
           for (int q = 0; q < CPL; ++q) dot_acc[q] += (double)(T)xw[1][1].e[q] * (double)out.e[q];
           if (a.y) dia_store(reinterpret_cast<YV*>(a.y + (size_t)id * K + c0), out);
@@ -558,7 +570,7 @@ inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p
 // its index-free tile form)
 template <class T, int K>
 inline void dia_sq_product(const Dia<T>& Sd, const LatticeQ<T>& Q, const T* b, const T* xc, T* out, double* partials,
-                           const int* skip, hipStream_t st) {
+                           const int* skip, hipStream_t st, const T* xadd = nullptr) {
   DiaArgs<T, T> a;
   a.n = Sd.n;
   a.R = Sd.R;
@@ -581,27 +593,58 @@ inline void dia_sq_product(const Dia<T>& Sd, const LatticeQ<T>& Q, const T* b, c
   a.r = nullptr;
   a.rp = nullptr;
   a.xsol = nullptr;
+  a.xadd = xadd;
   hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_SQ>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// y = D x, or y = bsub - D x when bsub is given (D in lattice form; no dot partials)
+template <class T, int K>
+inline void dia_apply(const Dia<T>& D, const T* x, T* y, const T* bsub, const int* skip, hipStream_t st) {
+  DiaArgs<T, T> a;
+  a.n = D.n;
+  a.R = D.R;
+  a.C = (int)(D.n / D.R);
+  int grid;
+  dia_tiling<T, T, K>(D, a.nstrips, a.nseg, a.seg, grid);
+  a.rows = D.data();
+  a.S = nullptr;
+  a.z = nullptr;
+  a.pin = x;
+  a.pout = nullptr;
+  a.y = y;
+  a.partials = nullptr;
+  a.beta_dev = nullptr;
+  a.skip = skip;
+  a.qell = nullptr;
+  a.Rc = a.Cc = 0;
+  a.xc = nullptr;
+  a.r = nullptr;
+  a.rp = nullptr;
+  a.xsol = nullptr;
+  a.bsub = bsub;
+  hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_PLAIN>), dim3(grid), dim3(256), 0, st, a);
 }
 
 // Lattice form of S = 2 w D^-1 - w D^-1 A w D^-1 (w = damped-Jacobi weight) from the lattice form of A (precision U,
 // rounded to T first -- the hierarchy's level-0 matrix is the element-wise rounded CG matrix) and dinv = 1/diag(A):
 // the same values build_sq_kernel puts into the CSR form of [S Q].
+// General form: two Jacobi sweeps with weights w0, w1 from a zero initial guess are x = S b with
+// S = (w0 + w1) D^-1 - w0 w1 D^-1 A D^-1 (the two-product level: w0 = w1 = w).
 template <class U, class T>
 __global__ __launch_bounds__(256) void dia_build_s_kernel(int64_t n, int R, const U* __restrict__ arows,
-                                                          const T* __restrict__ dinv, double omega,
+                                                          const T* __restrict__ dinv, double w0, double w1,
                                                           T* __restrict__ srows) {
   const int off[5] = {0, 1, R - 1, R, R + 1};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double wi = omega * (double)dinv[i];
+    const double wi = w0 * (double)dinv[i];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const int64_t j = i + off[s];
       const T av = (T)arows[i * 5 + s];
       double v = 0.0;
       if (j < n) {
-        v = -wi * (double)av * omega * (double)dinv[j];
-        if (s == 0) v += 2.0 * wi;
+        v = -wi * (double)av * w1 * (double)dinv[j];
+        if (s == 0) v += (w0 + w1) * (double)dinv[i];
       }
       srows[i * 5 + s] = (T)v;
     }
@@ -609,11 +652,12 @@ __global__ __launch_bounds__(256) void dia_build_s_kernel(int64_t n, int R, cons
 }
 
 template <class U, class T>
-inline void dia_build_s(const Dia<U>& A, const T* dinv, double omega, Dia<T>& S, hipStream_t st) {
+inline void dia_build_s(const Dia<U>& A, const T* dinv, double w0, Dia<T>& S, hipStream_t st, double w1 = -1.0) {
+  if (w1 < 0.0) w1 = w0;
   S.n = A.n;
   S.R = A.R;
   S.rows.alloc((size_t)A.n * 5 * sizeof(T));
-  hipLaunchKernelGGL((dia_build_s_kernel<U, T>), dim3(grid_for(A.n)), dim3(256), 0, st, A.n, A.R, A.data(), dinv, omega,
+  hipLaunchKernelGGL((dia_build_s_kernel<U, T>), dim3(grid_for(A.n)), dim3(256), 0, st, A.n, A.R, A.data(), dinv, w0, w1,
                      dptr<T>(S.rows));
   check_launch("lattice form of S");
 }

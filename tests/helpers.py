@@ -926,3 +926,55 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
                 assert np.max(np.abs(a["Rv"] - a["R"][:2]) / a["R"][:2]) < 1e-6
                 assert abs(a["it"] - b["it"]) <= (0 if pb == 0 else 2)
                 assert np.allclose(a["y"], a["A0"] @ a["x"], rtol=1e-12, atol=1e-12)
+
+
+def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4):
+    """lattice_setup.h lattice_level1_setup + the lattice branch of vcycle() (pcg.h): level 1 of a raster hierarchy as four
+    marching products (x = S b, b_c = Q2' b, t = b - A x, out = x + S t + Q2 x_c) against the seven CSR products of the
+    generic branch (CSGPU_NO_LATTICE_L1=1, read once per process -> child processes): the same algebra, so the same
+    iteration counts and resistances equal to rounding; fp64 and fp32 hierarchies, 8- and 4-neighbour, and a raster with
+    NODATA cells (cell space: the level declines the lattice form when the piece analysis refined its tiles, or keeps
+    it -- either way the results must agree)."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        lib.load(%r)
+        out = []
+        for (R, C) in %r:
+            rng = np.random.default_rng(R + C)
+            base = np.exp(rng.standard_normal((R, C)))
+            holes = np.where(rng.random((R, C)) < 0.1, 0.0, base)
+            for name, g, four in (("full8", base, False), ("full4", base, True), ("holes8", holes, False)):
+                for pb in (0, 4):
+                    with lib.raster_setup(g, lib.default_opts(batch=%d, precond_bytes=pb), four_neighbors=four) as h:
+                        labels, _ = h.components()
+                        big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                        ids = np.random.default_rng(5).choice(big, size=2 * %d, replace=False)
+                        Rr, _, _, st = h.solve_pairs([int(v) for v in ids[:%d]], [int(v) for v in ids[%d:]])
+                        out.append({"case": name, "pb": pb, "shape": [R, C], "iters": int(st["total_iters"]),
+                                    "nc": int(st["not_converged"]), "R": [float(v) for v in Rr],
+                                    "level_n": h.info["level_n"][:h.info["levels"]], "bytes": int(h.info["device_bytes"])})
+        print("RESULT" + json.dumps(out))
+    ''') % (root, L.loaded_path(), tuple(tuple(s) for s in shapes), batch, batch, batch, batch)
+    res = {}
+    for tag, extra in (("lattice", {}), ("csr", {"CSGPU_NO_LATTICE_L1": "1"})):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("CSGPU_NO_LATTICE_L1", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1800, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        res[tag] = json.loads(line[len("RESULT"):])
+    used = 0
+    for a, b in zip(res["lattice"], res["csr"]):
+        assert a["case"] == b["case"] and a["pb"] == b["pb"] and a["level_n"] == b["level_n"]
+        assert a["nc"] == 0 and b["nc"] == 0
+        assert abs(a["iters"] - b["iters"]) <= (0 if a["pb"] == 0 else 1), (a["case"], a["pb"], a["iters"], b["iters"])
+        Ra, Rb = np.array(a["R"]), np.array(b["R"])
+        assert np.max(np.abs(Ra - Rb) / Rb) < (1e-10 if a["pb"] == 0 else 1e-8), (a["case"], a["pb"])
+        used += a["bytes"] > b["bytes"]            # (the lattice forms are held in addition to the CSR operators)
+    assert used >= 4, used                         # the all-valid rasters, both precisions, must have taken the lattice form

@@ -1133,3 +1133,9 @@ def test_omniscape_moving_window_driver(emu_lib):
         assert nwin == nref
         assert np.all(got[cond == 0] == 0)
         assert np.max(np.abs(got - ref)) < 1e-7 * ref.max(), np.max(np.abs(got - ref)) / ref.max()
+
+
+def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
+    """see helpers.check_lattice_level1"""
+    from helpers import check_lattice_level1
+    check_lattice_level1(emu_lib, monkeypatch, shapes=((390, 396),))

@@ -489,3 +489,9 @@ def test_raster_above_2_31_stored_entries(gpu_lib):
         assert o["symmetry_rel"] < 1e-6 and o["triangle_slack"] > -1e-9
         assert o["iters_max"] <= (14 if holes == 0.0 else 20), o["iters_max"]
         gpu_lib.trim_memory()
+
+
+def test_lattice_level1_matches_csr_level1_gpu(gpu_lib, monkeypatch):
+    """level 1 of a raster hierarchy as four marching products == the seven CSR products: helpers.check_lattice_level1"""
+    from helpers import check_lattice_level1
+    check_lattice_level1(gpu_lib, monkeypatch, shapes=((1500, 1400), (601, 777)), batch=16)
