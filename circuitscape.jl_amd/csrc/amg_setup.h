@@ -883,6 +883,33 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   return Pinv;
 }
 
+// ---- strength of connection inside the regular tiles (heterogeneous rasters) ----------------------------------------
+// The reference's aggregation treats every coupling as strong (SymmetricStrength, theta = 0) and relies on symmetric
+// Gauss-Seidel to cope with conductances that differ by orders of magnitude (src/core.jl:164-167). With Jacobi sweeps
+// the 3 x 3 tiles themselves must respect the weak couplings: a cell tied to its tile-mates only through couplings below
+// theta * sqrt(a_ii a_jj) (the symmetric measure) does not follow the tile's coarse unknown. The piece analysis written
+// for NODATA rasters (tile_pieces_kernel) does exactly the bookkeeping needed -- pieces of a tile, the main piece keeps
+// the aggregate, the other cells join the neighbouring tile they are strongly coupled to -- so weak couplings are
+// simply not followed there. Measured (log-normal conductances exp(sigma N(0,1)), PCG iterations per pair, oracle =
+// the reference's algorithm with its Gauss-Seidel smoother):
+//                     sigma = 1        sigma = 2          sigma = 3
+//   300^2   before    10.0             22.5               50.3
+//           after     (not triggered)  16.0   oracle 15   34.0   oracle 36
+//   1000^2  before    10.0             29.8               114
+//           after     (not triggered)  22.5   oracle 19   68.3   oracle 61
+// theta between 0.03 and 0.1 gives the same counts within one iteration; 0.15 starts to cost on sigma = 1. The filter is
+// only used when it matters -- when more than tile_split_min of the cells would leave their tile -- because regular
+// tiles are what keeps level 1 a nine-point lattice (lattice_level1_setup). CSGPU_TILE_THETA / CSGPU_TILE_SPLIT_MIN
+// override the defaults (theta 0 switches the filter off).
+inline double default_tile_theta() {
+  static const double t = getenv("CSGPU_TILE_THETA") ? atof(getenv("CSGPU_TILE_THETA")) : 0.06;
+  return t;
+}
+inline double default_tile_split_min() {
+  static const double t = getenv("CSGPU_TILE_SPLIT_MIN") ? atof(getenv("CSGPU_TILE_SPLIT_MIN")) : 0.02;
+  return t;
+}
+
 template <class T>
 struct Level {
   Csr<T> A, P, R;       // P, R empty on the coarsest level
@@ -947,6 +974,10 @@ struct SetupParams {
   // 0 = the isolated row of a NODATA cell) and the number of real nodes; null / 0 = every row is a node
   const long long* size0 = nullptr;
   int64_t n_real = 0;
+  // Heterogeneous rasters (tile_strength in amg_setup.h): couplings weaker than tile_theta * sqrt(a_ii a_jj) do not hold
+  // a 3 x 3 tile together; used when more than tile_split_min of the cells leave their tile because of it
+  double tile_theta = default_tile_theta();
+  double tile_split_min = default_tile_split_min();
 };
 
 // Q^T (with its traversal order) of the two-product form in CSR
@@ -1007,6 +1038,7 @@ __global__ __launch_bounds__(256) void tile_aggregate_kernel(int n, const int* _
 // its far end can be three cells from the tile it joins.)
 constexpr int kPieceAttached = 100;  // piece[] value of a cell attached to a neighbouring tile's aggregate (+ round of pass 3)
 constexpr int kOrphanRounds = 3;
+
 __device__ __forceinline__ void tile_extent(int t, int nt, int len, int& lo, int& hi) {
   lo = 3 * t;
   hi = t == nt - 1 ? len : 3 * t + 3;
@@ -1020,7 +1052,7 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
                                                           const int* __restrict__ ci, const T* __restrict__ va,
                                                           long long* __restrict__ size_f, signed char* __restrict__ piece,
                                                           signed char* __restrict__ mainlab, int* __restrict__ agg,
-                                                          int full_connected) {
+                                                          int full_connected, const T* __restrict__ diag, double theta2) {
   const int ntiles = Rc * Cc;
   for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
     const int I = tile % Rc, J = tile / Rc;
@@ -1038,7 +1070,7 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
           lab[kc * h + kr] = valid ? kc * h + kr : -1;
           nvalid += valid ? 1 : 0;
         }
-      if (nvalid > 0 && (nvalid < h * w || !full_connected)) {
+      if (nvalid > 0 && (nvalid < h * w || !full_connected || theta2 > 0.0)) {
         for (int sweep = 0; sweep < 16; ++sweep) {
           bool changed = false;
           for (int kc = 0; kc < w; ++kc)
@@ -1049,6 +1081,7 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
               for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
                 const int nb = ci[e];
                 if (nb == cell || va[e] == T(0)) continue;
+                if (theta2 > 0.0 && (double)va[e] * (double)va[e] < theta2 * (double)diag[cell] * (double)diag[nb]) continue;
                 const int ni = nb % R - r0, nj = nb / R - c0;
                 if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
                 const int l2 = lab[nj * h + ni];
@@ -1089,6 +1122,7 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
           for (int e = rp[cell]; e < rp[cell + 1]; ++e) {
             const int nb = ci[e];
             if (nb == cell || va[e] == T(0)) continue;
+            if (theta2 > 0.0 && (double)va[e] * (double)va[e] < theta2 * (double)diag[cell] * (double)diag[nb]) continue;
             const int ni = nb % R, nj = nb / R;
             if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
             const int nt = min(nj / 3, Cc - 1) * Rc + min(ni / 3, Rc - 1);
@@ -1121,7 +1155,8 @@ __global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc,
                                                            const int* __restrict__ ci, const T* __restrict__ va,
                                                            long long* __restrict__ size_f, signed char* __restrict__ piece,
                                                            const signed char* __restrict__ mainlab, int* __restrict__ agg,
-                                                           int round, int last, int C, int constrain) {
+                                                           int round, int last, int C, int constrain,
+                                                           const T* __restrict__ diag, double theta2) {
   for (int cell = blockIdx.x * 256 + threadIdx.x; cell < n; cell += gridDim.x * 256) {
     const int pc = piece[cell];
     if (pc < 0 || pc >= kPieceAttached) continue;
@@ -1149,6 +1184,7 @@ __global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc,
       const int nb = ci[e];
       if (nb == cell || va[e] == T(0)) continue;
       coupled = true;
+      if (theta2 > 0.0 && (double)va[e] * (double)va[e] < theta2 * (double)diag[cell] * (double)diag[nb]) continue;
       const int pn = piece[nb];
       if (pn < kPieceAttached || pn >= kPieceAttached + round) continue;
       const int ta = agg[nb], tI = ta % Rc, tJ = ta / Rc;
@@ -1168,6 +1204,43 @@ __global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc,
   }
 }
 
+// cnt[0] += cells with weight, cnt[1] += those outside their tile's main piece (after pass 1 of the piece analysis)
+__global__ __launch_bounds__(256) void piece_count_kernel(int64_t n, int R, int Rc, int Cc, const signed char* __restrict__ piece,
+                                                          const signed char* __restrict__ mainlab, int* __restrict__ cnt) {
+  int valid = 0, out = 0;
+  for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < n; cell += (int64_t)gridDim.x * 256) {
+    const int pc = piece[cell];
+    if (pc < 0) continue;
+    ++valid;
+    const int I = min((int)(cell % R) / 3, Rc - 1), J = min((int)(cell / R) / 3, Cc - 1);
+    out += pc != mainlab[(int64_t)J * Rc + I] ? 1 : 0;
+  }
+  if (valid) atomicAdd(&cnt[0], valid);
+  if (out) atomicAdd(&cnt[1], out);
+}
+
+inline void piece_counts(int64_t n, int R, int Rc, int Cc, const DBuf& piece, const DBuf& mainlab, int64_t& valid, int64_t& out,
+                         hipStream_t st) {
+  DBuf cnt = dalloc<int>(2);
+  CS_HIP(hipMemsetAsync(cnt.p, 0, 2 * sizeof(int), st));
+  hipLaunchKernelGGL(piece_count_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, R, Rc, Cc, (const signed char*)piece.p,
+                     (const signed char*)mainlab.p, dptr<int>(cnt));
+  int h[2];
+  CS_HIP(hipMemcpyAsync(h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  valid = h[0];
+  out = h[1];
+}
+
+// How the strength filter is decided for a hierarchy (level 0) and handed down the levels
+struct TileStrength {
+  double theta = 0.0;       // in: the threshold to try (0 = none). out (decide): the threshold in effect
+  double split_min = 0.0;   // decide: use theta only if more than this fraction of the weighted cells leaves its tile
+  bool decide = false;      // level 0: run the test; deeper levels just apply theta
+  bool unit_weights = false;  // size_f was allocated as all ones for this test only (an all-valid raster): without the
+                              // filter the piece analysis has nothing to do
+};
+
 // Aggregate the nodes of A. Returns nagg; fills agg (n ints) and, when coordinates are tracked, the coarse ones.
 // size_f (may be null): weight of every row (cell-space rasters: 0 for the rows of NODATA cells / empty tiles). With
 // weights the regular tiles are refined by the piece analysis above (which may zero further weights) -- on EVERY level:
@@ -1179,7 +1252,7 @@ __global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc,
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
                      DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0, long long* size_f = nullptr,
-                     bool cell_level = false) {
+                     bool cell_level = false, TileStrength* ts = nullptr) {
   const int n = A.nrows;
   const double theta2 = theta * theta;
   static const bool no_direct_tiles = getenv("CSGPU_NO_DIRECT_TILES") != nullptr;  // A/B knob
@@ -1194,20 +1267,51 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
     if (size_f && !no_pieces) {
       DBuf piece((size_t)n), mainlab((size_t)Rc * Cc);
       const int gt = grid_for((int64_t)Rc * Cc);
-      hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
+      auto pass1 = [&](double t2) {
+        hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
+                           size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0, diag, t2);
+      };
+      double th2 = ts ? ts->theta * ts->theta : 0.0;
+      if (ts && ts->decide) {
+        // heterogeneity test (TileStrength): cells that leave their tile's main piece BECAUSE of the filter
+        int64_t valid = 0, out0 = 0, out1 = 0;
+        if (th2 > 0.0) {
+          if (!ts->unit_weights) {
+            pass1(0.0);
+            piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out0, st);
+          }
+          pass1(th2);
+          piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out1, st);
+        }
+        const bool hetero = th2 > 0.0 && (double)(out1 - out0) > ts->split_min * (double)std::max<int64_t>(valid, 1);
+        if (getenv("CSGPU_VERBOSE"))
+          fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
+                  (long long)out1, (long long)valid, ts->theta, (long long)out0, hetero ? "filter ON" : "filter off");
+        if (!hetero) {
+          ts->theta = 0.0;
+          th2 = 0.0;
+          if (ts->unit_weights) {  // regular tiles, nothing to analyse
+            check_launch("tile aggregation");
+            return Rc * Cc;
+          }
+          pass1(0.0);
+        }
+      } else {
+        pass1(th2);
+      }
       hipLaunchKernelGGL((tile_pieces_kernel<T, 2>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0);
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0, diag, th2);
       for (int round = 1; round <= kOrphanRounds; ++round)
         hipLaunchKernelGGL((tile_orphans_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, n, gridR, Rc, Cc, A.rp(), A.ci(),
                            A.va(), size_f, (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
-                           round == kOrphanRounds ? 1 : 0, gridC, cell_level ? 1 : 0);
+                           round == kOrphanRounds ? 1 : 0, gridC, cell_level ? 1 : 0, diag, th2);
       check_launch("tile pieces");
       CS_HIP(hipStreamSynchronize(st));  // piece / mainlab are released on return
     }
     check_launch("tile aggregation");
     return Rc * Cc;
   }
+  if (ts && ts->decide) ts->theta = 0.0;  // (no regular tiles here: nothing for the strength filter to refine)
   DBuf key = dalloc<unsigned long long>(n), k1 = dalloc<unsigned long long>(n), k2 = dalloc<unsigned long long>(n);
   DBuf counter = dalloc<int>(1);
   const int g = grid_for(n);
@@ -1292,6 +1396,8 @@ struct SetupCarry {
   DBuf crow, ccol;   // raster coordinates of the current level's nodes (may be empty)
   DBuf size;         // long long: fine nodes under every node of the current level (empty: all ones)
   int gridR = 0, gridC = 0;  // raster extent of the current level while the aggregates are the regular tiles (0: unknown)
+  bool weighted = false;     // rows carry weights although the caller gave none (strength filter on an all-valid raster)
+  double tile_theta = -1.0;  // strength filter of this hierarchy's piece analyses (< 0: level 0 decides, TileStrength)
 };
 
 template <class T>
@@ -1371,12 +1477,35 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       }
     }
     DBuf agg, crow, ccol;
-    long long* wts = (sp.size0 && size_prev.p) ? dptr<long long>(size_prev) : (long long*)nullptr;
-    const bool cell_level = sp.size0 && H.levels.size() == 1;
-    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level);
+    long long* wts = ((sp.size0 || carry.weighted) && size_prev.p) ? dptr<long long>(size_prev) : (long long*)nullptr;
+    TileStrength ts;
+    ts.theta = carry.tile_theta < 0.0 ? sp.tile_theta : carry.tile_theta;
+    ts.split_min = sp.tile_split_min;
+    ts.decide = carry.tile_theta < 0.0;
+    if (ts.decide && ts.theta > 0.0 && !wts && sp.theta == 0.0 && cur_row && gridR >= 6 && gridC >= 6 &&
+        (int64_t)gridR * gridC == n && sp.aggregation != CSGPU_AGG_MIS2) {
+      // an all-valid raster: unit weights so that the piece analysis can run the heterogeneity test
+      size_prev.alloc((size_t)n * sizeof(long long));
+      hipLaunchKernelGGL(fill_ll_kernel, dim3(grid_for(n)), dim3(256), 0, st, dptr<long long>(size_prev), (int64_t)n, 1LL);
+      wts = dptr<long long>(size_prev);
+      ts.unit_weights = true;
+    }
+    const bool cell_level = (sp.size0 || ts.unit_weights) && H.levels.size() == 1;
+    int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level, &ts);
+    if (ts.decide) {
+      carry.tile_theta = ts.theta;  // (0 when the test declined, or when this level has no regular tiles)
+      if (ts.unit_weights) {
+        if (ts.theta > 0.0) {
+          carry.weighted = true;
+        } else {
+          size_prev.release();
+          wts = nullptr;
+        }
+      }
+    }
     if (sp.theta > 0.0 && (double)nagg > 0.5 * (double)n) {
       // the strength filter left too few strong couplings to coarsen this level: aggregate on the full pattern
-      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level);
+      nagg = aggregate(L.A, dptr<T>(diag), 0.0, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level, &ts);
     }
     const int lvlR = gridR, lvlC = gridC;  // raster extent of THIS level
     // coarse raster extent (tile counts), valid while the aggregates are the regular tiles

@@ -223,11 +223,21 @@ __global__ __launch_bounds__(256) void lattice_tile_kernel(int64_t n, int R, int
   }
 }
 
+// a coupling below theta * sqrt(a_ii a_jj) (TileStrength, amg_setup.h); round32: the hierarchy computes on the values
+// rounded to fp32 (the CSR pipeline applies the test to its fp32 copy of the matrix: same decisions)
+template <class U>
+__device__ __forceinline__ bool dia_weak(U a, U di, U dj, double theta2, int round32) {
+  const double x = round32 ? (double)(float)a : (double)a;
+  const double p = round32 ? (double)(float)di : (double)di, q = round32 ? (double)(float)dj : (double)dj;
+  return x * x < theta2 * p * q;
+}
+
 // piece analysis of amg_setup.h (tile_pieces_kernel) on the lattice form; see the comment there
 template <class U, int PASS>
 __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                          long long* __restrict__ size_f, signed char* __restrict__ piece,
-                                                         signed char* __restrict__ mainlab, int* __restrict__ agg) {
+                                                         signed char* __restrict__ mainlab, int* __restrict__ agg,
+                                                         double theta2, int round32) {
   const int ntiles = Rc * Cc;
   const int64_t n = (int64_t)R * C;
   for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, i
           lab[kc * h + kr] = valid ? kc * h + kr : -1;
           nvalid += valid ? 1 : 0;
         }
-      if (nvalid > 0 && nvalid < h * w) {  // (a full tile is connected: adjacent valid cells are always coupled)
+      if (nvalid > 0 && (nvalid < h * w || theta2 > 0.0)) {  // (a full tile is connected: adjacent valid cells are always coupled)
         for (int sweep = 0; sweep < 16; ++sweep) {
           bool changed = false;
           for (int kc = 0; kc < w; ++kc)
@@ -257,7 +267,9 @@ __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, i
               for (int k = 0; k < 9; ++k) {
                 if (k == 4) continue;
                 int64_t nb;
-                if (dia_row_entry(rows, n, R, cell, k, nb) == U(0)) continue;
+                const U av = dia_row_entry(rows, n, R, cell, k, nb);
+                if (av == U(0)) continue;
+                if (theta2 > 0.0 && dia_weak(av, rows[cell * 5], rows[nb * 5], theta2, round32)) continue;
                 const int ni = (int)(nb % R) - r0, nj = (int)(nb / R) - c0;
                 if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
                 const int l2 = lab[nj * h + ni];
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, i
             int64_t nb;
             const U v = dia_row_entry(rows, n, R, cell, k, nb);
             if (v == U(0)) continue;
+            if (theta2 > 0.0 && dia_weak(v, rows[cell * 5], rows[nb * 5], theta2, round32)) continue;
             const int ni = (int)(nb % R), nj = (int)(nb / R);
             if (ni >= r0 && ni < r1 && nj >= c0 && nj < c1) continue;  // inside this tile
             const int nt = lat_tile(nj, Cc) * Rc + lat_tile(ni, Rc);
@@ -326,7 +339,7 @@ template <class U>
 __global__ __launch_bounds__(256) void dia_orphans_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                           long long* __restrict__ size_f, signed char* __restrict__ piece,
                                                           const signed char* __restrict__ mainlab, int* __restrict__ agg,
-                                                          int round, int last) {
+                                                          int round, int last, double theta2, int round32) {
   const int64_t n = (int64_t)R * C;
   for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < n; cell += (int64_t)gridDim.x * 256) {
     const int pc = piece[cell];
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(256) void dia_orphans_kernel(int R, int C, int Rc, 
       const U v = dia_row_entry(rows, n, R, cell, k, nb);
       if (v == U(0)) continue;
       coupled = true;
+      if (theta2 > 0.0 && dia_weak(v, rows[cell * 5], rows[nb * 5], theta2, round32)) continue;
       const int pn = piece[nb];
       if (pn < kPieceAttached || pn >= kPieceAttached + round) continue;  // attached in an EARLIER round (deterministic)
       const int ta = agg[nb], tI = ta % Rc, tJ = ta / Rc;
@@ -640,19 +654,58 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   hipLaunchKernelGGL(lattice_tile_kernel, dim3(g), dim3(256), 0, st, n, R, Rc, Cc, dptr<int>(agg), dptr<int>(carry.crow),
                      dptr<int>(carry.ccol));
   static const bool no_pieces = getenv("CSGPU_NO_TILE_PIECES") != nullptr;  // A/B knob
-  if (size0 && !no_pieces) {
+  // strength filter of the piece analysis (TileStrength in amg_setup.h): decided here for the whole hierarchy
+  DBuf ones;  // unit weights of an all-valid raster that turns out heterogeneous
+  double th2 = 0.0;
+  carry.tile_theta = 0.0;
+  if ((size0 || sp.tile_theta > 0.0) && !no_pieces) {
     DBuf piece((size_t)n), mainlab((size_t)nc);
     const int gt = grid_for(nc);
-    hipLaunchKernelGGL((dia_pieces_kernel<U, 1>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
-                       (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
-    hipLaunchKernelGGL((dia_pieces_kernel<U, 2>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
-                       (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg));
-    for (int round = 1; round <= kOrphanRounds; ++round)
-      hipLaunchKernelGGL((dia_orphans_kernel<U>), dim3(g), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
-                         (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
-                         round == kOrphanRounds ? 1 : 0);
-    check_launch("tile pieces (lattice)");
-    CS_HIP(hipStreamSynchronize(st));
+    const bool unit = size0 == nullptr;
+    if (unit) {
+      ones.alloc((size_t)n * sizeof(long long));
+      hipLaunchKernelGGL(fill_ll_kernel, dim3(g), dim3(256), 0, st, dptr<long long>(ones), n, 1LL);
+      size0 = dptr<long long>(ones);
+    }
+    const int r32 = sizeof(T) < sizeof(U) ? 1 : 0;
+    auto pass1 = [&](double t2) {
+      hipLaunchKernelGGL((dia_pieces_kernel<U, 1>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                         (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), t2, r32);
+    };
+    const double t2 = sp.tile_theta * sp.tile_theta;
+    int64_t valid = 0, out0 = 0, out1 = 0;
+    if (t2 > 0.0) {
+      if (!unit) {
+        pass1(0.0);
+        piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out0, st);
+      }
+      pass1(t2);
+      piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out1, st);
+    }
+    const bool hetero = t2 > 0.0 && (double)(out1 - out0) > sp.tile_split_min * (double)std::max<int64_t>(valid, 1);
+    if (getenv("CSGPU_VERBOSE"))
+      fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
+              (long long)out1, (long long)valid, sp.tile_theta, (long long)out0, hetero ? "filter ON" : "filter off");
+    if (hetero) {
+      th2 = t2;
+      carry.tile_theta = sp.tile_theta;
+      carry.weighted = true;  // (no effect when the caller's weights exist anyway)
+    } else if (unit) {
+      size0 = nullptr;  // regular tiles, every cell a node: nothing to analyse
+      ones.release();
+    } else {
+      pass1(0.0);
+    }
+    if (size0) {
+      hipLaunchKernelGGL((dia_pieces_kernel<U, 2>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                         (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), th2, r32);
+      for (int round = 1; round <= kOrphanRounds; ++round)
+        hipLaunchKernelGGL((dia_orphans_kernel<U>), dim3(g), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
+                           (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
+                           round == kOrphanRounds ? 1 : 0, th2, r32);
+      check_launch("tile pieces (lattice)");
+      CS_HIP(hipStreamSynchronize(st));
+    }
   }
   DBuf size_c = dalloc<unsigned long long>((size_t)nc);
   CS_HIP(hipMemsetAsync(size_c.p, 0, size_c.bytes, st));

@@ -114,6 +114,10 @@ inline void fill(V* p, int64_t n, V v, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL((fill_kernel<V>), dim3(grid_for(n)), dim3(kBlock), 0, st, p, n, v);
 }
 
+__global__ __launch_bounds__(256) void fill_ll_kernel(long long* __restrict__ p, int64_t n, long long v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
 __global__ __launch_bounds__(256) void fill_int_kernel(int* __restrict__ p, int64_t n, int v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }

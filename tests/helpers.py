@@ -978,3 +978,60 @@ def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4):
         assert np.max(np.abs(Ra - Rb) / Rb) < (1e-10 if a["pb"] == 0 else 1e-8), (a["case"], a["pb"])
         used += a["bytes"] > b["bytes"]            # (the lattice forms are held in addition to the CSR operators)
     assert used >= 4, used                         # the all-valid rasters, both precisions, must have taken the lattice form
+
+
+def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
+    """strongly heterogeneous conductances (log-normal sigma = 2, 3: cell-to-cell ratios up to e^+-9).
+    The reference copes through symmetric Gauss-Seidel (src/core.jl:166-167); here the regular tiles are refined by the
+    strength-aware piece analysis (TileStrength, amg_setup.h) when the raster is heterogeneous. Checked: resistances
+    against the tight oracle (1e-6); iteration counts within 1.5x of the oracle's own (= the reference's algorithm with
+    its Gauss-Seidel smoother) at the reference's tolerances; clearly fewer iterations than with the filter switched off
+    (CSGPU_TILE_THETA=0, read once per process -> child processes); the sigma = 1 raster of the bench is NOT touched
+    (same iteration count with and without)."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        lib.load(%r)
+        out = []
+        N = %d
+        z = np.random.default_rng(11).standard_normal((N, N))
+        ids = np.random.default_rng(5).choice(N * N, size=2 * %d, replace=False)
+        for sigma in (1.0, 2.0, 3.0):
+            for pb in (0, 4):
+                with lib.raster_setup(np.exp(sigma * z), lib.default_opts(batch=%d, precond_bytes=pb)) as h:
+                    R, _, _, st = h.solve_pairs([int(v) for v in ids[:%d]], [int(v) for v in ids[%d:]])
+                    out.append({"sigma": sigma, "pb": pb, "iters": st["total_iters"] / float(%d), "nc": int(st["not_converged"]),
+                                "R": [float(v) for v in R], "lat": int(h.info["lattice_period"])})
+        print("RESULT" + json.dumps(out))
+    ''') % (root, L.loaded_path(), N, batch, batch, batch, batch, batch)
+    res = {}
+    for tag, extra in (("filter", {}), ("plain", {"CSGPU_TILE_THETA": "0"})):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("CSGPU_TILE_THETA", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
+    z = np.random.default_rng(11).standard_normal((N, N))
+    ids = np.random.default_rng(5).choice(N * N, size=2 * batch, replace=False)
+    for sigma in (1.0, 2.0, 3.0):
+        g = np.exp(sigma * z)
+        A = oracle.regularize(rg.laplacian(rg.construct_graph(g, rg.construct_node_map(g, None), False, False)))
+        S = oracle.OracleAMG(A)
+        Rt, _, _ = S.solve_pairs(ids[:batch], ids[batch:], rtol=1e-12, atol=0.0, criterion=1, nthreads=4)
+        _, _, o = S.solve_pairs(ids[:batch], ids[batch:], nthreads=4)                  # the reference's tolerances
+        it_oracle = float(np.mean([x["iters"] for x in o]))
+        for pb in (0, 4):
+            a = next(x for x in res["filter"] if x["sigma"] == sigma and x["pb"] == pb)
+            b = next(x for x in res["plain"] if x["sigma"] == sigma and x["pb"] == pb)
+            assert a["nc"] == 0 and b["nc"] == 0 and a["lat"] == N
+            assert np.max(np.abs(np.array(a["R"]) - Rt) / Rt) < 1e-6, (sigma, pb)
+            assert a["iters"] <= 1.5 * it_oracle + 1.0, (sigma, pb, a["iters"], it_oracle)
+            if sigma == 1.0:
+                assert a["iters"] == b["iters"] and a["R"] == b["R"], "the filter must not trigger on the bench's raster"
+            if sigma == 3.0:
+                assert a["iters"] <= 0.85 * b["iters"], (a["iters"], b["iters"])

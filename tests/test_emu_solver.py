@@ -1139,3 +1139,9 @@ def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
     """see helpers.check_lattice_level1"""
     from helpers import check_lattice_level1
     check_lattice_level1(emu_lib, monkeypatch, shapes=((390, 396),))
+
+
+def test_heterogeneous_rasters_strength_aware_tiles(emu_lib, oracle):
+    """see helpers.check_heterogeneous_rasters"""
+    from helpers import check_heterogeneous_rasters
+    check_heterogeneous_rasters(emu_lib, oracle, N=150, batch=4)

@@ -495,3 +495,10 @@ def test_lattice_level1_matches_csr_level1_gpu(gpu_lib, monkeypatch):
     """level 1 of a raster hierarchy as four marching products == the seven CSR products: helpers.check_lattice_level1"""
     from helpers import check_lattice_level1
     check_lattice_level1(gpu_lib, monkeypatch, shapes=((1500, 1400), (601, 777)), batch=16)
+
+
+def test_heterogeneous_rasters_strength_aware_tiles_gpu(gpu_lib, oracle):
+    """log-normal sigma = 2, 3 rasters: strength-aware tiles keep the iteration count within 1.5x of the oracle's
+    Gauss-Seidel hierarchy (helpers.check_heterogeneous_rasters)"""
+    from helpers import check_heterogeneous_rasters
+    check_heterogeneous_rasters(gpu_lib, oracle, N=600, batch=16)
