@@ -902,11 +902,15 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
 // tiles are what keeps level 1 a nine-point lattice (lattice_level1_setup). CSGPU_TILE_THETA / CSGPU_TILE_SPLIT_MIN
 // override the defaults (theta 0 switches the filter off).
 inline double default_tile_theta() {
-  static const double t = getenv("CSGPU_TILE_THETA") ? atof(getenv("CSGPU_TILE_THETA")) : 0.06;
+  static const double t = getenv("CSGPU_TILE_THETA") ? atof(getenv("CSGPU_TILE_THETA")) : 0.03;
   return t;
 }
+inline int tile_sample_stride(int64_t ntiles) {  // the heterogeneity test looks at ~65 k tiles
+  const int64_t s = ntiles / 65536;
+  return (int)std::max<int64_t>(1, s);
+}
 inline double default_tile_split_min() {
-  static const double t = getenv("CSGPU_TILE_SPLIT_MIN") ? atof(getenv("CSGPU_TILE_SPLIT_MIN")) : 0.02;
+  static const double t = getenv("CSGPU_TILE_SPLIT_MIN") ? atof(getenv("CSGPU_TILE_SPLIT_MIN")) : 0.005;
   return t;
 }
 
@@ -1052,9 +1056,12 @@ __global__ __launch_bounds__(256) void tile_pieces_kernel(int R, int C, int Rc, 
                                                           const int* __restrict__ ci, const T* __restrict__ va,
                                                           long long* __restrict__ size_f, signed char* __restrict__ piece,
                                                           signed char* __restrict__ mainlab, int* __restrict__ agg,
-                                                          int full_connected, const T* __restrict__ diag, double theta2) {
+                                                          int full_connected, const T* __restrict__ diag, double theta2,
+                                                          int stride) {
   const int ntiles = Rc * Cc;
-  for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
+  // (stride > 1: every stride-th tile only -- the sampled heterogeneity test of TileStrength)
+  for (int64_t tl = ((int64_t)blockIdx.x * 256 + threadIdx.x) * stride; tl < ntiles; tl += (int64_t)gridDim.x * 256 * stride) {
+    const int tile = (int)tl;
     const int I = tile % Rc, J = tile / Rc;
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
@@ -1206,25 +1213,28 @@ __global__ __launch_bounds__(256) void tile_orphans_kernel(int n, int R, int Rc,
 
 // cnt[0] += cells with weight, cnt[1] += those outside their tile's main piece (after pass 1 of the piece analysis)
 __global__ __launch_bounds__(256) void piece_count_kernel(int64_t n, int R, int Rc, int Cc, const signed char* __restrict__ piece,
-                                                          const signed char* __restrict__ mainlab, int* __restrict__ cnt) {
+                                                          const signed char* __restrict__ mainlab, int* __restrict__ cnt,
+                                                          int stride) {
   int valid = 0, out = 0;
   for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < n; cell += (int64_t)gridDim.x * 256) {
+    const int I = min((int)(cell % R) / 3, Rc - 1), J = min((int)(cell / R) / 3, Cc - 1);
+    const int64_t tile = (int64_t)J * Rc + I;
+    if (tile % stride != 0) continue;  // (only the sampled tiles hold labels of this pass)
     const int pc = piece[cell];
     if (pc < 0) continue;
     ++valid;
-    const int I = min((int)(cell % R) / 3, Rc - 1), J = min((int)(cell / R) / 3, Cc - 1);
-    out += pc != mainlab[(int64_t)J * Rc + I] ? 1 : 0;
+    out += pc != mainlab[tile] ? 1 : 0;
   }
   if (valid) atomicAdd(&cnt[0], valid);
   if (out) atomicAdd(&cnt[1], out);
 }
 
 inline void piece_counts(int64_t n, int R, int Rc, int Cc, const DBuf& piece, const DBuf& mainlab, int64_t& valid, int64_t& out,
-                         hipStream_t st) {
+                         hipStream_t st, int stride = 1) {
   DBuf cnt = dalloc<int>(2);
   CS_HIP(hipMemsetAsync(cnt.p, 0, 2 * sizeof(int), st));
   hipLaunchKernelGGL(piece_count_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, R, Rc, Cc, (const signed char*)piece.p,
-                     (const signed char*)mainlab.p, dptr<int>(cnt));
+                     (const signed char*)mainlab.p, dptr<int>(cnt), stride);
   int h[2];
   CS_HIP(hipMemcpyAsync(h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
@@ -1237,6 +1247,7 @@ struct TileStrength {
   double theta = 0.0;       // in: the threshold to try (0 = none). out (decide): the threshold in effect
   double split_min = 0.0;   // decide: use theta only if more than this fraction of the weighted cells leaves its tile
   bool decide = false;      // level 0: run the test; deeper levels just apply theta
+  bool theta_tried = false;   // (internal) the sampled pass ran with the filter
   bool unit_weights = false;  // size_f was allocated as all ones for this test only (an all-valid raster): without the
                               // filter the piece analysis has nothing to do
 };
@@ -1267,21 +1278,27 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
     if (size_f && !no_pieces) {
       DBuf piece((size_t)n), mainlab((size_t)Rc * Cc);
       const int gt = grid_for((int64_t)Rc * Cc);
-      auto pass1 = [&](double t2) {
-        hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                           size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0, diag, t2);
+      auto pass1 = [&](double t2, int stride) {
+        hipLaunchKernelGGL((tile_pieces_kernel<T, 1>), dim3(grid_for(ceil_div((int64_t)Rc * Cc, stride))), dim3(256), 0, st,
+                           gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(), size_f, (signed char*)piece.p, (signed char*)mainlab.p,
+                           dptr<int>(agg), cell_level ? 1 : 0, diag, t2, stride);
       };
       double th2 = ts ? ts->theta * ts->theta : 0.0;
       if (ts && ts->decide) {
-        // heterogeneity test (TileStrength): cells that leave their tile's main piece BECAUSE of the filter
+        // heterogeneity test (TileStrength): cells that leave their tile's main piece BECAUSE of the filter, counted on
+        // a sample of the tiles (every stride-th; ~65 k tiles: the full analysis costs 50 ms at 1e8 cells)
+        const int stride = tile_sample_stride((int64_t)Rc * Cc);
         int64_t valid = 0, out0 = 0, out1 = 0;
+        bool ran_plain = false;
         if (th2 > 0.0) {
           if (!ts->unit_weights) {
-            pass1(0.0);
-            piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out0, st);
+            pass1(0.0, 1);
+            ran_plain = true;
+            piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out0, st, stride);
           }
-          pass1(th2);
-          piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out1, st);
+          pass1(th2, stride);
+          ts->theta_tried = true;
+          piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out1, st, stride);
         }
         const bool hetero = th2 > 0.0 && (double)(out1 - out0) > ts->split_min * (double)std::max<int64_t>(valid, 1);
         if (getenv("CSGPU_VERBOSE"))
@@ -1294,13 +1311,18 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
             check_launch("tile aggregation");
             return Rc * Cc;
           }
-          pass1(0.0);
+          if (!ran_plain)
+            pass1(0.0, 1);
+          else if (ts->theta_tried)
+            pass1(0.0, stride);  // (the sampled tiles hold the labels of the filtered pass)
+        } else {
+          pass1(th2, 1);
         }
       } else {
-        pass1(th2);
+        pass1(th2, 1);
       }
       hipLaunchKernelGGL((tile_pieces_kernel<T, 2>), dim3(gt), dim3(256), 0, st, gridR, gridC, Rc, Cc, A.rp(), A.ci(), A.va(),
-                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0, diag, th2);
+                         size_f, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), cell_level ? 1 : 0, diag, th2, 1);
       for (int round = 1; round <= kOrphanRounds; ++round)
         hipLaunchKernelGGL((tile_orphans_kernel<T>), dim3(grid_for(n)), dim3(256), 0, st, n, gridR, Rc, Cc, A.rp(), A.ci(),
                            A.va(), size_f, (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,

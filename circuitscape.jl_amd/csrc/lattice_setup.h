@@ -237,10 +237,11 @@ template <class U, int PASS>
 __global__ __launch_bounds__(256) void dia_pieces_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                          long long* __restrict__ size_f, signed char* __restrict__ piece,
                                                          signed char* __restrict__ mainlab, int* __restrict__ agg,
-                                                         double theta2, int round32) {
+                                                         double theta2, int round32, int stride) {
   const int ntiles = Rc * Cc;
   const int64_t n = (int64_t)R * C;
-  for (int tile = blockIdx.x * 256 + threadIdx.x; tile < ntiles; tile += gridDim.x * 256) {
+  for (int64_t tl = ((int64_t)blockIdx.x * 256 + threadIdx.x) * stride; tl < ntiles; tl += (int64_t)gridDim.x * 256 * stride) {
+    const int tile = (int)tl;
     const int I = tile % Rc, J = tile / Rc;
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
@@ -668,19 +669,20 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
       size0 = dptr<long long>(ones);
     }
     const int r32 = sizeof(T) < sizeof(U) ? 1 : 0;
-    auto pass1 = [&](double t2) {
-      hipLaunchKernelGGL((dia_pieces_kernel<U, 1>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
-                         (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), t2, r32);
+    auto pass1 = [&](double t2, int stride) {
+      hipLaunchKernelGGL((dia_pieces_kernel<U, 1>), dim3(grid_for(ceil_div(nc, stride))), dim3(256), 0, st, R, C, Rc, Cc,
+                         A0.data(), size0, (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), t2, r32, stride);
     };
     const double t2 = sp.tile_theta * sp.tile_theta;
+    const int stride = tile_sample_stride(nc);  // the test looks at a sample of the tiles (amg_setup.h, aggregate)
     int64_t valid = 0, out0 = 0, out1 = 0;
     if (t2 > 0.0) {
       if (!unit) {
-        pass1(0.0);
-        piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out0, st);
+        pass1(0.0, 1);
+        piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out0, st, stride);
       }
-      pass1(t2);
-      piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out1, st);
+      pass1(t2, stride);
+      piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out1, st, stride);
     }
     const bool hetero = t2 > 0.0 && (double)(out1 - out0) > sp.tile_split_min * (double)std::max<int64_t>(valid, 1);
     if (getenv("CSGPU_VERBOSE"))
@@ -690,15 +692,18 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
       th2 = t2;
       carry.tile_theta = sp.tile_theta;
       carry.weighted = true;  // (no effect when the caller's weights exist anyway)
+      pass1(t2, 1);
     } else if (unit) {
       size0 = nullptr;  // regular tiles, every cell a node: nothing to analyse
       ones.release();
+    } else if (t2 > 0.0) {
+      pass1(0.0, stride);  // (the sampled tiles hold the labels of the filtered pass)
     } else {
-      pass1(0.0);
+      pass1(0.0, 1);
     }
     if (size0) {
       hipLaunchKernelGGL((dia_pieces_kernel<U, 2>), dim3(gt), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
-                         (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), th2, r32);
+                         (signed char*)piece.p, (signed char*)mainlab.p, dptr<int>(agg), th2, r32, 1);
       for (int round = 1; round <= kOrphanRounds; ++round)
         hipLaunchKernelGGL((dia_orphans_kernel<U>), dim3(g), dim3(256), 0, st, R, C, Rc, Cc, A0.data(), size0,
                            (signed char*)piece.p, (const signed char*)mainlab.p, dptr<int>(agg), round,
