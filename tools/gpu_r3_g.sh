@@ -3,8 +3,8 @@
 ulimit -c 0
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3g
 rm -rf $OUT; mkdir -p $OUT
-timeout 900 python -m pytest tests -m gpu -q -x -k "heterogeneous or lattice_level1 or lattice_pipeline or cellspace or nodata or chebyshev" > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-ORACLE=1 timeout 600 python tools/hetero_bench.py 3000 > $OUT/hetero_3000.jsonl 2> $OUT/hetero_3000.err; cut -c1-700 $OUT/hetero_3000.jsonl
+timeout 900 python -m pytest tests -m gpu -q -x -k "heterogeneous or lattice_pipeline or cellspace" > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 300 python tools/hetero_bench.py 3000 > $OUT/hetero_3000.jsonl 2> $OUT/hetero_3000.err; cut -c1-700 $OUT/hetero_3000.jsonl
 CSGPU_TILE_THETA=0 timeout 300 python tools/hetero_bench.py 3000 > $OUT/hetero_3000_off.jsonl 2> $OUT/hetero_3000_off.err; cut -c1-500 $OUT/hetero_3000_off.jsonl
 timeout 400 python bench.py --steps 6 --warmup 2 --cpu-sample 0 --host-csr 0 > $OUT/bench.json 2> $OUT/bench.err
 python - <<'PY'
