@@ -460,27 +460,47 @@ __global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc
   }
 }
 
-// A P and Q = P - w D^-1 A P, both index-free ([n][9]); ap may be null (only Q wanted)
+// A P and Q = P - w D^-1 A P, both index-free ([n][9]); ap may be null (only Q wanted).
+// A workgroup owns 256 consecutive cells. The rows of `pl` it needs -- the cells themselves and their eight lattice
+// neighbours -- are three contiguous runs of 258 rows (raster columns j-1, j, j+1), staged in LDS with coalesced loads:
+// read directly, every lane would fetch nine 72-byte rows at a 72-byte lane stride, 81 load instructions that each touch
+// 36 cache lines (measured at 1e8 cells, fp64: 52 ms -- the largest kernel of the setup; staged: see profiles/r3_setup_*).
 template <class U, class T>
 __global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
                                                            const T* __restrict__ pl, const T* __restrict__ dinv, T omega,
                                                            T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad,
-                                                           const T* __restrict__ base = nullptr) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int I = lat_tile((int)(i % R), Rc), J = lat_tile((int)(i / R), Cc);
+                                                           const T* __restrict__ base) {
+  constexpr int RUN = 258 * 9;
+  __shared__ T s_x[3][RUN];
+  const int tid = threadIdx.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+    __syncthreads();  // (the previous round's reads)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int64_t c0 = i0 + (int64_t)(r - 1) * R - 1;  // first cell of the run
+      for (int e = tid; e < RUN; e += 256) {
+        const int64_t cell = c0 + e / 9;
+        s_x[r][e] = (cell >= 0 && cell < n) ? pl[c0 * 9 + e] : T(0);
+      }
+    }
+    __syncthreads();
+    const int64_t i = i0 + tid;
+    const bool on = i < n;
+    const int I = on ? lat_tile((int)(i % R), Rc) : 0, J = on ? lat_tile((int)(i / R), Cc) : 0;
     T acc[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) acc[s] = T(0);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 9 && on; ++k) {
       int64_t j;
       const T a = (T)dia_row_entry(rows, n, R, i, k, j);
       if (a == T(0)) continue;
       const int Ij = lat_tile((int)(j % R), Rc), Jj = lat_tile((int)(j / R), Cc);
       const int sI = Ij - I, sJ = Jj - J;  // tile of j relative to tile of i: -1, 0, 1
+      const T* xr = &s_x[k / 3][(tid + k % 3) * 9];  // row j of pl
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
-        const T pv = pl[j * 9 + s];
+        const T pv = xr[s];
         if (pv == T(0)) continue;
         const int dI = s % 3 - 1 + sI, dJ = s / 3 - 1 + sJ;
         if (dI < -1 || dI > 1 || dJ < -1 || dJ > 1) {
@@ -493,13 +513,27 @@ __global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int
           if (s2 == so) acc[s2] += a * pv;
       }
     }
-    // q = base - w (M pl) with w = omega * dinv (dinv null: w = omega) and base = pl unless given
-    const T w = dinv ? omega * dinv[i] : omega;
-    const T* bs = base ? base : pl;
+    // q = base - w (M pl) with w = omega * dinv (dinv null: w = omega) and base = pl unless given; both results leave
+    // through LDS so that the stores are contiguous too
+    T qv[9];
+    if (on) {
+      const T w = dinv ? omega * dinv[i] : omega;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      if (ap) ap[i * 9 + s] = acc[s];
-      if (q) q[i * 9 + s] = -w * acc[s] + bs[i * 9 + s];
+      for (int s = 0; s < 9; ++s) qv[s] = -w * acc[s] + (base ? base[i * 9 + s] : s_x[1][(tid + 1) * 9 + s]);
+    }
+    __syncthreads();  // every lane has taken its rows out of the staged runs
+    if (on) {
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        s_x[0][tid * 9 + s] = acc[s];
+        s_x[2][tid * 9 + s] = qv[s];
+      }
+    }
+    __syncthreads();
+    const int cnt = (int)(n - i0 < 256 ? n - i0 : 256) * 9;
+    for (int e = tid; e < cnt; e += 256) {
+      if (ap) ap[i0 * 9 + e] = s_x[0][e];
+      if (q) q[i0 * 9 + e] = s_x[2][e];
     }
   }
 }

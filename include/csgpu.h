@@ -50,8 +50,11 @@
  *     column/row form (identical by symmetry) exactly as Julia's SparseMatrixCSC stores it:
  *     rowptr[n+1], colidx[nnz] (sorted within a row), vals[nnz]; idx_bytes in {4,8}, val_bytes in {4,8},
  *     index_base in {0,1}. The library COPIES it to the device; host pointers are never retained.
- *   - On device everything is int32 / 0-based; nnz < 2^31 (and n < 2^31 - 1) are required (status 4 otherwise);
- *     vector element indices (node * batch + column) are 64-bit.
+ *   - On device everything is int32 / 0-based; nnz < 2^31 (and n < 2^31 - 1) are required of matrices handed over in
+ *     CSR form (status 4 otherwise); vector element indices (node * batch + column) are 64-bit. csgpu_raster_setup builds
+ *     the fine level of a raster without a CSR matrix, so rasters are limited by n = rows * cols < 2^31 - 1 only (tested
+ *     at 21000 x 21000 = 441 M cells, 3.97e9 stored entries); calls that need the CSR form of such a raster (voltage /
+ *     current maps, explicit_check) return status 4, resistance-only csgpu_solve_pairs does not.
  *   - All calls are blocking; a handle is serialised internally (one caller at a time per handle).
  *   - Return value: 0 ok, 1 not converged (some right-hand side hit itmax or failed the reference's
  *     1e-4 true-residual check), 2 HIP runtime error, 3 out of memory, 4 bad arguments, 5 internal error.
@@ -104,7 +107,10 @@ typedef struct csgpu_opts {
                              the hierarchy is fp32 above 3e7 rows, which keeps one damped weight. Default 2 (measured
                              on the 10000^2 raster: 3 -> 324.7 ms per batch of 16 at 12.8 iterations, 2 -> 309.2 ms at
                              12.9, 1 -> 327.4 ms at 14.9; profiles/r2_polling_graph_nucoarse.json) */
-  double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength), default 0 */
+  double theta;           /* symmetric strength threshold (AlgebraicMultigrid SymmetricStrength) of the MIS(2) aggregation,
+                             default 0 (the reference's). Raster lattices keep their regular 3x3 tiles and apply a
+                             strength filter of their own (0.03 sqrt(a_ii a_jj), only on heterogeneous rasters: csrc/amg_setup.h,
+                             TileStrength); theta != 0 switches the lattice paths off */
   double omega_p;         /* prolongator smoothing weight over local row-abs-sum weighting: P = T - omega_p Dl^-1 A T.
                              The reference's JacobiProlongation uses 4/3; 1.6 (default) measured 35 % fewer PCG
                              iterations on the 10000^2 raster (tools/sweep.sh) */
@@ -186,7 +192,9 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
                 int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out);
 
 /* Build the 4/8-neighbour Laplacian of a conductance raster (no polygons) directly in HBM and set up AMG.
- * Cells with conductance <= 0 are NODATA (no node), as in construct_node_map.
+ * Cells with conductance <= 0 are NODATA (no node), as in construct_node_map. (A raster that is at least half valid keeps
+ * one device row per CELL so that the index-free lattice kernels apply -- "cell space"; node ids, n and
+ * every n-vector at this boundary stay in the reference's compact numbering.)
  * cond: host pointer, nrows*ncols values (row-major, the orientation of the reference's cellmap[i,j]),
  * all > 0; node numbering is column-major like construct_node_map (raster/pairwise.jl:273-275).
  * reg != 0 applies the reference's regularisation nzval .+= eps(T)*norm(nzval) (core.jl:161). On a raster with several
