@@ -928,7 +928,7 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
                 assert np.allclose(a["y"], a["A0"] @ a["x"], rtol=1e-12, atol=1e-12)
 
 
-def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4):
+def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4, extra_env=None):
     """lattice_setup.h lattice_level1_setup + the lattice branch of vcycle() (pcg.h): level 1 of a raster hierarchy as four
     marching products (x = S b, b_c = Q2' b, t = b - A x, out = x + S t + Q2 x_c) against the seven CSR products of the
     generic branch (CSGPU_NO_LATTICE_L1=1, read once per process -> child processes): the same algebra, so the same
@@ -963,6 +963,7 @@ def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4):
     res = {}
     for tag, extra in (("lattice", {}), ("csr", {"CSGPU_NO_LATTICE_L1": "1"})):
         env = dict(os.environ, **extra)
+        env.update(extra_env or {})   # (small rasters: CSGPU_LATTICE_L1_MIN_ROWS / CSGPU_TAIL_ROWS let level 1 take the form)
         if not extra:
             env.pop("CSGPU_NO_LATTICE_L1", None)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1800, cwd=root)

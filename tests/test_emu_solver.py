@@ -1105,7 +1105,7 @@ def test_cellspace_raster_is_indistinguishable_at_the_boundary(emu_lib, oracle, 
 def test_lattice_pipeline_matches_csr_pipeline(emu_lib, monkeypatch):
     """see helpers.check_lattice_pipeline"""
     from helpers import check_lattice_pipeline
-    check_lattice_pipeline(emu_lib, monkeypatch, shapes=((37, 41), (48, 36)))
+    check_lattice_pipeline(emu_lib, monkeypatch, shapes=((37, 41),))
 
 
 def _omniscape_landscape(shape, seed):
@@ -1138,10 +1138,12 @@ def test_omniscape_moving_window_driver(emu_lib):
 def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
     """see helpers.check_lattice_level1"""
     from helpers import check_lattice_level1
-    check_lattice_level1(emu_lib, monkeypatch, shapes=((390, 396),))
+    # (small raster: the knobs let its 62 x 64 level 1 take the lattice form instead of running inside the coarse tail)
+    check_lattice_level1(emu_lib, monkeypatch, shapes=((186, 192),),
+                         extra_env={"CSGPU_LATTICE_L1_MIN_ROWS": "1024", "CSGPU_TAIL_ROWS": "1024"})
 
 
 def test_heterogeneous_rasters_strength_aware_tiles(emu_lib, oracle):
     """see helpers.check_heterogeneous_rasters"""
     from helpers import check_heterogeneous_rasters
-    check_heterogeneous_rasters(emu_lib, oracle, N=150, batch=4)
+    check_heterogeneous_rasters(emu_lib, oracle, N=120, batch=4)

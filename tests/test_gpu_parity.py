@@ -502,3 +502,25 @@ def test_heterogeneous_rasters_strength_aware_tiles_gpu(gpu_lib, oracle):
     Gauss-Seidel hierarchy (helpers.check_heterogeneous_rasters)"""
     from helpers import check_heterogeneous_rasters
     check_heterogeneous_rasters(gpu_lib, oracle, N=600, batch=16)
+
+
+@pytest.mark.parametrize("sigma", [1.0, 3.0])
+def test_recurrence_residual_post_check_at_size(gpu_lib, sigma):
+    """resistance-only pair solves evaluate the reference's 1e-4 post-check (core.jl:640) on the fp64
+    recurrence residual instead of an explicit ||Ax - b|| (explicit_check = 0, csgpu.h). Held against the explicit
+    product where a drift could show: 3000 x 3000, fp32 hierarchy with an fp32-stored search direction, the bench raster
+    (11 iterations) and a log-normal sigma = 3 raster (> 100 iterations of recurrence): identical resistances and
+    iteration counts (the two modes run the same fma sequence), residuals equal to 1e-3 of their value."""
+    N = 3000
+    g = np.exp(sigma * np.random.default_rng(11).standard_normal((N, N)))
+    ids = np.random.default_rng(5).choice(N * N, size=32, replace=False)
+    src, dst = [int(v) for v in ids[:16]], [int(v) for v in ids[16:]]
+    out = {}
+    for explicit in (0, 1):
+        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, precond_bytes=4, explicit_check=explicit)) as h:
+            R, _, _, st = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+            out[explicit] = (R, st)
+    (Ra, sa), (Rb, sb) = out[0], out[1]
+    assert np.array_equal(Ra, Rb) and sa["total_iters"] == sb["total_iters"]
+    assert abs(sa["max_relres"] - sb["max_relres"]) <= 1e-3 * sb["max_relres"], (sa["max_relres"], sb["max_relres"])
