@@ -305,7 +305,62 @@ struct Solver : ISolver {
     CS_HIP(hipStreamSynchronize(st));
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     opts.node_row = opts.node_col = nullptr;  // host pointers are never retained
+    if (prow && pcol && setup_cellspace_from_csr(A, prow, pcol)) return;
     finish_setup(std::move(A), prow, pcol, 0);
+  }
+
+  // The Julia host path for rasters WITH NODATA cells (lattice_setup.h, csr_to_cell_dia_kernel): a compact CSR Laplacian
+  // with the raster cell of every node becomes the cell-space lattice matrix csgpu_raster_setup would have built, and takes
+  // the index-free pipeline and the marching kernels from there (an all-valid raster needs none of this: its lattice
+  // period is detected from the matrix, detect_lattice). False -- nothing changed -- when the matrix is no such raster
+  // (polygons: couplings between cells that are not neighbours; two nodes on one cell; too few valid cells).
+  bool setup_cellspace_from_csr(Csr<T>& A, const int* prow, const int* pcol) {
+    static const bool off = getenv("CSGPU_NO_CELLSPACE_FROM_CSR") != nullptr;  // A/B knob
+    if (off || n_api < 36 || A.nnz < 1) return false;
+    DBuf mm = dalloc<int>(4);
+    const int init[4] = {-0x7fffffff, -0x7fffffff, 0x7fffffff, 0x7fffffff};
+    CS_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(coord_range_kernel, dim3(grid_for(n_api)), dim3(256), 0, st, (int)n_api, prow, pcol, dptr<int>(mm));
+    int h[4];
+    CS_HIP(hipMemcpyAsync(h, mm.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    // the lattice is the bounding box of the nodes' cells (a connected component of a larger raster brings its own box)
+    const int r0 = h[2], c0 = h[3];
+    const int64_t R = (int64_t)h[0] - r0 + 1, C = (int64_t)h[1] - c0 + 1, ncells = R * C;
+    if (R < 6 || C < 6 || ncells >= ((int64_t)1 << 31) - 1 || ncells <= n_api) return false;
+    if (!(want_cellspace(n_api, ncells, R, C) && want_lattice_pipeline(R, C))) return false;
+    DBuf n2c((size_t)n_api * sizeof(int)), c2n = dalloc<int>((size_t)ncells), bad = dalloc<int>(1);
+    CS_HIP(hipMemsetAsync(c2n.p, 0, (size_t)ncells * sizeof(int), st));
+    CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(csr_cells_kernel, dim3(grid_for(n_api)), dim3(256), 0, st, (int)n_api, (int)R, r0, c0, prow, pcol,
+                       dptr<int>(n2c), dptr<int>(c2n), dptr<int>(bad));
+    DBuf rows((size_t)ncells * 5 * sizeof(T)), size0((size_t)ncells * sizeof(long long));
+    CS_HIP(hipMemsetAsync(rows.p, 0, rows.bytes, st));
+    hipLaunchKernelGGL((csr_to_cell_dia_kernel<T>), dim3(grid_for(n_api)), dim3(256), 0, st, (int)n_api, (int)R, A.rp(), A.ci(),
+                       A.va(), prow, pcol, (const int*)dptr<int>(n2c), dptr<T>(rows), dptr<int>(bad));
+    hipLaunchKernelGGL((cell_identity_kernel<T>), dim3(grid_for(ncells)), dim3(256), 0, st, ncells, (const int*)dptr<int>(c2n),
+                       dptr<T>(rows), dptr<long long>(size0));
+    check_launch("CSR -> cell space");
+    if (read_int(dptr<int>(bad), st) != 0) return false;
+    cellspace = true;
+    n = ncells;
+    nnz = nnz_api + (ncells - n_api);
+    node2cell = std::move(n2c);
+    cell2node = std::move(c2n);
+    dia.n = ncells;
+    dia.R = (int)R;
+    dia.rows = std::move(rows);
+    if (lattice_pipeline_hierarchy(size0, R, C)) {
+      A = Csr<T>();  // (compact numbering: of no use to a cell-space handle; its CSR form is built on demand)
+      return true;
+    }
+    cellspace = false;
+    n = n_api;
+    nnz = nnz_api;
+    node2cell.release();
+    cell2node.release();
+    dia = Dia<T>();
+    return false;
   }
 
   const Csr<T>& cg_matrix() const {
@@ -427,6 +482,42 @@ struct Solver : ISolver {
     return R >= 6 && C >= 6 && R * C > opts.max_coarse && opts.max_levels >= 2;
   }
 
+  // Hierarchy of a lattice-form matrix `dia` (R x C, every cell a row; size0: weights of a cell-space matrix, may be
+  // empty) through the index-free pipeline of lattice_setup.h. False when the pipeline declined (nothing changed).
+  bool lattice_pipeline_hierarchy(DBuf& size0, int64_t R, int64_t C) {
+    hipEvent_t e0, e1;
+    CS_HIP(hipEventCreate(&e0));
+    CS_HIP(hipEventCreate(&e1));
+    CS_HIP(hipEventRecord(e0, st));
+
+    SetupParams sp = setup_params();
+    sp.grid_rows = (int)R;
+    sp.grid_cols = (int)C;
+    sp.lattice_s = true;
+    sp.size0 = cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr;
+    sp.n_real = cellspace ? n_api : 0;
+    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;  // (see finish_setup)
+    SetupCarry carry;
+    const bool ok = lattice_level0_setup<T, TP>(H, dia, (int)R, (int)C, cellspace ? dptr<long long>(size0) : (long long*)nullptr,
+                                                sp, carry, st);
+    if (ok) {
+      amg_setup_levels(H, sp, nullptr, nullptr, carry, st);
+      CS_HIP(hipEventRecord(e1, st));
+      CS_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+      H.setup_ms = ms;
+      if constexpr (MIXED) Aouter.nrows = Aouter.ncols = (int)n;
+      csr_ready = false;
+      if (getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: %lld x %lld raster through the index-free pipeline (%lld rows, %lld nodes, %d levels)\n",
+                (long long)R, (long long)C, (long long)n, (long long)n_api, (int)H.levels.size());
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ok;
+  }
+
   // Raster -> lattice form -> hierarchy, no CSR (lattice_setup.h). dcond / dground: device rasters (row-major); node: the
   // exclusive scan of the valid flags (column-major). Returns false when the pipeline declined (the caller falls back).
   bool setup_lattice_direct(DBuf& dcond, DBuf& dground, DBuf& node, int64_t R, int64_t C, int four, int avg_res, int reg,
@@ -465,36 +556,7 @@ struct Solver : ISolver {
     dground.release();
     node.release();
     upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    hipEvent_t e0, e1;
-    CS_HIP(hipEventCreate(&e0));
-    CS_HIP(hipEventCreate(&e1));
-    CS_HIP(hipEventRecord(e0, st));
-    SetupParams sp = setup_params();
-    sp.grid_rows = (int)R;
-    sp.grid_cols = (int)C;
-    sp.lattice_s = true;
-    sp.size0 = cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr;
-    sp.n_real = cellspace ? n_api : 0;
-    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;  // (see finish_setup)
-    SetupCarry carry;
-    const bool ok = lattice_level0_setup<T, TP>(H, dia, (int)R, (int)C, cellspace ? dptr<long long>(size0) : (long long*)nullptr,
-                                                sp, carry, st);
-    if (ok) {
-      amg_setup_levels(H, sp, nullptr, nullptr, carry, st);
-      CS_HIP(hipEventRecord(e1, st));
-      CS_HIP(hipEventSynchronize(e1));
-      float ms = 0;
-      CS_HIP(hipEventElapsedTime(&ms, e0, e1));
-      H.setup_ms = ms;
-      if constexpr (MIXED) Aouter.nrows = Aouter.ncols = (int)n;
-      csr_ready = false;
-      if (getenv("CSGPU_VERBOSE"))
-        fprintf(stderr, "csgpu: %lld x %lld raster through the index-free pipeline (%lld rows, %lld nodes, %d levels)\n",
-                (long long)R, (long long)C, (long long)n, (long long)n_api, (int)H.levels.size());
-    }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (ok) return true;
+    if (lattice_pipeline_hierarchy(size0, R, C)) return true;
     // declined (cannot happen for tile aggregates): CSR pipeline on the CSR form of the same matrix
     CS_REQUIRE(nnz < ((int64_t)1 << 31), CSGPU_BAD_ARGS, "raster too large for the CSR pipeline");
     Csr<T> A;

@@ -138,6 +138,77 @@ __global__ __launch_bounds__(256) void raster_dia_finish_kernel(int R, int C, co
   }
 }
 
+// ---- cell space from a CSR matrix with raster coordinates (the Julia host path) ------------------------------------------
+// A host that built its graph itself (construct_graph, src/raster/pairwise.jl:316-362) hands over a CSR Laplacian in the
+// compact numbering plus the raster cell of every node (csgpu_opts.node_row / node_col). When every node sits on a cell
+// of its own and every coupling joins lattice neighbours (no polygons), the matrix is scattered into the lattice form of
+// the R x C raster spanned by the coordinates -- the same cell-space matrix csgpu_raster_setup builds from the raster.
+__global__ __launch_bounds__(256) void coord_range_kernel(int n, const int* __restrict__ row, const int* __restrict__ col,
+                                                          int* __restrict__ mm) {  // mm = {max row, max col, min row, min col}
+  int r = -0x7fffffff, c = -0x7fffffff, r0 = 0x7fffffff, c0 = 0x7fffffff;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    r = max(r, row[i]);
+    c = max(c, col[i]);
+    r0 = min(r0, row[i]);
+    c0 = min(c0, col[i]);
+  }
+  atomicMax(&mm[0], r);
+  atomicMax(&mm[1], c);
+  atomicMin(&mm[2], r0);
+  atomicMin(&mm[3], c0);
+}
+
+// node2cell[i] = column-major cell id inside the bounding box (origin r0, c0; height R); cell2node[cell] = i + 1 (0 = no
+// node); bad when two nodes share a cell
+__global__ __launch_bounds__(256) void csr_cells_kernel(int n, int R, int r0, int c0, const int* __restrict__ row,
+                                                        const int* __restrict__ col, int* __restrict__ node2cell,
+                                                        int* __restrict__ cell2node, int* __restrict__ bad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t c = (int64_t)(col[i] - c0) * R + (row[i] - r0);
+    node2cell[i] = (int)c;
+    if (atomicCAS(&cell2node[c], 0, i + 1) != 0) atomicOr(bad, 2);
+  }
+}
+
+// rows[cell] of the lattice form from the CSR rows of the nodes (upper triangle + diagonal; the matrix is symmetric);
+// bad when a coupling does not join lattice neighbours
+template <class T>
+__global__ __launch_bounds__(256) void csr_to_cell_dia_kernel(int n, int R, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                              const T* __restrict__ va, const int* __restrict__ row,
+                                                              const int* __restrict__ col, const int* __restrict__ node2cell,
+                                                              T* __restrict__ rows, int* __restrict__ bad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t c = node2cell[i];
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int j = ci[k];
+      if (j == i) {
+        rows[c * 5] = va[k];
+        continue;
+      }
+      const int dr = row[j] - row[i], dc = col[j] - col[i];
+      if (dr < -1 || dr > 1 || dc < -1 || dc > 1) {
+        atomicOr(bad, 4);
+        continue;
+      }
+      const int d = dc * R + dr;  // 1, R-1, R, R+1 or their negatives (never 0: two nodes never share a cell)
+      if (d < 0) continue;        // (the mirror image lives in row j)
+      const int slot = d == 1 ? 1 : (d == R - 1 ? 2 : (d == R ? 3 : 4));
+      rows[c * 5 + slot] = va[k];
+    }
+  }
+}
+
+// cells without a node: identity rows; size0 = 1 for a cell with a node
+template <class T>
+__global__ __launch_bounds__(256) void cell_identity_kernel(int64_t ncells, const int* __restrict__ cell2node, T* __restrict__ rows,
+                                                            long long* __restrict__ size0) {
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncells; c += (int64_t)gridDim.x * 256) {
+    const bool node = cell2node[c] != 0;
+    size0[c] = node ? 1 : 0;
+    if (!node) rows[c * 5] = T(1);
+  }
+}
+
 // node numbering of the reference for a cell-space / all-valid raster: nodemap (row-major, 1-based node id), cellmap
 // (row-major, 1-based row id of the device matrix), node2cell, cell2node (see Solver in csgpu.hip). node = exclusive scan
 // of the valid flags in column-major order.

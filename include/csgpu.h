@@ -121,7 +121,11 @@ typedef struct csgpu_opts {
   double atol;            /* < 0 means sqrt(eps(T)) (Krylov.jl default); default -1 */
   /* Optional raster coordinates of every node (length n, 0-based cell row / col of the node's first
    * cell). When given, aggregation seeds 3x3 tiles (the shape the reference's greedy StandardAggregation
-   * produces on rasters). NULL for network graphs. */
+   * produces on rasters). NULL for network graphs. With coordinates a raster graph WITH NODATA cells (every node on a
+   * cell of its own, couplings between neighbouring cells only, at least half of the bounding box valid) is scattered
+   * into the lattice of its bounding box and runs the index-free kernels exactly like a raster handed to
+   * csgpu_raster_setup (setup_cellspace_from_csr, csrc/csgpu.hip); node ids and n-vectors at this boundary keep the
+   * caller's numbering. An all-valid raster needs no coordinates for that: its lattice period is read off the matrix. */
   const int32_t* node_row;
   const int32_t* node_col;
   /* Storage / arithmetic precision of the AMG preconditioner (hierarchy + V-cycle): 0 = same as val_bytes,

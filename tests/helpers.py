@@ -1036,3 +1036,64 @@ def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
                 assert a["iters"] == b["iters"] and a["R"] == b["R"], "the filter must not trigger on the bench's raster"
             if sigma == 3.0:
                 assert a["iters"] <= 0.85 * b["iters"], (a["iters"], b["iters"])
+
+
+def check_cellspace_from_host_csr(L, oracle, shape=(52, 47), batch=4):
+    """The Julia host path for rasters with NODATA cells: the reference builds its graph itself (construct_node_map /
+    construct_graph, src/raster/pairwise.jl:271-362), extracts a connected component and hands its CSR Laplacian to the
+    solver hook with the raster cell of every node (csgpu_opts.node_row / node_col, CircuitscapeHIPExt.jl::node_coords).
+    That matrix must take the cell-space lattice path (setup_cellspace_from_csr, csgpu.hip) and be indistinguishable from
+    the handle csgpu_raster_setup builds from the raster: same level sizes, resistances and iteration counts, products,
+    voltages; against the tight oracle; the knob CSGPU_NO_CELLSPACE_FROM_CSR is not needed for correctness (a matrix with
+    short-circuit polygons -- couplings between cells that are not neighbours -- declines by itself)."""
+    import scipy.sparse as sp
+    from circuitscape_jl_amd import solver as ps
+    g = _nodata_raster(shape, 17, frac=0.12, wall=False)
+    g[:, :3] = 0.0                                   # the component's bounding box does not start at the raster's corner
+    g[:2, :] = 0.0
+    nm = rg.construct_node_map(g, None)
+    Afull = rg.laplacian(rg.construct_graph(g, nm, False, False))
+    cc = rg.connected_components(rg.construct_graph(g, nm, False, False))
+    comp = np.asarray(max(cc, key=len), dtype=np.int64)            # 1-based node ids of the largest component
+    A = oracle.regularize(sp.csr_matrix(Afull)[comp - 1][:, comp - 1])
+    row, col = ps._node_coords(nm, comp)
+    ids = np.random.default_rng(5).choice(len(comp), size=2 * batch, replace=False)
+    src, dst = [int(v) for v in ids[:batch]], [int(v) for v in ids[batch:]]
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    for pb in (0, 4):
+        with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb), node_row=row, node_col=col) as h:
+            info = h.info
+            R0, C0 = int(row.max() - row.min() + 1), int(col.max() - col.min() + 1)
+            assert info["n"] == len(comp) and info["lattice_period"] == R0 and info["level_n"][0] == R0 * C0, info
+            R, gath, volt, st = h.solve_pairs(src, dst, gather=ids[:3], want_voltages=True)
+            R2, _, _, st2 = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0 and st2["not_converged"] == 0
+            assert np.max(np.abs(R - Ro) / Ro) < 1e-6 and np.max(np.abs(R2 - Ro) / Ro) < 1e-6
+            x = np.random.default_rng(1).standard_normal(len(comp))
+            assert np.allclose(h.spmv(x.copy()), A @ x, rtol=1e-12, atol=1e-12)
+            A0 = h.level_matrix(0, "A")
+            assert A0.shape == A.shape and abs(A0 - A).max() <= 1e-15 * abs(A).max()
+            labels, nc = h.components()
+            assert nc == 1 and np.all(labels == 0)
+            for p in range(batch):                       # voltages grounded at the source, resistance at the destination
+                assert abs(volt[src[p], p]) < 1e-12 and abs(volt[dst[p], p] - R[p]) < 1e-9 * R[p]
+            it_cell = st2["total_iters"]
+        # the same component with every other cell of the raster NODATA, built from the raster by the library
+        gc = np.zeros_like(g)
+        m = np.isin(nm, comp)
+        gc[m] = g[m]
+        with L.raster_setup(gc, L.default_opts(batch=batch, precond_bytes=pb)) as hr:
+            Rr, _, _, str_ = hr.solve_pairs(src, dst)
+            assert np.max(np.abs(Rr - R2) / Rr) < 1e-8
+            assert abs(str_["total_iters"] - it_cell) <= batch       # (the raster handle's lattice includes the empty margin)
+    # polygons: node 1 also holds a far-away cell -> a coupling between cells that are not neighbours -> plain CSR path
+    B = sp.lil_matrix(A)
+    far = len(comp) - 1
+    B[0, far] -= 0.5
+    B[far, 0] -= 0.5
+    B[0, 0] += 0.5
+    B[far, far] += 0.5
+    with L.setup(sp.csr_matrix(B), L.default_opts(batch=batch), node_row=row, node_col=col) as h:
+        assert h.info["lattice_period"] == 0 and h.info["level_n"][0] == len(comp)
+        Rp, _, _, stp = h.solve_pairs(src[:2], dst[:2])
+        assert stp["not_converged"] == 0

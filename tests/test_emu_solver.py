@@ -1147,3 +1147,9 @@ def test_heterogeneous_rasters_strength_aware_tiles(emu_lib, oracle):
     """see helpers.check_heterogeneous_rasters"""
     from helpers import check_heterogeneous_rasters
     check_heterogeneous_rasters(emu_lib, oracle, N=120, batch=4)
+
+
+def test_cellspace_from_host_csr_with_coordinates(emu_lib, oracle):
+    """see helpers.check_cellspace_from_host_csr"""
+    from helpers import check_cellspace_from_host_csr
+    check_cellspace_from_host_csr(emu_lib, oracle)

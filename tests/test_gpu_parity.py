@@ -524,3 +524,9 @@ def test_recurrence_residual_post_check_at_size(gpu_lib, sigma):
     (Ra, sa), (Rb, sb) = out[0], out[1]
     assert np.array_equal(Ra, Rb) and sa["total_iters"] == sb["total_iters"]
     assert abs(sa["max_relres"] - sb["max_relres"]) <= 1e-3 * sb["max_relres"], (sa["max_relres"], sb["max_relres"])
+
+
+def test_cellspace_from_host_csr_with_coordinates_gpu(gpu_lib, oracle):
+    """The Julia host path on a raster with NODATA cells takes the lattice kernels: helpers.check_cellspace_from_host_csr"""
+    from helpers import check_cellspace_from_host_csr
+    check_cellspace_from_host_csr(gpu_lib, oracle, shape=(420, 377), batch=8)
