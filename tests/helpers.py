@@ -1001,12 +1001,19 @@ def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
         N = %d
         z = np.random.default_rng(11).standard_normal((N, N))
         ids = np.random.default_rng(5).choice(N * N, size=2 * %d, replace=False)
-        for sigma in (1.0, 2.0, 3.0):
+        holes = np.random.default_rng(12).random((N, N)) < 0.1
+        for sigma, hl in ((1.0, 0), (2.0, 0), (3.0, 0), (3.0, 1)):
+            g = np.exp(sigma * z)
+            if hl:
+                g[holes] = 0.0           # NODATA cells AND heterogeneity: the filter on top of the caller's weights
+                g.flat[ids] = 1.0        # (the focal cells stay valid)
             for pb in (0, 4):
-                with lib.raster_setup(np.exp(sigma * z), lib.default_opts(batch=%d, precond_bytes=pb)) as h:
-                    R, _, _, st = h.solve_pairs([int(v) for v in ids[:%d]], [int(v) for v in ids[%d:]])
-                    out.append({"sigma": sigma, "pb": pb, "iters": st["total_iters"] / float(%d), "nc": int(st["not_converged"]),
-                                "R": [float(v) for v in R], "lat": int(h.info["lattice_period"])})
+                with lib.raster_setup(g, lib.default_opts(batch=%d, precond_bytes=pb)) as h:
+                    nm = h.raster_nodemap()
+                    nodes = (nm.ravel()[ids] - 1).astype(int)
+                    R, _, _, st = h.solve_pairs([int(v) for v in nodes[:%d]], [int(v) for v in nodes[%d:]])
+                    out.append({"sigma": sigma, "holes": hl, "pb": pb, "iters": st["total_iters"] / float(%d),
+                                "nc": int(st["not_converged"]), "R": [float(v) for v in R], "lat": int(h.info["lattice_period"])})
         print("RESULT" + json.dumps(out))
     ''') % (root, L.loaded_path(), N, batch, batch, batch, batch, batch)
     res = {}
@@ -1019,16 +1026,22 @@ def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
         res[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
     z = np.random.default_rng(11).standard_normal((N, N))
     ids = np.random.default_rng(5).choice(N * N, size=2 * batch, replace=False)
-    for sigma in (1.0, 2.0, 3.0):
+    holes = np.random.default_rng(12).random((N, N)) < 0.1
+    for sigma, hl in ((1.0, 0), (2.0, 0), (3.0, 0), (3.0, 1)):
         g = np.exp(sigma * z)
-        A = oracle.regularize(rg.laplacian(rg.construct_graph(g, rg.construct_node_map(g, None), False, False)))
+        if hl:
+            g[holes] = 0.0
+            g.flat[ids] = 1.0
+        nm = rg.construct_node_map(g, None)
+        A = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+        nodes = (nm.ravel()[ids] - 1).astype(np.int64)
         S = oracle.OracleAMG(A)
-        Rt, _, _ = S.solve_pairs(ids[:batch], ids[batch:], rtol=1e-12, atol=0.0, criterion=1, nthreads=4)
-        _, _, o = S.solve_pairs(ids[:batch], ids[batch:], nthreads=4)                  # the reference's tolerances
+        Rt, _, _ = S.solve_pairs(nodes[:batch], nodes[batch:], rtol=1e-12, atol=0.0, criterion=1, nthreads=4)
+        _, _, o = S.solve_pairs(nodes[:batch], nodes[batch:], nthreads=4)              # the reference's tolerances
         it_oracle = float(np.mean([x["iters"] for x in o]))
         for pb in (0, 4):
-            a = next(x for x in res["filter"] if x["sigma"] == sigma and x["pb"] == pb)
-            b = next(x for x in res["plain"] if x["sigma"] == sigma and x["pb"] == pb)
+            a = next(x for x in res["filter"] if x["sigma"] == sigma and x["pb"] == pb and x["holes"] == hl)
+            b = next(x for x in res["plain"] if x["sigma"] == sigma and x["pb"] == pb and x["holes"] == hl)
             assert a["nc"] == 0 and b["nc"] == 0 and a["lat"] == N
             assert np.max(np.abs(np.array(a["R"]) - Rt) / Rt) < 1e-6, (sigma, pb)
             assert a["iters"] <= 1.5 * it_oracle + 1.0, (sigma, pb, a["iters"], it_oracle)
