@@ -843,11 +843,12 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
             n > 1 ? ev[1] / smax : 0.0, n > 2 ? ev[2] / smax : 0.0, cut / smax);
   }
   std::vector<double> Pinv((size_t)n * n, 0.0);
-  std::vector<int> kind((size_t)n, 0);  // 0: null space (below the cutoff), 1: near-kernel eigenpair, 2: kept
+  std::vector<int> kind((size_t)n, 0);  // 0: null space, 1: near-kernel eigenpair, 2: kept, 3: kept with the gain 1 / cutoff
   double lam_ref = 0;                   // smallest kept eigenvalue
   for (int e = 0; e < n; ++e) {
     const double lam = M[(size_t)e * n + e];
-    if (!(std::fabs(lam) > cut)) continue;
+    const bool below = !(std::fabs(lam) > cut);
+    if (below && !(kernel_cand && lam > 0)) continue;  // null space (as Julia's pinv treats it)
     kind[e] = 2;
     if (kernel_cand && std::fabs(lam) < kernel_thr * smax) {  // near-kernel eigenpair of an fp32 hierarchy (see above)
       double overlap = 0;
@@ -857,10 +858,16 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
         overlap += d * d;
       }
       if (overlap >= 0.8) {
-        kind[e] = 1;
-        if (kernel_dropped) ++*kernel_dropped;
+        kind[e] = below ? 0 : 1;
+        if (!below && kernel_dropped) ++*kernel_dropped;
       }
     }
+    // fp32 hierarchies: a POSITIVE eigenvalue below the cutoff (n eps(fp32) lambda_max ~ 1e-5 lambda_max) that is not the
+    // candidate's is a genuine mode of a badly conditioned operator more often than it is noise -- a single-level handle
+    // of a component with conductances spread over ten orders of magnitude has several. Dropping it makes the
+    // preconditioner singular on a mode the right-hand side excites, and CG then cannot converge (found by fuzzing: 69
+    // nodes, sigma = 3.5, relative residual stuck at 2.5). It keeps a bounded gain instead: 1 / cutoff.
+    if (kind[e] == 2 && below) kind[e] = 3;
     if (kind[e] == 2 && lam > 0 && (lam_ref == 0 || lam < lam_ref)) lam_ref = lam;
   }
   // A near-kernel eigenpair gets NO gain: the coarsest problem is solved in the orthogonal complement of the candidate.
@@ -870,7 +877,7 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   static const bool kernel_ref = getenv("CSGPU_KERNEL_GAIN_REF") != nullptr;  // A/B knob
   for (int e = 0; e < n; ++e) {
     if (kind[e] == 0) continue;
-    double inv = 1.0 / M[(size_t)e * n + e];
+    double inv = kind[e] == 3 ? 1.0 / cut : 1.0 / M[(size_t)e * n + e];
     if (kind[e] == 1) {
       if (!kernel_ref || !(lam_ref > 0)) continue;
       inv = 1.0 / lam_ref;

@@ -1110,3 +1110,42 @@ def check_cellspace_from_host_csr(L, oracle, shape=(52, 47), batch=4):
         assert h.info["lattice_period"] == 0 and h.info["level_n"][0] == len(comp)
         Rp, _, _, stp = h.solve_pairs(src[:2], dst[:2])
         assert stp["not_converged"] == 0
+
+
+def check_single_level_fp32_handle_on_heterogeneous_component(L):
+    """Found by fuzzing (round 3): a 69-node component of a 17 x 6 raster, 4-neighbour, averaged resistances, log-normal
+    sigma = 3.5. The handle has ONE level (n <= max_coarse): the preconditioner is the dense pseudo-inverse. With an fp32
+    hierarchy its cutoff (n eps(fp32) lambda_max) lies above several genuine eigenvalues of such a matrix; dropped, they
+    left the preconditioner singular on modes the right-hand side excites and CG stuck at a relative residual of 2.5.
+    They now keep the bounded gain 1 / cutoff (dense_sym_pinv, amg_setup.h)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(8012)
+    R, C = int(rng.integers(6, 40)), int(rng.integers(6, 40))
+    sigma = float(rng.choice([0.5, 1.0, 2.5, 3.5]))
+    frac = float(rng.choice([0.0, 0.05, 0.2, 0.35]))
+    four, avg, _pb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.choice([0, 4]))
+    assert (R, C, sigma, frac, four, avg) == (17, 6, 3.5, 0.35, True, True)
+    g = np.exp(sigma * rng.standard_normal((R, C)))
+    g[rng.random((R, C)) < frac] = 0.0
+    rng.random(), rng.random()
+    nm = rg.construct_node_map(g, None)
+    W = rg.construct_graph(g, nm, avg, four)
+    _, lab = sp.csgraph.connected_components(W, directed=False)
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    assert len(big) == 69
+    A = sp.csr_matrix(rg.laplacian(W))[big][:, big]
+    A = (A + sp.diags(np.full(len(big), 1e-13 * abs(A).max()))).tocsr()
+    src, dst = [3, 11], [40, 60]
+    ref = []
+    for s, d in zip(src, dst):
+        keep = np.setdiff1d(np.arange(69), [s])
+        b = np.zeros(69)
+        b[d] = 1.0
+        ref.append(spla.spsolve(A[keep][:, keep].tocsc(), b[keep])[np.searchsorted(keep, d)])
+    for pb in (4, 0):
+        with L.setup(A, L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10, itmax=500)) as h:
+            assert h.info["levels"] == 1
+            Rr, _, _, st = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0 and st["total_iters"] <= 60
+            assert np.max(np.abs(Rr - np.array(ref)) / np.array(ref)) < 1e-6

@@ -1153,3 +1153,9 @@ def test_cellspace_from_host_csr_with_coordinates(emu_lib, oracle):
     """see helpers.check_cellspace_from_host_csr"""
     from helpers import check_cellspace_from_host_csr
     check_cellspace_from_host_csr(emu_lib, oracle)
+
+
+def test_single_level_fp32_handle_on_heterogeneous_component(emu_lib):
+    """see helpers.check_single_level_fp32_handle_on_heterogeneous_component"""
+    from helpers import check_single_level_fp32_handle_on_heterogeneous_component
+    check_single_level_fp32_handle_on_heterogeneous_component(emu_lib)

@@ -530,3 +530,9 @@ def test_cellspace_from_host_csr_with_coordinates_gpu(gpu_lib, oracle):
     """The Julia host path on a raster with NODATA cells takes the lattice kernels: helpers.check_cellspace_from_host_csr"""
     from helpers import check_cellspace_from_host_csr
     check_cellspace_from_host_csr(gpu_lib, oracle, shape=(420, 377), batch=8)
+
+
+def test_single_level_fp32_handle_on_heterogeneous_component_gpu(gpu_lib):
+    """dense pseudo-inverse of an fp32 single-level handle keeps sub-cutoff modes with a bounded gain (fuzz finding)"""
+    from helpers import check_single_level_fp32_handle_on_heterogeneous_component
+    check_single_level_fp32_handle_on_heterogeneous_component(gpu_lib)

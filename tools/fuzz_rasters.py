@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Fuzzer for the raster paths (round 3): random small rasters -- 6..39 cells a side, log-normal sigma 0.5..3.5, 0..35 % NODATA,
+whole NODATA rows / columns, 4- / 8-neighbour, averaged resistances or conductances, fp64 / fp32 hierarchy -- through
+csgpu_raster_setup (cell space, strength-aware tiles, index-free pipeline) AND through csgpu_setup with node coordinates
+(the Julia host path), two pairs each, against a direct solve of the component's grounded system (scipy). Found the
+single-level fp32 pseudo-inverse defect fixed in dense_sym_pinv. The graph is built by oracle/refgraph.py (test
+infrastructure; input generation and checking only). The host path solves the matrix shifted by 1e-13 max|A|, so at
+sigma = 3.5 its resistances may differ from the unshifted direct solve by up to ~1e-5: reported, not counted.
+usage: fuzz_rasters.py SEED NCASES    (env CSGPU_LIB: library to load, default the emulator build)"""
+import os, sys, json, numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import circuitscape_jl_amd  # noqa: E402,F401
+from circuitscape_jl_amd import lib as L, solver as ps  # noqa: E402
+from oracle import refgraph as rg  # noqa: E402
+L.load(os.environ.get("CSGPU_LIB", os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so")))
+seed0 = int(sys.argv[1]); ncase = int(sys.argv[2])
+def direct_R(A, s, d):
+    n = A.shape[0]
+    keep = np.setdiff1d(np.arange(n), [s])
+    b = np.zeros(n); b[d] = 1.0
+    x = spla.spsolve(A[keep][:, keep].tocsc(), b[keep])
+    return x[np.searchsorted(keep, d)]
+bad = 0
+for case in range(ncase):
+    rng = np.random.default_rng(seed0 * 1000 + case)
+    R = int(rng.integers(6, 40)); C = int(rng.integers(6, 40))
+    sigma = float(rng.choice([0.5, 1.0, 2.5, 3.5]))
+    frac = float(rng.choice([0.0, 0.05, 0.2, 0.35]))
+    four = bool(rng.integers(0, 2)); avg = bool(rng.integers(0, 2)); pb = int(rng.choice([0, 4]))
+    g = np.exp(sigma * rng.standard_normal((R, C)))
+    g[rng.random((R, C)) < frac] = 0.0
+    if rng.random() < 0.3: g[rng.integers(0, R), :] = 0.0          # an all-NODATA row
+    if rng.random() < 0.3: g[:, rng.integers(0, C)] = 0.0          # an all-NODATA column
+    if (g > 0).sum() < 12: continue
+    nm = rg.construct_node_map(g, None)
+    W = rg.construct_graph(g, nm, avg, four)
+    A = sp.csr_matrix(rg.laplacian(W))
+    ncomp, lab = sp.csgraph.connected_components(W, directed=False)
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    if len(big) < 4: continue
+    ids = rng.choice(big, size=4, replace=False)
+    src, dst = [int(ids[0]), int(ids[1])], [int(ids[2]), int(ids[3])]
+    loc0 = {int(v): k for k, v in enumerate(big)}
+    Ab = A[big][:, big]
+    Rd = np.array([direct_R(Ab, loc0[s], loc0[d]) for s, d in zip(src, dst)])
+    tag = dict(case=case, R=R, C=C, sigma=sigma, frac=frac, four=four, avg=avg, pb=pb)
+    try:
+        with L.raster_setup(g, L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10), four_neighbors=four, avg_resistances=avg) as h:
+            Rr, _, volt, st = h.solve_pairs(src, dst, want_voltages=True)
+            e1 = float(np.max(np.abs(Rr - Rd) / Rd))
+            lat = h.info["lattice_period"]
+        # host CSR path with coordinates (largest component)
+        comp = big + 1
+        Ac = A[big][:, big]
+        Ac = Ac + sp.diags(np.full(len(big), 1e-13 * abs(Ac).max()))
+        row, col = ps._node_coords(nm, comp)
+        loc = {int(v): k for k, v in enumerate(big)}
+        with L.setup(sp.csr_matrix(Ac), L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10), node_row=row, node_col=col) as h2:
+            R2, _, _, st2 = h2.solve_pairs([loc[s] for s in src], [loc[d] for d in dst])
+            e2 = float(np.max(np.abs(R2 - Rd) / Rd))
+            lat2 = h2.info["lattice_period"]
+        ok = e1 < 1e-6 and e2 < (1e-6 if sigma < 3 else 2e-5) and st["not_converged"] == 0 and st2["not_converged"] == 0
+        if not ok:
+            bad += 1
+            print("BAD", tag, e1, e2, lat, lat2, st["total_iters"], st2["total_iters"], flush=True)
+    except Exception as ex:
+        bad += 1
+        print("EXC", tag, str(ex)[:200], flush=True)
+print("seed", seed0, "cases", ncase, "bad", bad)
