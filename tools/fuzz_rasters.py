@@ -4,8 +4,7 @@ whole NODATA rows / columns, 4- / 8-neighbour, averaged resistances or conductan
 csgpu_raster_setup (cell space, strength-aware tiles, index-free pipeline) AND through csgpu_setup with node coordinates
 (the Julia host path), two pairs each, against a direct solve of the component's grounded system (scipy). Found the
 single-level fp32 pseudo-inverse defect fixed in dense_sym_pinv. The graph is built by oracle/refgraph.py (test
-infrastructure; input generation and checking only). The host path solves the matrix shifted by 1e-13 max|A|, so at
-sigma = 3.5 its resistances may differ from the unshifted direct solve by up to ~1e-5: reported, not counted.
+infrastructure; input generation and checking only). Both paths carry the reference's regularisation shift eps * norm(nzval) (core.jl:161).
 usage: fuzz_rasters.py SEED NCASES    (env CSGPU_LIB: library to load, default the emulator build)"""
 import os, sys, json, numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +23,8 @@ def direct_R(A, s, d):
 bad = 0
 for case in range(ncase):
     rng = np.random.default_rng(seed0 * 1000 + case)
-    R = int(rng.integers(6, 40)); C = int(rng.integers(6, 40))
+    lo_, hi_ = int(os.environ.get("FUZZ_MIN", "6")), int(os.environ.get("FUZZ_MAX", "40"))
+    R = int(rng.integers(lo_, hi_)); C = int(rng.integers(lo_, hi_))
     sigma = float(rng.choice([0.5, 1.0, 2.5, 3.5]))
     frac = float(rng.choice([0.0, 0.05, 0.2, 0.35]))
     four = bool(rng.integers(0, 2)); avg = bool(rng.integers(0, 2)); pb = int(rng.choice([0, 4]))
@@ -53,14 +53,15 @@ for case in range(ncase):
         # host CSR path with coordinates (largest component)
         comp = big + 1
         Ac = A[big][:, big]
-        Ac = Ac + sp.diags(np.full(len(big), 1e-13 * abs(Ac).max()))
+        Ac = sp.csr_matrix(Ac, copy=True)
+        Ac.data = Ac.data + np.finfo(np.float64).eps * np.linalg.norm(Ac.data)   # the reference's shift (core.jl:161)
         row, col = ps._node_coords(nm, comp)
         loc = {int(v): k for k, v in enumerate(big)}
         with L.setup(sp.csr_matrix(Ac), L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10), node_row=row, node_col=col) as h2:
             R2, _, _, st2 = h2.solve_pairs([loc[s] for s in src], [loc[d] for d in dst])
             e2 = float(np.max(np.abs(R2 - Rd) / Rd))
             lat2 = h2.info["lattice_period"]
-        ok = e1 < 1e-6 and e2 < (1e-6 if sigma < 3 else 2e-5) and st["not_converged"] == 0 and st2["not_converged"] == 0
+        ok = e1 < 1e-6 and e2 < 1e-6 and st["not_converged"] == 0 and st2["not_converged"] == 0
         if not ok:
             bad += 1
             print("BAD", tag, e1, e2, lat, lat2, st["total_iters"], st2["total_iters"], flush=True)
