@@ -46,10 +46,32 @@ for case in range(ncase):
     Rd = np.array([direct_R(Ab, loc0[s], loc0[d]) for s, d in zip(src, dst)])
     tag = dict(case=case, R=R, C=C, sigma=sigma, frac=frac, four=four, avg=avg, pb=pb)
     try:
-        with L.raster_setup(g, L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10), four_neighbors=four, avg_resistances=avg) as h:
+        with L.raster_setup(g, L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10, atol=0.0), four_neighbors=four, avg_resistances=avg) as h:
             Rr, _, volt, st = h.solve_pairs(src, dst, want_voltages=True)
             e1 = float(np.max(np.abs(Rr - Rd) / Rd))
             lat = h.info["lattice_period"]
+            # node currents, cumulative and maximum maps (N1) and a grounded solve (N2) on the same handle, against the
+            # direct solve of the component
+            from oracle import refmaps
+            n_all = A.shape[0]
+            cum = np.zeros(n_all); mx = np.zeros(n_all)
+            Rc, _, cur, _ = h.solve_pairs_currents(src, dst, cum=cum, mx=mx)
+            ec = 0.0
+            exp_cum = np.zeros(n_all); exp_mx = np.zeros(n_all)
+            for p_, (s_, d_) in enumerate(zip(src, dst)):
+                keep = np.setdiff1d(np.arange(len(big)), [loc0[s_]])
+                b_ = np.zeros(len(big)); b_[loc0[d_]] = 1.0
+                v_ = np.zeros(len(big)); v_[keep] = spla.spsolve(Ab[keep][:, keep].tocsc(), b_[keep])
+                nc_ = np.zeros(n_all); nc_[big] = refmaps.get_node_currents(Ab, v_)
+                ec = max(ec, float(np.max(np.abs(cur[:, p_] - nc_)) / max(nc_.max(), 1e-300)))
+                exp_cum += nc_; exp_mx = np.maximum(exp_mx, nc_)
+            ec = max(ec, float(np.max(np.abs(cum - exp_cum)) / exp_cum.max()), float(np.max(np.abs(mx - exp_mx)) / exp_mx.max()))
+            Bg = np.zeros((n_all, 1)); Bg[src[0], 0] = 1.0
+            Xg, _, stg = h.solve_grounded(Bg, [[dst[0]]])
+            eg = abs(Xg[src[0], 0] - Rd[0]) / Rd[0]
+            if ec > 1e-5 or eg > 1e-6 or stg["not_converged"]:
+                bad += 1
+                print("BAD-MAPS", tag, ec, eg, flush=True)
         # host CSR path with coordinates (largest component)
         comp = big + 1
         Ac = A[big][:, big]
@@ -57,7 +79,7 @@ for case in range(ncase):
         Ac.data = Ac.data + np.finfo(np.float64).eps * np.linalg.norm(Ac.data)   # the reference's shift (core.jl:161)
         row, col = ps._node_coords(nm, comp)
         loc = {int(v): k for k, v in enumerate(big)}
-        with L.setup(sp.csr_matrix(Ac), L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10), node_row=row, node_col=col) as h2:
+        with L.setup(sp.csr_matrix(Ac), L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10, atol=0.0), node_row=row, node_col=col) as h2:
             R2, _, _, st2 = h2.solve_pairs([loc[s] for s in src], [loc[d] for d in dst])
             e2 = float(np.max(np.abs(R2 - Rd) / Rd))
             lat2 = h2.info["lattice_period"]
