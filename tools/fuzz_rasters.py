@@ -42,7 +42,8 @@ for case in range(ncase):
     ids = rng.choice(big, size=4, replace=False)
     src, dst = [int(ids[0]), int(ids[1])], [int(ids[2]), int(ids[3])]
     loc0 = {int(v): k for k, v in enumerate(big)}
-    Ab = A[big][:, big]
+    Ab = sp.csr_matrix(A[big][:, big], copy=True)
+    Ab.data = Ab.data + np.finfo(np.float64).eps * np.linalg.norm(Ab.data)   # the reference's shift (core.jl:161): part of the problem
     Rd = np.array([direct_R(Ab, loc0[s], loc0[d]) for s, d in zip(src, dst)])
     tag = dict(case=case, R=R, C=C, sigma=sigma, frac=frac, four=four, avg=avg, pb=pb)
     try:
