@@ -788,9 +788,13 @@ inline std::vector<std::vector<double>> component_candidates(const std::vector<d
 }
 
 // Dense symmetric pseudo-inverse (cyclic Jacobi eigen-solver); n is at most a few hundred.
+// `defl_cand` / `defl_out`: a second pseudo-inverse from the same decomposition that leaves out every eigenpair below
+// kernel_thr * lambda_max lying along one of `defl_cand` (Dirichlet-masked solves, pcg.h).
 inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double eps,
                                           const std::vector<std::vector<double>>* kernel_cand = nullptr,
-                                          double kernel_thr = 0.0, int* kernel_dropped = nullptr) {
+                                          double kernel_thr = 0.0, int* kernel_dropped = nullptr,
+                                          const std::vector<std::vector<double>>* defl_cand = nullptr,
+                                          std::vector<double>* defl_out = nullptr) {
   std::vector<double> V((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j) {
@@ -875,9 +879,25 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   // CSGPU_KERNEL_GAIN_REF=1: fine up to 5000^2, but at 10000^2 the fp32 restriction chain of eight levels has put so much
   // spurious weight on the candidate that any gain feeds it back: 13.3 iterations instead of 11.1.)
   static const bool kernel_ref = getenv("CSGPU_KERNEL_GAIN_REF") != nullptr;  // A/B knob
+  if (defl_out) defl_out->assign((size_t)n * n, 0.0);
   for (int e = 0; e < n; ++e) {
     if (kind[e] == 0) continue;
     double inv = kind[e] == 3 ? 1.0 / cut : 1.0 / M[(size_t)e * n + e];
+    bool in_defl = defl_out != nullptr && kind[e] != 1;
+    if (in_defl && defl_cand && std::fabs(M[(size_t)e * n + e]) < kernel_thr * smax) {
+      double overlap = 0;
+      for (const auto& v : *defl_cand) {
+        double d = 0;
+        for (int i = 0; i < n; ++i) d += v[i] * V[(size_t)i * n + e];
+        overlap += d * d;
+      }
+      if (overlap >= 0.8) in_defl = false;
+    }
+    if (in_defl)
+      for (int i = 0; i < n; ++i) {
+        const double vi = V[(size_t)i * n + e] * inv;
+        for (int j = 0; j < n; ++j) (*defl_out)[(size_t)i * n + j] += vi * V[(size_t)j * n + e];
+      }
     if (kind[e] == 1) {
       if (!kernel_ref || !(lam_ref > 0)) continue;
       inv = 1.0 / lam_ref;
@@ -960,6 +980,13 @@ struct Hierarchy {
   // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
   // per-column scratch area and the batch width it is allocated for
   bool near_singular = false;  // the coarsest operator's near-kernel eigenpair was dropped (fp32 hierarchy of a Laplacian)
+  // Dirichlet-masked solves on this hierarchy (pcg.h, DirichletCoarse): the pseudo-inverse WITHOUT the near-kernel
+  // eigenpair (empty: coarse_inv already is that one), the coarsest level's candidate, and whether the coarsest graph is
+  // one connected component (the correction is defined for that case only)
+  DBuf coarse_inv_defl;
+  DBuf coarse_cand;
+  bool single_component = false;
+  const double* dir_coef = nullptr;  // [K] device, set for the duration of a Dirichlet-masked solve
   double cand_norm2 = 0;       // |candidate|^2 (= number of fine nodes: the same on every level)
   int tail_first = -2;
   DBuf tail_ws;
@@ -1648,19 +1675,33 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
         for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + ci[k]] += (double)va[k];
       std::vector<std::vector<double>> kc;
       const bool deflate = sizeof(T) == 4 && !getenv("CSGPU_NO_DEFLATION");
-      if (deflate) {
-        std::vector<double> cand((size_t)n, 1.0);
-        if (size_prev.p) {
-          std::vector<long long> sz((size_t)n);
-          CS_HIP(hipMemcpyAsync(sz.data(), size_prev.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, st));
-          CS_HIP(hipStreamSynchronize(st));
-          for (int i = 0; i < n; ++i) cand[i] = std::sqrt((double)sz[i]);
-        }
-        kc = component_candidates(M, n, cand);
+      std::vector<double> cand((size_t)n, 1.0);
+      if (size_prev.p) {
+        std::vector<long long> sz((size_t)n);
+        CS_HIP(hipMemcpyAsync(sz.data(), size_prev.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, st));
+        CS_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < n; ++i) cand[i] = std::sqrt((double)sz[i]);
       }
+      kc = component_candidates(M, n, cand);
+      // the coarsest graph has ONE component that carries weight (weightless rows of a cell-space hierarchy have a zero
+      // candidate entry and form no candidate; NODATA rows of a single-level cell-space handle are components of their
+      // own): Dirichlet-masked solves may use the correction along the candidate (pcg.h, DirichletCoarse)
+      H.single_component = kc.size() == 1 && !getenv("CSGPU_NO_DIRICHLET_COARSE");
       int dropped = 0;
+      std::vector<double> Pdefl;
       std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon(),
-                                              deflate ? &kc : nullptr, 1e-2, &dropped);
+                                              deflate ? &kc : nullptr, 1e-2, &dropped, &kc,
+                                              H.single_component ? &Pdefl : nullptr);
+      if (H.single_component) {
+        std::vector<T> Dt((size_t)n * n), ct((size_t)n);
+        for (size_t i = 0; i < Dt.size(); ++i) Dt[i] = (T)Pdefl[i];
+        for (int i = 0; i < n; ++i) ct[i] = (T)cand[i];
+        H.coarse_inv_defl.alloc(std::max<size_t>(Dt.size(), 1) * sizeof(T));
+        H.coarse_cand.alloc((size_t)n * sizeof(T));
+        CS_HIP(hipMemcpyAsync(H.coarse_inv_defl.p, Dt.data(), Dt.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        CS_HIP(hipMemcpyAsync(H.coarse_cand.p, ct.data(), ct.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        CS_HIP(hipStreamSynchronize(st));
+      }
       H.near_singular = deflate && dropped > 0;
       H.cand_norm2 = sp.n_real > 0 ? (double)sp.n_real : (double)H.levels[0].A.nrows;
       if (deflate && getenv("CSGPU_VERBOSE"))

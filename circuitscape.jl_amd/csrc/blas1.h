@@ -22,6 +22,7 @@ struct CgScalars {
   double rnorm[kMaxK];   // current value of the monitored norm
   double rnorm0[kMaxK];
   double eps[kMaxK];     // stopping threshold atol + rtol*rnorm0
+  double eps2[kMaxK];    // criterion 2 only: threshold atol + rtol*||r0||_2 of the second (true-residual) test
   double bnorm[kMaxK];   // ||b||_2 (for the final relative residual)
   double relres[kMaxK];  // ||A x - b|| / ||b|| from the explicit post-check
   int done[kMaxK];       // 1 converged, 2 breakdown (p'Ap <= 0 or non-finite)
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256) void mask_grounds_kernel(const int* __restrict
 }
 
 // ---- scalar kernel 2: gamma' = r'z -> convergence test, beta.   criterion 0: monitored norm = sqrt(|r'z|),
-// criterion 1: sqrt(r'r) from `partials_rr`.   `init` != 0: first evaluation (sets rnorm0 / eps, no beta).
+// criterion 1: sqrt(r'r) from `partials_rr`, criterion 2: both tests must hold (Dirichlet-masked solves on a shared
+// hierarchy, pcg.h).   `init` != 0: first evaluation (sets rnorm0 / eps, no beta).
 template <int K>
 __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double* partials_rz, int nparts_rz,
                                                       const double* partials_rr, int nparts_rr, int criterion,
@@ -304,24 +306,26 @@ __global__ __launch_bounds__(256) void cg_beta_kernel(CgScalars* S, const double
   for (int c = 0; c < K; ++c) {
     const double rz = reduce_partials<K>(partials_rz, nparts_rz, c, sm);
     double rr = 0.0;
-    if (criterion == 1 || init) rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
+    if (criterion != 0 || init) rr = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
     if (threadIdx.x == 0) {
       const double mon = criterion == 1 ? sqrt(rr) : sqrt(fabs(rz));
+      const double mon2 = sqrt(rr);  // second test of criterion 2
       if (init) {
         S->bnorm[c] = sqrt(rr);  // r0 = b: ||b||_2 for the relative-residual post-check
         S->rnorm0[c] = mon;
         S->eps[c] = atol + rtol * mon;
+        S->eps2[c] = atol + rtol * mon2;
         S->rnorm[c] = mon;
         S->gamma[c] = rz;
         S->beta[c] = 0.0;
         S->iters[c] = 0;
-        S->done[c] = (c >= ncols_active || mon <= S->eps[c] || !(rz == rz)) ? 1 : 0;
+        S->done[c] = (c >= ncols_active || (mon <= S->eps[c] && (criterion != 2 || mon2 <= S->eps2[c])) || !(rz == rz)) ? 1 : 0;
       } else {
         if (!S->done[c]) {
           S->iters[c] += 1;
           S->rnorm[c] = mon;
           const double g = S->gamma[c];
-          if (mon <= S->eps[c] || mon + 1.0 <= 1.0) {
+          if ((mon <= S->eps[c] && (criterion != 2 || mon2 <= S->eps2[c])) || mon + 1.0 <= 1.0) {
             S->done[c] = 1;
             S->beta[c] = 0.0;
           } else if (!(rz == rz) || g == 0.0) {
@@ -364,6 +368,67 @@ __global__ __launch_bounds__(256) void dense_apply_kernel(int n, const T* __rest
     for (int j = 0; j < n; ++j) s += M[(size_t)i * n + j] * b[(size_t)j * K + c];
     y[e] = s;
   }
+}
+
+// ---- y[:,c] += v (v'b[:,c]) coef[c]: the correction along the candidate after the dense coarse solve of a Dirichlet-masked
+//      solve (pcg.h, DirichletCoarse). One workgroup per column; n is at most a few hundred.
+template <class T, int K>
+__global__ __launch_bounds__(256) void dense_rank_one_kernel(int n, const T* __restrict__ v, const double* __restrict__ coef,
+                                                             const T* __restrict__ b, T* __restrict__ y, const int* skip) {
+  if (skip && *skip) return;
+  __shared__ double s_red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s = 0;
+  for (int i = tid; i < n; i += 256) s += (double)v[i] * (double)b[(size_t)i * K + c];
+  s_red[tid] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) s_red[tid] += s_red[tid + h];
+    __syncthreads();
+  }
+  const T g = (T)(s_red[0] * coef[c]);
+  for (int i = tid; i < n; i += 256) y[(size_t)i * K + c] += g * v[i];
+}
+
+// ---- Dirichlet sets as a marker vector: m[gidx[e], c] = 1 for the entries of column c's set (m zeroed by the caller)
+template <class M, int K>
+__global__ __launch_bounds__(256) void mark_grounds_kernel(const int* __restrict__ gptr, const int* __restrict__ gidx,
+                                                           M* __restrict__ m) {
+  const int total = gptr[K];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int c = 0;
+    while (c + 1 < K && e >= gptr[c + 1]) ++c;
+    m[(size_t)gidx[e] * K + c] = M(1);
+  }
+}
+
+// ---- coef[c] = 1 / (1_f' A 1_f) for column c, 1_f = indicator of the nodes that are NOT in column c's Dirichlet set:
+//      the total conductance between the set and the rest, sum over grounded rows j of |a_ij| over their free neighbours i
+//      (the diagonal shift of the regularisation is left out: it is not a coupling). `mark` from mark_grounds_kernel. One
+//      workgroup per column, fixed summation order (bit-reproducible). 0 when the set is empty or isolated.
+template <class T, class M, int K>
+__global__ __launch_bounds__(256) void dirichlet_conductance_kernel(const int* __restrict__ rp, const int* __restrict__ ci,
+                                                                    const T* __restrict__ va, const int* __restrict__ gptr,
+                                                                    const int* __restrict__ gidx, const M* __restrict__ mark,
+                                                                    double* __restrict__ coef) {
+  __shared__ double s_red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int g0 = gptr[c], g1 = gptr[c + 1];
+  double s = 0;
+  for (int e = g0 + tid; e < g1; e += 256) {
+    const int j = gidx[e];
+    for (int k = rp[j]; k < rp[j + 1]; ++k) {
+      const int i = ci[k];
+      if (i != j && mark[(size_t)i * K + c] == M(0)) s += fabs((double)va[k]);
+    }
+  }
+  s_red[tid] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) s_red[tid] += s_red[tid + h];
+    __syncthreads();
+  }
+  if (tid == 0) coef[c] = s_red[0] > 0.0 ? 1.0 / s_red[0] : 0.0;
 }
 
 // ---- relative residual post-check: partials of ||b - A x||^2 come from a DOT-fused SpMV; this finishes it

@@ -48,6 +48,9 @@ struct TailArgs {
   T* xout;               // [n_first][K] its solution
   T cand_inv_norm2;      // 1 / |candidate|^2 (the same on every level); 0: no projection
   const int* skip;
+  // Dirichlet-masked solves (pcg.h, DirichletCoarse): x_coarsest += v (v'b) coef[c], v = the coarsest level's candidate
+  const T* rank1_cand;
+  const double* rank1_coef;  // [K], null: none
 };
 
 // b <- b - v (v'b) / (v'v): in exact arithmetic the restricted right-hand sides of a near-singular Laplacian system have no
@@ -67,6 +70,24 @@ __device__ __forceinline__ void tail_project(T* b, const T* __restrict__ v, int 
   const T c = (T)(s_red[0] * (double)inv_norm2);
   __syncthreads();
   for (int i = tid; i < n; i += kTailThreads) b[i] -= c * v[i];
+  __syncthreads();
+}
+
+// x <- x + v (v'b) coef: the coarsest-level correction along the candidate of a Dirichlet-masked solve (pcg.h)
+template <class T>
+__device__ __forceinline__ void tail_rank_one(T* x, const T* b, const T* __restrict__ v, int n, double coef, double* s_red,
+                                              int tid) {
+  double s = 0;
+  for (int i = tid; i < n; i += kTailThreads) s += (double)v[i] * (double)b[i];
+  s_red[tid] = s;
+  __syncthreads();
+  for (int h = kTailThreads / 2; h > 0; h >>= 1) {
+    if (tid < h) s_red[tid] += s_red[tid + h];
+    __syncthreads();
+  }
+  const T c = (T)(s_red[0] * coef);
+  __syncthreads();
+  for (int i = tid; i < n; i += kTailThreads) x[i] += c * v[i];
   __syncthreads();
 }
 
@@ -149,6 +170,10 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
           x = y;
           y = t;
         }
+      }
+      if (a.dense && a.rank1_coef) {
+        __syncthreads();
+        tail_rank_one(x, b, a.rank1_cand, n, a.rank1_coef[c], s_red, tid);
       }
       if (tid == 0) s_x[l] = x;
       __syncthreads();

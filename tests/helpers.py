@@ -2,6 +2,7 @@
 restatement of the reference's graph construction, which is outside the hot-path boundary) and runs the product's
 host mirror of the solver layer on it. Mirrors raster_pairwise / network_pairwise of the reference
 (src/raster/pairwise.jl:14-135, src/network/pairwise.jl:4-29)."""
+import os
 import numpy as np
 
 from oracle import refgraph as rg
@@ -1149,3 +1150,118 @@ def check_single_level_fp32_handle_on_heterogeneous_component(L):
             Rr, _, _, st = h.solve_pairs(src, dst)
             assert st["not_converged"] == 0 and st["total_iters"] <= 60
             assert np.max(np.abs(Rr - np.array(ref)) / np.array(ref)) < 1e-6
+
+
+def check_grounded_solves_meet_the_true_residual(L):
+    """Found by fuzzing (round 3, tools/fuzz_networks.py): Dirichlet-masked solves (csgpu_solve_grounded) run on the
+    hierarchy of the UNGROUNDED Laplacian, whose coarsest pseudo-inverse answers the constant vector with the gain
+    1 / (regularisation shift). A unit source has a non-zero mean, so sqrt(r0' M^-1 r0) was astronomically large and the
+    reference's relative rule on that norm (core.jl:639) was met with ||Ax-b||/||b|| = 7e-5 at rtol = 1e-10; the reference
+    itself builds a hierarchy of the grounded matrix (advanced.jl:282-312), whose norm has no such mode. These solves now
+    also have to meet ||r|| <= atol + rtol ||b|| (CSGPU_CRIT_BOTH, csrc/pcg.h). A random tree, a path and a raster."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(19)
+
+    def lap(I, J, w, n):
+        W = sp.coo_matrix((w, (I, J)), shape=(n, n)).tocsr()
+        W = W + W.T
+        A = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
+        A.sort_indices()
+        A.data = A.data + np.finfo(np.float64).eps * np.linalg.norm(A.data)   # core.jl:161
+        return A
+
+    n = 155
+    mats = [lap(np.arange(1, n), np.array([rng.integers(0, v) for v in range(1, n)]), np.ones(n - 1), n),
+            lap(np.arange(231), np.arange(1, 232), 10.0 ** (rng.random(231) - 0.5), 232),
+            None]
+    Gr = sp.csr_matrix(rg.raster_laplacian_from_conductance(np.exp(rng.standard_normal((31, 27)))))
+    Gr.data = Gr.data + np.finfo(np.float64).eps * np.linalg.norm(Gr.data)
+    mats[2] = Gr
+    for A in mats:
+        nb = A.shape[0]
+        ncol = 3
+        B = np.zeros((nb, ncol))
+        grounds = []
+        Xd = np.zeros((nb, ncol))
+        for c in range(ncol):
+            gs = np.unique(rng.integers(0, nb, c + 1))
+            s = int(rng.integers(0, nb))
+            while s in gs:
+                s = int(rng.integers(0, nb))
+            B[s, c] = 1.0
+            grounds.append([int(v) for v in gs])
+            keep = np.setdiff1d(np.arange(nb), gs)
+            Xd[keep, c] = spla.spsolve(A[keep][:, keep].tocsc(), B[keep, c])
+        for pb in (0, 4):
+            for rtol, tol_res, tol_x in ((1e-10, 1e-9, 1e-7), (1e-6, 1e-5, 1e-3)):
+                with L.setup(A, L.default_opts(batch=2, precond_bytes=pb, rtol=rtol, atol=0.0)) as h:
+                    X, _, st = h.solve_grounded(B, grounds)
+                assert st["not_converged"] == 0 and st["polished_batches"] == 0
+                for c in range(ncol):
+                    keep = np.setdiff1d(np.arange(nb), grounds[c])
+                    res = np.linalg.norm((A @ X[:, c] - B[:, c])[keep]) / np.linalg.norm(B[keep, c])
+                    assert res < tol_res, (nb, pb, rtol, c, res)
+                assert np.max(np.abs(X - Xd)) / np.max(np.abs(Xd)) < tol_x, (nb, pb, rtol)
+
+
+def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8):
+    """Dirichlet-masked solves on a single-component hierarchy take the coarsest-level correction along the candidate,
+    x_c = pinv_without_the_near_kernel_pair(b) + v (v'b) / G_c (csrc/pcg.h, DirichletCoarse): same solutions as without it
+    (knob CSGPU_NO_DIRICHLET_COARSE=1), markedly fewer iterations on both hierarchy precisions, one-to-all and all-to-one
+    right-hand sides, lattice and CSR product; a raster with an island (two components) declines it and still solves."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(5)
+    g = np.exp(rng.standard_normal((N, N)))
+    n = N * N
+    pts = rng.choice(n, size=npts, replace=False)
+    B1 = np.zeros((n, npts))
+    g1 = []
+    B2 = np.zeros((n, npts))
+    g2 = []
+    for c, p in enumerate(pts):
+        B1[p, c] = 1.0
+        g1.append([int(q) for q in pts if q != p])
+        B2[[q for q in pts if q != p], c] = 1.0
+        g2.append([int(p)])
+    G = rg.raster_laplacian_from_conductance(g).tocsc()
+    keep = np.setdiff1d(np.arange(n), g1[0])
+    x_direct = np.zeros(n)
+    x_direct[keep] = spla.spsolve(G[keep][:, keep].tocsc(), B1[keep, 0])
+    for pb in (0, 4):
+        for stencil in (0, -1):
+            out = {}
+            for off in (False, True):
+                if off:
+                    monkeypatch.setenv("CSGPU_NO_DIRICHLET_COARSE", "1")
+                else:
+                    monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
+                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, stencil=stencil)) as h:
+                    X1, _, s1 = h.solve_grounded(B1, g1)
+                    X2, _, s2 = h.solve_grounded(B2, g2)
+                assert s1["not_converged"] == 0 and s2["not_converged"] == 0
+                assert s1["max_relres"] < 1e-5 and s2["max_relres"] < 1e-5
+                out[off] = (X1, X2, s1["total_iters"], s2["total_iters"])
+            monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
+            assert np.max(np.abs(out[False][0][:, 0] - x_direct)) / np.max(np.abs(x_direct)) < 1e-4
+            for k in (0, 1):
+                assert np.max(np.abs(out[False][k] - out[True][k])) / np.max(np.abs(out[True][k])) < 1e-4
+            # (fp32 hierarchies gain with depth: 51 -> 19.5 iterations per column at 300^2, little on a three-level one)
+            gain = 0.8 if (pb == 0 or N >= 300) else 1.0
+            assert out[False][2] <= gain * out[True][2], (pb, stencil, out[False][2], out[True][2])
+            assert out[False][3] <= gain * out[True][3], (pb, stencil, out[False][3], out[True][3])
+            if os.environ.get("CSGPU_TEST_VERBOSE"):
+                print("dirichlet coarse: pb", pb, "stencil", stencil, "iterations with / without", out[False][2:], out[True][2:])
+    # two components: the correction is declined (it is defined for one), the solve is what it was
+    g2c = g.copy()
+    g2c[:, N // 2] = 0.0
+    nm = rg.construct_node_map(g2c, None)
+    left = [int(nm[5, 5]) - 1, int(nm[N - 7, 9]) - 1, int(nm[40, N // 2 - 3]) - 1]
+    n2 = int(nm.max())
+    Bc = np.zeros((n2, 1))
+    Bc[left[0], 0] = 1.0
+    with L.raster_setup(g2c, L.default_opts(batch=1)) as h:
+        Xc, _, sc = h.solve_grounded(Bc, [left[1:]])
+    assert sc["not_converged"] == 0 and sc["max_relres"] < 1e-5
+    right = int(nm[N // 2, N - 3]) - 1
+    assert Xc[right, 0] == 0.0 and Xc[left[0], 0] > 0

@@ -1159,3 +1159,15 @@ def test_single_level_fp32_handle_on_heterogeneous_component(emu_lib):
     """see helpers.check_single_level_fp32_handle_on_heterogeneous_component"""
     from helpers import check_single_level_fp32_handle_on_heterogeneous_component
     check_single_level_fp32_handle_on_heterogeneous_component(emu_lib)
+
+
+def test_grounded_solves_meet_the_true_residual(emu_lib):
+    """see helpers.check_grounded_solves_meet_the_true_residual"""
+    from helpers import check_grounded_solves_meet_the_true_residual
+    check_grounded_solves_meet_the_true_residual(emu_lib)
+
+
+def test_dirichlet_coarse_correction(emu_lib, monkeypatch):
+    """see helpers.check_dirichlet_coarse_correction"""
+    from helpers import check_dirichlet_coarse_correction
+    check_dirichlet_coarse_correction(emu_lib, monkeypatch, N=120)

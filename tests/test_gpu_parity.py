@@ -536,3 +536,15 @@ def test_single_level_fp32_handle_on_heterogeneous_component_gpu(gpu_lib):
     """dense pseudo-inverse of an fp32 single-level handle keeps sub-cutoff modes with a bounded gain (fuzz finding)"""
     from helpers import check_single_level_fp32_handle_on_heterogeneous_component
     check_single_level_fp32_handle_on_heterogeneous_component(gpu_lib)
+
+
+def test_grounded_solves_meet_the_true_residual_gpu(gpu_lib):
+    """Dirichlet-masked solves on the shared hierarchy also meet the true-residual rule (fuzz finding)"""
+    from helpers import check_grounded_solves_meet_the_true_residual
+    check_grounded_solves_meet_the_true_residual(gpu_lib)
+
+
+def test_dirichlet_coarse_correction_gpu(gpu_lib, monkeypatch):
+    """coarsest-level correction along the candidate for Dirichlet-masked solves: fewer iterations, same solutions"""
+    from helpers import check_dirichlet_coarse_correction
+    check_dirichlet_coarse_correction(gpu_lib, monkeypatch, N=400, npts=8)
