@@ -1777,6 +1777,15 @@ static int check_common(int64_t n, int64_t nnz, int val_bytes, const csgpu_opts*
   return CSGPU_OK;
 }
 
+// A problem that will not be coarsened (n <= max_coarse: the preconditioner IS the dense pseudo-inverse) gains nothing from
+// an fp32 preconditioner and loses a lot: the pseudo-inverse's cutoff n eps(fp32) lambda_max sits inside the spectrum of a
+// heterogeneous component, and sqrt(r'z) of an fp32 z is noise once r is small (fuzz findings: a 75-node path with
+// conductances over three decades did not converge, a 94-node graph stopped at ||Ax-b||/||b|| = 3e-7 for rtol = 1e-10).
+// Such handles compute in the matrix precision whatever precond_bytes says.
+static void single_level_precision(csgpu_opts& o, int64_t n) {
+  if (n <= (int64_t)o.max_coarse) o.precond_bytes = 0;
+}
+
 int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
                 int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out) {
   CS_API_BEGIN
@@ -1788,6 +1797,7 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
   if (rc) return rc;
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
+  single_level_precision(o, n);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);
@@ -1822,6 +1832,7 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;
+  single_level_precision(o, nrows * ncols);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);
@@ -1861,6 +1872,7 @@ int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nr
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;
+  single_level_precision(o, nrows * ncols);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);

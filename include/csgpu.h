@@ -133,7 +133,8 @@ typedef struct csgpu_opts {
   const int32_t* node_col;
   /* Storage / arithmetic precision of the AMG preconditioner (hierarchy + V-cycle): 0 = same as val_bytes,
    * 4 = fp32 preconditioner under an fp64 CG iteration (residuals, search directions, dot products and the
-   * reference's residual check stay in val_bytes precision). Default 0. */
+   * reference's residual check stay in val_bytes precision). Default 0. A problem that is not coarsened
+   * (n <= max_coarse: the preconditioner is the dense pseudo-inverse) computes in val_bytes precision whatever this says. */
   int32_t precond_bytes;
   /* Replay the PCG iteration as a captured hipGraph of check_every iterations between two host polls:
    * 0 = auto (on when n*batch <= 2^25, the launch-latency-bound regime), 1 = always, -1 = never. Default 0. */

@@ -1205,7 +1205,7 @@ def check_grounded_solves_meet_the_true_residual(L):
                 assert np.max(np.abs(X - Xd)) / np.max(np.abs(Xd)) < tol_x, (nb, pb, rtol)
 
 
-def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8):
+def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8, stencils=(0, -1)):
     """Dirichlet-masked solves on a single-component hierarchy take the coarsest-level correction along the candidate,
     x_c = pinv_without_the_near_kernel_pair(b) + v (v'b) / G_c (csrc/pcg.h, DirichletCoarse): same solutions as without it
     (knob CSGPU_NO_DIRICHLET_COARSE=1), markedly fewer iterations on both hierarchy precisions, one-to-all and all-to-one
@@ -1229,7 +1229,7 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8):
     x_direct = np.zeros(n)
     x_direct[keep] = spla.spsolve(G[keep][:, keep].tocsc(), B1[keep, 0])
     for pb in (0, 4):
-        for stencil in (0, -1):
+        for stencil in stencils:
             out = {}
             for off in (False, True):
                 if off:
@@ -1246,8 +1246,9 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8):
             assert np.max(np.abs(out[False][0][:, 0] - x_direct)) / np.max(np.abs(x_direct)) < 1e-4
             for k in (0, 1):
                 assert np.max(np.abs(out[False][k] - out[True][k])) / np.max(np.abs(out[True][k])) < 1e-4
-            # (fp32 hierarchies gain with depth: 51 -> 19.5 iterations per column at 300^2, little on a three-level one)
-            gain = 0.8 if (pb == 0 or N >= 300) else 1.0
+            # (fp32 hierarchies: from 51 -> 19.5 iterations per column on one 300^2 raster to 22.1 -> 20.4 on a 400^2 one;
+            # what they lose without the correction is the tail's candidate projection, which depends on the raster)
+            gain = 0.8 if pb == 0 else 1.0
             assert out[False][2] <= gain * out[True][2], (pb, stencil, out[False][2], out[True][2])
             assert out[False][3] <= gain * out[True][3], (pb, stencil, out[False][3], out[True][3])
             if os.environ.get("CSGPU_TEST_VERBOSE"):
@@ -1265,3 +1266,35 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8):
     assert sc["not_converged"] == 0 and sc["max_relres"] < 1e-5
     right = int(nm[N // 2, N - 3]) - 1
     assert Xc[right, 0] == 0.0 and Xc[left[0], 0] > 0
+
+
+def check_single_level_handles_compute_in_matrix_precision(L):
+    """Found by fuzzing (round 3, tools/fuzz_networks.py): a handle that is not coarsened (n <= max_coarse: the
+    preconditioner is the dense pseudo-inverse) ignores precond_bytes = 4. In fp32 the pseudo-inverse's cutoff sits inside
+    the spectrum of a heterogeneous component (a 75-node path with conductances over three decades did not converge) and
+    sqrt(r'z) of an fp32 z is noise once r is small (a 94-node graph stopped at ||Ax-b||/||b|| = 3e-7 for rtol = 1e-10)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(65)
+    n = 75
+    w = 10.0 ** (3.0 * (rng.random(n - 1) - 0.5))
+    W = sp.coo_matrix((w, (np.arange(n - 1), np.arange(1, n))), shape=(n, n)).tocsr()
+    W = W + W.T
+    A = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
+    gd = np.zeros(n)
+    gd[[3, 40]] = 0.05
+    Ag = sp.csr_matrix(A + sp.diags(gd))
+    Ag.sort_indices()
+    b = rng.standard_normal(n)
+    xd = spla.spsolve(Ag.tocsc(), b)
+    for pb in (4, 0):
+        with L.setup(Ag, L.default_opts(batch=1, precond_bytes=pb, rtol=1e-10, atol=0.0)) as h:
+            assert h.info["levels"] == 1 and h.info["precond_bytes"] == 8
+            x, st = h.solve_rhs(b)
+        assert st["not_converged"] == 0 and st["total_iters"] <= 10
+        assert np.linalg.norm(Ag @ x - b) / np.linalg.norm(b) < 1e-9
+        assert np.max(np.abs(x - xd)) / np.max(np.abs(xd)) < 1e-8
+    # a coarsened problem keeps what was asked for
+    g = np.exp(np.random.default_rng(1).standard_normal((24, 21)))
+    with L.raster_setup(g, L.default_opts(batch=1, precond_bytes=4)) as h:
+        assert h.info["levels"] >= 2 and h.info["precond_bytes"] == 4

@@ -1170,4 +1170,10 @@ def test_grounded_solves_meet_the_true_residual(emu_lib):
 def test_dirichlet_coarse_correction(emu_lib, monkeypatch):
     """see helpers.check_dirichlet_coarse_correction"""
     from helpers import check_dirichlet_coarse_correction
-    check_dirichlet_coarse_correction(emu_lib, monkeypatch, N=120)
+    check_dirichlet_coarse_correction(emu_lib, monkeypatch, N=96, npts=4, batch=4, stencils=(0,))
+
+
+def test_single_level_handles_compute_in_matrix_precision(emu_lib):
+    """see helpers.check_single_level_handles_compute_in_matrix_precision"""
+    from helpers import check_single_level_handles_compute_in_matrix_precision
+    check_single_level_handles_compute_in_matrix_precision(emu_lib)

@@ -548,3 +548,9 @@ def test_dirichlet_coarse_correction_gpu(gpu_lib, monkeypatch):
     """coarsest-level correction along the candidate for Dirichlet-masked solves: fewer iterations, same solutions"""
     from helpers import check_dirichlet_coarse_correction
     check_dirichlet_coarse_correction(gpu_lib, monkeypatch, N=400, npts=8)
+
+
+def test_single_level_handles_compute_in_matrix_precision_gpu(gpu_lib):
+    """a handle that is not coarsened ignores precond_bytes = 4 (fuzz findings)"""
+    from helpers import check_single_level_handles_compute_in_matrix_precision
+    check_single_level_handles_compute_in_matrix_precision(gpu_lib)
