@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libcsgpu.so")
 
 CSGPU_OK, CSGPU_NOT_CONVERGED, CSGPU_HIP_ERROR, CSGPU_OOM, CSGPU_BAD_ARGS, CSGPU_INTERNAL = range(6)
-CRIT_KRYLOV, CRIT_TRUE_RESIDUAL = 0, 1
+CRIT_KRYLOV, CRIT_TRUE_RESIDUAL, CRIT_BOTH = 0, 1, 2
 AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
