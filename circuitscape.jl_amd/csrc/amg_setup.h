@@ -969,6 +969,8 @@ struct Level {
   DBuf xa, rb, b, qs;
 };
 
+static const int kMaxDirComp = 256;  // components of the coarsest graph the Dirichlet correction handles (pcg.h)
+
 template <class T>
 struct Hierarchy {
   std::vector<Level<T>> levels;
@@ -981,12 +983,16 @@ struct Hierarchy {
   // per-column scratch area and the batch width it is allocated for
   bool near_singular = false;  // the coarsest operator's near-kernel eigenpair was dropped (fp32 hierarchy of a Laplacian)
   // Dirichlet-masked solves on this hierarchy (pcg.h, DirichletCoarse): the pseudo-inverse WITHOUT the near-kernel
-  // eigenpair (empty: coarse_inv already is that one), the coarsest level's candidate, and whether the coarsest graph is
-  // one connected component (the correction is defined for that case only)
+  // eigenpairs, the coarsest level's candidate, the connected component of the coarsest graph every coarse node lies in
+  // (-1: a weightless row of a cell-space hierarchy) and their number (0: the correction is not available)
   DBuf coarse_inv_defl;
   DBuf coarse_cand;
-  bool single_component = false;
-  const double* dir_coef = nullptr;  // [K] device, set for the duration of a Dirichlet-masked solve
+  DBuf coarse_comp;
+  int dir_ncomp = 0;
+  // set for the duration of a Dirichlet-masked solve: coef[k * kMaxK + c] = 1 / G of component k for column c (device);
+  // mode 1: the coarsest solve applies the correction, 2: it WRITES coef from the restricted probe vector instead
+  double* dir_coef = nullptr;
+  int dir_mode = 0;
   double cand_norm2 = 0;       // |candidate|^2 (= number of fine nodes: the same on every level)
   int tail_first = -2;
   DBuf tail_ws;
@@ -1683,23 +1689,29 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
         for (int i = 0; i < n; ++i) cand[i] = std::sqrt((double)sz[i]);
       }
       kc = component_candidates(M, n, cand);
-      // the coarsest graph has ONE component that carries weight (weightless rows of a cell-space hierarchy have a zero
-      // candidate entry and form no candidate; NODATA rows of a single-level cell-space handle are components of their
-      // own): Dirichlet-masked solves may use the correction along the candidate (pcg.h, DirichletCoarse)
-      H.single_component = kc.size() == 1 && !getenv("CSGPU_NO_DIRICHLET_COARSE");
+      // Dirichlet-masked solves may use the correction along the per-component candidates (pcg.h, DirichletCoarse);
+      // weightless rows of a cell-space hierarchy have a zero candidate entry and belong to no component
+      const bool dir_ok = !kc.empty() && (int)kc.size() <= kMaxDirComp && !getenv("CSGPU_NO_DIRICHLET_COARSE");
+      H.dir_ncomp = dir_ok ? (int)kc.size() : 0;
       int dropped = 0;
       std::vector<double> Pdefl;
       std::vector<double> Pi = dense_sym_pinv(std::move(M), n, (double)std::numeric_limits<T>::epsilon(),
                                               deflate ? &kc : nullptr, 1e-2, &dropped, &kc,
-                                              H.single_component ? &Pdefl : nullptr);
-      if (H.single_component) {
+                                              dir_ok ? &Pdefl : nullptr);
+      if (dir_ok) {
         std::vector<T> Dt((size_t)n * n), ct((size_t)n);
+        std::vector<int> cc((size_t)n, -1);
         for (size_t i = 0; i < Dt.size(); ++i) Dt[i] = (T)Pdefl[i];
         for (int i = 0; i < n; ++i) ct[i] = (T)cand[i];
+        for (size_t k = 0; k < kc.size(); ++k)
+          for (int i = 0; i < n; ++i)
+            if (kc[k][i] != 0) cc[i] = (int)k;
         H.coarse_inv_defl.alloc(std::max<size_t>(Dt.size(), 1) * sizeof(T));
         H.coarse_cand.alloc((size_t)n * sizeof(T));
+        H.coarse_comp.alloc((size_t)n * sizeof(int));
         CS_HIP(hipMemcpyAsync(H.coarse_inv_defl.p, Dt.data(), Dt.size() * sizeof(T), hipMemcpyHostToDevice, st));
         CS_HIP(hipMemcpyAsync(H.coarse_cand.p, ct.data(), ct.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        CS_HIP(hipMemcpyAsync(H.coarse_comp.p, cc.data(), cc.size() * sizeof(int), hipMemcpyHostToDevice, st));
         CS_HIP(hipStreamSynchronize(st));
       }
       H.near_singular = deflate && dropped > 0;

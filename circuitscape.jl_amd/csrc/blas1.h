@@ -370,24 +370,34 @@ __global__ __launch_bounds__(256) void dense_apply_kernel(int n, const T* __rest
   }
 }
 
-// ---- y[:,c] += v (v'b[:,c]) coef[c]: the correction along the candidate after the dense coarse solve of a Dirichlet-masked
-//      solve (pcg.h, DirichletCoarse). One workgroup per column; n is at most a few hundred.
+// ---- the coarsest-level correction of a Dirichlet-masked solve when the coarsest level is not inside the tail kernel
+//      (pcg.h, DirichletCoarse; same arithmetic as tail_dirichlet in tail.h). One workgroup per column.
 template <class T, int K>
-__global__ __launch_bounds__(256) void dense_rank_one_kernel(int n, const T* __restrict__ v, const double* __restrict__ coef,
-                                                             const T* __restrict__ b, T* __restrict__ y, const int* skip) {
+__global__ __launch_bounds__(256) void dense_dirichlet_kernel(int n, const T* __restrict__ v, const int* __restrict__ comp,
+                                                              int ncomp, double* __restrict__ coef, int mode,
+                                                              const T* __restrict__ b, T* __restrict__ y, const int* skip) {
   if (skip && *skip) return;
   __shared__ double s_red[256];
   const int c = blockIdx.x, tid = threadIdx.x;
-  double s = 0;
-  for (int i = tid; i < n; i += 256) s += (double)v[i] * (double)b[(size_t)i * K + c];
-  s_red[tid] = s;
-  __syncthreads();
-  for (int h = 128; h > 0; h >>= 1) {
-    if (tid < h) s_red[tid] += s_red[tid + h];
-    __syncthreads();
+  if (tid < ncomp) {
+    double s = 0;
+    for (int i = 0; i < n; ++i)
+      if (comp[i] == tid) s += (double)v[i] * (double)b[(size_t)i * K + c];
+    s_red[tid] = s;
   }
-  const T g = (T)(s_red[0] * coef[c]);
-  for (int i = tid; i < n; i += 256) y[(size_t)i * K + c] += g * v[i];
+  __syncthreads();
+  if (mode == 2) {
+    if (tid == 0) {
+      double smax = 0;
+      for (int k = 0; k < ncomp; ++k) smax = fmax(smax, s_red[k]);
+      for (int k = 0; k < ncomp; ++k) coef[(size_t)k * kMaxK + c] = (s_red[k] > 1e-9 * smax && s_red[k] > 0) ? 1.0 / s_red[k] : 0.0;
+    }
+    return;
+  }
+  for (int i = tid; i < n; i += 256) {
+    const int k = comp[i];
+    if (k >= 0) y[(size_t)i * K + c] += (T)(s_red[k] * coef[(size_t)k * kMaxK + c]) * v[i];
+  }
 }
 
 // ---- Dirichlet sets as a marker vector: m[gidx[e], c] = 1 for the entries of column c's set (m zeroed by the caller)
@@ -402,33 +412,26 @@ __global__ __launch_bounds__(256) void mark_grounds_kernel(const int* __restrict
   }
 }
 
-// ---- coef[c] = 1 / (1_f' A 1_f) for column c, 1_f = indicator of the nodes that are NOT in column c's Dirichlet set:
-//      the total conductance between the set and the rest, sum over grounded rows j of |a_ij| over their free neighbours i
-//      (the diagonal shift of the regularisation is left out: it is not a coupling). `mark` from mark_grounds_kernel. One
-//      workgroup per column, fixed summation order (bit-reproducible). 0 when the set is empty or isolated.
+// ---- penalty vector of the Dirichlet sets: d[j, c] = sum of |a_ij| over the FREE neighbours i of node j of column c's
+//      set (the conductance that ties the rest of the graph to the set through j), zero elsewhere (d zeroed by the caller;
+//      `mark` from mark_grounds_kernel). Its sum over a connected component is G = 1_f' A_g 1_f of that component.
 template <class T, class M, int K>
-__global__ __launch_bounds__(256) void dirichlet_conductance_kernel(const int* __restrict__ rp, const int* __restrict__ ci,
-                                                                    const T* __restrict__ va, const int* __restrict__ gptr,
-                                                                    const int* __restrict__ gidx, const M* __restrict__ mark,
-                                                                    double* __restrict__ coef) {
-  __shared__ double s_red[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const int g0 = gptr[c], g1 = gptr[c + 1];
-  double s = 0;
-  for (int e = g0 + tid; e < g1; e += 256) {
+__global__ __launch_bounds__(256) void dirichlet_penalty_kernel(const int* __restrict__ rp, const int* __restrict__ ci,
+                                                                const T* __restrict__ va, const int* __restrict__ gptr,
+                                                                const int* __restrict__ gidx, const M* __restrict__ mark,
+                                                                M* __restrict__ d) {
+  const int total = gptr[K];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int c = 0;
+    while (c + 1 < K && e >= gptr[c + 1]) ++c;
     const int j = gidx[e];
+    double s = 0;
     for (int k = rp[j]; k < rp[j + 1]; ++k) {
       const int i = ci[k];
       if (i != j && mark[(size_t)i * K + c] == M(0)) s += fabs((double)va[k]);
     }
+    d[(size_t)j * K + c] = (M)s;
   }
-  s_red[tid] = s;
-  __syncthreads();
-  for (int h = 128; h > 0; h >>= 1) {
-    if (tid < h) s_red[tid] += s_red[tid + h];
-    __syncthreads();
-  }
-  if (tid == 0) coef[c] = s_red[0] > 0.0 ? 1.0 / s_red[0] : 0.0;
 }
 
 // ---- relative residual post-check: partials of ||b - A x||^2 come from a DOT-fused SpMV; this finishes it

@@ -81,10 +81,13 @@ inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_f
   TailArgs<T> a;
   a.nlev = nl - first;
   a.dense = H.coarse_dense ? 1 : 0;
-  const bool dirichlet = H.dir_coef != nullptr && H.coarse_dense;  // DirichletCoarse (below)
+  const bool dirichlet = H.dir_mode != 0 && H.coarse_dense;  // DirichletCoarse (below)
   a.inv = dirichlet ? dptr<T>(H.coarse_inv_defl) : dptr<T>(H.coarse_inv);
-  a.rank1_cand = dirichlet ? (const T*)dptr<T>(H.coarse_cand) : nullptr;
-  a.rank1_coef = dirichlet ? H.dir_coef : nullptr;
+  a.dir_cand = dirichlet ? (const T*)dptr<T>(H.coarse_cand) : nullptr;
+  a.dir_comp = dirichlet ? (const int*)dptr<int>(H.coarse_comp) : nullptr;
+  a.dir_coef = dirichlet ? H.dir_coef : nullptr;
+  a.dir_ncomp = dirichlet ? H.dir_ncomp : 0;
+  a.dir_mode = dirichlet ? H.dir_mode : 0;
   int64_t off = 0;
   for (int t = 0; t < a.nlev; ++t) {
     Level<T>& L = H.levels[first + t];
@@ -165,12 +168,12 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     return;
   }
   if (last && H.coarse_dense) {
-    const bool dirichlet = H.dir_coef != nullptr;
+    const bool dirichlet = H.dir_mode != 0;
     hipLaunchKernelGGL((dense_apply_kernel<T, K>), dim3(gv), dim3(256), 0, st, n,
                        dirichlet ? dptr<T>(H.coarse_inv_defl) : dptr<T>(H.coarse_inv), b, out, skip);
     if (dirichlet)
-      hipLaunchKernelGGL((dense_rank_one_kernel<T, K>), dim3(K), dim3(256), 0, st, n, (const T*)dptr<T>(H.coarse_cand),
-                         H.dir_coef, b, out, skip);
+      hipLaunchKernelGGL((dense_dirichlet_kernel<T, K>), dim3(K), dim3(256), 0, st, n, (const T*)dptr<T>(H.coarse_cand),
+                         (const int*)dptr<int>(H.coarse_comp), H.dir_ncomp, H.dir_coef, H.dir_mode, b, out, skip);
     if (want_dot)
       hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
                          (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
@@ -410,7 +413,7 @@ struct PcgWork {
   int nf = 0;
   bool have_x = false;        // x holds the solution of the last solve (need_x was set)
   DBuf scalars;               // CgScalars
-  DBuf dir_coef;              // [kMaxK] doubles: 1 / G_c of a Dirichlet-masked solve (DirichletCoarse in pcg_solve)
+  DBuf dir_coef;              // [kMaxDirComp][kMaxK] doubles: 1 / G of a Dirichlet-masked solve (DirichletCoarse in pcg_solve)
   DBuf part_a, part_b, part_c;
   DBuf part_ca, part_cc;      // collapsed copies of part_a / part_c (collapse_partials_kernel)
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
@@ -548,31 +551,28 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // matrix, whose preconditioned norm has no such mode (advanced.jl:282-312). These solves therefore must ALSO meet
   // ||r||_2 <= atol + rtol ||b||_2.
   const int crit0 = (grounded && pp.criterion == CSGPU_CRIT_KRYLOV) ? CSGPU_CRIT_BOTH : pp.criterion;
-  // DirichletCoarse. The same mode is what makes that preconditioner weak for these solves: along the constant the
-  // grounded operator has the eigenvalue G_c / n (G_c = total conductance between column c's Dirichlet set and the free
-  // nodes), the ungrounded hierarchy answers with 1 / shift (fp64) or not at all (fp32: eigenpair dropped, right-hand sides
-  // projected), and CG spends its iterations repairing one direction (300^2 raster, 8 one-to-all columns: 26 / 51
-  // iterations against 10 for a pair solve). Galerkin along the candidate v of the coarsest level gives the exact
-  // answer for that direction: v'(R A_g P) v = 1' A_g 1 = G_c, so the coarsest solve of these solves is
-  //     x = pinv_without_the_near_kernel_pair(b) + v (v'b) / G_c
-  // (coef = 1 / G_c per column from dirichlet_conductance_kernel; hierarchies whose coarsest graph is one component).
+  // DirichletCoarse. The same mode is what makes that preconditioner weak for these solves: along the constant of a
+  // connected component the grounded operator has the eigenvalue G / n (G = total conductance between the column's
+  // Dirichlet set and the free nodes of the component), the ungrounded hierarchy answers with 1 / shift (fp64) or not at
+  // all (fp32: eigenpair dropped, right-hand sides projected), and CG spends its iterations repairing one direction per
+  // component (300^2 raster, 8 one-to-all columns: 26 / 51 iterations against 10 for a pair solve). Galerkin along the
+  // candidate v_k of component k on the coarsest level gives the exact answer for that direction:
+  // v_k'(R A_g P) v_k = 1_k' A_g 1_k = G_k, so the coarsest solve of these solves is
+  //     x = pinv_without_the_near_kernel_pairs(b) + sum_k v_k (v_k'b) / G_k.
+  // G_k per column comes from a PROBE: the penalty vector d (d_j = conductance from the free nodes to node j of the set)
+  // goes down the V-cycle once; every level hands down R (I - A S) d, and v'(R (I - A S) d) = (P v)'d - (A P v)'S d =
+  // (P v)'d because A annihilates the candidates -- so the component sums of d arrive at the coarsest level intact and
+  // the coarsest solve, in probe mode, writes coef = 1 / G_k instead of solving (no component labels on the fine level,
+  // no index structure of the transfer operators needed: the index-free levels serve as they are).
   struct DirichletCoarse {
-    const double** slot = nullptr;
+    int* mode = nullptr;
+    double** coef = nullptr;
     ~DirichletCoarse() {
-      if (slot) *slot = nullptr;
+      if (mode) *mode = 0;
+      if (coef) *coef = nullptr;
     }
   } dirichlet_guard;
-  if (grounded && H.single_component && H.coarse_dense && H.coarse_cand.p && A.nnz > 0) {
-    if (W.dir_coef.bytes < kMaxK * sizeof(double)) W.dir_coef.alloc(kMaxK * sizeof(double));
-    double* coef = dptr<double>(W.dir_coef);
-    TP* mark = z;   // free until the first V-cycle writes it
-    CS_HIP(hipMemsetAsync(mark, 0, (size_t)n * K * sizeof(TP), st));
-    hipLaunchKernelGGL((mark_grounds_kernel<TP, K>), dim3(ceil_div(pp.gtotal, 256)), dim3(256), 0, st, pp.gptr, pp.gidx, mark);
-    hipLaunchKernelGGL((dirichlet_conductance_kernel<T, TP, K>), dim3(K), dim3(256), 0, st, A.rp(), A.ci(), A.va(), pp.gptr,
-                       pp.gidx, (const TP*)mark, coef);
-    H.dir_coef = coef;
-    dirichlet_guard.slot = &H.dir_coef;
-  }
+  const bool dirichlet = grounded && H.dir_ncomp > 0 && H.coarse_dense && H.coarse_cand.p && A.nnz > 0 && !pp.rhs_in_r;
   const int gm = grounded ? ceil_div(pp.gtotal, 256) : 1;
   const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product && !grounded;
   // lattice path: the residual update recomputes A p from the lattice form (one read of p, 5 matrix values per row)
@@ -588,6 +588,25 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   fuse.dotw = rp;
   fuse.partials = pa;
 
+  if (dirichlet) {
+    const size_t cbytes = (size_t)kMaxDirComp * kMaxK * sizeof(double);
+    if (W.dir_coef.bytes < cbytes) W.dir_coef.alloc(cbytes);
+    double* coef = dptr<double>(W.dir_coef);
+    TP* mark = pbuf[0];  // free until the first iteration; rp (the V-cycle's input, with its tail) takes the penalty vector
+    CS_HIP(hipMemsetAsync(mark, 0, (size_t)n * K * sizeof(TP), st));
+    CS_HIP(hipMemsetAsync(rp, 0, (size_t)n * K * sizeof(TP), st));
+    CS_HIP(hipMemsetAsync(coef, 0, cbytes, st));
+    hipLaunchKernelGGL((mark_grounds_kernel<TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, mark);
+    hipLaunchKernelGGL((dirichlet_penalty_kernel<T, TP, K>), dim3(gm), dim3(256), 0, st, A.rp(), A.ci(), A.va(), pp.gptr,
+                       pp.gidx, (const TP*)mark, rp);
+    H.dir_coef = coef;
+    H.dir_mode = 2;
+    dirichlet_guard.mode = &H.dir_mode;
+    dirichlet_guard.coef = &H.dir_coef;
+    vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    H.dir_mode = 1;
+    check_launch("pcg dirichlet probe");
+  }
   if (need_x) CS_HIP(hipMemsetAsync(x, 0, vbytes, st));
   if (nf > 0) CS_HIP(hipMemsetAsync(xf, 0, (size_t)nf * K * sizeof(T), st));
   W.have_x = need_x;

@@ -13,6 +13,7 @@
 // src/core.jl:164-167, 178) -- the reference recurses level by level on the host.
 #pragma once
 #include "amg_setup.h"
+#include "blas1.h"
 
 namespace csgpu {
 
@@ -48,9 +49,12 @@ struct TailArgs {
   T* xout;               // [n_first][K] its solution
   T cand_inv_norm2;      // 1 / |candidate|^2 (the same on every level); 0: no projection
   const int* skip;
-  // Dirichlet-masked solves (pcg.h, DirichletCoarse): x_coarsest += v (v'b) coef[c], v = the coarsest level's candidate
-  const T* rank1_cand;
-  const double* rank1_coef;  // [K], null: none
+  // Dirichlet-masked solves (pcg.h, DirichletCoarse): x_coarsest += sum_k v_k (v_k'b) coef[k][c], v_k = the coarsest level's
+  // candidate on component k (dir_mode 1); dir_mode 2 writes coef from b instead (probe), 0: none
+  const T* dir_cand;
+  const int* dir_comp;
+  double* dir_coef;  // [ncomp][kMaxK]
+  int dir_ncomp, dir_mode;
 };
 
 // b <- b - v (v'b) / (v'v): in exact arithmetic the restricted right-hand sides of a near-singular Laplacian system have no
@@ -73,21 +77,32 @@ __device__ __forceinline__ void tail_project(T* b, const T* __restrict__ v, int 
   __syncthreads();
 }
 
-// x <- x + v (v'b) coef: the coarsest-level correction along the candidate of a Dirichlet-masked solve (pcg.h)
+// The coarsest-level correction of a Dirichlet-masked solve (pcg.h, DirichletCoarse), column c of the batch.
+// s_k = sum over the coarse nodes of component k of v_i b_i (one thread per component, fixed order: bit-reproducible).
+// mode 1: x_i += v_i s_k coef[k][c].  mode 2 (probe: b is the restricted penalty vector, s_k = G_k): coef[k][c] = 1 / s_k for
+// the components that hold a share of the column's Dirichlet set, 0 for the others.
 template <class T>
-__device__ __forceinline__ void tail_rank_one(T* x, const T* b, const T* __restrict__ v, int n, double coef, double* s_red,
-                                              int tid) {
-  double s = 0;
-  for (int i = tid; i < n; i += kTailThreads) s += (double)v[i] * (double)b[i];
-  s_red[tid] = s;
-  __syncthreads();
-  for (int h = kTailThreads / 2; h > 0; h >>= 1) {
-    if (tid < h) s_red[tid] += s_red[tid + h];
-    __syncthreads();
+__device__ __forceinline__ void tail_dirichlet(T* x, const T* b, const T* __restrict__ v, const int* __restrict__ comp, int n,
+                                               int ncomp, double* coef, int c, int mode, double* s_red, int tid) {
+  if (tid < ncomp) {
+    double s = 0;
+    for (int i = 0; i < n; ++i)
+      if (comp[i] == tid) s += (double)v[i] * (double)b[i];
+    s_red[tid] = s;
   }
-  const T c = (T)(s_red[0] * coef);
   __syncthreads();
-  for (int i = tid; i < n; i += kTailThreads) x[i] += c * v[i];
+  if (mode == 2) {
+    if (tid == 0) {
+      double smax = 0;
+      for (int k = 0; k < ncomp; ++k) smax = fmax(smax, s_red[k]);
+      for (int k = 0; k < ncomp; ++k) coef[(size_t)k * kMaxK + c] = (s_red[k] > 1e-9 * smax && s_red[k] > 0) ? 1.0 / s_red[k] : 0.0;
+    }
+  } else {
+    for (int i = tid; i < n; i += kTailThreads) {
+      const int k = comp[i];
+      if (k >= 0) x[i] += (T)(s_red[k] * coef[(size_t)k * kMaxK + c]) * v[i];
+    }
+  }
   __syncthreads();
 }
 
@@ -171,9 +186,9 @@ __global__ __launch_bounds__(kTailThreads) void coarse_tail_kernel(TailArgs<T> a
           y = t;
         }
       }
-      if (a.dense && a.rank1_coef) {
+      if (a.dense && a.dir_mode) {
         __syncthreads();
-        tail_rank_one(x, b, a.rank1_cand, n, a.rank1_coef[c], s_red, tid);
+        tail_dirichlet(x, b, a.dir_cand, a.dir_comp, n, a.dir_ncomp, a.dir_coef, c, a.dir_mode, s_red, tid);
       }
       if (tid == 0) s_x[l] = x;
       __syncthreads();

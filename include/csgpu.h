@@ -289,11 +289,12 @@ int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out,
  * The residual check of core.jl:640 is evaluated on the rows of the reduced system.
  * Two things make the shared hierarchy fit these systems (csrc/pcg.h): (1) the stopping rule is CSGPU_CRIT_BOTH when
  * KRYLOV is configured -- sqrt(r0'M^-1 r0) of the UNGROUNDED hierarchy is dominated by the constant mode (gain 1 / shift)
- * whenever the right-hand side has a non-zero mean, so the reference's relative rule alone would stop at once; (2) on a
- * hierarchy whose coarsest graph is one component the coarsest solve is pinv-without-the-near-kernel-pair plus the exact
- * Galerkin answer along the candidate, v (v'b) / G_c with G_c = total conductance between column c's ground set and the
- * free nodes (26 -> 17 iterations per column with an fp64 hierarchy, 51 -> 19.5 with an fp32 one: 300^2 raster, 8
- * one-to-all columns; pair solves on the same handle: 10). Hierarchies with several components keep the plain pinv. */
+ * whenever the right-hand side has a non-zero mean, so the reference's relative rule alone would stop at once; (2) the
+ * coarsest solve is pinv-without-the-near-kernel-pairs plus the exact Galerkin answer along the candidate v_k of every
+ * connected component k, v_k (v_k'b) / G_k with G_k = total conductance between column c's ground set and the free nodes of
+ * the component, found per batch by sending the sets' penalty vector down the V-cycle once (26 -> 17 iterations per column
+ * with an fp64 hierarchy, 51 -> 19.5 with an fp32 one: 300^2 raster, 8 one-to-all columns; two components of a 240^2 raster:
+ * 36 -> 21; pair solves on the same handles: 10). Up to 256 components of the coarsest graph; more: plain pinv. */
 int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
                          const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats);
 
