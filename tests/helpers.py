@@ -1297,3 +1297,35 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8, st
     monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
     # (the constant mode costs more the larger the component: 36 -> 21 iterations per column at 240^2, 18.2 -> 17.5 at 96^2)
     assert its[False] <= (0.9 if N >= 200 else 1.0) * its[True], its
+
+
+def check_single_level_handles_compute_in_matrix_precision(L):
+    """Found by fuzzing (round 3, tools/fuzz_networks.py): a handle that is not coarsened (n <= max_coarse: the
+    preconditioner is the dense pseudo-inverse) ignores precond_bytes = 4. In fp32 the pseudo-inverse's cutoff sits inside
+    the spectrum of a heterogeneous component (a 75-node path with conductances over three decades did not converge) and
+    sqrt(r'z) of an fp32 z is noise once r is small (a 94-node graph stopped at ||Ax-b||/||b|| = 3e-7 for rtol = 1e-10)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(65)
+    n = 75
+    w = 10.0 ** (3.0 * (rng.random(n - 1) - 0.5))
+    W = sp.coo_matrix((w, (np.arange(n - 1), np.arange(1, n))), shape=(n, n)).tocsr()
+    W = W + W.T
+    A = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
+    gd = np.zeros(n)
+    gd[[3, 40]] = 0.05
+    Ag = sp.csr_matrix(A + sp.diags(gd))
+    Ag.sort_indices()
+    b = rng.standard_normal(n)
+    xd = spla.spsolve(Ag.tocsc(), b)
+    for pb in (4, 0):
+        with L.setup(Ag, L.default_opts(batch=1, precond_bytes=pb, rtol=1e-10, atol=0.0)) as h:
+            assert h.info["levels"] == 1 and h.info["precond_bytes"] == 8
+            x, st = h.solve_rhs(b)
+        assert st["not_converged"] == 0 and st["total_iters"] <= 10
+        assert np.linalg.norm(Ag @ x - b) / np.linalg.norm(b) < 1e-9
+        assert np.max(np.abs(x - xd)) / np.max(np.abs(xd)) < 1e-8
+    # a coarsened problem keeps what was asked for
+    g = np.exp(np.random.default_rng(1).standard_normal((24, 21)))
+    with L.raster_setup(g, L.default_opts(batch=1, precond_bytes=4)) as h:
+        assert h.info["levels"] >= 2 and h.info["precond_bytes"] == 4
