@@ -58,6 +58,7 @@ def direct(A, b, ground):
 
 bad = 0
 for case in range(ncase):
+    if case and case % 20 == 0: print("# seed", seed0, "cases done", case, "bad", bad, flush=True)
     rng = np.random.default_rng(seed0 * 1000 + case)
     kind = str(rng.choice(["er", "pa", "tree", "path", "star", "ring", "barbell"]))
     n = int(rng.integers(NMIN, NMAX))

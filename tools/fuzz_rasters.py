@@ -22,6 +22,7 @@ def direct_R(A, s, d):
     return x[np.searchsorted(keep, d)]
 bad = 0
 for case in range(ncase):
+    if case and case % 20 == 0: print("# seed", seed0, "cases done", case, "bad", bad, flush=True)
     rng = np.random.default_rng(seed0 * 1000 + case)
     lo_, hi_ = int(os.environ.get("FUZZ_MIN", "6")), int(os.environ.get("FUZZ_MAX", "40"))
     R = int(rng.integers(lo_, hi_)); C = int(rng.integers(lo_, hi_))
