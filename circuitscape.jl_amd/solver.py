@@ -233,7 +233,7 @@ def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, 
             node = nodemap[rows, cols].astype(np.int64) - 1          # -1: the focal cell is NODATA
             comp, _ = h.components()
             B = np.zeros((n, len(ids)))
-            grounds, solvable = [], []
+            grounds, solvable, ground_comps = [], [], []
             for i in range(len(ids)):
                 others = [int(node[k]) for k in range(len(ids)) if k != i and node[k] >= 0]
                 if flags.is_onetoall:
@@ -245,7 +245,16 @@ def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, 
                 B[src, i] = 1.0
                 grounds.append(gnd)
                 solvable.append(len(src) > 0)
+                ground_comps.append(gcomps)
             X, C, st = h.solve_grounded(B, grounds, want_currents=want_cur)
+            # a component without a ground is not part of the column's system (advanced.jl:186-191). An island whose cells
+            # share a 3x3 aggregate with a solved component can pick up a constant from the preconditioner (residual-free:
+            # a constant is in the kernel of its block); the reference has no voltage there
+            for i, gcomps in enumerate(ground_comps):
+                outside = ~np.isin(comp, list(gcomps))
+                X[outside, i] = 0.0
+                if C is not None:
+                    C[outside, i] = 0.0
             if stats is not None:
                 stats.update(st)
     except lib.CsgpuError as e:
