@@ -31,20 +31,43 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+KERNEL_SOURCES = ("stencil.h", "lattice.h", "spmv.h", "blas1.h", "prims.h", "common.h")
+
+
+def kernel_source_hash():
+    """sha256[:16] over the csrc files that define the roofline kernels (the marching lattice kernels and the CSR SpMM).
+    A committed PMC pass is only reported as `roofline.traffic` while it describes THIS code: tools/pmc_update.py stores the
+    hash next to the counters, and a mismatch prints null (the figure used to be keyed by workload
+    only and went stale silently after a kernel change)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "circuitscape.jl_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(size, batch, vb, lattice=False, pb=4):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh -> profiles/),
-    collected with rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md prescribes. None when no
-    profile matches the current workload. (PMC passes cannot run inside this process; the key names size, batch width,
-    CG precision, matrix form and -- for the all-fp64 path -- the preconditioner precision.)"""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh + tools/pmc_update.py
+    -> profiles/pmc_traffic.json), collected with rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md
+    prescribes. Returns (bytes or None, note): None when no profile matches the current workload OR the entry was taken
+    with different kernel sources (entry["kernel_src_sha16"] != kernel_source_hash()). (PMC passes cannot run inside this
+    process; the key names size, batch width, CG precision, matrix form and the preconditioner precision.)"""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = "%d_k%d_f%d%s%s" % (size, batch, vb * 8, "_lattice" if lattice else "",
+                              "_fp64precond" if (vb == 8 and pb == 8) else "")
     try:
         with open(path) as f:
-            d = json.load(f)
-        key = "%d_k%d_f%d%s%s" % (size, batch, vb * 8, "_lattice" if lattice else "",
-                                  "_fp64precond" if (vb == 8 and pb == 8) else "")
-        return d.get(key, {}).get("traffic_bytes_per_launch")
-    except Exception:
-        return None
+            e = json.load(f).get(key)
+        if not e or e.get("traffic_bytes_per_launch") is None:
+            return None, "no committed PMC pass for %s" % key
+        cur = kernel_source_hash()
+        if e.get("kernel_src_sha16") != cur:
+            return None, ("committed PMC pass %s was taken with kernel sources %s, this build is %s: stale, not reported"
+                          % (key, e.get("kernel_src_sha16"), cur))
+        return e["traffic_bytes_per_launch"], "PMC pass %s (kernel sources %s)" % (key, cur)
+    except Exception as ex:
+        return None, "pmc_traffic.json unreadable: %r" % (ex,)
 
 
 def make_raster(size, seed=12345, sigma=1.0, dtype=np.float64):
@@ -160,6 +183,64 @@ def cg_product_name(info, B, vb):
     return "spmv_kernel<%s,%d,PLAIN,DOT,x=%s> (fine-level CSR CG SpMM)" % (tn[vb], B, tn[xb])
 
 
+def rank_identity(torch, rank, dev_index, has_cuda, ms_per_step, pairs_done, agg):
+    """Per-rank facts for the N-GPU line: which physical device this rank ran on and what it did."""
+    import socket
+    bus, name = None, None
+    if has_cuda:
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            name = pr.name
+            if hasattr(pr, "pci_bus_id"):
+                bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+        except Exception:
+            pass
+        if bus is None:
+            try:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                buf = ctypes.create_string_buffer(64)
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(dev_index)) == 0:
+                    bus = buf.value.decode()
+            except Exception:
+                pass
+    return {"rank": int(rank), "host": socket.gethostname(), "device_ordinal": int(dev_index), "pci_bus_id": bus,
+            "device_name": name, "ms_per_step": float(ms_per_step), "pairs_done": int(pairs_done),
+            "iters_mean": agg["total_iters"] / float(max(pairs_done, 1)), "max_relres": float(agg["max_relres"]),
+            "not_converged": int(agg["not_converged"])}
+
+
+def shortcut_leg(h, cells, setup_s, check_pairs):
+    """what a real no-map run does (src/core.jl:137-146, 563-587, 685-739) -- K - 1 solves from the anchor
+    point with the K focal voltages gathered on the device, then R_ij = R_1i + R_1j - 2 v_i^(1j) (update_shortcut_resistances!)
+    for all K (K - 1) / 2 pairs. One untimed + one timed pass; a sample of the derived resistances is checked against direct
+    solves of the same pairs on the same handle."""
+    anchor = int(cells[0])
+    others = [int(c) for c in cells[1:]]
+    gather = [int(c) for c in cells]
+    h.solve_pairs([anchor] * len(others), others, gather=gather)
+    t0 = time.perf_counter()
+    R1, Gv, _, st = h.solve_pairs([anchor] * len(others), others, gather=gather)
+    t = time.perf_counter() - t0
+    npts = len(cells)
+    R = np.zeros((npts, npts))
+    for j in range(1, npts):
+        R[0, j] = R[j, 0] = R1[j - 1]
+    for j in range(1, npts):           # solve p = j - 1 has its sink at point j; Gv[p, i] = v_i - v_anchor
+        for i in range(1, j):
+            R[i, j] = R[j, i] = R1[i - 1] + R1[j - 1] - 2.0 * Gv[j - 1, i]
+    src = [p[0] for p in check_pairs]
+    dst = [p[1] for p in check_pairs]
+    Rd, _, _, _ = h.solve_pairs(src, dst)
+    idx = {int(c): k for k, c in enumerate(cells)}
+    rel = max(abs(R[idx[a], idx[b]] - rd) / abs(rd) for a, b, rd in zip(src, dst, Rd))
+    nres = npts * (npts - 1) // 2
+    return {"value": nres / (t + setup_s), "unit": "pair resistances/s, whole shortcut job (setup + K-1 anchor solves)",
+            "focal_points": npts, "solves": len(others), "resistances": nres, "solve_s": t, "setup_s": setup_s,
+            "iters_mean": st["total_iters"] / float(len(others)), "max_relres": st["max_relres"],
+            "max_rel_diff_vs_direct_solves": float(rel), "direct_pairs_checked": len(src)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +273,10 @@ def main():
                     help="N=1 only: also time csgpu_setup from host CSR arrays the way Julia hands them (Int64, 1-based) "
                          "at the bench size and report setup_host_csr_s (needs ~30 GB of host memory and ~20 s at "
                          "10000^2; 0 = skip)")
+    ap.add_argument("--extra-legs", type=int, default=1,
+                    help="N=1 only: also report value_shortcut (K-1 anchor solves + focal-voltage gather -> all K(K-1)/2 "
+                         "resistances, SURVEY.md 8d) and value_with_voltages (whole solution vector carried, explicit 1e-4 "
+                         "check); 0 = skip")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="N_FULL",
                     help="internal: run only the CPU-baseline leg on a --cpu-sample raster, scale to N_FULL nodes, print "
                          "its JSON object and exit (the bench runs this in a child process so that nothing on the host "
@@ -236,9 +321,11 @@ def main():
     B = args.batch
     K, Wm = args.steps, args.warmup
 
-    def make_opts(precond):
+    def make_opts(precond, **kw):
+        o = dict(extra)
+        o.update(kw)
         return lib.default_opts(device=dev_index, batch=B, criterion=args.criterion,
-                                precond_bytes=4 if (precond == "fp32" and vb == 8) else 0, **extra)
+                                precond_bytes=4 if (precond == "fp32" and vb == 8) else 0, **o)
 
     has_cuda = torch.cuda.is_available()  # False only in the CPU self-test (emulator library via CSGPU_LIB)
 
@@ -291,11 +378,28 @@ def main():
         gathered = [torch.empty_like(res_local) for _ in range(world)]
         dist.all_gather(gathered, res_local)  # the path's only collective: final result gather over RCCL/xGMI
     sync()
-    elapsed += time.perf_counter() - t1
+    t_gather = time.perf_counter() - t1
+    elapsed_rank = elapsed + t_gather
+    elapsed = elapsed_rank
+    rank_reports = [rank_identity(torch, rank, dev_index, has_cuda, elapsed_rank / K * 1e3, K * B, agg)]
+    multi = None
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # what lets a reader check an N-GPU line without trusting it (outside the timed region): the process group's own
+        # idea of its size and backend, every rank's device ordinal / PCI bus id / step time / pairs, the gather's size
+        rank_reports = [None] * world
+        dist.all_gather_object(rank_reports, rank_identity(torch, rank, dev_index, has_cuda, elapsed_rank / K * 1e3,
+                                                           K * B, agg))
+        allR = torch.cat([t_.cpu() for t_ in gathered]).numpy()
+        multi = {"rccl_world_size": int(dist.get_world_size()), "dist_backend": str(dist.get_backend()),
+                 "ranks": rank_reports, "distinct_devices": len({(r_["host"], r_["pci_bus_id"] or r_["device_ordinal"])
+                                                                 for r_ in rank_reports}),
+                 "gather": {"collective": "all_gather", "bytes_per_rank": int(res_local.numel() * res_local.element_size()),
+                            "bytes_total": int(res_local.numel() * res_local.element_size() * world),
+                            "seconds_incl_barrier": t_gather, "pairs_received": int(allR.size),
+                            "all_finite": bool(np.all(np.isfinite(allR)))}}
 
     def roofline_of(info_p, agg_p):
         """roofline object of the fine-level CG product of one path: algorithmic bytes per launch (reported by the
@@ -303,9 +407,9 @@ def main():
         avg_ms = agg_p["cg_spmv_ms"] / max(agg_p["cg_spmv_calls"], 1)
         nbytes = agg_p["cg_spmv_bytes"]
         ach = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, tnote = pmc_traffic(size, B, vb, info_p["lattice_period"] > 0, info_p["precond_bytes"] or vb)
         return {"bound": "hbm", "kernel": cg_product_name(info_p, B, vb), "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(size, B, vb, info_p["lattice_period"] > 0, info_p["precond_bytes"] or vb),
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tnote,
                 "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms, "launches_timed": agg_p["cg_spmv_calls"]}
 
     if rank == 0:
@@ -356,6 +460,17 @@ def main():
             "roofline": roof,
         }
         out["value_" + path_name] = value
+        if multi is not None:
+            out["multi_gpu"] = multi
+        else:
+            out["rank0"] = rank_reports[0]
+        if world == 1 and args.extra_legs:
+            try:   # shortcut mode on the handle just timed: 14 anchor solves -> all 105 resistances
+                non_anchor = [p for p in pairs if p[0] != int(cells[0])][:B]
+                out["shortcut"] = shortcut_leg(h, cells, setup_s, non_anchor)
+                out["value_shortcut"] = out["shortcut"]["value"]
+            except Exception as e:
+                out["shortcut"] = {"failed": repr(e)}
         h.close()
         h = None
         csteps = K if args.compare_steps < 0 else args.compare_steps
@@ -383,6 +498,26 @@ def main():
                 "max_rel_diff_R_vs_%s_path" % path_name: float(max(np.max(np.abs(res2[k] - results[k]) / np.abs(res2[k]))
                                                                    for k in range(ncmp)))}
             h2.close()
+        if world == 1 and args.extra_legs:
+            # what a maps-on run pays on the solve side: the whole solution vector carried (x += alpha p fused into the
+            # residual update) and the reference's 1e-4 check evaluated as ||A x - b|| / ||b|| with an explicit product
+            # (opts.explicit_check = 1; csgpu_solve_pairs without volt_out otherwise carries x at the focal nodes only)
+            try:
+                hv = lib.raster_setup(g, make_opts(args.precond, explicit_check=1))
+                vsteps = max(1, min(K, 3))
+                elv, resv, aggv = run_pairs(hv, batch_pairs, vsteps, 1, sync)
+                iv = hv.info
+                sv = (iv["setup_ms"] + iv["upload_ms"]) / 1e3
+                hv.close()
+                out["value_with_voltages"] = vsteps * B / (elv + sv * vsteps * B / 100.0)
+                out["with_voltages"] = {"value": out["value_with_voltages"], "steps": vsteps, "ms_per_step": elv / vsteps * 1e3,
+                                        "iters_mean": aggv["total_iters"] / float(vsteps * B), "max_relres_explicit": aggv["max_relres"],
+                                        "not_converged": aggv["not_converged"],
+                                        "max_rel_diff_R_vs_value_path": float(max(np.max(np.abs(resv[k] - results[k]) / np.abs(results[k]))
+                                                                                  for k in range(min(vsteps, K)))),
+                                        "note": "x carried over all n rows + explicit ||Ax-b||/||b|| check; no D2H of voltages"}
+            except Exception as e:
+                out["with_voltages"] = {"failed": repr(e)}
         if world == 1 and args.host_csr:
             try:
                 out.update(host_csr_setup(lib, g, make_opts(args.precond)))
@@ -497,6 +632,12 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
     h.close()
     busy = [t_busy]
     setups = [t_setup]
+    has_cuda = torch.cuda.is_available()
+    dev_index = dev.index if dev is not None and dev.index is not None else 0
+    agg = {"total_iters": st["total_iters"], "max_relres": st["max_relres"], "not_converged": st["not_converged"]}
+    nb_mine = max(1, -(-(hi - lo) // B))
+    reports = [rank_identity(torch, rank, dev_index, has_cuda, (t_busy - t_setup) / nb_mine * 1e3, hi - lo, agg)]
+    multi = None
     if dist is not None:
         t = torch.tensor([elapsed, t_busy, t_setup], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         allt = [torch.empty_like(t) for _ in range(world)]
@@ -504,6 +645,14 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
         elapsed = max(float(x[0]) for x in allt)
         busy = [float(x[1]) for x in allt]
         setups = [float(x[2]) for x in allt]
+        reports = [None] * world
+        dist.all_gather_object(reports, rank_identity(torch, rank, dev_index, has_cuda, (t_busy - t_setup) / nb_mine * 1e3,
+                                                      hi - lo, agg))
+        slot = max(-(-npairs // world), 1)
+        multi = {"rccl_world_size": int(dist.get_world_size()), "dist_backend": str(dist.get_backend()), "ranks": reports,
+                 "distinct_devices": len({(r_["host"], r_["pci_bus_id"] or r_["device_ordinal"]) for r_ in reports}),
+                 "gather": {"collective": "all_gather of (index, value) rows", "bytes_per_rank": slot * 16,
+                            "bytes_total": slot * 16 * world, "pairs_received": int(np.sum(~np.isnan(full)))}}
     if rank == 0:
         per_batch = (busy[0] - setups[0]) / max(1, -(-(hi - lo) // B))
         nb1 = -(-npairs // B)
@@ -518,9 +667,17 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
                        "preconditioner_precision": "fp32" if info["precond_bytes"] == 4 else "fp64"},
             "job_s": elapsed, "rank_busy_s": busy, "rank_setup_s": setups, "pairs_per_rank": -(-npairs // world),
             "per_batch_s_rank0": per_batch,
+            # predicted: T_1 / T_N = (s + nb_1 b) / (s + nb_N b) from rank 0's measured setup s and per-batch time b;
+            # achieved: the one-GPU time RECONSTRUCTED from this run's own pieces -- one setup plus every rank's solve
+            # time back to back -- over the measured job time (an N = 1 run of the same command gives the true T_1)
             "predicted_speedup_vs_1gpu": (setups[0] + nb1 * per_batch) / (setups[0] + nbN * per_batch),
+            "achieved_speedup_vs_1gpu_reconstructed": (setups[0] + sum(b_ - s_ for b_, s_ in zip(busy, setups))) / elapsed,
             "max_relres": st["max_relres"], "all_pairs_gathered": bool(not np.any(np.isnan(full))),
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
+        else:
+            out["rank0"] = reports[0]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -74,7 +74,7 @@ struct DevicePool {
   std::vector<Blk> pending[kMaxDev];          // released, device not drained yet
   size_t pooled[kMaxDev] = {0};               // bytes in ready + pending
   size_t limit[kMaxDev] = {0};                // cap in bytes (0: not initialised yet)
-  uint64_t seq = 0;
+  std::atomic<uint64_t> seq{0};  // one release counter for all devices, bumped under different per-device mutexes
   bool enabled = getenv("CSGPU_NO_POOL") == nullptr;
   // (caller holds mu[dev] and has `dev` current) drain the device and make the pending blocks reusable
   void promote(int dev) {
@@ -112,8 +112,15 @@ struct DevicePool {
         size_t fr = 0, tot = 0;
         const char* e = getenv("CSGPU_POOL_MAX_GB");
         if (e) limit[dev] = (size_t)(atof(e) * 1073741824.0) + 1;
-        else if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) limit[dev] = tot / 10 * 6;
-        else limit[dev] = (size_t)64 << 30;
+        else {
+          // the cap is a fraction of THIS device's memory: hipMemGetInfo answers for the current device
+          int cur = dev;
+          (void)hipGetDevice(&cur);
+          if (cur != dev) (void)hipSetDevice(dev);
+          const bool ok = hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0;
+          if (cur != dev) (void)hipSetDevice(cur);
+          limit[dev] = ok ? tot / 10 * 6 : (size_t)64 << 30;
+        }
       }
       pending[dev].push_back(Blk{p, cap, ++seq});
       pooled[dev] += cap;

@@ -428,6 +428,11 @@ struct Solver : ISolver {
     } else {
       amg_setup(H, std::move(A), sp, prow, pcol, st);
     }
+    // The coarsest-level Dirichlet correction (pcg.h, DirichletCoarse) probes G_k = 1_f' A_g 1_f as the sum of the penalty
+    // vector, which assumes that A annihilates the per-component candidate. A handle with finite ground conductances on
+    // its diagonal (csgpu_raster_setup_grounded) leaks there and the correction would be over-weighted by (G + leak) / G
+    // (SPD either way, but slower): such handles keep the plain deflated pseudo-inverse.
+    if (ground_node.p) H.dir_ncomp = 0;
     Level<TP>& L0 = H.levels[0];
     if (sp.lattice_s && L0.agg0.p) {
       // two-product level from the lattice: b_c = Q^T b and out = S b + Q x_c with index-free Q (lattice.h) and S in
@@ -1786,6 +1791,28 @@ static void single_level_precision(csgpu_opts& o, int64_t n) {
   if (n <= (int64_t)o.max_coarse) o.precond_bytes = 0;
 }
 
+// Raster entry points: whether the handle is coarsened depends on the number of NODES, not of cells (a raster
+// with few valid cells stays in compact numbering with n = valid cells). Upper bound of the node count -- valid cells
+// outside polygons + polygons holding a valid cell -- with an early exit once it exceeds max_coarse, so the scan of the
+// host raster costs nothing on real landscapes.
+static void single_level_precision_raster(csgpu_opts& o, const void* cond_, const int32_t* poly, int64_t cells) {
+  typedef double T;  // (only fp64 matrices can carry an fp32 preconditioner)
+  if (o.precond_bytes == 0) return;
+  const T* cond = (const T*)cond_;
+  const int64_t limit = (int64_t)o.max_coarse;
+  int64_t nodes = 0;
+  std::vector<int32_t> seen;  // polygon ids counted so far (at most `limit` + 1 of them)
+  for (int64_t i = 0; i < cells && nodes <= limit; ++i) {
+    if (!(cond[i] > T(0))) continue;
+    if (poly && poly[i] > 0) {
+      if (std::find(seen.begin(), seen.end(), poly[i]) != seen.end()) continue;
+      seen.push_back(poly[i]);
+    }
+    ++nodes;
+  }
+  single_level_precision(o, nodes);
+}
+
 int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
                 int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out) {
   CS_API_BEGIN
@@ -1832,7 +1859,7 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;
-  single_level_precision(o, nrows * ncols);
+  if (val_bytes == 8) single_level_precision_raster(o, cond, nullptr, nrows * ncols);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);
@@ -1872,7 +1899,7 @@ int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nr
   csgpu_opts o;
   if (opts) o = *opts; else csgpu_default_opts(&o);
   o.node_row = o.node_col = nullptr;
-  single_level_precision(o, nrows * ncols);
+  if (val_bytes == 8) single_level_precision_raster(o, cond, polymap, nrows * ncols);
   std::unique_ptr<csgpu_handle> h(new csgpu_handle());
   if (val_bytes == 8 && o.precond_bytes == 4) {
     auto* s = new csgpu::Solver<double, float>(o);

@@ -293,19 +293,172 @@ function solve_pairs(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst:
 end
 
 """
-0-based raster row / column of the first cell (column-major order) of every node of `comp` (sorted global node ids), or
-`nothing` when a node of the component has no cell in `nodemap`.
+`node_cell_table(nodemap)`: 0-based raster row / column of the FIRST cell (column-major order) of every node id of the
+node map, built ONCE per problem (one pass over the raster); `node_coords(table, comp)` then picks the entries of a
+connected component (any order of `comp`), or returns `nothing` -- with a warning -- when a node of the component has no
+cell, in which case the component runs without the lattice / 3 x 3-tile paths.
 """
-function node_coords(nodemap::Matrix{V}, comp::Vector{V}) where {V}
-    rows = fill(Int32(-1), length(comp)); cols = fill(Int32(-1), length(comp))
+function node_cell_table(nodemap::Matrix{V}) where {V}
+    nmax = isempty(nodemap) ? 0 : Int(maximum(nodemap))
+    rows = fill(Int32(-1), nmax); cols = fill(Int32(-1), nmax)
     for j in axes(nodemap, 2), i in axes(nodemap, 1)
-        id = nodemap[i, j]
-        id == 0 && continue
-        k = searchsortedfirst(comp, id)
-        (k <= length(comp) && comp[k] == id && rows[k] < 0) || continue
-        rows[k] = Int32(i - 1); cols[k] = Int32(j - 1)
+        id = Int(nodemap[i, j])
+        (id == 0 || rows[id] >= 0) && continue
+        rows[id] = Int32(i - 1); cols[id] = Int32(j - 1)
     end
-    any(<(0), rows) ? nothing : (rows, cols)
+    (rows, cols)
+end
+
+function node_coords(table::Tuple{Vector{Int32},Vector{Int32}}, comp::Vector{V}) where {V}
+    rows = Vector{Int32}(undef, length(comp)); cols = Vector{Int32}(undef, length(comp))
+    for (k, id) in enumerate(comp)
+        if id > length(table[1]) || table[1][id] < 0
+            @warn("node $id of a connected component has no raster cell: the component runs on the CSR kernels")
+            return nothing
+        end
+        rows[k] = table[1][id]; cols[k] = table[2][id]
+    end
+    (rows, cols)
+end
+
+"""
+Scatter a node vector into the raster through a component's local node map (the loop of `_create_current_maps`,
+out.jl:163-173, and `_create_voltage_map`, out.jl:421-434).
+"""
+function scatter_nodes(vals::AbstractVector{T}, local_nodemap, hbmeta) where {T}
+    m = zeros(T, hbmeta.nrows, hbmeta.ncols)
+    for j in axes(local_nodemap, 2), i in axes(local_nodemap, 1)
+        idx = local_nodemap[i, j]
+        idx == 0 && continue
+        m[i, j] = vals[idx]
+    end
+    m
+end
+
+"""
+`postprocess` with maps on (core.jl:655-683 -> write_volt_maps / write_cur_maps, out.jl:29-115, 388-410) for the pair
+list of ONE connected component, in chunks of `s.bs` pairs through `solve_pairs_currents`:
+
+  * node currents (get_node_currents, out.jl:178-207, incl. the 1e-8 * max branch-current threshold) come from the device;
+  * raster, linear maps: cumulative and maximum node currents are accumulated ON THE DEVICE across all chunks (weights =
+    number of id combinations a node pair serves -- the reference post-processes once per combination) and scattered into
+    `cum.cum_curr` / `cum.max_curr` once per component; per-pair current vectors cross PCIe only when per-pair maps are
+    written (`write_cur_maps && !write_cum_cur_map_only`) or `log_transform_maps` makes the accumulation non-linear;
+  * voltages cross PCIe only when `write_volt_maps` is set;
+  * network mode: node and branch current tables per pair from the device's node / branch currents, accumulated into
+    `cum.cum_node_curr` / `cum.cum_branch_curr` like out.jl:60-80.
+
+Host memory is O(n * bs) (O(nnz * bs) in network mode), as in the reference's batched driver (core.jl:448-493).
+Returns the resistance of every pair of `src0` / `dst0`.
+"""
+function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::SparseMatrixCSC{T,V}, component_data,
+                                src0::Vector{Int64}, dst0::Vector{Int64}, fan, points, orig_pts, cum, flags, cfg) where {T,V}
+    of = flags.outputflags
+    n = size(matrix, 1)
+    np = length(src0)
+    res = Vector{T}(undef, np)
+    comp = component_data.cc
+    hbmeta = component_data.hbmeta
+    cellmap = component_data.cellmap
+    local_nodemap = component_data.local_nodemap
+    bs = max(1, s.bs)
+    if flags.is_raster
+        linear = !of.log_transform_maps
+        per_pair_cur = (of.write_cur_maps && !of.write_cum_cur_map_only) || !linear
+        node_cum = linear ? zeros(T, n) : T[]
+        node_max = (linear && of.write_max_cur_maps) ? zeros(T, n) : T[]
+        ncombos = 0
+        for lo in 1:bs:np
+            hi = min(lo + bs - 1, np)
+            w = Int32[length(fan[p]) for p in lo:hi]
+            ncombos += sum(w)
+            r, volt, curr, _, _ = solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi]; weights = w,
+                                      want_voltages = of.write_volt_maps, want_currents = per_pair_cur,
+                                      cum = node_cum, mx = node_max)
+            res[lo:hi] = r
+            for (k, p) in enumerate(lo:hi), (ci, cj) in fan[p]
+                name = "_$(orig_pts[ci])_$(orig_pts[cj])"
+                if of.write_volt_maps
+                    out = Output(points, volt[:, k], (orig_pts[ci], orig_pts[cj]), (V(src0[p] + 1), V(dst0[p] + 1)), r[k], V(cj), cum)
+                    write_volt_maps(name, out, component_data, flags, cfg)
+                end
+                if per_pair_cur
+                    cmap = scatter_nodes(view(curr, :, k), local_nodemap, hbmeta)
+                    process_grid!(cmap, cellmap, hbmeta, log_transform = of.log_transform_maps,
+                                  set_null_to_nodata = of.set_null_currents_to_nodata)
+                    if !linear                                     # log-transformed maps accumulate map by map (out.jl:96-107)
+                        lock(cum.lock) do
+                            cum.cum_curr .+= cmap
+                            of.write_max_cur_maps && (cum.max_curr .= max.(cum.max_curr, cmap))
+                        end
+                    end
+                    !of.write_cum_cur_map_only && of.write_cur_maps && write_grid(cmap, name, cfg, hbmeta)
+                end
+            end
+        end
+        if linear
+            # one scatter per component; the NODATA value lands in the cumulative map once per id combination, exactly as
+            # process_grid! + `cum_curr .+= cmap` do per pair in the reference (out.jl:89-100)
+            cmap = scatter_nodes(node_cum, local_nodemap, hbmeta)
+            if of.set_null_currents_to_nodata
+                for i in eachindex(cmap)
+                    cellmap[i] == 0 && (cmap[i] = hbmeta.nodata * ncombos)
+                end
+            end
+            lock(cum.lock) do
+                cum.cum_curr .+= cmap
+                if of.write_max_cur_maps
+                    mmap = scatter_nodes(node_max, local_nodemap, hbmeta)
+                    process_grid!(mmap, cellmap, hbmeta, set_null_to_nodata = of.set_null_currents_to_nodata)
+                    cum.max_curr .= max.(cum.max_curr, mmap)
+                end
+            end
+        end
+    else
+        # network mode (out.jl:46-84): the stored entries (row < col) of the symmetric matrix, in the order
+        # _get_branch_currents enumerates them (column by column of the upper triangle, out.jl:223-240)
+        I = V[]; J = V[]; K = Int[]
+        for i in 1:n, k in nzrange(matrix, i)
+            row = matrix.rowval[k]
+            i > row && (push!(I, row); push!(J, V(i)); push!(K, k))
+        end
+        for lo in 1:bs:np
+            hi = min(lo + bs - 1, np)
+            r, volt, curr, br, _ = solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi];
+                                      want_voltages = of.write_volt_maps, want_currents = true, want_branch = true)
+            res[lo:hi] = r
+            for (k, p) in enumerate(lo:hi), (ci, cj) in fan[p]
+                name = "_$(orig_pts[ci])_$(orig_pts[cj])"
+                of.write_volt_maps && write_voltages(cfg.output_file, name, volt[:, k], comp)
+                # |g (v_i - v_j)| is symmetric in (i, j): the device stores it at the (row < col) position of its CSR
+                # arrays = the mirror image of entry K of the upper triangle; read it through the transpose position
+                bvals = T[max(br[kk, k], br[mirror_entry(matrix, kk), k]) for kk in K]
+                branch_currents_array = _convert_to_3col(sparse(I, J, bvals, n, n), comp)
+                node_currents_array = _append_name_to_node_currents(curr[:, k], comp)
+                lock(cum.lock) do
+                    for i in 1:size(branch_currents_array, 1)
+                        a1 = (Int(branch_currents_array[i, 1]), Int(branch_currents_array[i, 2]))
+                        idx = findfirst(isequal(a1), cum.coords)
+                        idx === nothing && (idx = findfirst(isequal((a1[2], a1[1])), cum.coords))
+                        cum.cum_branch_curr[idx] += branch_currents_array[i, 3]
+                    end
+                    for i in 1:size(node_currents_array, 1)
+                        cum.cum_node_curr[Int(node_currents_array[i, 1])] += node_currents_array[i, 2]
+                    end
+                end
+                write_currents(node_currents_array, branch_currents_array, name, cfg)
+            end
+        end
+    end
+    res
+end
+
+"position of the mirror image (column `rowval[k]`, row = the column of entry k) of stored entry `k` of a symmetric CSC matrix"
+function mirror_entry(matrix::SparseMatrixCSC, k::Int)
+    col = searchsortedlast(matrix.colptr, k)          # column holding entry k
+    row = matrix.rowval[k]
+    rng = nzrange(matrix, row)
+    first(rng) + searchsortedfirst(view(matrix.rowval, rng), col) - 1
 end
 
 """
@@ -316,8 +469,12 @@ for `solver = hip`. Same results and the same bookkeeping as solve(prob, ::AMGSo
 is the shape of the work: per connected component the hierarchy is built ONCE on the device and the component's whole
 pair list goes down in ONE `solve_pairs` call (batched `s.bs` right-hand sides per pass) instead of one
 `Threads.@spawn` task per source point each cloning the AMG workspace (core.jl:173-180, 262-285).
-`circuitscape.jl_amd/solver.py::solve` is the Python mirror of this method, line for line, and is what the parity
-tests run against the reference's golden files.
+With maps on, the pair list goes down in CHUNKS of `s.bs` pairs through `solve_pairs_currents`: node currents are
+computed on the device, the cumulative and maximum node currents are accumulated there across chunks, voltages cross
+PCIe only when `write_volt_maps` is set -- host memory is O(n * bs) like the reference's batched driver
+(core.jl:448-493), never n x npairs.
+`circuitscape.jl_amd/solver.py::solve` is the Python mirror of this method (same structure, same device calls; it is
+what the parity tests run against the reference's golden files -- this file cannot be executed in the build image).
 """
 function solve(prob::GraphProblem{T,V}, s::HIPAMGSolver, flags, cfg, log)::Matrix{T} where {T,V}
     a = prob.G
@@ -346,6 +503,8 @@ function solve(prob::GraphProblem{T,V}, s::HIPAMGSolver, flags, cfg, log)::Matri
     end
     shortcut = Shortcut(use_shortcut, voltmatrix, shortcut_res)
     want_maps = !use_shortcut && (of.write_volt_maps || of.write_cur_maps || of.write_cum_cur_map_only || of.write_max_cur_maps)
+    # raster cell of every node, one pass over the node map for ALL components (seeds 3 x 3 tiles / the cell-space lattice)
+    cell_table = (flags.is_raster && !isempty(prob.nodemap)) ? node_cell_table(prob.nodemap) : nothing
 
     for comp in cc
         csub = unique(filter(x -> x in comp, points))
@@ -375,31 +534,36 @@ function solve(prob::GraphProblem{T,V}, s::HIPAMGSolver, flags, cfg, log)::Matri
 
         if !isempty(src0)
             # raster coordinates of the component's nodes seed the aggregation with 3 x 3 tiles (csgpu_opts.node_row/col)
-            coords = (flags.is_raster && !isempty(prob.nodemap)) ? node_coords(prob.nodemap, comp) : nothing
+            coords = cell_table === nothing ? nothing : node_coords(cell_table, comp)
             factor = @timeit CSTIMER "construct preconditioner" construct_cholesky_factor(matrix, s; coords = coords)
-            focal_in_comp = findall(x -> x in comp, points)
-            gather = use_shortcut ? Int64[findfirst(isequal(points[i]), comp) - 1 for i in focal_in_comp] : Int64[]
-            res, gat, volt, _ = @timeit CSTIMER "solve and accumulate pairs" solve_pairs(factor, T, n, src0, dst0;
-                                                  gather = gather, want_voltages = want_maps)
-            finalize(factor)
-
-            component_data = want_maps ?
-                ComponentData(comp, matrix, construct_local_node_map(prob.nodemap, comp, prob.polymap), prob.hbmeta, prob.cellmap) :
-                nothing
-            for (p, combos) in enumerate(fan)
-                r = res[p]
-                for (ci, cj) in combos
-                    resistances[ci, cj] = r
-                    resistances[cj, ci] = r
-                    if use_shortcut
-                        # update_voltmatrix! (core.jl:685-703) on the focal voltages the device gathered (v - v[src])
-                        for (g, i) in enumerate(focal_in_comp)
-                            i >= 2 && (voltmatrix[i, cj] = 1 - gat[g, p] / r)
+            if want_maps
+                # maps on: chunks of s.bs pairs, currents on the device (see the doc string)
+                component_data = ComponentData(comp, matrix, construct_local_node_map(prob.nodemap, comp, prob.polymap),
+                                               prob.hbmeta, prob.cellmap)
+                res = @timeit CSTIMER "solve and accumulate pairs" solve_pairs_with_maps!(factor, s, matrix, component_data,
+                                                  src0, dst0, fan, points, orig_pts, cum, flags, cfg)
+                finalize(factor)
+                for (p, combos) in enumerate(fan), (ci, cj) in combos
+                    resistances[ci, cj] = res[p]
+                    resistances[cj, ci] = res[p]
+                end
+            else
+                focal_in_comp = findall(x -> x in comp, points)
+                gather = use_shortcut ? Int64[findfirst(isequal(points[i]), comp) - 1 for i in focal_in_comp] : Int64[]
+                res, gat, _, _ = @timeit CSTIMER "solve and accumulate pairs" solve_pairs(factor, T, n, src0, dst0;
+                                                      gather = gather, want_voltages = false)
+                finalize(factor)
+                for (p, combos) in enumerate(fan)
+                    r = res[p]
+                    for (ci, cj) in combos
+                        resistances[ci, cj] = r
+                        resistances[cj, ci] = r
+                        if use_shortcut
+                            # update_voltmatrix! (core.jl:685-703) on the focal voltages the device gathered (v - v[src])
+                            for (g, i) in enumerate(focal_in_comp)
+                                i >= 2 && (voltmatrix[i, cj] = 1 - gat[g, p] / r)
+                            end
                         end
-                    elseif want_maps
-                        out = Output(points, volt[:, p], (orig_pts[ci], orig_pts[cj]),
-                                     (V(src0[p] + 1), V(dst0[p] + 1)), r, V(cj), cum)
-                        postprocess(out, component_data, flags, shortcut, cfg)
                     end
                 end
             end

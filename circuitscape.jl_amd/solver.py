@@ -355,7 +355,9 @@ def omniscape_windows(conductance, source_strength, radius, block_size=1):
             disc = (ii - ci) ** 2 + (jj - cj) ** 2 <= radius * radius
             wc = np.where(disc, cond[r0:r1, c0:c1], 0.0)
             ws = np.where(disc & (wc > 0), strength[r0:r1, c0:c1], 0.0)
-            ws[b0 - r0:b1 - r0, d0 - c0:d1 - c0] = 0.0
+            # the target's own block, clipped to the window: with radius < block_size // 2 the block reaches beyond the
+            # disc's bounding box and b0 - r0 would be negative (numpy reads that from the END of the axis: ADVICE r3)
+            ws[max(b0, r0) - r0:min(b1, r1) - r0, max(d0, c0) - c0:min(d1, c1) - c0] = 0.0
             total = ws.sum()
             if not total > 0:
                 continue
@@ -579,28 +581,46 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
                 try:
                     if raster_maps:
                         R, gathered, V, st = _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts,
-                                                                   of, maps, want_volt)
+                                                                   of, maps, want_volt, bs=getattr(solver, "bs", 16))
                     elif network_tables:
-                        R, V, C, st, Bc = factor.solve_pairs_currents(src_nodes, dst_nodes, want_voltages=True,
-                                                                      want_currents=True, want_branch=True)
+                        # chunks of solver.bs pairs: host memory O((n + nnz) * bs), never (n + nnz) x npairs
                         gathered = None
+                        V = np.zeros((matrix.shape[0], len(src_nodes)), dtype=factor.dtype, order="F") if want_volt else None
                         mcsr = matrix.tocsr()
                         mcsr.sort_indices()
                         rows_of = np.repeat(np.arange(mcsr.shape[0]), np.diff(mcsr.indptr))
                         upper = mcsr.indices > rows_of                      # stored entries (row < col), CSR order
-                        for p, combos in enumerate(fan):
-                            br = np.column_stack([comp[rows_of[upper]], comp[mcsr.indices[upper]], Bc[upper, p]])
-                            node = np.column_stack([comp, C[:, p]])
-                            volt = np.column_stack([comp, V[:, p]])
-                            for (ci, cj) in combos:
-                                for row in br:                                   # cumulative branch currents by edge
-                                    k = coord_index.get((int(row[0]), int(row[1])), coord_index.get((int(row[1]), int(row[0]))))
-                                    if k is not None:
-                                        net_cum["branch"][k] += row[2]
-                                net_cum["node"][comp - 1] += C[:, p]
-                                tables[(int(orig_pts[ci]), int(orig_pts[cj]))] = {
-                                    "branch": br[~np.isclose(br[:, 2], 0.0, atol=1e-6)],   # write_currents, out.jl:117-124
-                                    "node": node, "voltages": volt}
+                        R = np.zeros(len(src_nodes), dtype=factor.dtype)
+                        st = None
+                        cbs = max(1, int(getattr(solver, "bs", 16)))
+                        for lo in range(0, len(src_nodes), cbs):
+                            hi = min(lo + cbs, len(src_nodes))
+                            Rc, Vc, C, stc, Bc = factor.solve_pairs_currents(src_nodes[lo:hi], dst_nodes[lo:hi],
+                                                                             want_voltages=True, want_currents=True,
+                                                                             want_branch=True)
+                            R[lo:hi] = Rc
+                            if V is not None:
+                                V[:, lo:hi] = Vc
+                            if st is None:
+                                st = dict(stc)
+                            else:
+                                for key_ in ("total_iters", "solve_ms", "device_ms", "not_converged", "nrhs"):
+                                    st[key_] += stc[key_]
+                                st["max_iters"] = max(st["max_iters"], stc["max_iters"])
+                                st["max_relres"] = max(st["max_relres"], stc["max_relres"])
+                            for k, p in enumerate(range(lo, hi)):
+                                br = np.column_stack([comp[rows_of[upper]], comp[mcsr.indices[upper]], Bc[upper, k]])
+                                node = np.column_stack([comp, C[:, k]])
+                                volt = np.column_stack([comp, Vc[:, k]])
+                                for (ci, cj) in fan[p]:
+                                    for row in br:                               # cumulative branch currents by edge
+                                        kk = coord_index.get((int(row[0]), int(row[1])), coord_index.get((int(row[1]), int(row[0]))))
+                                        if kk is not None:
+                                            net_cum["branch"][kk] += row[2]
+                                    net_cum["node"][comp - 1] += C[:, k]
+                                    tables[(int(orig_pts[ci]), int(orig_pts[cj]))] = {
+                                        "branch": br[~np.isclose(br[:, 2], 0.0, atol=1e-6)],   # write_currents, out.jl:117-124
+                                        "node": node, "voltages": volt}
                     else:
                         R, gathered, V, st = factor.solve_pairs(src_nodes, dst_nodes, gather=gather,
                                                                 want_voltages=want_volt)
@@ -641,10 +661,15 @@ def solve(prob, solver, flags, cfg=None, log=True, postprocess=None, stats=None)
     return r
 
 
-def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts, of, maps, want_volt):
+def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_pts, of, maps, want_volt, bs=16):
     """postprocess() with maps on (core.jl:655-683 -> out.jl:29-115): voltage maps, per-pair current maps, cumulative and
-    maximum current maps. Node currents come from the device (csgpu_solve_pairs_currents)."""
+    maximum current maps. Node currents come from the device (csgpu_solve_pairs_currents), in CHUNKS of `bs` pairs: the
+    cumulative / maximum node currents are accumulated on the device across the chunks, per-pair vectors cross PCIe only
+    when per-pair maps are asked for, so host memory is O(n * bs) like the reference's batched driver (core.jl:448-493) --
+    unless the caller's postprocess hook wants every voltage vector (want_volt), which then is what it asked for.
+    julia/CircuitscapeHIPExt.jl::solve_pairs_with_maps! is the same routine on the reference's side."""
     n = len(comp)
+    npairs = len(src_nodes)
     local_nodemap = construct_local_node_map(prob.nodemap, comp, prob.polymap)       # core.jl:170
     per_pair_cur = (of.write_cur_maps and not of.write_cum_cur_map_only) or of.log_transform_maps
     need_volt = of.write_volt_maps or want_volt
@@ -652,9 +677,45 @@ def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_p
     linear = not of.log_transform_maps
     node_cum = np.zeros(n, dtype=factor.dtype) if linear else None     # the handle's value type (float32 problems too)
     node_max = np.zeros(n, dtype=factor.dtype) if (linear and prob.cum.max_curr is not None) else None
-    R, V, C, st = factor.solve_pairs_currents(src_nodes, dst_nodes, weights=weights, want_voltages=need_volt,
-                                              want_currents=per_pair_cur, cum=node_cum, mx=node_max)
     cum = prob.cum
+    R = np.zeros(npairs, dtype=factor.dtype)
+    Vall = np.zeros((n, npairs), dtype=factor.dtype, order="F") if want_volt else None
+    st = None
+    bs = max(1, int(bs))
+    for lo in range(0, npairs, bs):
+        hi = min(lo + bs, npairs)
+        Rc, V, C, stc = factor.solve_pairs_currents(src_nodes[lo:hi], dst_nodes[lo:hi], weights=weights[lo:hi],
+                                                    want_voltages=need_volt, want_currents=per_pair_cur, cum=node_cum,
+                                                    mx=node_max)
+        R[lo:hi] = Rc
+        if Vall is not None:
+            Vall[:, lo:hi] = V
+        if st is None:
+            st = dict(stc)
+        else:
+            for k in ("total_iters", "solve_ms", "device_ms", "cg_spmv_ms", "cg_spmv_calls", "not_converged",
+                      "graph_launches", "polished_batches", "nrhs"):
+                st[k] += stc[k]
+            st["max_iters"] = max(st["max_iters"], stc["max_iters"])
+            st["max_relres"] = max(st["max_relres"], stc["max_relres"])
+        for k, p in enumerate(range(lo, hi)):
+            cm = vm = None
+            if per_pair_cur:
+                cm = _process_grid(_scatter(C[:, k], local_nodemap), prob.cellmap, of.log_transform_maps,
+                                   of.set_null_currents_to_nodata)
+            if of.write_volt_maps:
+                vm = _process_grid(_scatter(V[:, k], local_nodemap), prob.cellmap, False, of.set_null_voltages_to_nodata)
+            for (ci, cj) in fan[p]:
+                key = (int(orig_pts[ci]), int(orig_pts[cj]))
+                if cm is not None:
+                    if of.write_cur_maps and not of.write_cum_cur_map_only:
+                        maps["cur"][key] = cm
+                    if not linear:
+                        cum.cum_curr += cm
+                        if cum.max_curr is not None:
+                            np.maximum(cum.max_curr, cm, out=cum.max_curr)
+                if vm is not None:
+                    maps["volt"][key] = vm
     if linear:
         cmap = _scatter(node_cum, local_nodemap)
         if of.set_null_currents_to_nodata and prob.cellmap is not None:
@@ -663,25 +724,7 @@ def _solve_pairs_with_maps(factor, prob, comp, src_nodes, dst_nodes, fan, orig_p
         if cum.max_curr is not None:
             mmap = _process_grid(_scatter(node_max, local_nodemap), prob.cellmap, False, of.set_null_currents_to_nodata)
             np.maximum(cum.max_curr, mmap, out=cum.max_curr)
-    for p, combos in enumerate(fan):
-        cm = vm = None
-        if per_pair_cur:
-            cm = _process_grid(_scatter(C[:, p], local_nodemap), prob.cellmap, of.log_transform_maps,
-                               of.set_null_currents_to_nodata)
-        if of.write_volt_maps:
-            vm = _process_grid(_scatter(V[:, p], local_nodemap), prob.cellmap, False, of.set_null_voltages_to_nodata)
-        for (ci, cj) in combos:
-            key = (int(orig_pts[ci]), int(orig_pts[cj]))
-            if cm is not None:
-                if of.write_cur_maps and not of.write_cum_cur_map_only:
-                    maps["cur"][key] = cm
-                if not linear:
-                    cum.cum_curr += cm
-                    if cum.max_curr is not None:
-                        np.maximum(cum.max_curr, cm, out=cum.max_curr)
-            if vm is not None:
-                maps["volt"][key] = vm
-    return R, None, V, st
+    return R, None, Vall, st
 
 
 def _update_shortcut_resistances(anchor, voltmatrix, shortcut, resistances, check):

@@ -64,7 +64,11 @@ def lib():
 def regularize(matrix, dtype=np.float64):
     """core.jl:161  matrix.nzval .+= eps(T) * norm(matrix.nzval)  (every STORED entry is shifted)."""
     m = matrix.tocsr().astype(dtype).copy()
-    m.data = (m.data + np.finfo(dtype).eps * np.linalg.norm(m.data.astype(dtype))).astype(dtype)
+    # The norm is accumulated in double and rounded to T (what BLAS nrm2 kernels and the device do). numpy's float32
+    # norm is a float32 dot product: on 8e7 entries it is off by ~4e-4 relative, which at precision = single moves the
+    # shift -- the only grounding of that problem -- and with it every resistance by ~2e-4 (measured, round 4).
+    T = np.dtype(dtype).type
+    m.data = (m.data + T(np.finfo(dtype).eps) * T(np.linalg.norm(m.data.astype(np.float64)))).astype(dtype)
     return m
 
 

@@ -80,9 +80,26 @@ def test_bench_two_ranks_weak_scaling_line(emu_lib, tmp_path):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] > 0
     # whole-job aggregate: 2 ranks x 2 steps x 4 pairs
     assert abs(d["solve_only_pairs_per_s"] * d["ms_per_step"] * 1e-3 * 2 - 16) < 1e-6
+    _check_multi_gpu_block(d, pairs_per_rank=[8, 8])
+    assert d["multi_gpu"]["gather"]["bytes_per_rank"] == 8 * 8 and d["multi_gpu"]["gather"]["all_finite"] is True
+    assert d["multi_gpu"]["gather"]["seconds_incl_barrier"] >= 0
+
+
+def _check_multi_gpu_block(d, pairs_per_rank):
+    """what lets a reader verify an N-GPU line without trust -- the process group's own world size and
+    backend, and per rank the device ordinal, PCI bus id (None on the CPU emulator), step time and pairs done."""
+    m = d["multi_gpu"]
+    assert m["rccl_world_size"] == 2 and m["dist_backend"] == "gloo"
+    assert [r["rank"] for r in m["ranks"]] == [0, 1]
+    for r, want in zip(m["ranks"], pairs_per_rank):
+        assert set(r) >= {"host", "device_ordinal", "pci_bus_id", "ms_per_step", "pairs_done", "iters_mean", "max_relres"}
+        assert r["pairs_done"] == want and r["ms_per_step"] > 0 and r["not_converged"] == 0
+    assert m["gather"]["pairs_received"] == sum(pairs_per_rank)
 
 
 def test_bench_two_ranks_strong_scaling_line(emu_lib, tmp_path):
     d = _run_bench(tmp_path, ["--scaling", "strong", "--pairs", "11"], 29543)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["all_pairs_gathered"] is True
     assert len(d["rank_busy_s"]) == 2 and d["pairs_per_rank"] == 6 and d["value"] > 0
+    _check_multi_gpu_block(d, pairs_per_rank=[6, 5])
+    assert d["predicted_speedup_vs_1gpu"] > 1.0 and d["achieved_speedup_vs_1gpu_reconstructed"] > 0.5

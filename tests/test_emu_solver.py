@@ -1135,6 +1135,27 @@ def test_omniscape_moving_window_driver(emu_lib):
         assert np.max(np.abs(got - ref)) < 1e-7 * ref.max(), np.max(np.abs(got - ref)) / ref.max()
 
 
+def test_omniscape_windows_with_a_block_wider_than_the_disc(emu_lib):
+    """ADVICE r3: radius < block_size // 2 -- the target's block reaches beyond the window, the slice that zeroes it must
+    be clipped to the window (negative numpy indices count from the end). Multi-window mosaic against the independent
+    per-window host solves of the checker, which zeroes the block on the full raster before cutting the window out."""
+    from circuitscape_jl_amd import solver as ps
+    from oracle import refmaps
+    cond, strength = _omniscape_landscape((25, 22), 9)
+    tight = ps.HIPAMGSolver(bs=1, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1})
+    for radius, block in ((2, 7), (3, 9)):
+        ref, nref = refmaps.omniscape_moving_window(cond, strength, radius=radius, block_size=block)
+        got, nwin = ps.omniscape_moving_window(cond, strength, radius=radius, block_size=block, solver=tight,
+                                               windows_per_solve=5)
+        assert nwin == nref
+        if nref:
+            assert np.max(np.abs(got - ref)) <= 1e-7 * max(ref.max(), 1e-30), (radius, block)
+    # the generator itself: sources are zero inside the target's block and nowhere negative-indexed
+    for r0, c0, wc, ws, wg, disc in ps.omniscape_windows(cond, strength, 2, 7):
+        ci, cj = [int(x) for x in np.argwhere(np.isinf(wg))[0]]
+        assert np.all(ws[max(ci - 3, 0):ci + 4, max(cj - 3, 0):cj + 4] == 0.0)
+
+
 def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
     """see helpers.check_lattice_level1"""
     from helpers import check_lattice_level1

@@ -1,0 +1,173 @@
+"""BASELINE.json configs[3] and configs[4] at scale on the real device.
+
+configs[3]: 10000 x 10000 raster, fp32 (`precision = single`, /root/reference/src/run.jl:29). The contract tested here:
+
+  WHAT IS SOLVED   the reference's single-precision problem: the Float32 Laplacian with EVERY stored entry shifted by
+                   eps(Float32) * norm(nzval) (src/core.jl:161) -- at n = 2.5e7 that is ~2.6e-3 per entry, i.e. a
+                   strongly grounded system, not an approximation of the fp64 one;
+  HOW              val_bytes = 4 handle, the library's (= the reference's) defaults: regularisation on, rtol 1e-6,
+                   atol = sqrt(eps(Float32)) on sqrt(r'M^-1 r) (Krylov.cg, core.jl:639), the 1e-4 check of core.jl:640;
+  AGAINST          the TIGHT CPU oracle (fp64, true-residual rtol 1e-12) on that same fp32-shifted matrix, downloaded
+                   from the handle; the shift itself is checked independently against eps32 * ||nzval||;
+  TOLERANCE        1e-4 relative on the resistances (stated; the reference's own single-precision tolerance is 1e-2
+                   absolute, test/test_utils.jl:72-73).
+
+configs[4]: network mode, advanced one-to-all (src/raster/advanced.jl:274-312, src/network/advanced.jl:1-51) on random
+graphs at n = 1e6 (BASELINE: 5e6 nodes / 5e7 edges; same generator as tools/network_bench.py): an Erdos-Renyi graph
+(does not coarsen: the expander bail-out leaves ONE level, i.e. Jacobi-preconditioned CG) and a random geometric graph
+(locality: coarsens to >= 4 levels through hashed MIS(2)), both checked against independent host solves.
+"""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_single_precision_reference_semantics_5000(gpu_lib, oracle):
+    import scipy.sparse as sp
+    N = 5000
+    g = (1.0 / np.exp(np.random.default_rng(12345).standard_normal((N, N)))).astype(np.float32)
+    cells = np.random.default_rng(67890).choice(N * N, size=5, replace=False)
+    src = [int(cells[i]) for i in range(5) for j in range(i + 1, 5)]
+    dst = [int(cells[j]) for i in range(5) for j in range(i + 1, 5)]
+    h = gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16))          # library defaults = the reference's
+    info = h.info
+    assert info["val_bytes"] == 4 and info["n"] == N * N and info["lattice_period"] == N
+    R, _, _, st = h.solve_pairs(src, dst)
+    assert R.dtype == np.float32
+    assert st["not_converged"] == 0 and st["max_relres"] < 1e-4           # core.jl:640
+    A = h.level_matrix(0, "A")                                             # the fp32 matrix the device solves with
+    h.close()
+    assert A.dtype == np.float32 and A.shape == (N * N, N * N)
+    # the shift is the reference's: every stored entry + eps(Float32) * norm(nzval)  (core.jl:161)
+    nnz_row = np.diff(A.indptr)
+    rowsum = np.asarray(A.astype(np.float64).sum(axis=1)).ravel()
+    shift = float(np.median(rowsum / nnz_row))                             # rows of the unshifted Laplacian sum to ~0
+    unshifted_norm = float(np.sqrt(np.sum((A.data.astype(np.float64) - shift) ** 2)))
+    want = float(np.finfo(np.float32).eps) * unshifted_norm
+    assert abs(shift - want) < 2e-2 * want, (shift, want)
+    assert shift > 1e-3                                                    # the "strongly grounded" regime at this size
+    S = oracle.OracleAMG(sp.csr_matrix(A, dtype=np.float64))
+    Ro, _, res = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=len(src))
+    assert max(r["true_relres"] for r in res) < 1e-10
+    rel = float(np.max(np.abs(R.astype(np.float64) - Ro) / np.abs(Ro)))
+    print("fp32 5000^2: iters_mean %.2f max rel err vs tight oracle %.3e (shift %.3e)" % (st["total_iters"] / len(src), rel, shift))
+    assert rel < 1e-4, rel
+
+
+def _random_graph_laplacian(n, kind, seed):
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    rng = np.random.default_rng(seed)
+    if kind == "er":          # tools/network_bench.py: 10 n endpoints pairs, deduplicated
+        i = rng.integers(0, n, size=10 * n)
+        j = rng.integers(0, n, size=10 * n)
+        keep = i != j
+        lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+        key = np.unique(lo.astype(np.int64) * n + hi)
+        lo, hi = key // n, key % n
+    else:                     # random geometric graph in the unit square, mean degree ~10; node ids carry no locality
+        from scipy.spatial import cKDTree
+        pts = rng.random((n, 2))
+        pr = cKDTree(pts).query_pairs(np.sqrt(10.0 / (np.pi * n)), output_type="ndarray")
+        lo, hi = pr[:, 0].astype(np.int64), pr[:, 1].astype(np.int64)
+    w = rng.uniform(0.5, 2.0, size=len(lo))
+    A = sp.coo_matrix((w, (lo, hi)), shape=(n, n)).tocsr()
+    A = (A + A.T).tocsr()
+    _, lab = csg.connected_components(A, directed=False)
+    giant = np.flatnonzero(lab == np.bincount(lab).argmax())
+    A = A[giant][:, giant]
+    G = (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A).tocsr()
+    G.sort_indices()
+    return G, rng
+
+
+def _one_to_all_columns(n, focal, ns):
+    B = np.zeros((n, ns))
+    grounds = []
+    for s in range(ns):
+        B[focal[s], s] = 1.0
+        grounds.append([int(q) for q in focal if q != focal[s]])
+    return B, grounds
+
+
+def test_config5_network_one_to_all_1e6_erdos_renyi(gpu_lib):
+    """BASELINE configs[4] at 1/5 of its size: random network n = 1e6, ~1e7 undirected edges, conductances U(0.5, 2);
+    advanced one-to-all = unit source at one focal node, the other focal nodes tied to ground (advanced.jl:282-288), all 16
+    sources as columns of ONE csgpu_solve_grounded on ONE handle. This graph is an expander: the setup declines to coarsen
+    it (nnz(P) > 0.75 nnz(A), amg_setup.h), so the preconditioner is Jacobi -- stated, and asserted (levels == 1). Checked
+    against scipy's Jacobi-CG (true residual 1e-12) on the reduced systems of two sources."""
+    import scipy.sparse.linalg as spla
+    G, rng = _random_graph_laplacian(1000000, "er", 424242)
+    n = G.shape[0]
+    assert n > 990000 and G.nnz > 2.0e7
+    focal = rng.choice(n, size=16, replace=False)
+    t0 = time.perf_counter()
+    h = gpu_lib.setup(G, gpu_lib.default_opts(batch=16, precond_bytes=4, itmax=2000), index_dtype=np.int32, index_base=0)
+    t_setup = time.perf_counter() - t0
+    info = h.info
+    assert info["levels"] == 1, info["level_n"]          # Jacobi-PCG: the honest name of this config's preconditioner
+    B, grounds = _one_to_all_columns(n, focal, 16)
+    t0 = time.perf_counter()
+    X, _, st = h.solve_grounded(B, grounds)
+    t_solve = time.perf_counter() - t0
+    h.close()
+    assert st["not_converged"] == 0
+    for s in range(2):
+        keepn = np.setdiff1d(np.arange(n), grounds[s])
+        M = G[keepn][:, keepn].tocsr()
+        b = B[keepn, s]
+        dinv = 1.0 / M.diagonal()
+        xs, flag = spla.cg(M, b, rtol=1e-12, atol=0.0, maxiter=2000, M=spla.LinearOperator(M.shape, lambda v: dinv * v))
+        assert flag == 0
+        k = np.searchsorted(keepn, focal[s])
+        assert abs(X[focal[s], s] - xs[k]) < 1e-6 * abs(xs[k])            # resistance to the grounded set
+        assert np.max(np.abs(X[keepn, s] - xs)) < 1e-6 * np.max(np.abs(xs))
+        assert np.all(X[grounds[s], s] == 0.0)
+    print("ER 1e6: setup %.2fs, 16 sources in %.2fs (%.1f iterations)" % (t_setup, t_solve, st["total_iters"] / 16.0))
+    assert t_setup < 20.0 and t_solve < 20.0
+
+
+def test_network_with_locality_coarsens_1e6(gpu_lib, oracle):
+    """A network WITH locality (random geometric graph, n = 1e6, mean degree ~10, shuffled node ids, conductances
+    U(0.5, 2); src/network/pairwise.jl:31-65 is how such a graph reaches the solver): no raster coordinates, so the
+    hashed MIS(2) aggregation and the CSR kernels run. Asserted: the hierarchy really coarsens (>= 4 levels, operator
+    complexity < 1.6), setup finishes in seconds, pair resistances agree with the TIGHT CPU oracle (the reference's
+    algorithm restated) to 1e-6 relative, and one-to-all columns on the same handle pass an explicit residual check."""
+    G, rng = _random_graph_laplacian(1000000, "geo", 777)
+    n = G.shape[0]
+    assert n > 900000
+    A = oracle.regularize(G)
+    focal = rng.choice(n, size=9, replace=False)
+    src = [int(focal[0])] * 8
+    dst = [int(q) for q in focal[1:]]
+    for pb in (0, 4):
+        t0 = time.perf_counter()
+        h = gpu_lib.setup(A, gpu_lib.default_opts(batch=8, precond_bytes=pb), index_dtype=np.int32, index_base=0)
+        t_setup = time.perf_counter() - t0
+        info = h.info
+        assert info["levels"] >= 4, info["level_n"]
+        assert info["operator_complexity"] < 1.6
+        assert info["setup_ms"] < 5000.0 and t_setup < 30.0, (info["setup_ms"], t_setup)
+        R, _, _, st = h.solve_pairs(src, dst)
+        assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+        if pb == 0:
+            S = oracle.OracleAMG(A)
+            Ro, _, res = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=8)
+            assert max(r["true_relres"] for r in res) < 1e-10
+        rel = float(np.max(np.abs(R - Ro) / Ro))
+        print("geometric 1e6 (precond_bytes %d): levels %d %s, setup %.0f ms device / %.2fs wall, %.1f iterations, max rel err %.2e"
+              % (pb, info["levels"], info["level_n"], info["setup_ms"], t_setup, st["total_iters"] / 8.0, rel))
+        assert rel < 1e-6, (pb, rel)
+        assert st["max_iters"] < 80
+        if pb == 0:
+            B, grounds = _one_to_all_columns(n, focal[:8], 8)
+            X, _, st2 = h.solve_grounded(B, grounds)
+            assert st2["not_converged"] == 0
+            for s in range(8):
+                r = A @ X[:, s] - B[:, s]
+                r[grounds[s]] = 0.0
+                assert np.linalg.norm(r) < 1e-5, s
+        h.close()

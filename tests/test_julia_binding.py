@@ -97,9 +97,27 @@ def test_reference_dispatch_points_have_methods():
     body = m.group(1)
     for needed in ("get_num_pairs(", "get_num_pairs_shortcut(", "smash_repeats!(", "eps(eltype(matrix)) * norm(matrix.nzval)",
                    "construct_cholesky_factor(matrix, s", "solve_pairs(factor, T, n, src0, dst0", "update_shortcut_resistances!(",
-                   "postprocess(out, component_data, flags, shortcut, cfg)", "save_resistances(r, cfg)",
+                   "solve_pairs_with_maps!(factor, s, matrix, component_data", "save_resistances(r, cfg)",
                    "vcat(vcat(0, orig_pts)', hcat(orig_pts, resistances))"):
         assert needed in body, needed
+    # with maps on the method must not pull n x npairs voltages over PCIe and post-process on the CPU.
+    # The resistance-only call never asks for voltages; the maps branch goes through solve_pairs_currents in chunks of
+    # s.bs pairs (host memory O(n * bs), core.jl:448-493) with cumulative / maximum currents accumulated on the device.
+    assert "want_voltages = false" in body and "want_voltages = want_maps" not in body
+    assert "Matrix{T}(undef" not in body and "postprocess(" not in body
+    mm = re.search(r"^function solve_pairs_with_maps!\((.*?)^end$", JL, re.S | re.M)
+    assert mm, "solve_pairs_with_maps! is missing"
+    mbody = mm.group(1)
+    assert mbody.count("solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi]") == 2   # raster, network
+    assert mbody.count("for lo in 1:bs:np") == 2
+    for needed in ("cum = node_cum, mx = node_max", "want_voltages = of.write_volt_maps", "want_currents = per_pair_cur",
+                   "write_volt_maps(name, out, component_data, flags, cfg)", "write_grid(cmap, name, cfg, hbmeta)",
+                   "process_grid!(cmap, cellmap, hbmeta", "write_currents(node_currents_array, branch_currents_array, name, cfg)",
+                   "_convert_to_3col(", "want_branch = true"):
+        assert needed in mbody, needed
+    assert "solve_pairs(factor" not in mbody            # no full-voltage detour inside the maps routine
+    # per-chunk host arrays only: the binding's wrapper allocates n x (chunk length), the chunk is at most s.bs pairs
+    assert "bs = max(1, s.bs)" in mbody
     assert re.search(r"^function multiple_solve\(s::HIPAMGSolver, matrix::SparseMatrixCSC\{T,V\}, sources::Vector\{T\}\) where \{T,V\}",
                      JL, re.M)
     # every block has its `end`: statement-leading openers against statement-leading `end`s (comments / strings stripped)

@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r2_parity_10000.json"))
     ap.add_argument("--oracle-rtol", type=float, default=1e-10)
     ap.add_argument("--skip-oracle", type=int, default=0)
+    ap.add_argument("--skip-host-csr", type=int, default=0)
+    ap.add_argument("--fixture", default="",
+                    help="also write the tight oracle's resistances as a golden fixture (tests/golden/full_size_10000.json "
+                         "layout) to this path")
     args = ap.parse_args()
     import bench
     import circuitscape_jl_amd  # noqa: F401
@@ -63,22 +67,23 @@ def main():
     out["max_rel_diff_mixed_vs_fp64_16pairs"] = float(np.max(np.abs(res["mixed"] - res["fp64"]) / res["fp64"]))
     del g
     # ---- 2. host CSR entry point (Julia's arrays: Int64, 1-based)
-    rp = np.ascontiguousarray(A.indptr.astype(np.int64) + 1)
-    ci = np.ascontiguousarray(A.indices.astype(np.int64) + 1)
-    va = np.ascontiguousarray(A.data, dtype=np.float64)
-    t0 = time.perf_counter()
-    h2 = lib.setup_arrays(rp, ci, va, A.shape[0], A.nnz, lib.default_opts(batch=16, precond_bytes=4), index_base=1)
-    wall = time.perf_counter() - t0
-    i2 = h2.info
-    R2, _, _, st2 = h2.solve_pairs(src, dst)
-    h2.close()
-    out["host_csr"] = {"setup_wall_s": wall, "upload_convert_s": i2["upload_ms"] / 1e3, "device_setup_s": i2["setup_ms"] / 1e3,
+    if not args.skip_host_csr:
+      rp = np.ascontiguousarray(A.indptr.astype(np.int64) + 1)
+      ci = np.ascontiguousarray(A.indices.astype(np.int64) + 1)
+      va = np.ascontiguousarray(A.data, dtype=np.float64)
+      t0 = time.perf_counter()
+      h2 = lib.setup_arrays(rp, ci, va, A.shape[0], A.nnz, lib.default_opts(batch=16, precond_bytes=4), index_base=1)
+      wall = time.perf_counter() - t0
+      i2 = h2.info
+      R2, _, _, st2 = h2.solve_pairs(src, dst)
+      h2.close()
+      del rp, ci, va
+      out["host_csr"] = {"setup_wall_s": wall, "upload_convert_s": i2["upload_ms"] / 1e3, "device_setup_s": i2["setup_ms"] / 1e3,
                        "host_bytes": int(rp.nbytes + ci.nbytes + va.nbytes), "lattice_period_detected": i2["lattice_period"],
                        "levels": i2["levels"], "iters_mean": st2["total_iters"] / 16.0,
                        "max_rel_diff_R_vs_raster_entry_point": float(np.max(np.abs(R2 - res["mixed"]) / res["mixed"])),
                        "note": "no raster coordinates are handed over on this path: the lattice period detected from the "
                                "matrix supplies them (same 3x3-tile aggregation as the raster entry point)"}
-    del rp, ci, va
     json.dump(out, open(args.out, "w"), indent=1)
     # ---- 1. oracle on the same matrix
     if not args.skip_oracle:
@@ -97,6 +102,19 @@ def main():
             out["max_rel_err_vs_oracle_" + name] = float(np.max(np.abs(res[name][:np_] - Ro) / Ro))
         out["tolerance"] = 1e-6
         out["ok"] = bool(max(out["max_rel_err_vs_oracle_mixed"], out["max_rel_err_vs_oracle_fp64"]) < 1e-6)
+        if args.fixture:
+            fx = {"what": "BASELINE.json configs[2] raster (bench.make_raster(%d): r = exp(N(0,1)), seed 12345, g = 1/r; "
+                          "8-neighbour, average conductance, regularised like core.jl:161) -- effective resistances of the "
+                          "first %d pairs of bench.focal_pairs(%d) (one full batch of 16) from the TIGHT CPU oracle "
+                          "(oracle/cs_oracle.cpp, true-residual rtol %g) run on the very matrix the GPU handle holds "
+                          "(downloaded from the handle)" % (N, np_, N, args.oracle_rtol),
+                  "generated_by": "tools/full_size_checks.py --pairs %d --fixture ... on the GPU box's host cores "
+                                  "(oracle setup %.0f s + %.0f s for the %d pairs on %d threads)"
+                                  % (np_, out["oracle"]["setup_s"], out["oracle"]["solve_s"], np_, np_),
+                  "size": N, "pairs": [[int(a), int(b)] for a, b in zip(src[:np_], dst[:np_])],
+                  "R_tight": [float(x) for x in Ro], "oracle_true_relres": [float(x["true_relres"]) for x in r],
+                  "oracle_iters": [int(x["iters"]) for x in r], "tolerance_rel": 1e-6}
+            json.dump(fx, open(args.fixture, "w"), indent=1)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out))
 

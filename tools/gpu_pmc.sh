@@ -18,7 +18,10 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         agg[row.get("Kernel_Name", "")[:100]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, d in agg.items():
-    res[k] = {c: {"n": len(v), "mean": sum(v) / len(v), "max": max(v)} for c, v in d.items()}
+    # mean_fullsize: launches of the full-size workload only (the bench's 768^2 warm-up solves launch the same kernels)
+    res[k] = {c: {"n": len(v), "mean": sum(v) / len(v), "max": max(v),
+                  "n_fullsize": len([x for x in v if x >= 0.5 * max(v)]),
+                  "mean_fullsize": (lambda w: sum(w) / len(w))([x for x in v if x >= 0.5 * max(v)])} for c, v in d.items()}
 json.dump(res, open(out + "/pmc_by_kernel.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", {"max": 0})["max"])[:14]:
     print(k[:95], {c: (v["n"], round(v["max"])) for c, v in d.items()})
