@@ -982,6 +982,10 @@ struct Hierarchy {
   // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
   // per-column scratch area and the batch width it is allocated for
   bool near_singular = false;  // the coarsest operator's near-kernel eigenpair was dropped (fp32 hierarchy of a Laplacian)
+  // heterogeneity of the raster as the strength test of level 0 measured it (TileStrength / lattice_level0_setup):
+  // fraction of the cells that leave their 3x3 tile because of the strength filter (-1: the test did not run). The C
+  // API uses it to give strongly heterogeneous rasters an fp64 hierarchy (csgpu.hip, hetero_wants_fp64)
+  double hetero_frac = -1.0;
   // Dirichlet-masked solves on this hierarchy (pcg.h, DirichletCoarse): the pseudo-inverse WITHOUT the near-kernel
   // eigenpairs, the coarsest level's candidate, the connected component of the coarsest graph every coarse node lies in
   // (-1: a weightless row of a cell-space hierarchy) and their number (0: the correction is not available)
@@ -1284,6 +1288,7 @@ inline void piece_counts(int64_t n, int R, int Rc, int Cc, const DBuf& piece, co
 
 // How the strength filter is decided for a hierarchy (level 0) and handed down the levels
 struct TileStrength {
+  double hetero_frac = -1.0;  // out (decide): fraction of the cells the filter moves out of their tile (-1: not measured)
   double theta = 0.0;       // in: the threshold to try (0 = none). out (decide): the threshold in effect
   double split_min = 0.0;   // decide: use theta only if more than this fraction of the weighted cells leaves its tile
   bool decide = false;      // level 0: run the test; deeper levels just apply theta
@@ -1341,6 +1346,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
           piece_counts(n, gridR, Rc, Cc, piece, mainlab, valid, out1, st, stride);
         }
         const bool hetero = th2 > 0.0 && (double)(out1 - out0) > ts->split_min * (double)std::max<int64_t>(valid, 1);
+        if (th2 > 0.0) ts->hetero_frac = (double)(out1 - out0) / (double)std::max<int64_t>(valid, 1);
         if (getenv("CSGPU_VERBOSE"))
           fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
                   (long long)out1, (long long)valid, ts->theta, (long long)out0, hetero ? "filter ON" : "filter off");
@@ -1555,6 +1561,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
     const bool cell_level = (sp.size0 || ts.unit_weights) && H.levels.size() == 1;
     int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level, &ts);
     if (ts.decide) {
+      H.hetero_frac = ts.hetero_frac;
       carry.tile_theta = ts.theta;  // (0 when the test declined, or when this level has no regular tiles)
       if (ts.unit_weights) {
         if (ts.theta > 0.0) {

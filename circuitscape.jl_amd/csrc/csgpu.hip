@@ -28,6 +28,7 @@ struct ISolver {
   virtual void solve_region_pairs(const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets, const int64_t* src_set,
                                   const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
+  virtual double hetero_frac() const = 0;  // Hierarchy::hetero_frac of the handle's hierarchy
   virtual double spmv_bench(int k, int reps) = 0;
   virtual void spmv_host(const void* x, void* y, int k) = 0;
   virtual void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) = 0;
@@ -107,6 +108,7 @@ struct Solver : ISolver {
   csgpu_opts opts;
   Csr<T> Aouter;      // the matrix CG sees when MIXED (otherwise level 0 of the hierarchy is used)
   Hierarchy<TP> H;
+  double hetero_frac() const override { return H.hetero_frac; }
   Dia<T> dia;         // lattice form of the CG matrix (all-valid rasters; empty otherwise)
   PcgWork<T, TP> W;
   double upload_ms = 0;
@@ -1791,6 +1793,24 @@ static void single_level_precision(csgpu_opts& o, int64_t n) {
   if (n <= (int64_t)o.max_coarse) o.precond_bytes = 0;
 }
 
+// fp32 hierarchies on strongly heterogeneous rasters: conductance ratios of e^+-9 eat the fp32
+// mantissa of the Galerkin operators -- a coarse row whose entries are 1e4 and whose couplings to the next region are
+// 1e-4 loses those couplings to the rounding of the large ones -- and the fp32 hierarchy of a log-normal sigma = 3 raster
+// needs 135 iterations where the fp64 one needs 82 (3000^2; 460 ms vs 418 ms per batch, so the fp64 hierarchy is also
+// the faster one). At sigma = 2 both need 25 and fp32 is 1.5x faster. The strength test of level 0 measures which regime
+// a raster is in: the fraction of cells the 0.03 sqrt(a_ii a_jj) filter moves out of their 3x3 tile is 0.0 % at
+// sigma = 1, 0.3 % at 1.5, 1.7 % at 2, 4.4 % at 2.5, 7.8 % at 3. Above CSGPU_HETERO_FP64_FRAC (default 3 %) a handle
+// asked for with precond_bytes = 4 is rebuilt with an fp64 hierarchy (csgpu_get_info then reports the precision in effect);
+// CSGPU_HETERO_FP64_FRAC=1 switches the fallback off.
+static bool hetero_wants_fp64(const csgpu::ISolver& s) {
+  static const double lim = getenv("CSGPU_HETERO_FP64_FRAC") ? atof(getenv("CSGPU_HETERO_FP64_FRAC")) : 0.03;
+  const bool yes = s.hetero_frac() > lim;
+  if (yes && getenv("CSGPU_VERBOSE"))
+    fprintf(stderr, "csgpu: heterogeneous raster (%.1f %% of the cells leave their tile): fp64 hierarchy instead of fp32\n",
+            100.0 * s.hetero_frac());
+  return yes;
+}
+
 // Raster entry points: whether the handle is coarsened depends on the number of NODES, not of cells (a raster
 // with few valid cells stays in compact numbering with n = valid cells). Upper bound of the node count -- valid cells
 // outside polygons + polygons holding a valid cell -- with an early exit once it exceeds max_coarse, so the scan of the
@@ -1830,6 +1850,13 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
     auto* s = new csgpu::Solver<double, float>(o);
     h->solver.reset(s);
     s->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
+    if (hetero_wants_fp64(*s)) {
+      h->solver.reset();
+      o.precond_bytes = 0;
+      auto* s2 = new csgpu::Solver<double, double>(o);
+      h->solver.reset(s2);
+      s2->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
+    }
   } else if (val_bytes == 8) {
     auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);
@@ -1865,6 +1892,13 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
     auto* s = new csgpu::Solver<double, float>(o);
     h->solver.reset(s);
     s->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
+    if (hetero_wants_fp64(*s)) {
+      h->solver.reset();
+      o.precond_bytes = 0;
+      auto* s2 = new csgpu::Solver<double, double>(o);
+      h->solver.reset(s2);
+      s2->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
+    }
   } else if (val_bytes == 8) {
     auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);

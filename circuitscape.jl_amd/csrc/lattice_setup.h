@@ -790,6 +790,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
       piece_counts(n, R, Rc, Cc, piece, mainlab, valid, out1, st, stride);
     }
     const bool hetero = t2 > 0.0 && (double)(out1 - out0) > sp.tile_split_min * (double)std::max<int64_t>(valid, 1);
+    if (t2 > 0.0) H.hetero_frac = (double)(out1 - out0) / (double)std::max<int64_t>(valid, 1);
     if (getenv("CSGPU_VERBOSE"))
       fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
               (long long)out1, (long long)valid, sp.tile_theta, (long long)out0, hetero ? "filter ON" : "filter off");
