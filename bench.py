@@ -147,21 +147,37 @@ def cpu_baseline_entry(cb, n_full, size, sample_size):
     return entry
 
 
-def run_pairs(h, batch_pairs, K, Wm, sync=None, first_batch=0):
-    """Wm untimed + K timed batches through csgpu_solve_pairs; returns (elapsed_s, resistances per batch, stats sums)."""
-    for w in range(Wm):
-        s, d = batch_pairs(first_batch + w)
-        h.solve_pairs(s, d)
+def run_pairs(h, batch_pairs, K, Wm, sync=None, first_batch=0, one_call=True):
+    """Wm untimed + K timed steps (a step = one batch of pairs) through csgpu_solve_pairs; returns (elapsed_s, resistances
+    per step, stats sums). one_call: the pairs of all K timed steps are handed over in ONE call -- what a host does with
+    a component's pair list (solve(prob, ::HIPAMGSolver, ...) sends the whole list down) -- so the library can stream them
+    through its columns (pcg_stream_pairs: a column takes the next pair as soon as its own has converged); otherwise
+    one call per step (every batch runs at the pace of its slowest column)."""
+    def pairs_of(steps):
+        s, d = [], []
+        for k in steps:
+            a, b = batch_pairs(k)
+            s += a
+            d += b
+        return s, d
+    if Wm > 0:
+        if one_call:
+            h.solve_pairs(*pairs_of(range(first_batch, first_batch + Wm)))
+        else:
+            for w in range(Wm):
+                h.solve_pairs(*batch_pairs(first_batch + w))
     if sync:
         sync()
     t0 = time.perf_counter()
     results = []
     agg = dict(total_iters=0, max_iters=0, cg_spmv_ms=0.0, cg_spmv_calls=0, device_ms=0.0, max_relres=0.0,
-               not_converged=0)
-    for k in range(K):
-        s, d = batch_pairs(first_batch + Wm + k)
+               not_converged=0, stream_slots=0, calls=0)
+    calls = [range(first_batch + Wm, first_batch + Wm + K)] if one_call else [[first_batch + Wm + k] for k in range(K)]
+    for steps in calls:
+        s, d = pairs_of(steps)
         R, _, _, st = h.solve_pairs(s, d)
-        results.append(R)
+        per = len(R) // len(steps)
+        results += [R[i * per:(i + 1) * per] for i in range(len(steps))]
         agg["total_iters"] += st["total_iters"]
         agg["max_iters"] = max(agg["max_iters"], st["max_iters"])
         agg["cg_spmv_ms"] += st["cg_spmv_ms"]
@@ -170,7 +186,19 @@ def run_pairs(h, batch_pairs, K, Wm, sync=None, first_batch=0):
         agg["max_relres"] = max(agg["max_relres"], st["max_relres"])
         agg["not_converged"] += st["not_converged"]
         agg["cg_spmv_bytes"] = st["cg_spmv_bytes"]
+        agg["stream_slots"] += st.get("stream_slots", 0)
+        agg["calls"] += 1
     return time.perf_counter() - t0, results, agg
+
+
+def stream_block(agg, npairs, B):
+    """How the timed pairs went through the library's columns: K-wide iterations of the stream and the columns'
+    utilisation (a pair costs its own iterations + 1 slots: the +1 is its initial V-cycle), or the batch path's waste."""
+    if agg.get("stream_slots", 0) > 0:
+        return {"mode": "streaming (pcg_stream_pairs: a column takes the next pair when its own has converged)",
+                "slots": agg["stream_slots"], "column_utilisation": (agg["total_iters"] + npairs) / float(agg["stream_slots"] * B)}
+    return {"mode": "batches (every batch runs until its slowest column has converged)", "slots": 0,
+            "iters_mean_over_max": agg["total_iters"] / float(max(npairs, 1)) / max(agg["max_iters"], 1)}
 
 
 def cg_product_name(info, B, vb):
@@ -247,7 +275,14 @@ def main():
     ap.add_argument("--steps", type=int, default=7)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=10000)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=32,
+                    help="columns solved together per pass = pairs per step (32 since round 4: the matrix values of every "
+                         "marching pass are amortised over twice as many columns, +8 %% fp64 / +10 %% mixed pair-solves/s "
+                         "over 16 on one box, profiles/r4_batch16_vs_32_*.json)")
+    ap.add_argument("--calls", default="single", choices=["single", "per-step"],
+                    help="single (default): the pairs of all timed steps go down in ONE csgpu_solve_pairs call, as a host "
+                         "hands over a component's pair list, and the library streams them through its columns; per-step: "
+                         "one call per batch (every batch at the pace of its slowest column)")
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="raster edge of the CPU-baseline / parity sample (0 = skip)")
     ap.add_argument("--criterion", type=int, default=0)
@@ -324,7 +359,7 @@ def main():
     def make_opts(precond, **kw):
         o = dict(extra)
         o.update(kw)
-        return lib.default_opts(device=dev_index, batch=B, criterion=args.criterion,
+        return lib.default_opts(device=dev_index, batch=o.pop("batch", B), criterion=args.criterion,
                                 precond_bytes=4 if (precond == "fp32" and vb == 8) else 0, **o)
 
     has_cuda = torch.cuda.is_available()  # False only in the CPU self-test (emulator library via CSGPU_LIB)
@@ -370,7 +405,8 @@ def main():
     h = lib.raster_setup(g, make_opts(args.precond))
     t_setup_wall = time.time() - t0
     info = h.info
-    elapsed, results, agg = run_pairs(h, batch_pairs, K, Wm, sync)
+    one_call = args.calls == "single"
+    elapsed, results, agg = run_pairs(h, batch_pairs, K, Wm, sync, one_call=one_call)
     res_local = torch.from_numpy(np.concatenate(results).astype(np.float64))
     res_local = res_local.to(dev) if (has_cuda and (dist is None or args.backend == "nccl")) else res_local
     t1 = time.perf_counter()
@@ -457,6 +493,8 @@ def main():
             "iters_mean": agg["total_iters"] / float(K * B), "iters_max": agg["max_iters"],
             "max_relres": agg["max_relres"], "not_converged": agg["not_converged"],
             "pcg_device_ms_per_step": agg["device_ms"] / K,   # HIP-event time of the PCG loops (rest of ms_per_step: host side)
+            "ms_per_16_pairs": elapsed / K * 1e3 * 16.0 / B,
+            "calls": agg["calls"], "stream": stream_block(agg, K * B, B),
             "roofline": roof,
         }
         out["value_" + path_name] = value
@@ -482,7 +520,7 @@ def main():
             h2.solve_pairs(*batch_pairs(0))
             h2.close()
             h2 = lib.raster_setup(g, make_opts(other))
-            el2, res2, agg2 = run_pairs(h2, batch_pairs, csteps, Wm, sync)
+            el2, res2, agg2 = run_pairs(h2, batch_pairs, csteps, Wm, sync, one_call=one_call)
             i2 = h2.info
             s2 = (i2["setup_ms"] + i2["upload_ms"]) / 1e3
             out["value_" + oname] = csteps * B / (el2 + s2 * csteps * B / 100.0)
@@ -493,7 +531,8 @@ def main():
                 "setup_device_s": i2["setup_ms"] / 1e3,
                 "upload_s": i2["upload_ms"] / 1e3, "iters_mean": agg2["total_iters"] / float(csteps * B),
                 "iters_max": agg2["max_iters"], "max_relres": agg2["max_relres"], "not_converged": agg2["not_converged"],
-                "pcg_device_ms_per_step": agg2["device_ms"] / csteps,
+                "pcg_device_ms_per_step": agg2["device_ms"] / csteps, "ms_per_16_pairs": el2 / csteps * 1e3 * 16.0 / B,
+                "stream": stream_block(agg2, csteps * B, B),
                 "roofline": roofline_of(i2, agg2),
                 "max_rel_diff_R_vs_%s_path" % path_name: float(max(np.max(np.abs(res2[k] - results[k]) / np.abs(res2[k]))
                                                                    for k in range(ncmp)))}
@@ -503,9 +542,10 @@ def main():
             # residual update) and the reference's 1e-4 check evaluated as ||A x - b|| / ||b|| with an explicit product
             # (opts.explicit_check = 1; csgpu_solve_pairs without volt_out otherwise carries x at the focal nodes only)
             try:
-                hv = lib.raster_setup(g, make_opts(args.precond, explicit_check=1))
+                # (batches of at most 16 here: x, A p and b carried for all columns are 3 more n x K vectors)
+                hv = lib.raster_setup(g, make_opts(args.precond, explicit_check=1, batch=min(B, 16)))
                 vsteps = max(1, min(K, 3))
-                elv, resv, aggv = run_pairs(hv, batch_pairs, vsteps, 1, sync)
+                elv, resv, aggv = run_pairs(hv, batch_pairs, vsteps, 1, sync, one_call=one_call)
                 iv = hv.info
                 sv = (iv["setup_ms"] + iv["upload_ms"]) / 1e3
                 hv.close()

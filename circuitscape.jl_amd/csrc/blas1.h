@@ -13,7 +13,7 @@
 namespace csgpu {
 
 // Per-batch CG scalars living in device memory (one struct per handle, arrays indexed by column c < K).
-static const int kMaxK = 16;
+static const int kMaxK = 32;  // widest batch (32 since round 4: the matrix values of a marching pass are amortised over twice as many columns)
 struct CgScalars {
   double gamma[kMaxK];   // r'z
   double pAp[kMaxK];
@@ -25,10 +25,21 @@ struct CgScalars {
   double eps2[kMaxK];    // criterion 2 only: threshold atol + rtol*||r0||_2 of the second (true-residual) test
   double bnorm[kMaxK];   // ||b||_2 (for the final relative residual)
   double relres[kMaxK];  // ||A x - b|| / ||b|| from the explicit post-check
-  int done[kMaxK];       // 1 converged, 2 breakdown (p'Ap <= 0 or non-finite)
+  int done[kMaxK];       // 1 converged, 2 breakdown (p'Ap <= 0 or non-finite), 4 itmax reached (streaming solves only)
   int iters[kMaxK];
   int all_done;
   int pad;
+  // ---- streaming pair solves (pcg_stream_pairs, pcg.h): every column is a slot that takes the next pair of the call's
+  // list as soon as its own pair has converged. `ctl` is written by the host between two iterations (the device is idle
+  // then); restart[c] is consumed -- and cleared -- by the kernels of the next iteration.
+  struct Ctl {
+    int restart[kMaxK];  // 1: column c starts a new pair in the next iteration (r := e_dst - e_src, x := 0, p := z)
+    int src[kMaxK];      // row ids of the new pair
+    int dst[kMaxK];
+    int active[kMaxK];   // 0: the slot is idle (pair list exhausted)
+  } ctl;
+  int polish[kMaxK];     // the column met the configured rule with ||r|| / ||b|| >= 1e-4 and now runs to 2.5e-5 on the true
+                         // residual (what cg_reopen_kernel does for a whole batch)
 };
 
 // ---- dot products: partials[block][c] = sum_i a[i,c]*b[i,c]  (second pair optional: a2.b2 -> partials2)
@@ -268,8 +279,107 @@ __global__ __launch_bounds__(256) void cg_focal_x_kernel(const CgScalars* S, con
   if (S->all_done) return;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < nf * K; e += gridDim.x * 256) {
     const int m = e / K, c = e % K;
-    xf[e] = fma((T)S->alpha[c], (T)p[(size_t)fnode[m] * K + c], xf[e]);
+    const T al = (T)S->alpha[c];
+    // (alpha == 0: a finished column, or a slot that takes a new pair -- its p may be stale; fma(0, p, x) == x otherwise)
+    if (al != T(0)) xf[e] = fma(al, (T)p[(size_t)fnode[m] * K + c], xf[e]);
   }
+}
+
+// ---- streaming pair solves: a slot that takes a new pair gets its right-hand side b = e_dst - e_src as the residual
+//      (the residual update of the same iteration has just zeroed the column: dia_cg_kernel<DIA_RUPD>, `restart`), its
+//      preconditioner-precision copy, and a zero solution at the focal nodes. One workgroup.
+template <class T, class TP, int K>
+__global__ __launch_bounds__(256) void stream_restart_kernel(const CgScalars* S, T* __restrict__ r, TP* __restrict__ rp,
+                                                             int nf, T* __restrict__ xf) {
+  for (int c = 0; c < K; ++c) {
+    if (!S->ctl.restart[c]) continue;
+    for (int m = threadIdx.x; m < nf; m += 256) xf[(size_t)m * K + c] = T(0);
+    if (threadIdx.x == 0 && S->ctl.src[c] != S->ctl.dst[c]) {
+      const size_t a = (size_t)S->ctl.src[c] * K + c, b = (size_t)S->ctl.dst[c] * K + c;
+      r[a] = T(-1);
+      r[b] = T(1);
+      if (rp) {
+        rp[a] = TP(-1);
+        rp[b] = TP(1);
+      }
+    }
+  }
+}
+
+// ---- scalar kernel 2 of a streaming solve: cg_beta_kernel per SLOT. A slot with ctl.restart set is initialised (what
+//      cg_beta_kernel's init call does for a batch: ||b||^2 = 2 is known); a running slot is advanced, and when it meets
+//      the configured rule the reference's post-check ||r|| / ||b|| < 1e-4 (core.jl:640, on the fp64 recurrence residual
+//      whose ||r||^2 partials the residual update wrote) decides between "done" and polishing to 2.5e-5 on the true
+//      residual (cg_reopen_kernel's rule, without the restart). itmax is per pair.
+template <int K>
+__global__ __launch_bounds__(256) void cg_stream_beta_kernel(CgScalars* S, const double* partials_rz, int nparts_rz,
+                                                             const double* partials_rr, int nparts_rr, int criterion,
+                                                             double rtol, double atol, int itmax) {
+  __shared__ double sm[4];
+  __shared__ int s_all;
+  if (threadIdx.x == 0) s_all = 1;
+  __syncthreads();
+  for (int c = 0; c < K; ++c) {
+    const double rz = reduce_partials<K>(partials_rz, nparts_rz, c, sm);
+    const double rr_now = reduce_partials<K>(partials_rr, nparts_rr, c, sm);
+    if (threadIdx.x == 0) {
+      if (!S->ctl.active[c]) {
+        S->done[c] = 1;
+        S->beta[c] = 0.0;
+        S->alpha[c] = 0.0;
+      } else if (S->ctl.restart[c]) {
+        const double rr = S->ctl.src[c] != S->ctl.dst[c] ? 2.0 : 0.0;
+        const double mon = criterion == 1 ? sqrt(rr) : sqrt(fabs(rz));
+        const double mon2 = sqrt(rr);
+        S->bnorm[c] = sqrt(rr);
+        S->rnorm0[c] = mon;
+        S->eps[c] = atol + rtol * mon;
+        S->eps2[c] = atol + rtol * mon2;
+        S->rnorm[c] = mon;
+        S->gamma[c] = rz;
+        S->beta[c] = 0.0;
+        S->iters[c] = 0;
+        S->relres[c] = rr > 0.0 ? 1.0 : 0.0;
+        S->polish[c] = 0;
+        S->done[c] = ((mon <= S->eps[c] && (criterion != 2 || mon2 <= S->eps2[c])) || !(rz == rz)) ? 1 : 0;
+        S->ctl.restart[c] = 0;
+      } else if (!S->done[c]) {
+        S->iters[c] += 1;
+        const double bn = S->bnorm[c];
+        const double relres = bn > 0.0 ? sqrt(rr_now) / bn : sqrt(rr_now);
+        S->relres[c] = relres;
+        const double mon = (criterion == 1 || S->polish[c]) ? sqrt(rr_now) : sqrt(fabs(rz));
+        const double mon2 = sqrt(rr_now);
+        S->rnorm[c] = mon;
+        const double g = S->gamma[c];
+        bool met = (mon <= S->eps[c] && (criterion != 2 || S->polish[c] || mon2 <= S->eps2[c])) || mon + 1.0 <= 1.0;
+        if (met && !S->polish[c] && !(relres < 1e-4)) {
+          // the configured rule is met but the reference's own check would throw: keep iterating on the true residual
+          S->polish[c] = 1;
+          S->eps[c] = 2.5e-5 * bn;
+          met = sqrt(rr_now) <= S->eps[c];
+        }
+        if (met) {
+          S->done[c] = 1;
+          S->beta[c] = 0.0;
+        } else if (!(rz == rz) || g == 0.0) {
+          S->done[c] = 2;
+          S->beta[c] = 0.0;
+        } else if (S->iters[c] >= itmax) {
+          S->done[c] = 4;
+          S->beta[c] = 0.0;
+        } else {
+          S->beta[c] = rz / g;
+        }
+        S->gamma[c] = rz;
+      } else {
+        S->beta[c] = 0.0;
+      }
+      if (!S->done[c]) s_all = 0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) S->all_done = s_all;
 }
 
 // ---- Dirichlet mask: column c of the batch is tied to ground at the nodes gidx[gptr[c] .. gptr[c+1]) -- their entries of

@@ -912,7 +912,20 @@ struct Solver : ISolver {
       case 2: return run_batch<2>(ncols, need_x, bb_host);
       case 4: return run_batch<4>(ncols, need_x, bb_host);
       case 8: return run_batch<8>(ncols, need_x, bb_host);
+      case 32: return run_batch<32>(ncols, need_x, bb_host);
       default: return run_batch<16>(ncols, need_x, bb_host);
+    }
+  }
+
+  // streaming pair solves (pcg_stream_pairs, pcg.h) for the wide batches
+  PcgStreamResult run_stream_k(int K, const int64_t* src, const int64_t* dst, int64_t npairs, const int64_t* gather,
+                               int64_t ngather, T* resist_out, T* gathered_out) {
+    PcgParams pp = pcg_params(K);
+    switch (K) {
+      case 8: return pcg_stream_pairs<T, TP, 8>(H, W, pp, dia, src, dst, npairs, gather, ngather, resist_out, gathered_out, st);
+      case 16: return pcg_stream_pairs<T, TP, 16>(H, W, pp, dia, src, dst, npairs, gather, ngather, resist_out, gathered_out, st);
+      case 32: return pcg_stream_pairs<T, TP, 32>(H, W, pp, dia, src, dst, npairs, gather, ngather, resist_out, gathered_out, st);
+      default: return PcgStreamResult();
     }
   }
 
@@ -939,6 +952,7 @@ struct Solver : ISolver {
     case 2: { constexpr int KK = 2; __VA_ARGS__; } break;   \
     case 4: { constexpr int KK = 4; __VA_ARGS__; } break;   \
     case 8: { constexpr int KK = 8; __VA_ARGS__; } break;   \
+    case 32: { constexpr int KK = 32; __VA_ARGS__; } break; \
     default: { constexpr int KK = 16; __VA_ARGS__; } break; \
   }
 
@@ -981,6 +995,46 @@ struct Solver : ISolver {
       stats->nrhs = (int)npairs;
       stats->batch = K;
     }
+    // Streaming ("continuous batching", pcg.h): a resistance-only call with more pairs than columns on the lattice path
+    // can keep every column busy -- a column takes the next pair of the list when its own has converged -- instead of
+    // solving batch after batch at the pace of each batch's slowest column. A pair then costs its own iterations + 1
+    // K-wide iterations (the + 1 is its initial V-cycle, during which the column's CG product and residual update idle)
+    // against the batch's slowest column + an initial V-cycle: a gain when the iteration counts of a batch are spread
+    // (NODATA / heterogeneous rasters: 13.9 mean against 16 at 10000^2 with 15 % holes), a small loss when they are not
+    // (the bench raster: 10.76 against 11). The first batch of a call therefore always runs as a batch and its iteration
+    // counts decide for the rest of the list (re-evaluated after every further batch). Used where an iteration takes
+    // milliseconds (the host looks at the slots after every iteration): CSGPU_STREAM_MIN (vector elements n * K, default
+    // 2^25) moves that bound; CSGPU_STREAM=1 streams from the first pair on (tests, A/B), CSGPU_NO_STREAM=1 never.
+    bool stream_eligible = false, stream_now = false;
+    if (!(volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0) && dia_ptr() && npairs > K &&
+        K >= 8 && !getenv("CSGPU_NO_STREAM")) {
+      const char* sm = getenv("CSGPU_STREAM_MIN");
+      stream_eligible = (int64_t)n * K >= (sm ? atoll(sm) : ((int64_t)1 << 25));
+      const char* fs = getenv("CSGPU_STREAM");
+      stream_now = stream_eligible && fs && atoi(fs) > 0;
+    }
+    // the rest of the list [p0, npairs) as a stream; false when the stream declined (the batches go on)
+    auto stream_rest = [&](int64_t p0) -> bool {
+      PcgStreamResult sr = run_stream_k(K, src + p0, dst + p0, npairs - p0, gather, ngather,
+                                        resist_out ? (T*)resist_out + p0 : (T*)nullptr,
+                                        gathered_out ? (T*)gathered_out + (size_t)p0 * ngather : (T*)nullptr);
+      if (!sr.applicable) return false;
+      if (stats) {
+        for (size_t p = 0; p < sr.iters.size(); ++p) {
+          stats->total_iters += sr.iters[p];
+          stats->max_iters = std::max(stats->max_iters, sr.iters[p]);
+          stats->max_relres = std::max(stats->max_relres, sr.relres[p]);
+          if (sr.status[p] != 1 || !(sr.relres[p] < 1e-4)) stats->not_converged += 1;
+        }
+        stats->device_ms += sr.device_ms;
+        stats->cg_spmv_ms += sr.spmv_ms;
+        stats->cg_spmv_calls += sr.spmv_calls;
+        stats->cg_spmv_bytes = sr.spmv_bytes;
+        stats->polished_batches += sr.polished;
+        stats->stream_slots += sr.slots;
+      }
+      return true;
+    };
     DBuf dsrc = dalloc<int>(K), ddst = dalloc<int>(K);
     DBuf dgather = dalloc<int>((size_t)std::max<int64_t>(ngather, 1));
     if (ngather > 0) {
@@ -1021,6 +1075,10 @@ struct Solver : ISolver {
     }
     std::vector<int> s32(K), d32(K), w32(K);
     for (int64_t p0 = 0; p0 < npairs; p0 += K) {
+      if (stream_now && npairs - p0 > K) {
+        if (stream_rest(p0)) break;
+        stream_now = stream_eligible = false;  // (declined: not asked again in this call)
+      }
       const int ncols = (int)std::min<int64_t>(K, npairs - p0);
       for (int c = 0; c < K; ++c) {
         s32[c] = (int)src[p0 + std::min(c, ncols - 1)];
@@ -1050,6 +1108,16 @@ struct Solver : ISolver {
       }
       PcgBatchResult r = run_batch_k(K, ncols, need_x, bb);
       accumulate(stats, r, ncols);
+      if (stream_eligible && ncols == K) {
+        // spread of this batch's iteration counts: stream the rest when (mean + 1) slots per pair beat (max + 1/2)
+        double sum = 0;
+        int mx = 0;
+        for (int c = 0; c < K; ++c) {
+          sum += r.s.iters[c];
+          mx = std::max(mx, r.s.iters[c]);
+        }
+        stream_now = sum / K + 1.0 < 0.97 * (mx + 0.5);
+      }
       const int ge = grid_for((int64_t)ncols * (ngather + 1));
       if (need_x) {
         CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_extract_kernel<T, KK>), dim3(ge), dim3(256), 0, st,
@@ -1682,6 +1750,7 @@ struct Solver : ISolver {
       case 2: g = dia_grid<T, TP, 2>(dia); dia_cg_product<T, TP, 2>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
       case 4: g = dia_grid<T, TP, 4>(dia); dia_cg_product<T, TP, 4>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
       case 8: g = dia_grid<T, TP, 8>(dia); dia_cg_product<T, TP, 8>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
+      case 32: g = dia_grid<T, TP, 32>(dia); dia_cg_product<T, TP, 32>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
       default: g = dia_grid<T, TP, 16>(dia); dia_cg_product<T, TP, 16>(dia, nullptr, dptr<TP>(z), dptr<TP>(pin), dptr<TP>(pout), dptr<T>(y), dptr<double>(part), st, dptr<double>(dbeta)); break;
     }
     check_launch("dia_product_host");
@@ -2134,7 +2203,7 @@ int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const i
 
 int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms) {
   CS_API_BEGIN
-  if (!h || !avg_ms || reps < 1 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+  if (!h || !avg_ms || reps < 1 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }
@@ -2145,7 +2214,7 @@ int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms) {
 
 int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k) {
   CS_API_BEGIN
-  if (!h || !x || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+  if (!h || !x || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }
@@ -2156,7 +2225,7 @@ int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k) {
 
 int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, void* y, int k, double* dots) {
   CS_API_BEGIN
-  if (!h || !x || !y || which < 0 || which > 5 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+  if (!h || !x || !y || which < 0 || which > 5 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }
@@ -2180,7 +2249,7 @@ int csgpu_get_level_matrix(const csgpu_handle* h, int lvl, int which, int64_t* n
 int csgpu_dia_product_host(csgpu_handle* h, const void* z, const void* p_in, const double* beta, void* p_out, void* y,
                            int k, double* dots) {
   CS_API_BEGIN
-  if (!h || !z || !p_in || !beta || !p_out || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16)) {
+  if (!h || !z || !p_in || !beta || !p_out || !y || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }

@@ -7,6 +7,7 @@
 // The smoother is damped Jacobi fused into the SpMV epilogue (symmetric, so CG theory holds); the first
 // pre-smoothing sweep from the zero guess needs no matrix product at all.
 #pragma once
+#include <algorithm>
 #include <limits>
 #include <type_traits>
 
@@ -416,6 +417,7 @@ struct PcgWork {
   DBuf dir_coef;              // [kMaxDirComp][kMaxK] doubles: 1 / G of a Dirichlet-masked solve (DirichletCoarse in pcg_solve)
   DBuf part_a, part_b, part_c;
   DBuf part_ca, part_cc;      // collapsed copies of part_a / part_c (collapse_partials_kernel)
+  DBuf part_cb;               // collapsed copy of part_b (streaming solves: ||r||^2 of every iteration)
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
   std::vector<std::pair<PcgGraphKey, hipGraphExec_t>> graphs;  // captured iteration chunks
   bool graph_broken = false;                                   // capture failed once: stay on direct launches
@@ -923,6 +925,241 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     res.spmv_bytes = n * 5 * (int64_t)sizeof(T) + n * K * (3 * (int64_t)sizeof(TP) + (recompute ? 0 : (int64_t)sizeof(T)));
   else
     res.spmv_bytes = A.nnz * (int64_t)(sizeof(T) + 4) + (n + 1) * 4 + n * K * (int64_t)(sizeof(TP) + sizeof(T));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return res;
+}
+
+// ---- streaming pair solves ("continuous batching") ---------------------------------------------------------------------
+// pcg_solve streams all K columns of a batch until its SLOWEST column has converged (10.76 iterations on average against
+// 11 on the bench raster, but 13.9 against 16 on a raster with 15 % NODATA and 82 against 91 on a log-normal sigma = 3
+// one: up to 13 % of all traffic moved for columns that were done). The columns of a batch are
+// independent CG recurrences that merely share the passes over the matrix, so a column can take the NEXT pair of the
+// call's list the moment its own pair is done:
+//   iteration t, slot c restarts:   the CG product and alpha of the slot are idle (alpha = 0, beta = 0),
+//                                   the residual update writes r_c = 0 and stream_restart_kernel the two +-1 entries,
+//                                   the V-cycle of the same iteration delivers z_c = M^-1 b  (a batch's separate initial
+//                                   V-cycle), cg_stream_beta_kernel initialises the slot's scalars;
+//   iteration t + 1:                p_c = z_c (beta = 0) -- the slot's first CG step.
+// A pair therefore costs (its own iterations + 1) slots instead of max-over-the-batch iterations + an initial V-cycle.
+// Every per-column quantity (dot products reduced over the workgroups in a fixed order, the V-cycle, the focal-node
+// accumulation) is independent of what the neighbouring columns hold, so a pair's iterates are bit-identical to those of
+// the batch path (tests/helpers.py::check_stream_pairs); only a column that needs polishing continues without the restart
+// cg_reopen_kernel makes.
+// Applies to resistance-only pair solves on the lattice path (x at the focal nodes only, A p recomputed by the residual
+// update, two-product level 0); the host polls the slots after every iteration, so it is used in the bandwidth-bound
+// regime (an iteration takes milliseconds) and when the call has more pairs than columns. CSGPU_NO_STREAM=1: A/B knob.
+struct PcgStreamResult {
+  bool applicable = false;
+  std::vector<int> iters, status;       // per pair: iterations, CgScalars::done value (1 ok, 2 breakdown, 4 itmax)
+  std::vector<double> relres;           // per pair: ||r|| / ||b|| of the fp64 recurrence residual at the end
+  double device_ms = 0, spmv_ms = 0;
+  int64_t spmv_calls = 0, spmv_bytes = 0;
+  int64_t slots = 0;                    // iterations of the K-wide stream
+  int64_t polished = 0;
+};
+
+template <class T, class TP, int K>
+inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, const PcgParams& pp, const Dia<T>& dia,
+                                        const int64_t* src, const int64_t* dst, int64_t npairs, const int64_t* gather,
+                                        int64_t ngather, T* resist_out, T* gathered_out, hipStream_t st) {
+  constexpr bool MIXED = !std::is_same<T, TP>::value;
+  PcgStreamResult res;
+  Level<TP>& L0 = H.levels[0];
+  const int64_t n = dia.n;
+  const bool two_product = H.levels.size() > 1 && L0.two_product() && L0.lattice_two_product() && pp.nu_pre == 1 &&
+                           pp.nu_post == 1 && W.tail >= H.levels[1].A.nrows;
+  static const bool off = getenv("CSGPU_NO_STREAM") != nullptr || getenv("CSGPU_NO_RECOMPUTE") != nullptr;
+  if (off || !two_product || W.n != n || W.K != K) return res;
+  // focal nodes: the gathered nodes first, then every distinct node of the pair list
+  std::vector<int> focal;
+  std::vector<int64_t> keys;
+  keys.reserve((size_t)2 * npairs);
+  for (int64_t p = 0; p < npairs; ++p) {
+    keys.push_back(src[p]);
+    keys.push_back(dst[p]);
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  if ((int64_t)keys.size() + ngather > 8192) return res;  // (a pair list over that many distinct nodes: batch path)
+  for (int64_t g = 0; g < ngather; ++g) focal.push_back((int)gather[g]);
+  for (int64_t k : keys) focal.push_back((int)k);
+  auto focal_of = [&](int64_t node) {
+    return (int)ngather + (int)(std::lower_bound(keys.begin(), keys.end(), node) - keys.begin());
+  };
+  res.applicable = true;
+  res.iters.assign((size_t)npairs, 0);
+  res.status.assign((size_t)npairs, 1);
+  res.relres.assign((size_t)npairs, 0.0);
+  ensure_level_work(H, K);
+  if (W.p2.bytes < (size_t)n * K * sizeof(TP)) {
+    W.drop_graphs();
+    W.p2.alloc((size_t)n * K * sizeof(TP));
+  }
+  W.set_focal(focal, st);
+  W.have_x = false;
+  const int nf = W.nf;
+  T* r = dptr<T>(W.r);
+  TP* pbuf[2] = {dptr<TP>(W.p), dptr<TP>(W.p2)};
+  TP* z = dptr<TP>(W.z);
+  TP* rp = MIXED ? dptr<TP>(W.rp) : (TP*)r;
+  CgScalars* S = dptr<CgScalars>(W.scalars);
+  double* pa = dptr<double>(W.part_a);
+  double* pb = dptr<double>(W.part_b);
+  double* pc = dptr<double>(W.part_c);
+  double* pac = dptr<double>(W.part_ca);
+  double* pcc = dptr<double>(W.part_cc);
+  if (W.part_cb.bytes < (size_t)kCollapsedParts * kMaxK * sizeof(double)) W.part_cb.alloc((size_t)kCollapsedParts * kMaxK * sizeof(double));
+  double* pbc = dptr<double>(W.part_cb);
+  T* xf = dptr<T>(W.xf);
+  const int* fnode = dptr<int>(W.fnode);
+  const double atol = pp.atol < 0 ? std::sqrt((double)std::numeric_limits<T>::epsilon()) : pp.atol;
+  const int spmv_g = dia_grid<T, TP, K>(dia);
+  const int spmv_gp = dia_grid<TP, TP, K>(L0.Sdia);
+  const char* cm_env = getenv("CSGPU_COLLAPSE_MIN");
+  const int collapse_min = cm_env ? std::max(1, atoi(cm_env)) : 4 * kCollapsedParts;
+  auto collapsed = [&](double* from, int nparts, double* to) -> std::pair<const double*, int> {
+    if (nparts <= collapse_min) return {from, nparts};
+    hipLaunchKernelGGL((collapse_partials_kernel<K>), dim3(ceil_div(kCollapsedParts * K, 256)), dim3(256), 0, st,
+                       (const double*)from, nparts, to);
+    return {to, kCollapsedParts};
+  };
+  hipEvent_t e0, e1;
+  CS_HIP(hipEventCreate(&e0));
+  CS_HIP(hipEventCreate(&e1));
+  CS_HIP(hipEventRecord(e0, st));
+  // every vector finite before the first pass (a slot's first iteration multiplies stale values by zero)
+  CS_HIP(hipMemsetAsync(r, 0, (size_t)n * K * sizeof(T), st));
+  if (MIXED) CS_HIP(hipMemsetAsync(rp, 0, (size_t)n * K * sizeof(TP), st));
+  CS_HIP(hipMemsetAsync(z, 0, (size_t)n * K * sizeof(TP), st));
+  CS_HIP(hipMemsetAsync(pbuf[0], 0, (size_t)n * K * sizeof(TP), st));
+  CS_HIP(hipMemsetAsync(pbuf[1], 0, (size_t)n * K * sizeof(TP), st));
+  if (nf > 0) CS_HIP(hipMemsetAsync(xf, 0, (size_t)nf * K * sizeof(T), st));
+  // slots
+  CgScalars hs;
+  memset(&hs, 0, sizeof(hs));
+  std::vector<int64_t> slot_pair(K, -1);
+  int64_t next = 0;
+  int active = 0;
+  auto take_next = [&](int c) {
+    // pairs whose two nodes coincide have a zero right-hand side: R = 0 without a solve (the reference skips them,
+    // core.jl:210)
+    while (next < npairs && src[next] == dst[next]) {
+      if (resist_out) resist_out[next] = T(0);
+      if (gathered_out)
+        for (int64_t g = 0; g < ngather; ++g) gathered_out[(size_t)next * ngather + g] = T(0);
+      ++next;
+    }
+    if (next < npairs) {
+      slot_pair[c] = next;
+      hs.ctl.restart[c] = 1;
+      hs.ctl.src[c] = (int)src[next];
+      hs.ctl.dst[c] = (int)dst[next];
+      hs.ctl.active[c] = 1;
+      ++next;
+      ++active;
+    } else {
+      slot_pair[c] = -1;
+      hs.ctl.restart[c] = 0;
+      hs.ctl.active[c] = 0;
+    }
+  };
+  for (int c = 0; c < K; ++c) {
+    hs.done[c] = 1;  // (alpha = 0 until the slot's scalars are initialised)
+    take_next(c);
+  }
+  for (int c = K; c < kMaxK; ++c) hs.done[c] = 1;
+  CS_HIP(hipMemcpyAsync(S, &hs, sizeof(CgScalars), hipMemcpyHostToDevice, st));
+  VcycleFuse<TP> fuse;
+  fuse.b_has_tail = true;
+  fuse.dotw = rp;
+  fuse.partials = pa;
+  static const int max_timed = getenv("CSGPU_TIMED_LAUNCHES") ? atoi(getenv("CSGPU_TIMED_LAUNCHES")) : 512;
+  int timed = 0;
+  int parity = 0;
+  std::vector<T> hxf;
+  while (active > 0) {
+    const TP* pin = pbuf[parity];
+    TP* pcur = pbuf[parity ^ 1];
+    const bool time_it = timed < max_timed;
+    if (time_it) {
+      if ((int)W.ev.size() < 2 * (timed + 1)) {
+        hipEvent_t ea, eb;
+        CS_HIP(hipEventCreate(&ea));
+        CS_HIP(hipEventCreate(&eb));
+        W.ev.push_back(ea);
+        W.ev.push_back(eb);
+      }
+      CS_HIP(hipEventRecord(W.ev[2 * timed], st));
+    }
+    dia_cg_product<T, TP, K>(dia, (const CgScalars*)S, (const TP*)z, pin, pcur, (T*)nullptr, pc, st);
+    if (time_it) {
+      CS_HIP(hipEventRecord(W.ev[2 * timed + 1], st));
+      ++timed;
+    }
+    parity ^= 1;
+    {
+      auto pap = collapsed(pc, spmv_g, pcc);
+      hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, pap.first, pap.second);
+    }
+    dia_residual_update<T, TP, K>(dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, (T*)nullptr, pb, st,
+                                  (const int*)S->ctl.restart);
+    if (nf > 0)
+      hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
+                         fnode, nf, (const TP*)pcur, xf);
+    hipLaunchKernelGGL((stream_restart_kernel<T, TP, K>), dim3(1), dim3(256), 0, st, (const CgScalars*)S, r,
+                       MIXED ? rp : (TP*)nullptr, nf, xf);
+    vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    {
+      auto rz = collapsed(pa, spmv_gp, pac);
+      auto rr = collapsed(pb, spmv_g, pbc);
+      hipLaunchKernelGGL((cg_stream_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, rr.first, rr.second,
+                         pp.criterion, pp.rtol, atol, pp.itmax);
+    }
+    check_launch("pcg stream iteration");
+    ++res.slots;
+    CS_HIP(hipMemcpyAsync(&hs, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    bool any = false;
+    for (int c = 0; c < K; ++c)
+      if (slot_pair[c] >= 0 && hs.done[c] != 0 && !hs.ctl.restart[c]) any = true;
+    if (!any) continue;
+    hxf.resize((size_t)nf * K);
+    CS_HIP(hipMemcpyAsync(hxf.data(), xf, hxf.size() * sizeof(T), hipMemcpyDeviceToHost, st));
+    CS_HIP(hipStreamSynchronize(st));
+    for (int c = 0; c < K; ++c) {
+      const int64_t p = slot_pair[c];
+      if (p < 0 || hs.done[c] == 0 || hs.ctl.restart[c]) continue;
+      const T vs = hxf[(size_t)focal_of(src[p]) * K + c];
+      if (resist_out) resist_out[p] = hxf[(size_t)focal_of(dst[p]) * K + c] - vs;
+      if (gathered_out)
+        for (int64_t g = 0; g < ngather; ++g) gathered_out[(size_t)p * ngather + g] = hxf[(size_t)g * K + c] - vs;
+      res.iters[(size_t)p] = hs.iters[c];
+      res.status[(size_t)p] = hs.done[c];
+      res.relres[(size_t)p] = hs.relres[c];
+      res.polished += hs.polish[c] ? 1 : 0;
+      --active;
+      take_next(c);
+    }
+    hs.all_done = 0;
+    // the control block and the flags the next iteration's kernels look at (done stays set for a restarting slot: its
+    // alpha must be zero until cg_stream_beta_kernel has initialised it)
+    CS_HIP(hipMemcpyAsync(&S->ctl, &hs.ctl, sizeof(hs.ctl), hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemcpyAsync(&S->all_done, &hs.all_done, sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  CS_HIP(hipEventRecord(e1, st));
+  CS_HIP(hipStreamSynchronize(st));
+  check_launch("pcg stream finish");
+  float ms = 0;
+  CS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  res.device_ms = ms;
+  for (int t = 0; t < timed; ++t) {
+    float m2 = 0;
+    CS_HIP(hipEventElapsedTime(&m2, W.ev[2 * t], W.ev[2 * t + 1]));
+    res.spmv_ms += m2;
+  }
+  res.spmv_calls = timed;
+  res.spmv_bytes = n * 5 * (int64_t)sizeof(T) + n * K * 3 * (int64_t)sizeof(TP);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return res;

@@ -166,6 +166,8 @@ struct DiaArgs {
   T* r;                    // DIA_RUPD: residual (in/out), interleaved [n][K]
   XT* rp;                  // DIA_RUPD: copy of the new residual in the preconditioner's precision (null when XT == T)
   T* xsol;                 // DIA_RUPD: optional whole solution vector, xsol += alpha x
+  const int* restart = nullptr;  // DIA_RUPD, streaming pair solves (pcg_stream_pairs): columns with restart[c] != 0 take a
+                                 // new pair -- their residual is ZEROED here (stream_restart_kernel then writes the +-1)
   const T* bsub = nullptr; // DIA_PLAIN: y = bsub - A x instead of A x (residual of a lattice level, pcg.h)
   const T* xadd = nullptr; // DIA_SQ: y = xadd + S x + Q xc (second half of a lattice V(2,2) level, pcg.h)
 };
@@ -188,8 +190,9 @@ struct DiaShape {
 // workgroup per CU is worth two spilled registers: 128 VGPRs / 4 waves instead of 130 / 3 -> 4.27 -> 3.44 ms (measured,
 // profiles/r2_launch_bounds_ab.json). The second product (142 VGPRs) spills 13 registers under the same bound and gets
 // 1.9x slower; the residual update gains nothing from 3 waves instead of 2: both stay unconstrained.
+// (narrow batches, K <= 4, hold CPL = K columns per lane on fewer lanes per node and cannot reach 4 waves: no bound there)
 template <class T, class XT, int K, int MODE>
-__global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
+__global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia_cg_kernel(
     DiaArgs<T, XT> a) {
   constexpr bool FUSE = MODE == DIA_CG;
   typedef DiaShape<T, XT, K> SH;
@@ -217,6 +220,9 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
   T alpha[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) alpha[q] = (MODE == DIA_RUPD) ? (T)a.S->alpha[c0 + q] : T(0);
+  bool fresh[CPL];  // DIA_RUPD: the column takes a new pair (streaming solves)
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) fresh[q] = (MODE == DIA_RUPD) && a.restart && a.restart[c0 + q] != 0;
   double dot_acc[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
@@ -311,12 +317,13 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
       if (FUSE) {  // p = z + beta p (halo included); the tile's own entries are the new search direction
         XV v;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v.e[q] = (XT)fma(beta[q], (T)xr.e[q], (T)zr.e[q]);
+        // (beta == 0: the first step of a column -- p = z exactly, whatever the old p holds; same bits as the fma otherwise)
+        for (int q = 0; q < CPL; ++q) v.e[q] = beta[q] == T(0) ? zr.e[q] : (XT)fma(beta[q], (T)xr.e[q], (T)zr.e[q]);
         const int64_t id = (int64_t)jc * a.R + i0 + t;
         if (jc >= j0 && jc < j1 && row_on && id < a.n) dia_store(reinterpret_cast<XV*>(a.pout + (size_t)id * K + c0), v);
         xr = v;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) xh.e[q] = (XT)fma(beta[q], (T)xh.e[q], (T)zh.e[q]);
+        for (int q = 0; q < CPL; ++q) xh.e[q] = beta[q] == T(0) ? zh.e[q] : (XT)fma(beta[q], (T)xh.e[q], (T)zh.e[q]);
       }
       s_x[slot][(t + 1) * LPR + lq] = xr;
       if (tid < 2 * LPR) s_x[slot][(tid < LPR ? 0 : TI + 1) * LPR + lq] = xh;
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256, (MODE == DIA_CG ? 4 : 1)) void dia_cg_kernel(
           XV rq;
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            rn.e[q] = rv.e[q] - alpha[q] * out.e[q];
+            rn.e[q] = fresh[q] ? T(0) : rv.e[q] - alpha[q] * out.e[q];
             rq.e[q] = (XT)rn.e[q];
             if (a.partials) dot_acc[q] += (double)rn.e[q] * (double)rn.e[q];
           }
@@ -541,7 +548,7 @@ inline void dia_cg_product(const Dia<T>& D, const CgScalars* S, const XT* z, con
 // partials of r'r (may be null). alpha and the skip flag from the CG scalars S.
 template <class T, class XT, int K>
 inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p, T* r, XT* rp, T* xsol,
-                                double* partials_rr, hipStream_t st) {
+                                double* partials_rr, hipStream_t st, const int* restart = nullptr) {
   DiaArgs<T, XT> a;
   a.n = D.n;
   a.R = D.R;
@@ -563,6 +570,7 @@ inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p
   a.r = r;
   a.rp = rp;
   a.xsol = xsol;
+  a.restart = restart;
   hipLaunchKernelGGL((dia_cg_kernel<T, XT, K, DIA_RUPD>), dim3(grid), dim3(256), 0, st, a);
 }
 

@@ -27,8 +27,8 @@ end
 mutable struct CsgpuStats
     nrhs::Int32; max_iters::Int32; total_iters::Int64; max_relres::Float64; solve_ms::Float64; device_ms::Float64
     cg_spmv_ms::Float64; cg_spmv_calls::Int64; batch::Int32; not_converged::Int32; graph_launches::Int64; polished_batches::Int64
-    cg_spmv_bytes::Int64
-    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
+    cg_spmv_bytes::Int64; stream_slots::Int64
+    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0)
 end
 
 mutable struct HIPFactor          # cf. PardisoFactorize (Pardiso ext :8-13): owns the device-resident hierarchy

@@ -68,7 +68,7 @@ class Stats(ctypes.Structure):
         ("max_relres", ctypes.c_double), ("solve_ms", ctypes.c_double), ("device_ms", ctypes.c_double),
         ("cg_spmv_ms", ctypes.c_double), ("cg_spmv_calls", ctypes.c_int64), ("batch", ctypes.c_int32),
         ("not_converged", ctypes.c_int32), ("graph_launches", ctypes.c_int64),
-        ("polished_batches", ctypes.c_int64), ("cg_spmv_bytes", ctypes.c_int64),
+        ("polished_batches", ctypes.c_int64), ("cg_spmv_bytes", ctypes.c_int64), ("stream_slots", ctypes.c_int64),
     ]
 
     def as_dict(self):

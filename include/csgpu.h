@@ -100,7 +100,7 @@ typedef struct csgpu_opts {
   int32_t nu_post;        /* damped-Jacobi post-smoothing sweeps, default 1 */
   int32_t criterion;      /* CSGPU_CRIT_*, default KRYLOV (the reference's rule) */
   int32_t itmax;          /* default 100000 (core.jl:639) */
-  int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16; default 8 */
+  int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16,32; default 8 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
                              every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
   int32_t nu_coarse;      /* Jacobi sweeps (pre and post) on level 1; the levels below it (1/81 of the fine level's
@@ -190,6 +190,10 @@ typedef struct csgpu_stats {
   int64_t cg_spmv_bytes;        /* algorithmic bytes of ONE of the launches timed in cg_spmv_ms:
                                    CSR product: nnz*(val+4) + (n+1)*4 + n*K*(x + val);  lattice product with the fused
                                    search-direction update: n*5*val + n*K*3*x, plus n*K*val when it also stores A p */
+  int64_t stream_slots;         /* iterations of the K-wide stream when the call ran as a STREAMING solve (csrc/pcg.h,
+                                   pcg_stream_pairs: a column takes the next pair of the list as soon as its own has
+                                   converged; a pair costs its own iterations + 1 slots). 0: the batch path. The columns'
+                                   utilisation of a call is (total_iters + nrhs) / (stream_slots * batch) */
 } csgpu_stats;
 
 int csgpu_device_count(void);
@@ -299,7 +303,7 @@ int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const i
                          const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats);
 
 /* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
- * library's stream; returns the average milliseconds per launch. Used by bench.py for the roofline line. */
+ * library's stream (k up to 32); returns the average milliseconds per launch. Used by bench.py for the roofline line. */
 /* Scope row N2 / missing item "focal regions" -- effective resistance between SHORT-CIRCUITED NODE SETS on one
  * hierarchy. With focal regions (several cells per focal id) the reference merges the two regions of every pair into
  * one node each and builds a fresh graph and a fresh hierarchy per pair (_pt_file_polygons_path,

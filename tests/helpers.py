@@ -1339,3 +1339,70 @@ def check_single_level_handles_compute_in_matrix_precision(L):
     g = np.exp(np.random.default_rng(1).standard_normal((24, 21)))
     with L.raster_setup(g, L.default_opts(batch=1, precond_bytes=4)) as h:
         assert h.info["levels"] >= 2 and h.info["precond_bytes"] == 4
+
+
+def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nodata=False, sigma=1.0, oracle=None):
+    """Streaming pair solves (pcg_stream_pairs, csrc/pcg.h: a column takes the next pair of the call's list as soon as its
+    own pair has converged) against the batch path on the same handle options: every per-column quantity is independent
+    of the neighbouring columns, so resistances, gathered focal voltages and per-pair iteration counts must be IDENTICAL
+    (bit for bit) to the batch path's; the stream must have used fewer K-wide iterations than the batches' slowest columns
+    add up to; pairs with src == dst give R = 0 without occupying a slot. With `oracle`: resistances within 1e-6 of the
+    tight oracle's."""
+    rng = np.random.default_rng(3)
+    g = 1.0 / np.exp(sigma * np.random.default_rng(12345).standard_normal((N, N)))
+    if nodata:
+        g[rng.random((N, N)) < 0.12] = 0.0
+    valid = np.flatnonzero(g.ravel() > 0)
+    res = {}
+    for pb in pbs:
+        for mode in ("batch", "stream"):
+            monkeypatch.setenv("CSGPU_STREAM_MIN", "1")
+            if mode == "stream":
+                monkeypatch.setenv("CSGPU_STREAM", "1")          # from the first pair on
+                monkeypatch.delenv("CSGPU_NO_STREAM", raising=False)
+            else:
+                monkeypatch.delenv("CSGPU_STREAM", raising=False)
+                monkeypatch.setenv("CSGPU_NO_STREAM", "1")
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1)) as h:
+                nm = h.raster_nodemap()
+                lab, _ = h.components()
+                big = np.flatnonzero(lab == np.bincount(lab).argmax())
+                pts = np.random.default_rng(8).choice(big, size=12, replace=False)
+                src = [int(pts[i % 12]) for i in range(npairs)]
+                dst = [int(pts[(i * 5 + 1 + i // 12) % 12]) for i in range(npairs)]
+                src[3] = dst[3]                      # a degenerate pair in the middle of the list
+                gather = [int(p) for p in pts[:5]]
+                R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
+                assert st["not_converged"] == 0 and st["max_relres"] < 1e-4, (mode, st)
+                res[(pb, mode)] = (R.copy(), Gv.copy(), dict(st))
+                if mode == "stream":
+                    assert st["stream_slots"] > 0, "the streaming path did not run"
+                else:
+                    assert st["stream_slots"] == 0
+        Rb, Gb, sb = res[(pb, "batch")]
+        Rs, Gs, ss = res[(pb, "stream")]
+        assert np.array_equal(Rb, Rs), (pb, float(np.max(np.abs(Rb - Rs))))
+        assert np.array_equal(Gb, Gs)
+        assert Rs[3] == 0.0
+        assert ss["total_iters"] == sb["total_iters"] and ss["max_iters"] == sb["max_iters"]
+        # slots: every pair costs its iterations + 1, spread over `batch` columns, plus the drain at the end of the list
+        nsolved = npairs - 1
+        assert ss["stream_slots"] >= -(-(ss["total_iters"] + nsolved) // batch)
+        assert ss["stream_slots"] <= (ss["total_iters"] + nsolved) // batch + ss["max_iters"] + 2
+    # the adaptive rule (default): the first batch runs as a batch, the spread of its iteration counts decides for the rest
+    monkeypatch.delenv("CSGPU_NO_STREAM", raising=False)
+    monkeypatch.delenv("CSGPU_STREAM", raising=False)
+    for pb in pbs:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1)) as h:
+            R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
+            assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])
+            assert st["total_iters"] == res[(pb, "batch")][2]["total_iters"]
+    monkeypatch.delenv("CSGPU_STREAM_MIN", raising=False)
+    if oracle is not None:
+        A = oracle.regularize(rg.laplacian(rg.construct_graph(g, rg.construct_node_map(g, None), False, False)))
+        S = oracle.OracleAMG(A)
+        Ro, _, _ = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=4)
+        ok = np.asarray(src) != np.asarray(dst)
+        for pb in pbs:
+            Rs = res[(pb, "stream")][0]
+            assert np.max(np.abs(Rs[ok] - Ro[ok]) / Ro[ok]) < 1e-6, pb

@@ -1135,6 +1135,43 @@ def test_omniscape_moving_window_driver(emu_lib):
         assert np.max(np.abs(got - ref)) < 1e-7 * ref.max(), np.max(np.abs(got - ref)) / ref.max()
 
 
+def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch):
+    """see helpers.check_stream_pairs: all-valid raster, a raster with NODATA cells (cell space, very uneven iteration
+    counts), K = 8 and K = 16"""
+    from helpers import check_stream_pairs
+    check_stream_pairs(emu_lib, monkeypatch, N=90, batch=8, npairs=29, oracle=oracle)
+    check_stream_pairs(emu_lib, monkeypatch, N=84, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
+
+
+def test_batches_of_32_columns(emu_lib, oracle):
+    """opts.batch = 32 (round 4: the matrix values of every marching pass are amortised over twice as many columns): the
+    K = 32 instantiations of the marching kernels (TI = 16 rows per tile in fp64), the restriction, the CSR kernels of the
+    coarse levels and the coarse tail -- product hooks against the host products, and 37 pair solves (one full batch of 32
+    + a ragged one) against the tight oracle and against the K = 16 path."""
+    from helpers import check_lattice_product, check_lattice_transfer_products, check_level_products
+    from oracle import refgraph as rg
+    check_lattice_product(emu_lib, shapes=((70, 40),), ks=(32,), pbs=(0, 4))
+    check_lattice_transfer_products(emu_lib, shapes=((45, 45),), ks=(32,), pbs=(0, 4))
+    check_level_products(emu_lib, 70, 4, ks=(32,))
+    N = 96
+    G, g = rg.synthetic_raster_problem(N, N)
+    A = oracle.regularize(G)
+    cells = np.random.default_rng(5).choice(N * N, size=40, replace=False)
+    src = [int(cells[0])] * 32 + [int(cells[1])] * 5
+    dst = [int(c) for c in cells[1:33]] + [int(c) for c in cells[2:7]]
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=4)
+    for pb in (0, 4):
+        res = {}
+        for B in (16, 32):
+            with emu_lib.raster_setup(g, emu_lib.default_opts(batch=B, precond_bytes=pb)) as h:
+                R, _, _, st = h.solve_pairs(src, dst)
+                assert st["batch"] == B and st["not_converged"] == 0 and st["max_relres"] < 1e-4
+                assert np.max(np.abs(R - Ro) / Ro) < 1e-6, (pb, B)
+                res[B] = (R, st["total_iters"])
+        assert res[16][1] == res[32][1]                              # same iteration counts column by column
+        assert np.max(np.abs(res[16][0] - res[32][0]) / res[16][0]) < 1e-12
+
+
 def test_omniscape_windows_with_a_block_wider_than_the_disc(emu_lib):
     """ADVICE r3: radius < block_size // 2 -- the target's block reaches beyond the window, the slice that zeroes it must
     be clipped to the window (negative numpy indices count from the end). Multi-window mosaic against the independent

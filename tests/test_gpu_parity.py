@@ -554,3 +554,50 @@ def test_single_level_handles_compute_in_matrix_precision_gpu(gpu_lib):
     """a handle that is not coarsened ignores precond_bytes = 4 (fuzz findings)"""
     from helpers import check_single_level_handles_compute_in_matrix_precision
     check_single_level_handles_compute_in_matrix_precision(gpu_lib)
+
+
+def test_batches_of_32_columns_gpu(gpu_lib, oracle):
+    """opts.batch = 32 on the device (see tests/test_emu_solver.py::test_batches_of_32_columns): product hooks of the K = 32
+    kernels against host products, a full batch of 32 + a ragged batch at 1500^2 against the K = 16 path (same iteration
+    counts, resistances equal to rounding) and, at 600^2, against the tight oracle."""
+    from helpers import check_lattice_product, check_lattice_transfer_products, check_level_products
+    from oracle import refgraph as rg
+    check_lattice_product(gpu_lib, shapes=((270, 140), (64, 64)), ks=(32,), pbs=(0, 4))
+    check_lattice_transfer_products(gpu_lib, shapes=((145, 145), (35, 36)), ks=(32,), pbs=(0, 4))
+    check_level_products(gpu_lib, 200, 4, ks=(32,))
+    check_level_products(gpu_lib, 200, 0, ks=(32,))
+    N = 600
+    G, g = rg.synthetic_raster_problem(N, N)
+    A = oracle.regularize(G)
+    cells = np.random.default_rng(5).choice(N * N, size=40, replace=False)
+    src = [int(cells[0])] * 32 + [int(cells[1])] * 5
+    dst = [int(c) for c in cells[1:33]] + [int(c) for c in cells[2:7]]
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=16)
+    for pb in (0, 4):
+        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=32, precond_bytes=pb)) as h:
+            R, _, _, st = h.solve_pairs(src, dst)
+            assert st["batch"] == 32 and st["not_converged"] == 0 and st["max_relres"] < 1e-4
+            assert np.max(np.abs(R - Ro) / Ro) < 1e-6, pb
+    N = 1500
+    g = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((N, N)))
+    cells = np.random.default_rng(6).choice(N * N, size=40, replace=False)
+    src = [int(cells[0])] * 32 + [int(cells[1])] * 5
+    dst = [int(c) for c in cells[1:33]] + [int(c) for c in cells[2:7]]
+    for pb in (0, 4):
+        res = {}
+        for B in (16, 32):
+            with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=B, precond_bytes=pb)) as h:
+                R, _, _, st = h.solve_pairs(src, dst)
+                assert st["not_converged"] == 0
+                res[B] = (R, st["total_iters"])
+        assert res[16][1] == res[32][1]
+        assert np.max(np.abs(res[16][0] - res[32][0]) / res[16][0]) < 1e-10
+
+
+def test_streaming_pair_solves_match_the_batch_path_gpu(gpu_lib, oracle, monkeypatch):
+    """see helpers.check_stream_pairs (bit-identical resistances, gathered voltages and iteration counts of the streaming
+    and the batch path; the adaptive rule): all-valid and NODATA rasters, K = 8 / 16 / 32, on the device."""
+    from helpers import check_stream_pairs
+    check_stream_pairs(gpu_lib, monkeypatch, N=300, batch=8, npairs=29, oracle=oracle)
+    check_stream_pairs(gpu_lib, monkeypatch, N=700, batch=16, npairs=53, nodata=True, sigma=2.0)
+    check_stream_pairs(gpu_lib, monkeypatch, N=500, batch=32, npairs=75, pbs=(4,), nodata=True)
