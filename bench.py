@@ -211,6 +211,85 @@ def cg_product_name(info, B, vb):
     return "spmv_kernel<%s,%d,PLAIN,DOT,x=%s> (fine-level CSR CG SpMM)" % (tn[vb], B, tn[xb])
 
 
+def config3_fp32_leg(lib, size, B, dev_index, batch_pairs, sync, one_call):
+    """BASELINE configs[3] precision on one GPU: the all-fp32 handle (val_bytes = 4, the reference's `precision = single`,
+    src/run.jl:29) with the LIBRARY DEFAULTS = the reference's (regularisation eps(Float32) * norm(nzval) of every stored
+    entry, rtol 1e-6, atol sqrt(eps(Float32)), the 1e-4 check) on the bench raster; 1 warm-up + 3 timed steps. Parity of
+    this path at 5000^2 against the tight oracle on the same fp32-shifted matrix: tests/test_gpu_scale.py (2.3e-7)."""
+    g32 = make_raster(size, dtype=np.float32)
+    h = lib.raster_setup(g32, lib.default_opts(device=dev_index, batch=B))
+    try:
+        el, res, agg = run_pairs(h, batch_pairs, 3, 1, sync, one_call=one_call)
+        info = h.info
+    finally:
+        h.close()
+    sv = (info["setup_ms"] + info["upload_ms"]) / 1e3
+    return {"value": 3 * B / (el + sv * 3 * B / 100.0), "unit": "pair-solves/s", "dtype": "f32", "steps": 3,
+            "ms_per_16_pairs": el / 3 * 1e3 * 16.0 / B, "iters_mean": agg["total_iters"] / float(3 * B),
+            "max_relres": agg["max_relres"], "not_converged": agg["not_converged"], "setup_s": sv,
+            "note": "the reference's single-precision problem: every stored entry shifted by eps(Float32) * norm(nzval) "
+                    "(core.jl:161), ~4e-3 per entry at n = 1e8 -- a strongly grounded system, hence the low iteration count"}
+
+
+def random_network(n, seed=424242):
+    """BASELINE configs[4] generator (tools/network_bench.py, tests/test_gpu_scale.py): 10 n endpoint pairs, deduplicated,
+    giant component, conductances U(0.5, 2)."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    rng = np.random.default_rng(seed)
+    i = rng.integers(0, n, size=10 * n)
+    j = rng.integers(0, n, size=10 * n)
+    keep = i != j
+    lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+    key = np.unique(lo.astype(np.int64) * n + hi)
+    lo, hi = key // n, key % n
+    w = rng.uniform(0.5, 2.0, size=len(lo))
+    A = sp.coo_matrix((w, (lo, hi)), shape=(n, n)).tocsr()
+    A = (A + A.T).tocsr()
+    _, lab = csg.connected_components(A, directed=False)
+    giant = np.flatnonzero(lab == np.bincount(lab).argmax())
+    A = A[giant][:, giant]
+    G = (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A).tocsr()
+    G.sort_indices()
+    return G, rng
+
+
+def config4_network_leg(lib, dev_index, n=1000000, nsrc=16):
+    """BASELINE configs[4] at 1/5 of its size on one GPU: network mode, advanced one-to-all (src/raster/advanced.jl:274-312,
+    src/network/advanced.jl:1-51) -- unit current at one focal node, the other focal nodes tied to ground, every source a
+    column of ONE csgpu_solve_grounded on ONE handle. This random graph is an expander: the setup declines to coarsen it,
+    so the preconditioner is JACOBI (levels = 1), not AMG. Every column's residual is checked on the host."""
+    G, rng = random_network(n)
+    n = G.shape[0]
+    focal = rng.choice(n, size=nsrc, replace=False)
+    t0 = time.perf_counter()
+    h = lib.setup(G, lib.default_opts(device=dev_index, batch=16, precond_bytes=4, itmax=2000), index_dtype=np.int32,
+                  index_base=0)
+    t_setup = time.perf_counter() - t0
+    try:
+        info = h.info
+        B = np.zeros((n, nsrc))
+        grounds = []
+        for s_ in range(nsrc):
+            B[focal[s_], s_] = 1.0
+            grounds.append([int(q) for q in focal if q != focal[s_]])
+        t0 = time.perf_counter()
+        X, _, st = h.solve_grounded(B, grounds)
+        t_solve = time.perf_counter() - t0
+    finally:
+        h.close()
+    worst = 0.0
+    for s_ in range(nsrc):
+        r = G @ X[:, s_] - B[:, s_]
+        r[grounds[s_]] = 0.0
+        worst = max(worst, float(np.linalg.norm(r)))
+    return {"value": nsrc / (t_setup + t_solve), "unit": "one-to-all sources/s (setup + solves)", "n": int(n), "nnz": int(G.nnz),
+            "sources": nsrc, "levels": info["levels"],
+            "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi (expander: the setup declines to coarsen, amg_setup.h)",
+            "setup_s": t_setup, "solve_s_all_sources": t_solve, "iters_mean": st["total_iters"] / float(nsrc),
+            "not_converged": st["not_converged"], "worst_true_residual_norm": worst}
+
+
 def rank_identity(torch, rank, dev_index, has_cuda, ms_per_step, pairs_done, agg):
     """Per-rank facts for the N-GPU line: which physical device this rank ran on and what it did."""
     import socket
@@ -545,7 +624,8 @@ def main():
                 # (batches of at most 16 here: x, A p and b carried for all columns are 3 more n x K vectors)
                 hv = lib.raster_setup(g, make_opts(args.precond, explicit_check=1, batch=min(B, 16)))
                 vsteps = max(1, min(K, 3))
-                elv, resv, aggv = run_pairs(hv, batch_pairs, vsteps, 1, sync, one_call=one_call)
+                wv = min(1, Wm)   # (one warm-up step; the timed steps are the first `vsteps` steps of the main run)
+                elv, resv, aggv = run_pairs(hv, batch_pairs, vsteps, wv, sync, first_batch=Wm - wv, one_call=one_call)
                 iv = hv.info
                 sv = (iv["setup_ms"] + iv["upload_ms"]) / 1e3
                 hv.close()
@@ -558,6 +638,17 @@ def main():
                                         "note": "x carried over all n rows + explicit ||Ax-b||/||b|| check; no D2H of voltages"}
             except Exception as e:
                 out["with_voltages"] = {"failed": repr(e)}
+        if world == 1 and args.extra_legs and vb == 8:
+            # the two BASELINE configs the headline does not cover, driver-run: configs[3] precision (fp32) on this raster,
+            # configs[4] (network, advanced one-to-all) at n = 1e6
+            try:
+                out["config3_fp32"] = config3_fp32_leg(lib, size, B, dev_index, batch_pairs, sync, one_call)
+            except Exception as e:
+                out["config3_fp32"] = {"failed": repr(e)}
+            try:
+                out["config4_network"] = config4_network_leg(lib, dev_index)
+            except Exception as e:
+                out["config4_network"] = {"failed": repr(e)}
         if world == 1 and args.host_csr:
             try:
                 out.update(host_csr_setup(lib, g, make_opts(args.precond)))

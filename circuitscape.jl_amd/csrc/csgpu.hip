@@ -139,6 +139,19 @@ struct Solver : ISolver {
   DBuf comp_label;                    // connected-component label per node (computed on first use)
   int64_t ncomp = -1;
   int64_t raster_rows = 0, raster_cols = 0;
+  // Rasters with short-circuit polygons on the lattice path (poly.h): the handle solves in cell space (cellspace mapping:
+  // a polygon's node <-> its representative cell) with PCG projected onto the polygon-wise constants. Resistance-only
+  // pair solves run here; every other entry point of such a handle is served by a second solver built on first use from
+  // the MERGED graph (the CSR path csgpu_raster_setup_poly always had), from host copies of the two rasters.
+  bool poly_proj = false;
+  PolyProj proj;                       // device member lists (owned by the buffers below)
+  DBuf proj_ptr, proj_cells, proj_chunk_first, proj_chunk_poly, proj_poly_chunk0, proj_chunk_sum, cell_poly;
+  std::vector<int> poly_size;          // cells per polygon (dense index)
+  std::vector<T> poly_cond_host;       // the rasters the handle was built from (fallback solver)
+  std::vector<int32_t> poly_map_host;
+  int poly_four = 0, poly_avg = 0, poly_reg = 0;
+  std::unique_ptr<Solver<T, TP>> poly_fb;
+  std::mutex mu_fb;
   std::mutex mu;
 
   explicit Solver(const csgpu_opts& o) : opts(o) {
@@ -185,6 +198,7 @@ struct Solver : ISolver {
     pp.nu_post = opts.nu_post;
     pp.nu_coarse = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
     pp.use_graph = opts.use_graph;
+    pp.proj = poly_proj ? &proj : nullptr;
     return pp;
   }
   const Dia<T>* dia_ptr() const { return dia.n > 0 ? &dia : nullptr; }
@@ -504,6 +518,9 @@ struct Solver : ISolver {
     sp.size0 = cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr;
     sp.n_real = cellspace ? n_api : 0;
     if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;  // (see finish_setup)
+    // polygon handles: the strength-aware tiles are what keeps the strengthened polygon interiors (poly.h) out of the
+    // aggregates of their surroundings -- always on, however few cells the polygons cover
+    if (poly_proj) sp.tile_split_min = -1.0;
     SetupCarry carry;
     const bool ok = lattice_level0_setup<T, TP>(H, dia, (int)R, (int)C, cellspace ? dptr<long long>(size0) : (long long*)nullptr,
                                                 sp, carry, st);
@@ -662,9 +679,253 @@ struct Solver : ISolver {
       fprintf(stderr, "csgpu: cell-space raster without the index-free fine level (CSR kernels on %lld rows)\n", (long long)n);
   }
 
+  // Polygons on the lattice path (poly.h). Returns false -- nothing changed -- when the handle does not qualify (options
+  // that switch the index-free pipeline off, fewer than half of the cells carrying a row, no merged polygon) and the
+  // merged CSR graph is to be built instead. CSGPU_NO_POLY_LATTICE=1: A/B knob; CSGPU_POLY_STRENGTH: factor on the
+  // polygon-interior edges of the preconditioner's matrix (default 100; iterations on a 180^2 raster with 12 polygons: 23.6
+  // at 1 -- the plain projection --, 14.4 at 10, 12.0 at 60-100, 12.6 at 300, 16.8 at 1000, 24 at 1e4; 9 without polygons,
+  // 10.9 on the merged CSR graph).
+  bool setup_poly_lattice(const void* cond, const int32_t* polymap, int64_t R, int64_t C, int four, int avg_res, int reg,
+                          bool is_fallback) {
+    if (is_fallback || getenv("CSGPU_NO_POLY_LATTICE") || !want_lattice_pipeline(R, C)) return false;
+    if (getenv("CSGPU_NO_CELLSPACE") || ground_node.p) return false;
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t ncells = R * C;
+    const T* hc = (const T*)cond;
+    // ---- host: which polygons own a node, their member cells (column-major ids, ascending), rows of the lattice
+    int32_t maxid = 0;
+    for (int64_t k = 0; k < ncells; ++k) maxid = std::max(maxid, polymap[k]);
+    if (maxid <= 0 || maxid >= kMaxPolyId) return false;
+    std::vector<char> has_valid((size_t)maxid + 1, 0);
+    int64_t nvalid = 0;
+    for (int64_t k = 0; k < ncells; ++k) {
+      const bool v = hc[k] > T(0);
+      nvalid += v ? 1 : 0;
+      if (v && polymap[k] > 0) has_valid[(size_t)polymap[k]] = 1;
+    }
+    std::vector<int> dense((size_t)maxid + 1, -1);
+    int npoly = 0;
+    for (int32_t p = 1; p <= maxid; ++p)
+      if (has_valid[(size_t)p]) dense[(size_t)p] = npoly++;
+    if (npoly == 0) return false;
+    std::vector<int> count((size_t)npoly, 0);
+    int64_t nrows = 0;
+    for (int64_t k = 0; k < ncells; ++k) {
+      const int32_t p = polymap[k];
+      const bool member = p > 0 && dense[(size_t)p] >= 0;
+      if (member) ++count[(size_t)dense[(size_t)p]];
+      if (member || hc[k] > T(0)) ++nrows;
+    }
+    const double minfrac = getenv("CSGPU_CELLSPACE_MIN_FRAC") ? atof(getenv("CSGPU_CELLSPACE_MIN_FRAC")) : 0.5;
+    if ((double)nrows < minfrac * (double)ncells) return false;
+    // (polygons of a single cell are ordinary nodes: nothing to project)
+    std::vector<int> hptr((size_t)npoly + 1, 0);
+    for (int p = 0; p < npoly; ++p) hptr[(size_t)p + 1] = hptr[(size_t)p] + (count[(size_t)p] >= 2 ? count[(size_t)p] : 0);
+    std::vector<int> hcells((size_t)std::max(hptr[(size_t)npoly], 1));
+    {
+      std::vector<int> cur(hptr.begin(), hptr.end() - 1);
+      // row-major scan, column-major ids: every polygon's list is sorted afterwards (fixed summation order)
+      for (int64_t i = 0; i < R; ++i)
+        for (int64_t j = 0; j < C; ++j) {
+          const int32_t p = polymap[i * C + j];
+          if (p <= 0 || dense[(size_t)p] < 0) continue;
+          const int d = dense[(size_t)p];
+          if (count[(size_t)d] < 2) continue;
+          hcells[(size_t)cur[(size_t)d]++] = (int)(j * R + i);
+        }
+      for (int p = 0; p < npoly; ++p) std::sort(hcells.begin() + hptr[(size_t)p], hcells.begin() + hptr[(size_t)p + 1]);
+    }
+    std::vector<int> hchunk_first, hchunk_poly, hpoly_chunk0((size_t)npoly + 1, 0);
+    for (int p = 0; p < npoly; ++p) {
+      hpoly_chunk0[(size_t)p] = (int)hchunk_first.size();
+      for (int m = hptr[(size_t)p]; m < hptr[(size_t)p + 1]; m += kPolyChunk) {
+        hchunk_first.push_back(m);
+        hchunk_poly.push_back(p);
+      }
+    }
+    hpoly_chunk0[(size_t)npoly] = (int)hchunk_first.size();
+    // ---- host: shape of every polygon. CORE cells = members all of whose lattice neighbours (with a row) are members too.
+    std::vector<int> core((size_t)npoly, 0);
+    bool wire_like = false;
+    for (int p = 0; p < npoly; ++p) {
+      int64_t i0 = R, i1 = -1, j0 = C, j1 = -1;
+      for (int m = hptr[(size_t)p]; m < hptr[(size_t)p + 1]; ++m) {
+        const int64_t k = hcells[(size_t)m], ci = k % R, cj = k / R;
+        i0 = std::min(i0, ci);
+        i1 = std::max(i1, ci);
+        j0 = std::min(j0, cj);
+        j1 = std::max(j1, cj);
+        bool all = true;
+        for (int dj = -1; dj <= 1 && all; ++dj)
+          for (int di = -1; di <= 1 && all; ++di) {
+            if ((di == 0 && dj == 0) || (four && di != 0 && dj != 0)) continue;
+            const int64_t ii = ci + di, jj = cj + dj;
+            if (ii < 0 || ii >= R || jj < 0 || jj >= C) continue;
+            const int32_t q = polymap[ii * C + jj];
+            const bool row = hc[ii * C + jj] > T(0) || (q > 0 && dense[(size_t)q] >= 0);
+            if (row && !(q > 0 && dense[(size_t)q] == p)) all = false;
+          }
+        core[(size_t)p] += all ? 1 : 0;
+      }
+      // A LONG, THIN polygon (a river, a road, the sliver one polygon leaves of another) short-circuits cells many tiles
+      // apart, and its cells are minority pieces of their tiles: no strength of its interior edges makes the cell-space
+      // hierarchy see that. Measured at 5000^2 with 200 strips of up to 80 cells (profiles/r4_polygon_strip_width_sweep.txt):
+      // 2 cells wide 45 iterations against 13 on the merged graph (429 ms per batch against 201), 3-5 wide a tie
+      // (19-20 iterations, ~200 ms either way), 8 wide 16 iterations and 163 ms against 217. Such rasters keep the
+      // merged CSR graph: the lattice path requires every polygon that is at least 8 cells long to have 45 % core cells.
+      const int64_t extent = std::max(i1 - i0, j1 - j0) + 1;
+      if (count[(size_t)p] >= 2 && extent >= 8 && (double)core[(size_t)p] < 0.45 * (double)count[(size_t)p]) wire_like = true;
+    }
+    if (wire_like && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
+      if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a long thin polygon: merged CSR graph instead of the lattice path\n");
+      return false;
+    }
+    // ---- device: labels and node numbering exactly as the merged path computes them (raster.h)
+    const int gc = grid_for(ncells);
+    DBuf dcond((size_t)ncells * sizeof(T)), dpoly = dalloc<int>((size_t)ncells);
+    CS_HIP(hipMemcpyAsync(dcond.p, cond, (size_t)ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    CS_HIP(hipMemcpyAsync(dpoly.p, polymap, (size_t)ncells * sizeof(int), hipMemcpyHostToDevice, st));
+    DBuf rep = dalloc<int>((size_t)maxid + 2), present = dalloc<int>((size_t)maxid + 2);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(maxid + 2)), dim3(256), 0, st, dptr<int>(rep), (int64_t)maxid + 2,
+                       0x7fffffff);
+    hipLaunchKernelGGL((poly_rep_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       (const int*)dpoly.p, dptr<int>(rep));
+    DBuf label = dalloc<int>((size_t)ncells), flag = dalloc<int>((size_t)ncells + 1), total = dalloc<int>(1);
+    CS_HIP(hipMemsetAsync(flag.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+    hipLaunchKernelGGL((poly_label_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                       (const int*)dpoly.p, (const int*)dptr<int>(rep), dptr<int>(label), dptr<int>(flag));
+    exclusive_scan_i32(dptr<int>(flag), ncells + 1, st, dptr<int>(total));
+    n_api = read_int(dptr<int>(total), st);
+    CS_REQUIRE(n_api > 0, CSGPU_BAD_ARGS, "raster has no cell with positive conductance");
+    hipLaunchKernelGGL(poly_present_kernel, dim3(grid_for(maxid + 1)), dim3(256), 0, st, maxid, (const int*)dptr<int>(rep),
+                       dptr<int>(present));
+    CS_HIP(hipMemsetAsync(dptr<int>(present) + maxid + 1, 0, sizeof(int), st));
+    exclusive_scan_i32(dptr<int>(present), (int64_t)maxid + 2, st, dptr<int>(total));
+    CS_REQUIRE(read_int(dptr<int>(total), st) == npoly, CSGPU_INTERNAL, "polygon count of the device and the host scan differ");
+    raster_rows = R;
+    raster_cols = C;
+    n = ncells;
+    cellspace = true;
+    poly_proj = true;
+    nodemap.alloc((size_t)ncells * sizeof(int));
+    cellmap.alloc((size_t)ncells * sizeof(int));
+    node2cell.alloc((size_t)n_api * sizeof(int));
+    cell2node.alloc((size_t)ncells * sizeof(int));
+    cell_poly.alloc((size_t)ncells * sizeof(int));
+    {
+      DBuf node = dalloc<int>((size_t)ncells), drow((size_t)n_api * sizeof(int)), dcol((size_t)n_api * sizeof(int));
+      DBuf node_poly = dalloc<int>((size_t)n_api), poly_node = dalloc<int>((size_t)std::max(npoly, 1));
+      hipLaunchKernelGGL(poly_node_kernel, dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const int*)dpoly.p,
+                         (const int*)dptr<int>(rep), (const int*)dptr<int>(label), (const int*)dptr<int>(flag),
+                         (const int*)dptr<int>(present), dptr<int>(node), dptr<int>(nodemap), dptr<int>(drow), dptr<int>(dcol),
+                         dptr<int>(node_poly), dptr<int>(poly_node));
+      hipLaunchKernelGGL(poly_cell_maps_kernel, dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const int*)dptr<int>(label),
+                         (const int*)dptr<int>(node), (const int*)dptr<int>(node_poly), dptr<int>(cellmap),
+                         dptr<int>(cell2node), dptr<int>(cell_poly));
+      hipLaunchKernelGGL(poly_node2cell_kernel, dim3(grid_for(n_api)), dim3(256), 0, st, n_api, (int)R,
+                         (const int*)dptr<int>(drow), (const int*)dptr<int>(dcol), dptr<int>(node2cell));
+      check_launch("polygon maps");
+      CS_HIP(hipStreamSynchronize(st));
+    }
+    // ---- lattice form with strengthened polygon interiors, regularisation, weights
+    // Strength of the polygon-interior edges in the preconditioner's matrix, per polygon. Measured on MI355X at 5000^2
+    // (profiles/r4_polygon_strength_sweep.txt): polygons up to 100 cells across want ~1000 (11.2 iterations against 10.4
+    // without polygons; 18.5 at 100, 18.7 at 1e4), polygons up to 20 cells across ~100 (13.9; 33 at 1000), polygons of a
+    // few cells less still -- the hierarchy copes with a stiff inclusion once it spans several 3x3 tiles, while a stiff
+    // speck inside a tile only unbalances the smoother. Hence strength = coef * (member cells), clamped.
+    // CSGPU_POLY_STRENGTH fixes one value for all polygons (A/B knob).
+    const double s_fixed = getenv("CSGPU_POLY_STRENGTH") ? atof(getenv("CSGPU_POLY_STRENGTH")) : 0.0;
+    const double s_coef = getenv("CSGPU_POLY_COEF") ? atof(getenv("CSGPU_POLY_COEF")) : 1.0;
+    const double s_min = getenv("CSGPU_POLY_SMIN") ? atof(getenv("CSGPU_POLY_SMIN")) : 8.0;
+    const double s_max = getenv("CSGPU_POLY_SMAX") ? atof(getenv("CSGPU_POLY_SMAX")) : 1000.0;
+    // ... of a BLOB: the member count is discounted by the polygon's share of core cells -- full weight from 40 % core
+    // cells on (a square of 5 x 5 has 36 %), proportionally less below.
+    std::vector<double> hstrength((size_t)npoly);
+    for (int p = 0; p < npoly; ++p) {
+      const double cnt_p = (double)count[(size_t)p];
+      const double blob = std::min(1.0, 2.5 * (double)core[(size_t)p] / std::max(cnt_p, 1.0));
+      hstrength[(size_t)p] = s_fixed > 0.0 ? s_fixed : std::min(s_max, std::max(s_min, s_coef * cnt_p * blob));
+    }
+    DBuf dstrength = dalloc<double>((size_t)npoly);
+    CS_HIP(hipMemcpyAsync(dstrength.p, hstrength.data(), hstrength.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    const double strength = s_fixed;
+    dia.n = ncells;
+    dia.R = (int)R;
+    dia.rows.alloc((size_t)ncells * 5 * sizeof(T));
+    DBuf part = dalloc<double>(gc), cnt = dalloc<unsigned long long>(gc), size0;
+    hipLaunchKernelGGL((raster_dia_poly_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
+                       (const T*)dptr<T>(dcond), (const int*)dptr<int>(label), (const int*)dptr<int>(cell_poly),
+                       (const double*)dptr<double>(dstrength), dptr<T>(dia.rows), dptr<double>(part),
+                       dptr<unsigned long long>(cnt));
+    size0.alloc((size_t)ncells * sizeof(long long));
+    hipLaunchKernelGGL((raster_dia_poly_finish_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C,
+                       (const int*)dptr<int>(label), dptr<T>(dia.rows), (const double*)dptr<double>(part), gc,
+                       reg ? (double)std::numeric_limits<T>::epsilon() : 0.0, dptr<long long>(size0));
+    std::vector<unsigned long long> hcnt((size_t)gc);
+    CS_HIP(hipMemcpyAsync(hcnt.data(), cnt.p, hcnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    check_launch("raster + polygons -> lattice form");
+    CS_HIP(hipStreamSynchronize(st));
+    nnz_api = 0;
+    for (unsigned long long v : hcnt) nnz_api += (int64_t)v;  // (entries of the cell-space matrix outside the polygons' interiors)
+    nnz = nnz_api + (n - nrows);
+    // ---- member lists of the projection
+    auto up = [&](DBuf& d, const std::vector<int>& h) {
+      d.alloc(std::max<size_t>(h.size(), 1) * sizeof(int));
+      if (!h.empty()) CS_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    };
+    up(proj_ptr, hptr);
+    up(proj_cells, hcells);
+    up(proj_chunk_first, hchunk_first);
+    up(proj_chunk_poly, hchunk_poly);
+    up(proj_poly_chunk0, hpoly_chunk0);
+    proj_chunk_sum.alloc(std::max<size_t>(hchunk_first.size(), 1) * kMaxK * sizeof(double));
+    CS_HIP(hipStreamSynchronize(st));
+    proj.npoly = npoly;
+    proj.nchunks = (int)hchunk_first.size();
+    proj.ptr = dptr<int>(proj_ptr);
+    proj.cells = dptr<int>(proj_cells);
+    proj.chunk_first = dptr<int>(proj_chunk_first);
+    proj.chunk_poly = dptr<int>(proj_chunk_poly);
+    proj.poly_chunk0 = dptr<int>(proj_poly_chunk0);
+    proj.chunk_sum = dptr<double>(proj_chunk_sum);
+    poly_size = count;
+    dcond.release();
+    dpoly.release();
+    upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!lattice_pipeline_hierarchy(size0, R, C)) {
+      // (cannot happen for tile aggregates) undo: the merged CSR path takes over
+      poly_proj = cellspace = false;
+      dia = Dia<T>();
+      proj = PolyProj();
+      return false;
+    }
+    // the fallback solver (merged CSR graph) is built from these on first use
+    poly_cond_host.assign(hc, hc + ncells);
+    poly_map_host.assign(polymap, polymap + ncells);
+    poly_four = four;
+    poly_avg = avg_res;
+    poly_reg = reg;
+    if (getenv("CSGPU_VERBOSE"))
+      fprintf(stderr, "csgpu: %d polygons (%d member cells, %d chunks) on the lattice path, interior strength %s %g\n", npoly,
+              hptr[(size_t)npoly], proj.nchunks, strength > 0 ? "fixed at" : "per polygon, coefficient", strength > 0 ? strength : s_coef);
+    return true;
+  }
+
+  // the merged-graph solver behind a polygon handle of the lattice path (entry points other than resistance-only pairs)
+  Solver<T, TP>& poly_fallback() {
+    std::lock_guard<std::mutex> lk(mu_fb);
+    if (!poly_fb) {
+      poly_fb.reset(new Solver<T, TP>(opts));
+      poly_fb->setup_from_raster_poly(poly_cond_host.data(), poly_map_host.data(), raster_rows, raster_cols, poly_four,
+                                      poly_avg, poly_reg, /*is_fallback=*/true);
+    }
+    return *poly_fb;
+  }
+
   // csgpu_raster_setup_poly: raster with short-circuit polygons, graph built on the device (raster.h, second half)
   void setup_from_raster_poly(const void* cond, const int32_t* polymap, int64_t R, int64_t C, int four, int avg_res,
-                              int reg) {
+                              int reg, bool is_fallback = false) {
+    if (setup_poly_lattice(cond, polymap, R, C, four, avg_res, reg, is_fallback)) return;
     auto t0 = std::chrono::steady_clock::now();
     const int64_t ncells = R * C;
     const int gc = grid_for(ncells);
@@ -790,6 +1051,7 @@ struct Solver : ISolver {
   }
 
   int64_t components(int32_t* out) override {
+    if (poly_proj) return poly_fallback().components(out);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     ensure_components();
@@ -820,6 +1082,7 @@ struct Solver : ISolver {
   // one raster or for many windows stacked into one raster with NODATA separators -- every window is a component of
   // ONE block-diagonal system, solved by ONE PCG). curr_out / volt_out: row-major rasters, 0 where there is no node.
   void solve_raster(const void* source, void* curr_out, void* volt_out, csgpu_stats* stats) override {
+    if (poly_proj) return poly_fallback().solve_raster(source, curr_out, volt_out, stats);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -959,6 +1222,11 @@ struct Solver : ISolver {
   void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out, const int64_t* gather,
                    int64_t ngather, void* gathered_out, void* resist_out, csgpu_stats* stats, const int32_t* weights,
                    void* curr_out, void* cum_inout, void* max_inout, void* branch_out) override {
+    // polygon handle of the lattice path: resistances (and gathered focal voltages) here, everything else -- voltage /
+    // current maps, explicit checks of whole solutions -- on the merged graph
+    if (poly_proj && (volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0))
+      return poly_fallback().solve_pairs(src, dst, npairs, volt_out, gather, ngather, gathered_out, resist_out, stats, weights,
+                                         curr_out, cum_inout, max_inout, branch_out);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -975,6 +1243,23 @@ struct Solver : ISolver {
     src = src_r.p;
     dst = dst_r.p;
     gather = gather_r.p;
+    std::vector<int> src_psize, dst_psize;  // polygon handles: cells of the polygon a pair's node stands for (1: ordinary)
+    if (poly_proj && npairs > 0) {
+      DBuf ids = dalloc<int64_t>((size_t)2 * npairs), pidx = dalloc<int>((size_t)2 * npairs);
+      CS_HIP(hipMemcpyAsync(ids.p, src, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      CS_HIP(hipMemcpyAsync(dptr<int64_t>(ids) + npairs, dst, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(gather_int_kernel, dim3(grid_for(2 * npairs)), dim3(256), 0, st, 2 * npairs,
+                         (const int64_t*)dptr<int64_t>(ids), (const int*)dptr<int>(cell_poly), dptr<int>(pidx));
+      std::vector<int> hp((size_t)2 * npairs);
+      CS_HIP(hipMemcpyAsync(hp.data(), pidx.p, hp.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      src_psize.resize((size_t)npairs);
+      dst_psize.resize((size_t)npairs);
+      for (int64_t p = 0; p < npairs; ++p) {
+        src_psize[(size_t)p] = hp[(size_t)p] >= 0 ? poly_size[(size_t)hp[(size_t)p]] : 1;
+        dst_psize[(size_t)p] = hp[(size_t)npairs + p] >= 0 ? poly_size[(size_t)hp[(size_t)npairs + p]] : 1;
+      }
+    }
     if (ncomp > 1) {
       // a pair across two components is an inconsistent singular system (the reference only pairs points of one
       // component, core.jl:146-153): refuse it instead of iterating to itmax
@@ -1007,7 +1292,7 @@ struct Solver : ISolver {
     // 2^25) moves that bound; CSGPU_STREAM=1 streams from the first pair on (tests, A/B), CSGPU_NO_STREAM=1 never.
     bool stream_eligible = false, stream_now = false;
     if (!(volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0) && dia_ptr() && npairs > K &&
-        K >= 8 && !getenv("CSGPU_NO_STREAM")) {
+        K >= 8 && !poly_proj && !getenv("CSGPU_NO_STREAM")) {
       const char* sm = getenv("CSGPU_STREAM_MIN");
       stream_eligible = (int64_t)n * K >= (sm ? atoll(sm) : ((int64_t)1 << 25));
       const char* fs = getenv("CSGPU_STREAM");
@@ -1093,6 +1378,14 @@ struct Solver : ISolver {
                                            dptr<int>(ddst), ncols));
       double bb[kMaxK];
       for (int c = 0; c < kMaxK; ++c) bb[c] = (c < K && s32[c] != d32[c]) ? 2.0 : 0.0;
+      if (poly_proj) {
+        // ||Pi b||^2: a unit current into a polygon's node is spread evenly over the polygon's cells
+        for (int c = 0; c < K; ++c)
+          if (s32[c] != d32[c]) {
+            const int64_t q = p0 + std::min(c, ncols - 1);
+            bb[c] = 1.0 / (double)std::max(src_psize[(size_t)q], 1) + 1.0 / (double)std::max(dst_psize[(size_t)q], 1);
+          }
+      }
       if (!need_x && MIXED) {  // the fp32 copy of r0 the V-cycle reads, written directly
         CS_HIP(hipMemsetAsync(W.rp.p, 0, (size_t)n * K * sizeof(TP), st));
         CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<TP, KK>), dim3(1), dim3(64), 0, st, dptr<TP>(W.rp),
@@ -1116,7 +1409,11 @@ struct Solver : ISolver {
           sum += r.s.iters[c];
           mx = std::max(mx, r.s.iters[c]);
         }
-        stream_now = sum / K + 1.0 < 0.97 * (mx + 0.5);
+        // (measured on MI355X, profiles/r4_stream_*.jsonl: at 10000^2 with 15 % NODATA a batch's slowest column is only
+        // ~0.5 iterations above the batch's mean -- the 13.9 against 16 of round 3 compared the mean with the maximum over
+        // ALL batches -- and the stream's 91 slots for 96 pairs buy nothing against 6 batches; on a sigma = 3 raster, 82
+        // against ~90 per batch, streaming is 4 % faster)
+        stream_now = (sum / K + 1.0) * 1.04 < mx + 0.5;
       }
       const int ge = grid_for((int64_t)ncols * (ngather + 1));
       if (need_x) {
@@ -1191,6 +1488,7 @@ struct Solver : ISolver {
   }
 
   void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) override {
+    if (poly_proj) return poly_fallback().solve_rhs(rhs, nrhs, x_out, stats);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -1221,6 +1519,7 @@ struct Solver : ISolver {
   // N2: per-column Dirichlet sets on one hierarchy (see csgpu_solve_grounded in csgpu.h)
   void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
                       void* curr_out, csgpu_stats* stats) override {
+    if (poly_proj) return poly_fallback().solve_grounded(rhs, nrhs, gptr, gidx, x_out, curr_out, stats);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -1310,6 +1609,7 @@ struct Solver : ISolver {
   // J at 0, and R = 1 / v'Av (the energy form: its error is second order in the error of the iterate).
   void solve_region_pairs(const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets, const int64_t* src_set,
                           const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) override {
+    if (poly_proj) return poly_fallback().solve_region_pairs(set_ptr, set_nodes, nsets, src_set, dst_set, npairs, resistances, stats);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
@@ -1516,6 +1816,7 @@ struct Solver : ISolver {
   }
 
   double spmv_bench(int k, int reps) override {
+    if (poly_proj) return poly_fallback().spmv_bench(k, reps);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     ensure_csr();
@@ -1544,6 +1845,7 @@ struct Solver : ISolver {
   }
 
   void spmv_host(const void* xh, void* yh, int k) override {
+    if (poly_proj) return poly_fallback().spmv_host(xh, yh, k);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     ensure_csr();
@@ -1622,6 +1924,7 @@ struct Solver : ISolver {
   bool csr_ready_at_setup() const { return H.levels[0].Q.nnz > 0 || !H.levels[0].lattice_two_product() || H.levels.size() < 2; }
 
   void level_spmv_host(int lvl, int which, const void* xh, void* yh, int k, double* dots) override {
+    if (poly_proj) return poly_fallback().level_spmv_host(lvl, which, xh, yh, k, dots);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
@@ -1670,6 +1973,8 @@ struct Solver : ISolver {
 
   void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
                         int32_t* colidx, void* vals) const override {
+    if (poly_proj)
+      return const_cast<Solver<T, TP>*>(this)->poly_fallback().get_level_matrix(lvl, which, nrows, ncols, nnz_out, rowptr, colidx, vals);
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     auto* self = const_cast<Solver<T, TP>*>(this);  // (hooks may build the CSR forms they inspect)
     if (lvl == 0 && which == 0) self->ensure_csr();
@@ -1733,6 +2038,7 @@ struct Solver : ISolver {
 
   void dia_product_host(const void* zh, const void* ph, const double* beta, void* pout_h, void* yh, int k,
                         double* dots) override {
+    if (poly_proj) return poly_fallback().dia_product_host(zh, ph, beta, pout_h, yh, k, dots);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(dia.n > 0, CSGPU_BAD_ARGS, "matrix has no lattice form");

@@ -18,6 +18,7 @@
 #include "lattice.h"
 #include "tail.h"
 #include "raster.h"
+#include "poly.h"
 
 namespace csgpu {
 
@@ -375,6 +376,9 @@ struct PcgParams {
   const int* gptr = nullptr;
   const int* gidx = nullptr;
   int gtotal = 0;
+  // Rasters with short-circuit polygons on the lattice path (poly.h): PCG in the subspace of the vectors that are
+  // constant on every polygon -- r and z are projected (averaged over each polygon's cells) after every update.
+  const PolyProj* proj = nullptr;
 };
 
 // One captured chunk of `check_every` PCG iterations. Kernel arguments are baked in at capture time, so a graph is
@@ -390,11 +394,12 @@ struct PcgGraphKey {
   const void* gptr = nullptr;
   const void* gidx = nullptr;
   int gtotal = 0;
+  const void* proj = nullptr;  // member lists of a polygon handle (poly.h)
   bool operator==(const PcgGraphKey& o) const {
     return K == o.K && ncols_active == o.ncols_active && criterion == o.criterion && nu_pre == o.nu_pre &&
            nu_post == o.nu_post && nu_coarse == o.nu_coarse && iters == o.iters && rtol == o.rtol && atol == o.atol &&
            matrix == o.matrix && need_x == o.need_x && nf == o.nf && parity == o.parity && gptr == o.gptr &&
-           gidx == o.gidx && gtotal == o.gtotal;
+           gidx == o.gidx && gtotal == o.gtotal && proj == o.proj;
   }
 };
 
@@ -546,6 +551,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   TP* xa0 = dptr<TP>(L0.xa);
   const TP omega0 = (TP)L0.omega;
   const bool grounded = pp.gptr && pp.gtotal > 0;
+  const bool projected = pp.proj && pp.proj->nchunks > 0;  // polygons: PCG in the subspace of polygon-wise constants
   // Dirichlet-masked solves run on the hierarchy of the UNGROUNDED Laplacian: its coarsest pseudo-inverse answers the
   // constant vector with a gain of 1 / (regularisation shift), a right-hand side with a non-zero mean (a unit source)
   // then has an astronomically large r0' M^-1 r0, and the reference's relative rule on that norm is met at once (fuzz
@@ -617,8 +623,12 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
   if (MIXED && !(pp.rhs_in_r && pp.rp_ready))
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
+  // polygons: r0 = Pi b (a unit current into a polygon node is spread evenly over the polygon's cells)
+  if (projected) poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)nullptr, st);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
   vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+  // (the fused r'z partials are those of the projected z too: r is in the subspace, r'z = r'(Pi z))
+  if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)nullptr, st);
   // (the fused r'z partials are unaffected by masking z afterwards: r is zero at the grounded entries)
   if (grounded)
     hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
@@ -728,7 +738,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       else CS_UPD_R(false, false);
 #undef CS_UPD_R
     }
-    const bool rr_after_mask = grounded && criterion != CSGPU_CRIT_KRYLOV;
+    const bool rr_after_mask = (grounded || projected) && criterion != CSGPU_CRIT_KRYLOV;
+    if (projected) {  // r <- Pi r: the residual of the projected system (both precisions)
+      poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done, st);
+      if (rr_after_mask)
+        hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
+                           (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+    }
     if (grounded) {  // the update put (A p) at the grounded rows into r: back to zero, in both precisions
       hipLaunchKernelGGL((mask_grounds_kernel<T, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, r,
                          MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done);
@@ -742,6 +758,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)&S->all_done, st);
     if (grounded)
       hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
                          (const int*)&S->all_done);
@@ -783,6 +800,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   gkey.gptr = grounded ? (const void*)pp.gptr : nullptr;
   gkey.gidx = grounded ? (const void*)pp.gidx : nullptr;
   gkey.gtotal = grounded ? pp.gtotal : 0;
+  gkey.proj = projected ? (const void*)pp.proj->cells : nullptr;
   auto chunk_graph = [&]() -> hipGraphExec_t {
     for (auto& g : W.graphs)
       if (g.first == gkey) return g.second;
@@ -865,7 +883,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       }
     } else {
       // fp64 recurrence residual against ||b|| recorded at start-up
-      if (recompute && it > 0 && !grounded) {
+      if (recompute && it > 0 && !grounded && !projected) {
         // ||r||^2 partials of the last residual update that ran (surplus launches exit before writing)
         auto rr = collapsed(pb, spmv_g, pcc);
         hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, rr.first, rr.second, (const double*)nullptr, 0);

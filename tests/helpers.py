@@ -1381,8 +1381,17 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
                     assert st["stream_slots"] == 0
         Rb, Gb, sb = res[(pb, "batch")]
         Rs, Gs, ss = res[(pb, "stream")]
-        assert np.array_equal(Rb, Rs), (pb, float(np.max(np.abs(Rb - Rs))))
-        assert np.array_equal(Gb, Gs)
+        if pb == 0:
+            assert np.array_equal(Rb, Rs), (pb, float(np.max(np.abs(Rb - Rs))))
+            assert np.array_equal(Gb, Gs)
+        else:
+            # fp32 hierarchy on the device: a pair's result depends on the COLUMN it is solved in at the 1e-13 level (the
+            # same pair in columns 0, 5 and 15 of a batch: tools/debug/column_probe.py, profiles/r4_column_probe_1500.jsonl
+            # -- the compiler's per-element choices in the 4-column fp32 vectors; not on the emulator, not in fp64), and a
+            # streamed pair does not sit in the column the batch path gives it
+            ok = Rb != 0
+            assert np.max(np.abs(Rb[ok] - Rs[ok]) / np.abs(Rb[ok])) < 1e-10, pb
+            assert np.max(np.abs(Gb - Gs)) < 1e-10 * max(1.0, float(np.max(np.abs(Gb))))
         assert Rs[3] == 0.0
         assert ss["total_iters"] == sb["total_iters"] and ss["max_iters"] == sb["max_iters"]
         # slots: every pair costs its iterations + 1, spread over `batch` columns, plus the drain at the end of the list
@@ -1395,7 +1404,10 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
     for pb in pbs:
         with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1)) as h:
             R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
-            assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])
+            if pb == 0:
+                assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])
+            else:
+                assert np.max(np.abs(R - res[(pb, "batch")][0])) < 1e-10 * float(np.max(np.abs(R)))
             assert st["total_iters"] == res[(pb, "batch")][2]["total_iters"]
     monkeypatch.delenv("CSGPU_STREAM_MIN", raising=False)
     if oracle is not None:
@@ -1406,3 +1418,105 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
         for pb in pbs:
             Rs = res[(pb, "stream")][0]
             assert np.max(np.abs(Rs[ok] - Ro[ok]) / Ro[ok]) < 1e-6, pb
+
+
+def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=(0, 4), tol=2e-9):
+    """Rasters with short-circuit polygons on the index-free lattice path (csrc/poly.h: PCG projected onto the vectors that
+    are constant on every polygon, polygon interiors strengthened in the preconditioner's matrix) against the MERGED graph
+    the reference builds (construct_node_map with a polymap, src/raster/pairwise.jl:276-301) -- through the merged CSR
+    path of the same library (CSGPU_NO_POLY_LATTICE=1; that path is pinned on the reference's goldens and known answers,
+    check_polygon_graph_on_device) and through a direct solve of the merged matrix downloaded from it. The raster has
+    NODATA cells, a polygon that CONTAINS NODATA cells (they belong to the polygon's node, as in the reference), a polygon
+    id used in two separate places, a single-cell polygon; pairs between polygon nodes, ordinary nodes and both; gathered
+    focal voltages; voltages of a whole solution through the fall-back solver of the same handle."""
+    import scipy.sparse.linalg as spla
+    R_, C_ = shape
+    rng = np.random.default_rng(17)
+    g = np.exp(rng.standard_normal(shape))
+    g[rng.random(shape) < 0.06] = 0.0
+    poly = np.zeros(shape, dtype=np.int32)
+    poly[5:14, 8:17] = 1
+    g[7:9, 10:12] = 0.0                      # NODATA inside polygon 1
+    poly[30:37, 3:10] = 2
+    poly[40:46, 40:50] = 2                   # polygon 2 in two places
+    poly[20, 30] = 3                         # a single cell
+    poly[50:60, 20:26] = 4
+    g[20, 30] = 1.3
+    monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
+    with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-11, atol=0.0, criterion=1), polymap=poly) as h:
+        assert h.info["lattice_period"] == 0
+        nm_ref = h.raster_nodemap()
+        A = h.level_matrix(0, "A").astype(np.float64)
+        lab, _ = h.components()
+    monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
+    n = A.shape[0]
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    pnodes = [int(nm_ref[6, 9]) - 1, int(nm_ref[41, 41]) - 1, int(nm_ref[20, 30]) - 1, int(nm_ref[55, 21]) - 1]
+    assert int(nm_ref[31, 4]) - 1 == pnodes[1]                       # both places of polygon 2 share a node
+    assert int(nm_ref[7, 10]) - 1 == pnodes[0]                       # a NODATA cell inside polygon 1 shares its node
+    pnodes = [p for p in pnodes if p in set(big.tolist())]
+    others = [int(v) for v in np.random.default_rng(2).choice(np.setdiff1d(big, pnodes), size=6, replace=False)]
+    nodes = pnodes + others
+    src = [nodes[i % len(nodes)] for i in range(9)]
+    dst = [nodes[(i * 3 + 1) % len(nodes)] for i in range(9)]
+    keep = [k for k in range(9) if src[k] != dst[k]]
+    src, dst = [src[k] for k in keep], [dst[k] for k in keep]
+    gather = nodes[:5]
+    # direct solve of the merged (regularised) matrix, grounded at node 0 of the component
+    free = big[1:]
+    lu = spla.splu(A[free][:, free].tocsc())
+    Rd = np.zeros(len(src))
+    Gd = np.zeros((len(src), len(gather)))
+    pos = {int(v): k for k, v in enumerate(free)}
+    for k, (a, b) in enumerate(zip(src, dst)):
+        rhs = np.zeros(len(free))
+        if a in pos:
+            rhs[pos[a]] -= 1.0
+        if b in pos:
+            rhs[pos[b]] += 1.0
+        x = np.zeros(n)
+        x[free] = lu.solve(rhs)
+        Rd[k] = x[b] - x[a]
+        Gd[k] = x[gather] - x[a]
+    for pb in pbs:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, rtol=1e-11, atol=0.0, criterion=1),
+                            polymap=poly) as h:
+            info = h.info
+            assert info["lattice_period"] == R_ and info["n"] == n, (info["lattice_period"], info["n"], n)
+            assert np.array_equal(h.raster_nodemap(), nm_ref)
+            Rl, Gl, _, st = h.solve_pairs(src, dst, gather=gather)
+            assert st["not_converged"] == 0
+            assert np.max(np.abs(Rl - Rd) / np.abs(Rd)) < tol, (pb, Rl, Rd)
+            assert np.max(np.abs(Gl - Gd)) < tol * max(1.0, np.max(np.abs(Gd)))
+            # a whole solution: served by the merged-graph solver behind the same handle
+            _, _, V, _ = h.solve_pairs(src[:2], dst[:2], want_voltages=True)
+            assert V.shape == (n, 2) and abs((V[dst[0], 0] - V[src[0], 0]) - Rd[0]) < 10 * tol * abs(Rd[0])
+        # the reference's tolerances: same answers to 1e-6, iteration count within reach of the polygon-free raster's
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), polymap=poly) as h:
+            Rl, _, _, st = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+            assert np.max(np.abs(Rl - Rd) / np.abs(Rd)) < 1e-6
+            it_poly = st["total_iters"] / float(len(src))
+        gfree = np.where(g > 0, g, 0.0)
+        with L.raster_setup(gfree, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+            nm0 = h.raster_nodemap()
+            lab0, _ = h.components()
+            big0 = np.flatnonzero(lab0 == np.bincount(lab0).argmax())
+            pick = np.random.default_rng(4).choice(big0, size=2 * batch, replace=False)
+            _, _, _, st0 = h.solve_pairs([int(v) for v in pick[:batch]], [int(v) for v in pick[batch:]])
+            it_free = st0["total_iters"] / float(batch)
+        assert it_poly <= 2.0 * it_free + 2.0, (pb, it_poly, it_free)
+    # a long thin polygon (a river): such rasters keep the merged CSR graph (csgpu.hip, setup_poly_lattice) -- same answers
+    poly2 = poly.copy()
+    poly2[25, 5:45] = 9
+    res = {}
+    for mode in ("auto", "csr"):
+        if mode == "csr":
+            monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
+        with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-10), polymap=poly2) as h:
+            assert h.info["lattice_period"] == 0
+            nm2 = h.raster_nodemap()
+            ids = [int(nm2[25, 6]) - 1, int(nm2[6, 9]) - 1, int(nm2[60, 50]) - 1 if nm2[60, 50] > 0 else int(nm2[6, 9]) - 1]
+            res[mode] = h.solve_pairs([ids[0], ids[0]], [ids[1], ids[2]])[0]
+    monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
+    assert np.array_equal(res["auto"], res["csr"])

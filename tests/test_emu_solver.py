@@ -1143,6 +1143,12 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     check_stream_pairs(emu_lib, monkeypatch, N=84, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
 
 
+def test_polygon_rasters_on_the_lattice_path(emu_lib, monkeypatch):
+    """see helpers.check_polygons_on_lattice_path"""
+    from helpers import check_polygons_on_lattice_path
+    check_polygons_on_lattice_path(emu_lib, monkeypatch)
+
+
 def test_batches_of_32_columns(emu_lib, oracle):
     """opts.batch = 32 (round 4: the matrix values of every marching pass are amortised over twice as many columns): the
     K = 32 instantiations of the marching kernels (TI = 16 rows per tile in fp64), the restriction, the CSR kernels of the

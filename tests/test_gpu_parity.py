@@ -601,3 +601,40 @@ def test_streaming_pair_solves_match_the_batch_path_gpu(gpu_lib, oracle, monkeyp
     check_stream_pairs(gpu_lib, monkeypatch, N=300, batch=8, npairs=29, oracle=oracle)
     check_stream_pairs(gpu_lib, monkeypatch, N=700, batch=16, npairs=53, nodata=True, sigma=2.0)
     check_stream_pairs(gpu_lib, monkeypatch, N=500, batch=32, npairs=75, pbs=(4,), nodata=True)
+
+
+def test_polygon_rasters_on_the_lattice_path_gpu(gpu_lib, monkeypatch):
+    """see helpers.check_polygons_on_lattice_path (small raster: every special case against a direct solve of the merged
+    matrix), then a 1500^2 raster with 40 polygons: lattice path against the merged CSR path of the same library (1e-6 at
+    the reference's tolerances, same node map), iteration count within 1.6x of the polygon-free raster's."""
+    from helpers import check_polygons_on_lattice_path
+    check_polygons_on_lattice_path(gpu_lib, monkeypatch)
+    N = 1500
+    rng = np.random.default_rng(21)
+    g = np.exp(rng.standard_normal((N, N)))
+    poly = np.zeros((N, N), dtype=np.int32)
+    for k in range(40):
+        h_, w_ = rng.integers(3, 40, size=2)
+        i, j = rng.integers(0, N - h_), rng.integers(0, N - w_)
+        poly[i:i + h_, j:j + w_] = k + 1
+    free = np.flatnonzero(poly.ravel() == 0)
+    cells = np.random.default_rng(5).choice(free, size=28, replace=False)
+    pcell = [int(np.flatnonzero(poly.ravel() == k)[0]) for k in (3, 11, 17, 29)]     # four polygon nodes among the focal nodes
+    cells = np.concatenate([cells, pcell])
+    out = {}
+    for mode in ("lattice", "csr", "free"):
+        if mode == "csr":
+            monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
+        else:
+            monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
+        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16), polymap=None if mode == "free" else poly) as h:
+            nm = h.raster_nodemap()
+            nodes = nm.ravel()[cells].astype(np.int64) - 1
+            R, _, _, st = h.solve_pairs([int(v) for v in nodes[:16]], [int(v) for v in nodes[16:]])
+            assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
+            out[mode] = (R, st["total_iters"] / 16.0, h.info["lattice_period"], nm)
+    assert out["lattice"][2] == N and out["csr"][2] == 0
+    assert np.array_equal(out["lattice"][3], out["csr"][3])
+    assert np.max(np.abs(out["lattice"][0] - out["csr"][0]) / out["csr"][0]) < 1e-6
+    print("polygons 1500^2: iterations lattice %.2f, merged CSR %.2f, polygon-free %.2f" % (out["lattice"][1], out["csr"][1], out["free"][1]))
+    assert out["lattice"][1] <= 1.6 * out["free"][1] + 1.0

@@ -54,7 +54,10 @@ for case in cases:
                 src, dst = [p[0] for p in pairs], [p[1] for p in pairs]
                 h.solve_pairs(src[:B], dst[:B])          # warm-up (work vectors, code objects)
                 ref = None
-                for mode, env in (("batch", {"CSGPU_NO_STREAM": "1"}), ("stream", {"CSGPU_STREAM": "1"}), ("adaptive", {})):
+                modes = (("batch", {"CSGPU_NO_STREAM": "1"}), ("stream", {"CSGPU_STREAM": "1"}), ("adaptive", {}))
+                if os.environ.get("REPEAT"):   # run-to-run reproducibility probe: every mode twice
+                    modes = (modes[0], ("batch#2", modes[0][1]), modes[1], ("stream#2", modes[1][1]), ("batch#3", modes[0][1]))
+                for mode, env in modes:
                     for k in ("CSGPU_NO_STREAM", "CSGPU_STREAM"):
                         os.environ.pop(k, None)
                     os.environ.update(env)
@@ -71,6 +74,7 @@ for case in cases:
                                       "column_utilisation": (st["total_iters"] + len(src)) / float(slots * B) if slots else None,
                                       "not_converged": st["not_converged"], "max_relres": st["max_relres"],
                                       "identical_to_batch": bool(np.array_equal(R, ref)),
+                                      "max_rel_diff_vs_batch": float(np.max(np.abs(R - ref) / np.abs(ref))),
                                       "lattice_period": info["lattice_period"], "levels": info["levels"]}), flush=True)
 for k in ("CSGPU_NO_STREAM", "CSGPU_STREAM"):
     os.environ.pop(k, None)
