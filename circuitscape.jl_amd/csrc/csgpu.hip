@@ -772,9 +772,10 @@ struct Solver : ISolver {
       // hierarchy see that. Measured at 5000^2 with 200 strips of up to 80 cells (profiles/r4_polygon_strip_width_sweep.txt):
       // 2 cells wide 45 iterations against 13 on the merged graph (429 ms per batch against 201), 3-5 wide a tie
       // (19-20 iterations, ~200 ms either way), 8 wide 16 iterations and 163 ms against 217. Such rasters keep the
-      // merged CSR graph: the lattice path requires every polygon that is at least 8 cells long to have 45 % core cells.
+      // merged CSR graph: the lattice path requires every polygon that is at least 8 cells long to have 30 % core cells
+      // (strips from 3 cells of width on: never worse than a tie with the merged graph).
       const int64_t extent = std::max(i1 - i0, j1 - j0) + 1;
-      if (count[(size_t)p] >= 2 && extent >= 8 && (double)core[(size_t)p] < 0.45 * (double)count[(size_t)p]) wire_like = true;
+      if (count[(size_t)p] >= 2 && extent >= 8 && (double)core[(size_t)p] < 0.30 * (double)count[(size_t)p]) wire_like = true;
     }
     if (wire_like && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
       if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a long thin polygon: merged CSR graph instead of the lattice path\n");
@@ -1155,6 +1156,14 @@ struct Solver : ISolver {
     int kmax = opts.batch;
     if (kmax < 1) kmax = 1;
     if (kmax > kMaxK) kmax = kMaxK;
+    // Batches of 32 pay where the wide passes run in the marching kernels: handles whose level 0 is in lattice form. The
+    // general CSR SpMM of the coarser levels processes the 32 columns of an fp64 hierarchy as two halves of 16 (spmv.h);
+    // the level-0 kernels of a CSR-path handle (networks, rasters with thin polygons: spmv_launch_cg / _wide, the long-row
+    // kernel) have no such form and run 1.75x slower per column with 8 rows per lane, so fp64 hierarchies without a
+    // lattice level 0 stay at 16 columns. fp32 hierarchies (8 lanes per row at K = 32) are fine. CSGPU_WIDE_CSR=1 lifts it.
+    if (kmax > 16 && sizeof(TP) == 8 && !getenv("CSGPU_WIDE_CSR")) {
+      if (!(H.levels.size() > 1 && H.levels[0].lattice_two_product())) kmax = 16;
+    }
     int k = 1;
     while (k < kmax && k < ncols) k <<= 1;
     return k;

@@ -110,7 +110,13 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   // K = 16: half-size row blocks (128 rows / 1280 nonzeros per tile) keep the per-lane state (rows owned by a lane) the
   // same as at K = 8, so the kernel stays at 4 waves/SIMD; the traversal order (built for 256-row blocks) is followed
   // at half-block granularity.
-  constexpr int SPLIT = K >= 16 ? 2 : 1;
+  // K = 32 with 8-byte x: the columns are processed as TWO halves of 16 (KH = 16), one after the other, each exactly like a
+  // K = 16 launch on a vector of stride 32 -- with all 32 columns at once a lane would own 8 rows and the kernel ran
+  // 1.75x slower per column (measured: the CSR level 1 of a 10000^2 raster with 15 % NODATA, profiles/
+  // r4_nodata_kernel_stats_k32.csv). The matrix tile of the second half comes out of L2.
+  constexpr int KH = (K == 32 && sizeof(XT) == 8) ? 16 : K;
+  constexpr int NH = K / KH;
+  constexpr int SPLIT = KH >= 16 ? 2 : 1;
   constexpr int ROWS = kSpmvRows / SPLIT;
   constexpr int TILE = 256 * TPL / SPLIT;  // TPL = nonzeros per lane and 256-row tile (10; 16 for the [S Q] product)
   static_assert(TILE % 256 == 0, "every lane streams TILE / 256 nonzeros per tile");
@@ -123,16 +129,18 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
   const int tid = threadIdx.x;
   // K > 1: a row's K-wide x segment is gathered as 16-byte vectors: CPL adjacent columns per lane, LPR lanes per row.
   constexpr int VEC = 16 / (int)sizeof(XT);
-  constexpr int CPL = K < VEC ? K : VEC;   // columns per lane
-  constexpr int LPR = K / CPL;             // lanes per row
+  constexpr int CPL = KH < VEC ? KH : VEC;   // columns per lane
+  constexpr int LPR = KH / CPL;             // lanes per row
   constexpr int RPP = 256 / LPR;           // rows per pass (256 lanes / LPR)
   constexpr int NPASS = ROWS / RPP;        // rows owned by one lane
   typedef SpmvVec<XT, CPL> XV;  // gathered x segment
   typedef SpmvVec<T, CPL> YV;   // epilogue vectors (b, xadd, dotw, y)
-  const int c0 = K > 1 ? (tid % LPR) * CPL : 0;  // first column owned by the lane
-  double dot_acc[CPL];
+  const int c0b = K > 1 ? (tid % LPR) * CPL : 0;  // first column owned by the lane (within a half)
+  double dot_acc[NH][CPL];
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
+  for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) dot_acc[hh][q] = 0.0;
 
   // Row-block -> workgroup mapping. Workgroup b is dispatched to XCD b % 8 (observed, used for speed only): give each
   // XCD one CONTIGUOUS eighth of the row blocks and let its workgroups march through it in order, so the x rows a
@@ -155,6 +163,10 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
     for (int t = tid; t <= nr; t += 256) s_rp[t] = a.rowptr[row0 + t];
     __syncthreads();
     const int kbeg = s_rp[0], kend = s_rp[nr];
+#pragma unroll 1
+    for (int hh = 0; hh < NH; ++hh) {
+    const int c0 = c0b + hh * KH;
+    if (hh > 0) __syncthreads();  // the first half finished with the staged tile
 
     T acc[NPASS][CPL];
     // the row's own x values, captured when the diagonal entry is gathered (saves re-reading x in the epilogue)
@@ -305,11 +317,12 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
           if (EPI == EPI_ADD) v = xo.e[q] + v;
           if (EPI == EPI_QADD) v = xo.e[q] + sc * bv.e[q] + v;
           out.e[q] = v;
-          if (DOT) dot_acc[q] += (double)dw.e[q] * (double)v;
+          if (DOT) dot_acc[hh][q] += (double)dw.e[q] * (double)v;
         }
         stream_store(reinterpret_cast<YV*>(a.y + e0), out);
       }
     }
+    }  // halves
   }
 
   if (DOT) {
@@ -317,12 +330,14 @@ __global__ __launch_bounds__(256) void spmv_kernel(SpmvArgs<T, XT> a) {
     const int lane = tid & 63, w = tid >> 6;
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-      double v = dot_acc[q];
+    for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-      for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane < LPR) s_red[w * K + lane * CPL + q] = v;
-    }
+      for (int q = 0; q < CPL; ++q) {
+        double v = dot_acc[hh][q];
+#pragma unroll
+        for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane < LPR) s_red[w * K + hh * KH + lane * CPL + q] = v;
+      }
     __syncthreads();
     if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
   }

@@ -1159,6 +1159,20 @@ def test_batches_of_32_columns(emu_lib, oracle):
     check_lattice_product(emu_lib, shapes=((70, 40),), ks=(32,), pbs=(0, 4))
     check_lattice_transfer_products(emu_lib, shapes=((45, 45),), ks=(32,), pbs=(0, 4))
     check_level_products(emu_lib, 70, 4, ks=(32,))
+    check_level_products(emu_lib, 70, 0, ks=(32,))      # fp64 CSR products at K = 32: two halves of 16 (spmv.h)
+    # a raster with NODATA cells: its level 1 is a CSR level -- the two-halves SpMM inside the V-cycle
+    gh = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((90, 90)))
+    gh[np.random.default_rng(3).random((90, 90)) < 0.12] = 0.0
+    res = {}
+    for B in (16, 32):
+        with emu_lib.raster_setup(gh, emu_lib.default_opts(batch=B)) as h:
+            lab, _ = h.components()
+            big = np.flatnonzero(lab == np.bincount(lab).argmax())
+            pts = np.random.default_rng(8).choice(big, size=33, replace=False)
+            R, _, _, st = h.solve_pairs([int(pts[0])] * 32, [int(v) for v in pts[1:]])
+            assert st["batch"] == B and st["not_converged"] == 0
+            res[B] = (R, st["total_iters"])
+    assert res[16][1] == res[32][1] and np.max(np.abs(res[16][0] - res[32][0]) / res[16][0]) < 1e-12
     N = 96
     G, g = rg.synthetic_raster_problem(N, N)
     A = oracle.regularize(G)

@@ -566,6 +566,18 @@ def test_batches_of_32_columns_gpu(gpu_lib, oracle):
     check_lattice_transfer_products(gpu_lib, shapes=((145, 145), (35, 36)), ks=(32,), pbs=(0, 4))
     check_level_products(gpu_lib, 200, 4, ks=(32,))
     check_level_products(gpu_lib, 200, 0, ks=(32,))
+    gh = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((900, 900)))
+    gh[np.random.default_rng(3).random((900, 900)) < 0.12] = 0.0       # NODATA: level 1 is a CSR level (two halves of 16)
+    resh = {}
+    for B in (16, 32):
+        with gpu_lib.raster_setup(gh, gpu_lib.default_opts(batch=B)) as h:
+            lab, _ = h.components()
+            big = np.flatnonzero(lab == np.bincount(lab).argmax())
+            pts = np.random.default_rng(8).choice(big, size=33, replace=False)
+            R, _, _, st = h.solve_pairs([int(pts[0])] * 32, [int(v) for v in pts[1:]])
+            assert st["batch"] == B and st["not_converged"] == 0
+            resh[B] = (R, st["total_iters"])
+    assert resh[16][1] == resh[32][1] and np.max(np.abs(resh[16][0] - resh[32][0]) / resh[16][0]) < 1e-12
     N = 600
     G, g = rg.synthetic_raster_problem(N, N)
     A = oracle.regularize(G)
@@ -613,9 +625,9 @@ def test_polygon_rasters_on_the_lattice_path_gpu(gpu_lib, monkeypatch):
     rng = np.random.default_rng(21)
     g = np.exp(rng.standard_normal((N, N)))
     poly = np.zeros((N, N), dtype=np.int32)
-    for k in range(40):
-        h_, w_ = rng.integers(3, 40, size=2)
-        i, j = rng.integers(0, N - h_), rng.integers(0, N - w_)
+    for k in range(40):                       # blobs on a jittered 7 x 6 grid of slots: no overlaps, no slivers
+        h_, w_ = rng.integers(6, 40, size=2)
+        i, j = (k % 7) * 200 + rng.integers(10, 150), (k // 7) * 240 + rng.integers(10, 190)
         poly[i:i + h_, j:j + w_] = k + 1
     free = np.flatnonzero(poly.ravel() == 0)
     cells = np.random.default_rng(5).choice(free, size=28, replace=False)

@@ -57,6 +57,8 @@ for case in cases:
                 modes = (("batch", {"CSGPU_NO_STREAM": "1"}), ("stream", {"CSGPU_STREAM": "1"}), ("adaptive", {}))
                 if os.environ.get("REPEAT"):   # run-to-run reproducibility probe: every mode twice
                     modes = (modes[0], ("batch#2", modes[0][1]), modes[1], ("stream#2", modes[1][1]), ("batch#3", modes[0][1]))
+                if os.environ.get("MODES"):
+                    modes = tuple(m for m in modes if m[0] in os.environ["MODES"].split(","))
                 for mode, env in modes:
                     for k in ("CSGPU_NO_STREAM", "CSGPU_STREAM"):
                         os.environ.pop(k, None)
