@@ -45,7 +45,7 @@ csgpu_error() = unsafe_string(ccall((:csgpu_last_error, LIBCSGPU), Cstring, ()))
 function default_opts(bs::Int)
     o = CsgpuOpts()
     ccall((:csgpu_default_opts, LIBCSGPU), Cvoid, (Ref{CsgpuOpts},), o)
-    o.batch = Int32(clamp(nextpow(2, bs), 1, 16))
+    o.batch = Int32(clamp(nextpow(2, bs), 1, 32))   # up to 32 columns per pass (csgpu_opts.batch)
     o
 end
 
