@@ -777,6 +777,50 @@ struct Solver : ISolver {
       const int64_t extent = std::max(i1 - i0, j1 - j0) + 1;
       if (count[(size_t)p] >= 2 && extent >= 8 && (double)core[(size_t)p] < 0.30 * (double)count[(size_t)p]) wire_like = true;
     }
+    // A polygon in SEVERAL PIECES (one id used in two places) may be the only link between two parts of the raster: the
+    // merged graph is connected through its node, the cell-space lattice -- and with it the hierarchy, whose coarsest
+    // pseudo-inverse treats every connected component of ITS graph as a singular block -- is not. Contiguous polygons
+    // cannot change the connectivity (their interior edges, all positive, hold them together), so only rasters whose
+    // polygons are all contiguous (in the raster's own 4- / 8-neighbourhood) take the lattice path.
+    bool split_polygon = false;
+    {
+      std::vector<int> stack;
+      std::vector<char> seen;
+      for (int p = 0; p < npoly && !split_polygon; ++p) {
+        const int lo = hptr[(size_t)p], hi = hptr[(size_t)p + 1];
+        if (hi - lo < 2) continue;
+        seen.assign((size_t)(hi - lo), 0);
+        stack.clear();
+        stack.push_back(0);
+        seen[0] = 1;
+        int reached = 1;
+        while (!stack.empty()) {
+          const int m = stack.back();
+          stack.pop_back();
+          const int64_t k = hcells[(size_t)(lo + m)], ci = k % R, cj = k / R;
+          for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) {
+              if ((di == 0 && dj == 0) || (four && di != 0 && dj != 0)) continue;
+              const int64_t ii = ci + di, jj = cj + dj;
+              if (ii < 0 || ii >= R || jj < 0 || jj >= C) continue;
+              const int key = (int)(jj * R + ii);
+              const auto it = std::lower_bound(hcells.begin() + lo, hcells.begin() + hi, key);
+              if (it == hcells.begin() + hi || *it != key) continue;
+              const int q = (int)(it - (hcells.begin() + lo));
+              if (!seen[(size_t)q]) {
+                seen[(size_t)q] = 1;
+                ++reached;
+                stack.push_back(q);
+              }
+            }
+        }
+        if (reached != hi - lo) split_polygon = true;
+      }
+    }
+    if (split_polygon && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
+      if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a polygon in several pieces: merged CSR graph instead of the lattice path\n");
+      return false;
+    }
     if (wire_like && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
       if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a long thin polygon: merged CSR graph instead of the lattice path\n");
       return false;

@@ -191,8 +191,11 @@ struct DiaShape {
 // profiles/r2_launch_bounds_ab.json). The second product (142 VGPRs) spills 13 registers under the same bound and gets
 // 1.9x slower; the residual update gains nothing from 3 waves instead of 2: both stay unconstrained.
 // (narrow batches, K <= 4, hold CPL = K columns per lane on fewer lanes per node and cannot reach 4 waves: no bound there)
+#ifndef CSGPU_RUPD_WAVES
+#define CSGPU_RUPD_WAVES 1   // A/B knob (build-time): waves per SIMD asked of the residual update at K = 32
+#endif
 template <class T, class XT, int K, int MODE>
-__global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia_cg_kernel(
+__global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DIA_RUPD && K >= 32) ? CSGPU_RUPD_WAVES : 1))) void dia_cg_kernel(
     DiaArgs<T, XT> a) {
   constexpr bool FUSE = MODE == DIA_CG;
   typedef DiaShape<T, XT, K> SH;
@@ -254,7 +257,14 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia
     T mr[MU];
     T qr[SQ ? QU : 1];
     XV xcr;
+    YV r_pre;               // DIA_RUPD: the residual entries of the NEXT column, in flight one step ahead like the vector loads
     int pend_c = -1, next_c = 0;
+    auto load_r = [&](int jc) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) r_pre.e[q] = T(0);
+      const int64_t id = (int64_t)jc * a.R + i0 + t;
+      if (MODE == DIA_RUPD && jc < j1 && row_on && id < a.n) r_pre = dia_load(reinterpret_cast<const YV*>(a.r + (size_t)id * K + c0));
+    };
     auto load_coarse = [&](int Jc) {
 #pragma unroll
       for (int q = 0; q < CPL; ++q) xcr.e[q] = XT(0);
@@ -347,6 +357,7 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia
     load_column(j0);
     store_column(j0);
     load_column(j0 + 1);
+    if (MODE == DIA_RUPD) load_r(j0);
     if (SQ) {  // coarse columns J(j0)-1 .. J(j0)+2 up front; later ones one per step, two steps ahead of their use
       const int Jb = min(j0 / 3, a.Cc - 1);
       for (int d = -1; d <= 2; ++d) {
@@ -370,6 +381,11 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia
         pend_c = -1;
       }
       if (j + 2 <= j1) load_column(j + 2); // next one in flight while this column is computed
+      YV rv_cur;
+      if (MODE == DIA_RUPD) {              // this column's residual arrived during the previous step; fetch the next one
+        rv_cur = r_pre;
+        load_r(j + 1);
+      }
       if (SQ) {
         const int need = min((j + 2) / 3, a.Cc - 1) + 1;  // last coarse column read two steps from now
         if (need >= next_c) {
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia
         if (MODE == DIA_RUPD) {
           // r -= alpha * (A p): same arithmetic as cg_update_r_kernel on a stored A p
           const size_t e = (size_t)id * K + c0;
-          const YV rv = dia_load(reinterpret_cast<const YV*>(a.r + e));
+          const YV rv = rv_cur;
           YV rn;
           XV rq;
 #pragma unroll
@@ -483,20 +499,23 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : 1)) void dia
   if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
 }
 
-// raster columns per tile (tuning knob CSGPU_DIA_SEG)
-inline int dia_seg() {
+// raster columns per tile (tuning knob CSGPU_DIA_SEG). Default 32; 64 for batches of 32 columns, whose tiles hold half
+// as many rows (fp64: 16): measured at 10000^2, K = 32 (profiles/r4_dia_seg_k32.txt): 346.3 / 341.3 / 339.5 / 340.2 ms per
+// 16 pairs at 32 / 48 / 64 / 96 (fp64), 211.7 / 205.6 / 205.3 / 204.5 (mixed). At K = 16 the knob is inside the noise
+// (profiles/r3_tile_shape_knobs.txt).
+inline int dia_seg(int K = 16) {
   static int seg = [] {
     const char* e = getenv("CSGPU_DIA_SEG");
-    const int v = e ? atoi(e) : 32;
-    return v < 4 ? 4 : v;
+    const int v = e ? atoi(e) : 0;
+    return v <= 0 ? 0 : (v < 4 ? 4 : v);
   }();
-  return seg;
+  return seg > 0 ? seg : (K >= 32 ? 64 : 32);
 }
 
 template <class T, class XT, int K>
 inline void dia_tiling(const Dia<T>& D, int& nstrips, int& nseg, int& seg, int& grid) {
   const int C = (int)(D.n / D.R);
-  seg = std::min(dia_seg(), std::max(C, 1));
+  seg = std::min(dia_seg(K), std::max(C, 1));
   nstrips = ceil_div(D.R, DiaShape<T, XT, K>::TI);
   nseg = ceil_div(C, seg);
   int64_t g = (int64_t)nstrips * nseg;

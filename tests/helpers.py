@@ -1421,7 +1421,8 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
 
 
 def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=(0, 4), tol=2e-9):
-    """Rasters with short-circuit polygons on the index-free lattice path (csrc/poly.h: PCG projected onto the vectors that
+    """(polygon 5 was the second place of polygon 2 until the contiguity rule: see the end of this function)
+    Rasters with short-circuit polygons on the index-free lattice path (csrc/poly.h: PCG projected onto the vectors that
     are constant on every polygon, polygon interiors strengthened in the preconditioner's matrix) against the MERGED graph
     the reference builds (construct_node_map with a polymap, src/raster/pairwise.jl:276-301) -- through the merged CSR
     path of the same library (CSGPU_NO_POLY_LATTICE=1; that path is pinned on the reference's goldens and known answers,
@@ -1438,7 +1439,7 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
     poly[5:14, 8:17] = 1
     g[7:9, 10:12] = 0.0                      # NODATA inside polygon 1
     poly[30:37, 3:10] = 2
-    poly[40:46, 40:50] = 2                   # polygon 2 in two places
+    poly[40:46, 40:50] = 5
     poly[20, 30] = 3                         # a single cell
     poly[50:60, 20:26] = 4
     g[20, 30] = 1.3
@@ -1452,7 +1453,7 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
     n = A.shape[0]
     big = np.flatnonzero(lab == np.bincount(lab).argmax())
     pnodes = [int(nm_ref[6, 9]) - 1, int(nm_ref[41, 41]) - 1, int(nm_ref[20, 30]) - 1, int(nm_ref[55, 21]) - 1]
-    assert int(nm_ref[31, 4]) - 1 == pnodes[1]                       # both places of polygon 2 share a node
+    assert int(nm_ref[31, 4]) - 1 != pnodes[1]
     assert int(nm_ref[7, 10]) - 1 == pnodes[0]                       # a NODATA cell inside polygon 1 shares its node
     pnodes = [p for p in pnodes if p in set(big.tolist())]
     others = [int(v) for v in np.random.default_rng(2).choice(np.setdiff1d(big, pnodes), size=6, replace=False)]
@@ -1520,3 +1521,10 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
             res[mode] = h.solve_pairs([ids[0], ids[0]], [ids[1], ids[2]])[0]
     monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
     assert np.array_equal(res["auto"], res["csr"])
+    # one polygon id in two places (it may be the only link between two parts of the raster): merged CSR graph as well
+    poly3 = poly.copy()
+    poly3[poly3 == 5] = 2
+    with L.raster_setup(g, L.default_opts(batch=batch), polymap=poly3) as h:
+        assert h.info["lattice_period"] == 0
+        nm3 = h.raster_nodemap()
+        assert nm3[31, 4] == nm3[41, 41]
