@@ -1139,8 +1139,8 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     """see helpers.check_stream_pairs: all-valid raster, a raster with NODATA cells (cell space, very uneven iteration
     counts), K = 8 and K = 16"""
     from helpers import check_stream_pairs
-    check_stream_pairs(emu_lib, monkeypatch, N=90, batch=8, npairs=29, oracle=oracle)
-    check_stream_pairs(emu_lib, monkeypatch, N=84, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
+    check_stream_pairs(emu_lib, monkeypatch, N=66, batch=8, npairs=21, oracle=oracle)
+    check_stream_pairs(emu_lib, monkeypatch, N=60, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
 
 
 def test_polygon_rasters_on_the_lattice_path(emu_lib, monkeypatch):
@@ -1161,8 +1161,8 @@ def test_batches_of_32_columns(emu_lib, oracle):
     check_level_products(emu_lib, 70, 4, ks=(32,))
     check_level_products(emu_lib, 70, 0, ks=(32,))      # fp64 CSR products at K = 32: two halves of 16 (spmv.h)
     # a raster with NODATA cells: its level 1 is a CSR level -- the two-halves SpMM inside the V-cycle
-    gh = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((90, 90)))
-    gh[np.random.default_rng(3).random((90, 90)) < 0.12] = 0.0
+    gh = 1.0 / np.exp(np.random.default_rng(12345).standard_normal((66, 66)))
+    gh[np.random.default_rng(3).random((66, 66)) < 0.12] = 0.0
     res = {}
     for B in (16, 32):
         with emu_lib.raster_setup(gh, emu_lib.default_opts(batch=B)) as h:
@@ -1173,7 +1173,7 @@ def test_batches_of_32_columns(emu_lib, oracle):
             assert st["batch"] == B and st["not_converged"] == 0
             res[B] = (R, st["total_iters"])
     assert res[16][1] == res[32][1] and np.max(np.abs(res[16][0] - res[32][0]) / res[16][0]) < 1e-12
-    N = 96
+    N = 72
     G, g = rg.synthetic_raster_problem(N, N)
     A = oracle.regularize(G)
     cells = np.random.default_rng(5).choice(N * N, size=40, replace=False)
