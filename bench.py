@@ -690,10 +690,11 @@ def gpu_parity(lib, sample_size, tight, make_opts, dtype, both):
     src = [p[0] for p in pairs[:nt]]
     dst = [p[1] for p in pairs[:nt]]
     Ro = np.asarray(tight["R"])
-    # north_star tolerance for fp64; fp32 handles (BASELINE configs[3] precision) are held to 1e-3 (the reference's own
+    # north_star tolerance for fp64; fp32 handles (BASELINE configs[3] precision) are held to 1e-4 against the tight oracle
+    # on the same fp32-shifted matrix ("the fp32 contract"; measured 3e-7; the reference's own
     # single-precision tolerance is 1e-2 absolute, test/test_utils.jl:72-73)
     out = {"n": sample_size * sample_size, "pairs": nt, "oracle": "tight (true-residual rtol 1e-12)",
-           "oracle_max_true_relres": tight["max_true_relres"], "tolerance": 1e-6 if dtype == np.float64 else 1e-3}
+           "oracle_max_true_relres": tight["max_true_relres"], "tolerance": 1e-6 if dtype == np.float64 else 1e-4}
     for name, precond in ((("fp64", "same"), ("mixed", "fp32")) if both else (("uniform", "same"),)):
         h = lib.raster_setup(g, make_opts(precond))
         R, _, _, st = h.solve_pairs(src, dst)
@@ -746,21 +747,29 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
     hw = lib.raster_setup(g[:wn, :wn].copy(), make_opts(args.precond))
     hw.solve_pairs([0] * B, [wn * wn - 1] * B)
     hw.close()
-    sync()
-    t0 = time.perf_counter()
-    h = lib.raster_setup(g, make_opts(args.precond))
-    t_setup = time.perf_counter() - t0
-    R = np.zeros(0)
-    st = {"total_iters": 0, "max_relres": 0.0, "not_converged": 0}
-    if hi > lo:
-        R, _, _, st = h.solve_pairs([p[0] for p in plist[lo:hi]], [p[1] for p in plist[lo:hi]])
-    t_busy = time.perf_counter() - t0
-    full = shard.gather_pairs(np.asarray(R, dtype=np.float64), np.arange(lo, hi), npairs, dist,
-                              dev if (dist is None or args.backend == "nccl") else None)
-    sync()
-    elapsed = time.perf_counter() - t0
-    info = h.info
-    h.close()
+    # The job runs TWICE in this process. The first run pays the driver for ~100 GB of fresh device memory (page tables:
+    # seconds, profiles/r2_alloc_probe_*.jsonl -- 7.4 s against 2.4 s for the 100-pair fp64 job on one GPU); the second
+    # finds the blocks in the library's pool, which is the state of any process that solves more than one problem. `value`
+    # and the speed-up figures are the second run's; the first is reported as job_cold_s.
+    job_cold_s = None
+    for attempt in range(2):
+        sync()
+        t0 = time.perf_counter()
+        h = lib.raster_setup(g, make_opts(args.precond))
+        t_setup = time.perf_counter() - t0
+        R = np.zeros(0)
+        st = {"total_iters": 0, "max_relres": 0.0, "not_converged": 0}
+        if hi > lo:
+            R, _, _, st = h.solve_pairs([p[0] for p in plist[lo:hi]], [p[1] for p in plist[lo:hi]])
+        t_busy = time.perf_counter() - t0
+        full = shard.gather_pairs(np.asarray(R, dtype=np.float64), np.arange(lo, hi), npairs, dist,
+                                  dev if (dist is None or args.backend == "nccl") else None)
+        sync()
+        elapsed = time.perf_counter() - t0
+        info = h.info
+        h.close()
+        if attempt == 0:
+            job_cold_s = elapsed
     busy = [t_busy]
     setups = [t_setup]
     has_cuda = torch.cuda.is_available()
@@ -796,7 +805,7 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
             "config": {"workload": "%dx%d synthetic raster, 8-neighbour, %d pairs in total over %d GPU(s), batches of %d"
                                    % (size, size, npairs, world, B), "n": info["n"], "nnz": info["nnz"], "batch": B,
                        "preconditioner_precision": "fp32" if info["precond_bytes"] == 4 else "fp64"},
-            "job_s": elapsed, "rank_busy_s": busy, "rank_setup_s": setups, "pairs_per_rank": -(-npairs // world),
+            "job_s": elapsed, "job_cold_s": job_cold_s, "rank_busy_s": busy, "rank_setup_s": setups, "pairs_per_rank": -(-npairs // world),
             "per_batch_s_rank0": per_batch,
             # predicted: T_1 / T_N = (s + nb_1 b) / (s + nb_N b) from rank 0's measured setup s and per-batch time b;
             # achieved: the one-GPU time RECONSTRUCTED from this run's own pieces -- one setup plus every rank's solve
