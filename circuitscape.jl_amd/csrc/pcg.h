@@ -658,8 +658,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, rr_rows,
                        crit0, pp.rtol, atol, 1, ncols_active);
   }
-  // the first iteration runs p = z + beta p with beta = 0 (set by the init call above) on a zeroed p
-  CS_HIP(hipMemsetAsync(pbuf[0], 0, (size_t)n * K * sizeof(TP), st));
+  // the first iteration runs p = z + beta p with beta = 0 (set by the init call above): the lattice product takes p = z
+  // whatever the old p holds (stencil.h), the CSR path's update kernel multiplies the old p by zero and needs it finite
+  if (!use_dia) CS_HIP(hipMemsetAsync(pbuf[0], 0, (size_t)n * K * sizeof(TP), st));
   check_launch("pcg init");
 
   int host_done = 0;

@@ -100,7 +100,9 @@ typedef struct csgpu_opts {
   int32_t nu_post;        /* damped-Jacobi post-smoothing sweeps, default 1 */
   int32_t criterion;      /* CSGPU_CRIT_*, default KRYLOV (the reference's rule) */
   int32_t itmax;          /* default 100000 (core.jl:639) */
-  int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16,32; default 8 */
+  int32_t batch;          /* right-hand sides solved together per SpMM pass: 1,2,4,8,16,32; default 8. 32 is what the
+                             marching kernels of a raster want (+8 % fp64 / +10 % mixed over 16 at 10000^2); fp64
+                             hierarchies without a lattice level 0 (networks, thin-polygon rasters) are held at 16 */
   int32_t check_every;    /* host polls the device convergence flags every this many iterations; default 0 = auto:
                              every iteration when n*batch >= 2^25 (an iteration then takes milliseconds), else every 4th */
   int32_t nu_coarse;      /* Jacobi sweeps (pre and post) on level 1; the levels below it (1/81 of the fine level's
@@ -221,7 +223,16 @@ int csgpu_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int val_b
  * cell (i, j), 0 = none (host pointer, int32, same orientation as cond; NULL = no polygons). Every cell of a polygon --
  * NODATA cells included, as in the reference -- shares the node of the polygon's first valid cell in column-major
  * order; parallel edges are summed, edges inside a polygon vanish. Node numbering, merge and the CSR Laplacian are
- * produced on the device (csrc/raster.h); polygon ids must be < 2^26. */
+ * produced on the device (csrc/raster.h); polygon ids must be < 2^26.
+ * Round 4: when every polygon is contiguous and none is long and thin (>= 8 cells long with < 30 % core cells), the handle
+ * keeps the raster on the index-free lattice kernels instead (csrc/poly.h): a merged polygon is an equipotential, so PCG runs
+ * in the subspace of the vectors that are constant on every polygon (r and z are averaged over each polygon's cells after
+ * every update) and the polygon-interior edges, which carry no current for such vectors, are strengthened in the
+ * preconditioner's matrix. Same node numbering (csgpu_raster_nodemap is identical), same resistances (1e-7 of a direct
+ * solve of the merged matrix at tight tolerances, tools/fuzz_polygons.py); 5000^2 with 50 polygons: 1.22x the polygon-free
+ * time per batch instead of 2.25x. csgpu_get_info().lattice_period > 0 tells which path a handle took; everything but
+ * resistance-only csgpu_solve_pairs (voltages, currents, general right-hand sides, components, the test hooks) is served by
+ * the merged graph, built on first use. CSGPU_NO_POLY_LATTICE=1 forces the merged graph. */
 int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nrows, int64_t ncols, int val_bytes,
                             int four_neighbors, int avg_resistances, int reg, const csgpu_opts* opts,
                             csgpu_handle** out);
