@@ -1139,7 +1139,7 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     """see helpers.check_stream_pairs: all-valid raster, a raster with NODATA cells (cell space, very uneven iteration
     counts), K = 8 and K = 16"""
     from helpers import check_stream_pairs
-    check_stream_pairs(emu_lib, monkeypatch, N=66, batch=8, npairs=21, oracle=oracle)
+    check_stream_pairs(emu_lib, monkeypatch, N=66, batch=8, npairs=21, pbs=(0,), oracle=oracle)
     check_stream_pairs(emu_lib, monkeypatch, N=60, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
 
 
