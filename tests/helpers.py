@@ -1528,3 +1528,33 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
         assert h.info["lattice_period"] == 0
         nm3 = h.raster_nodemap()
         assert nm3[31, 4] == nm3[41, 41]
+
+
+def check_contrast_triggered_fp64_hierarchy(L):
+    """A graph handed over in CSR form whose conductances span more than five decades gets an fp64 hierarchy whatever
+    precond_bytes says (csgpu.hip, setup_from_host): tools/fuzz_networks.py, run on the DEVICE at the end of round 4, found a
+    696-node star with conductances over six decades on which the fp32 hierarchy broke down ("relative residual 338") while
+    the emulator build converged in 23 iterations. Three decades keep the fp32 hierarchy."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(41147)
+    n = 696
+    I, J = np.zeros(n - 1, dtype=np.int64), np.arange(1, n)
+    for decades, want in ((6.0, 8), (3.0, 4)):
+        w = 10.0 ** (decades * (rng.random(n - 1) - 0.5))
+        W = sp.coo_matrix((w, (I, J)), shape=(n, n)).tocsr()
+        W = W + W.T
+        A = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
+        A.sort_indices()
+        A.data = A.data + np.finfo(np.float64).eps * np.linalg.norm(A.data)
+        src, dst = [521, 285, 587, 289, 87], [386, 141, 361, 25, 299]
+        with L.setup(A, L.default_opts(batch=4, precond_bytes=4, rtol=1e-10, atol=0.0)) as h:
+            assert h.info["precond_bytes"] == want, (decades, h.info["precond_bytes"])
+            R, _, _, st = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0
+        lu = spla.splu(A.tocsc())
+        for k, (a, b) in enumerate(zip(src, dst)):
+            rhs = np.zeros(n)
+            rhs[a], rhs[b] = -1.0, 1.0
+            x = lu.solve(rhs)
+            assert abs(R[k] - (x[b] - x[a])) < 1e-6 * abs(x[b] - x[a]), (decades, k)

@@ -1143,6 +1143,12 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     check_stream_pairs(emu_lib, monkeypatch, N=60, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
 
 
+def test_contrast_triggered_fp64_hierarchy(emu_lib):
+    """see helpers.check_contrast_triggered_fp64_hierarchy"""
+    from helpers import check_contrast_triggered_fp64_hierarchy
+    check_contrast_triggered_fp64_hierarchy(emu_lib)
+
+
 def test_polygon_rasters_on_the_lattice_path(emu_lib, monkeypatch):
     """see helpers.check_polygons_on_lattice_path"""
     from helpers import check_polygons_on_lattice_path

@@ -650,3 +650,9 @@ def test_polygon_rasters_on_the_lattice_path_gpu(gpu_lib, monkeypatch):
     assert np.max(np.abs(out["lattice"][0] - out["csr"][0]) / out["csr"][0]) < 1e-6
     print("polygons 1500^2: iterations lattice %.2f, merged CSR %.2f, polygon-free %.2f" % (out["lattice"][1], out["csr"][1], out["free"][1]))
     assert out["lattice"][1] <= 1.6 * out["free"][1] + 1.0
+
+
+def test_contrast_triggered_fp64_hierarchy_gpu(gpu_lib):
+    """see helpers.check_contrast_triggered_fp64_hierarchy (the case was found on the device)"""
+    from helpers import check_contrast_triggered_fp64_hierarchy
+    check_contrast_triggered_fp64_hierarchy(gpu_lib)
