@@ -462,7 +462,13 @@ struct Solver : ISolver {
   void finish_setup(Csr<T>&& A, const int* prow, const int* pcol, int known_period, const long long* size0 = nullptr) {
     detect_lattice(A, known_period);
     DBuf lrow, lcol;
-    if (dia.n > 0 && !prow && !pcol) {
+    // A lattice detected from the matrix numbers ITS nodes column-major on an R x (n / R) raster; coordinates the caller
+    // handed over are those of the full raster the component was cut out of (a connected component below an all-NODATA row
+    // or right of an all-NODATA column: offset rows / columns) and would put the direct tiles outside the level's extent --
+    // found by tools/fuzz_rasters.py at 60..220 cells a side on the device at the end of round 4 (out-of-bounds writes,
+    // "rows without a stored diagonal entry"; the small cases of round 3 never reached a component that is an all-valid
+    // rectangle with an offset). The lattice's own coordinates are the ones that match sp.grid_rows / grid_cols below.
+    if (dia.n > 0) {
       lrow.alloc((size_t)n * sizeof(int));
       lcol.alloc((size_t)n * sizeof(int));
       hipLaunchKernelGGL(lattice_coords_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, dia.R, dptr<int>(lrow), dptr<int>(lcol));

@@ -1558,3 +1558,52 @@ def check_contrast_triggered_fp64_hierarchy(L):
             rhs[a], rhs[b] = -1.0, 1.0
             x = lu.solve(rhs)
             assert abs(R[k] - (x[b] - x[a])) < 1e-6 * abs(x[b] - x[a]), (decades, k)
+
+
+def check_host_csr_component_with_offset_coordinates(L, shape=(70, 50)):
+    """The Julia host path for a connected component that is an ALL-VALID rectangle cut out of a larger raster (below an
+    all-NODATA row, right of an all-NODATA column): the lattice is detected from the component's matrix, the coordinates the
+    host hands over are those of the full raster (offset). Found by tools/fuzz_rasters.py at 60..220 cells a side on the
+    device (round 4): the direct tiles were computed from the caller's coordinates against the lattice's extent --
+    out-of-bounds writes. Resistances against a direct solve, and identical to the handle built without coordinates."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    R_, C_ = shape
+    rng = np.random.default_rng(5)
+    g = np.exp(rng.standard_normal(shape))
+    g[:, 12] = 0.0
+    g[9, :] = 0.0
+    nm = rg.construct_node_map(g, None)
+    W = rg.construct_graph(g, nm, False, False)
+    A = sp.csr_matrix(rg.laplacian(W))
+    _, lab = sp.csgraph.connected_components(W, directed=False)
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    Ab = sp.csr_matrix(A[big][:, big], copy=True)
+    Ab.data = Ab.data + np.finfo(np.float64).eps * np.linalg.norm(Ab.data)
+    rows_all = np.zeros(A.shape[0], dtype=np.int32)
+    cols_all = np.zeros(A.shape[0], dtype=np.int32)
+    ii, jj = np.nonzero(nm)
+    rows_all[nm[ii, jj] - 1] = ii
+    cols_all[nm[ii, jj] - 1] = jj
+    assert cols_all[big].min() > 0 and rows_all[big].min() > 0          # the component sits at an offset in both directions
+    ids = rng.choice(len(big), size=4, replace=False)
+    src, dst = [int(ids[0]), int(ids[1])], [int(ids[2]), int(ids[3])]
+    lu = spla.splu(Ab.tocsc())
+    Rd = []
+    for a, b in zip(src, dst):
+        rhs = np.zeros(len(big))
+        rhs[a], rhs[b] = -1.0, 1.0
+        x = lu.solve(rhs)
+        Rd.append(x[b] - x[a])
+    Rd = np.array(Rd)
+    out = {}
+    for pb in (0, 4):
+        for coords in (True, False):
+            kw = dict(node_row=rows_all[big], node_col=cols_all[big]) if coords else {}
+            with L.setup(Ab, L.default_opts(batch=2, precond_bytes=pb, rtol=1e-10, atol=0.0), **kw) as h:
+                assert h.info["lattice_period"] == R_ - 10, h.info["lattice_period"]     # rows 10 .. R-1 of the raster
+                Rr, _, _, st = h.solve_pairs(src, dst)
+                assert st["not_converged"] == 0
+                assert np.max(np.abs(Rr - Rd) / Rd) < 1e-8, (pb, coords)
+                out[(pb, coords)] = Rr
+        assert np.array_equal(out[(pb, True)], out[(pb, False)])

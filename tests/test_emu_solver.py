@@ -1143,6 +1143,12 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     check_stream_pairs(emu_lib, monkeypatch, N=60, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
 
 
+def test_host_csr_component_with_offset_coordinates(emu_lib):
+    """see helpers.check_host_csr_component_with_offset_coordinates"""
+    from helpers import check_host_csr_component_with_offset_coordinates
+    check_host_csr_component_with_offset_coordinates(emu_lib)
+
+
 def test_contrast_triggered_fp64_hierarchy(emu_lib):
     """see helpers.check_contrast_triggered_fp64_hierarchy"""
     from helpers import check_contrast_triggered_fp64_hierarchy

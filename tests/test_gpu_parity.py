@@ -656,3 +656,11 @@ def test_contrast_triggered_fp64_hierarchy_gpu(gpu_lib):
     """see helpers.check_contrast_triggered_fp64_hierarchy (the case was found on the device)"""
     from helpers import check_contrast_triggered_fp64_hierarchy
     check_contrast_triggered_fp64_hierarchy(gpu_lib)
+
+
+def test_host_csr_component_with_offset_coordinates_gpu(gpu_lib):
+    """see helpers.check_host_csr_component_with_offset_coordinates (found on the device), also at a size whose level 1
+    takes the lattice form"""
+    from helpers import check_host_csr_component_with_offset_coordinates
+    check_host_csr_component_with_offset_coordinates(gpu_lib)
+    check_host_csr_component_with_offset_coordinates(gpu_lib, shape=(190, 160))

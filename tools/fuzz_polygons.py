@@ -25,7 +25,8 @@ bad = 0
 stats = {"lattice": 0, "csr": 0}
 for case in range(ncases):
     rng = np.random.default_rng(seed0 * 100003 + case)
-    R, C = int(rng.integers(12, 46)), int(rng.integers(12, 46))
+    lo_, hi_ = int(os.environ.get("FUZZ_MIN", "12")), int(os.environ.get("FUZZ_MAX", "46"))
+    R, C = int(rng.integers(lo_, hi_)), int(rng.integers(lo_, hi_))
     sigma = float(rng.choice([0.0, 1.0, 2.0]))
     g = np.exp(sigma * rng.standard_normal((R, C)))
     g[rng.random((R, C)) < float(rng.choice([0.0, 0.05, 0.2]))] = 0.0
