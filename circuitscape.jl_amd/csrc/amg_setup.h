@@ -29,6 +29,7 @@
 
 #include "prims.h"
 #include "spmv.h"
+#include "dia25.h"
 
 namespace csgpu {
 
@@ -952,6 +953,9 @@ struct Level {
   Dia<T> Adia;          // level 1 of a raster hierarchy in lattice form (lattice_level1_setup, lattice_setup.h): with it
                         // Sdia = the two-sweep smoother polynomial and Ql = (I - S A) P, and the level runs as four
                         // marching products (vcycle in pcg.h) instead of seven CSR ones
+  Dia25<T> A25;         // levels >= 1 of a raster hierarchy with REFINED tiles (cell-space NODATA rasters, strength-aware
+                        // tiles): A in its index-free 25-point lattice form (dia25.h); the level's Jacobi sweeps and its
+                        // residual march over it instead of going through the CSR SpMM (P, R, Q stay CSR)
   bool lattice_v22() const { return Adia.n > 0 && Sdia.n > 0 && Ql.n > 0; }
   bool lattice_two_product() const { return Adia.n == 0 && Sdia.n > 0 && Ql.n > 0; }
   bool two_product() const { return M.nnz > 0 || lattice_two_product(); }
@@ -1639,6 +1643,11 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
     if (H.levels.size() == 2 && sp.lattice_s && gridR > 0 && (int64_t)lvlR * lvlC == n && sp.nu_l1 == 2 &&
         (L.weights.empty() || L.weights.size() == 2))
       lattice_level1_setup(L, (const int*)dptr<int>(agg), lvlR, lvlC, nagg, st);
+    if (H.levels.size() >= 2 && !L.lattice_v22() && lvlR >= 6 && (int64_t)lvlR * lvlC == n && n >= dia25_min_rows()) {
+      // refined tiles: the level's operator reaches two lattice steps; index-free 25-point form when it fits (dia25.h)
+      if (dia25_from_csr(L.A, lvlR, L.A25, st) && getenv("CSGPU_VERBOSE"))
+        fprintf(stderr, "csgpu: level %d (%d x %d) in 25-point lattice form\n", (int)H.levels.size() - 1, lvlR, lvlC);
+    }
     if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
         (int64_t)n + nagg < 0x7fffffffLL) {
       if (sp.lattice_s) {

@@ -1896,7 +1896,7 @@ struct Solver : ISolver {
       }
       bytes += (int64_t)(L.A.device_bytes() + L.P.device_bytes() + L.R.device_bytes() + L.Q.device_bytes() + L.dinv.bytes +
                          L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
-                         L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes() + L.Ql.device_bytes() + L.Adia.device_bytes());
+                         L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes() + L.Ql.device_bytes() + L.Adia.device_bytes() + L.A25.device_bytes());
     }
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)nnz);
@@ -2063,6 +2063,9 @@ struct Solver : ISolver {
                                              dptr<TP>(y), dptr<double>(part), nullptr, st));
     } else if (which == 4 && L.lattice_two_product()) {  // index-free restriction
       CS_DISPATCH_K(k, lattice_restrict<TP, KK>(L.Ql, (const TP*)dptr<TP>(x), dptr<TP>(y), nullptr, st));
+    } else if (which == 0 && L.A25.n == M.nrows && k >= 8) {  // refined-tile lattice level: the 25-point marching product
+      CS_DISPATCH_K(k, dia25_launch<TP, (KK >= 8 ? KK : 8)>(L.A25, D25_PLAIN, (const TP*)dptr<TP>(x), dptr<TP>(y), (const TP*)nullptr,
+                                                           (const TP*)nullptr, TP(0), nullptr, st));
     } else if (sq) {
       CS_DISPATCH_K(k, spmv_launch_wide<TP, KK>(a, true, st));
     } else {

@@ -190,7 +190,12 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   T* cur = dptr<T>(L.xa);
   T* oth = dptr<T>(L.rb);
   const T omega = (T)L.omega;
+  const bool use25 = K >= 8 && L.A25.n == n && n > 0;  // refined-tile lattice level: index-free products with A (dia25.h)
   auto jacobi_sweep = [&](const T* xin, T* xout, bool dot, int sweep = 0) {
+    if (use25 && !dot) {
+      dia25_launch<T, (K >= 8 ? K : 8)>(L.A25, D25_JACOBI, xin, xout, b, (const T*)dptr<T>(L.dinv), weight(sweep), skip, st);
+      return;
+    }
     SpmvArgs<T> a = level_args(L, xin, xout, skip);
     a.b = b;
     a.dinv = dptr<T>(L.dinv);
@@ -271,7 +276,9 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     CS_HIP(hipMemsetAsync(cur, 0, (size_t)n * K * sizeof(T), st));
   }
   // residual r = b - A x  -> oth
-  {
+  if (use25) {
+    dia25_launch<T, (K >= 8 ? K : 8)>(L.A25, D25_RESID, (const T*)cur, oth, b, (const T*)nullptr, T(0), skip, st);
+  } else {
     SpmvArgs<T> a = level_args(L, (const T*)cur, oth, skip);
     a.b = b;
     spmv_launch<T, K>(a, EPI_RESID, false, st);

@@ -1607,3 +1607,47 @@ def check_host_csr_component_with_offset_coordinates(L, shape=(70, 50)):
                 assert np.max(np.abs(Rr - Rd) / Rd) < 1e-8, (pb, coords)
                 out[(pb, coords)] = Rr
         assert np.array_equal(out[(pb, True)], out[(pb, False)])
+
+
+def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=False):
+    """Index-free 25-point lattice form of the coarse levels under REFINED tiles (dia25.h; A/B knob CSGPU_DIA25): on a
+    raster with NODATA cells (hetero: an all-valid raster whose strength-aware tiles are refined) levels >= 1 must take
+    the form, its marching product must equal the level's CSR operator, and pair solves through it (coarse tail off, so
+    the V-cycle's generic branch really runs the levels) must take the same iterations and give the same resistances as
+    the CSR SpMM path. AMG cycle products: AlgebraicMultigrid.jl smoother / residual, called from src/core.jl:164-178."""
+    monkeypatch.setenv("CSGPU_TAIL_ROWS", "0")
+    if hetero:
+        rng = np.random.default_rng(3)
+        g = np.exp(3.0 * rng.standard_normal(shape))
+    else:
+        g = _nodata_raster(shape, 11)
+    out = {}
+    for mode in ("csr", "dia25"):
+        monkeypatch.setenv("CSGPU_DIA25", "64" if mode == "dia25" else "0")
+        for pb in (0, 4):
+            for K in batches:
+                with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb)) as h:
+                    info = h.info
+                    labels, _ = h.components()
+                    big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                    ids = np.random.default_rng(5).choice(big, size=2 * K, replace=False)
+                    R, _, _, st = h.solve_pairs([int(v) for v in ids[:K]], [int(v) for v in ids[K:]])
+                    assert st["not_converged"] == 0
+                    out[(mode, pb, K)] = (R, st["total_iters"])
+                    if mode == "dia25":
+                        for lvl in (1, 2):
+                            if lvl >= len(info["level_n"]) - 1 or info["level_n"][lvl] < 64:
+                                continue
+                            A = h.level_matrix(lvl, "A")
+                            x = np.random.default_rng(lvl).standard_normal((A.shape[0], K))
+                            y, _ = h.level_spmv(lvl, "A", x)
+                            ref = A @ x.astype(y.dtype)
+                            assert np.abs(y - ref).max() < (1e-13 if y.dtype == np.float64 else 2e-6) * np.abs(ref).max()
+    monkeypatch.delenv("CSGPU_DIA25", raising=False)
+    monkeypatch.delenv("CSGPU_TAIL_ROWS", raising=False)
+    for pb in (0, 4):
+        for K in batches:
+            a, b = out[("csr", pb, K)], out[("dia25", pb, K)]
+            assert abs(a[1] - b[1]) <= 1, (a[1], b[1])
+            assert np.max(np.abs(a[0] - b[0]) / a[0]) < 1e-9
+    return out

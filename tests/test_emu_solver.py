@@ -1267,3 +1267,11 @@ def test_single_level_handles_compute_in_matrix_precision(emu_lib):
     """see helpers.check_single_level_handles_compute_in_matrix_precision"""
     from helpers import check_single_level_handles_compute_in_matrix_precision
     check_single_level_handles_compute_in_matrix_precision(emu_lib)
+
+
+def test_coarse_levels_in_25_point_lattice_form(emu_lib, monkeypatch, capfd):
+    """refined tiles (NODATA cell space): levels >= 1 index-free (dia25.h), same products / iterations / resistances"""
+    from helpers import check_dia25_levels
+    monkeypatch.setenv("CSGPU_VERBOSE", "1")
+    check_dia25_levels(emu_lib, monkeypatch)
+    assert "in 25-point lattice form" in capfd.readouterr().err

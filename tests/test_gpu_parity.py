@@ -664,3 +664,12 @@ def test_host_csr_component_with_offset_coordinates_gpu(gpu_lib):
     from helpers import check_host_csr_component_with_offset_coordinates
     check_host_csr_component_with_offset_coordinates(gpu_lib)
     check_host_csr_component_with_offset_coordinates(gpu_lib, shape=(190, 160))
+
+
+@pytest.mark.gpu
+def test_coarse_levels_in_25_point_lattice_form_gpu(gpu_lib, monkeypatch):
+    """refined tiles: levels >= 1 in the index-free 25-point form (dia25.h), device twin of the emulator test at a
+    size where level 1 is a real level (1000 x 900: 100 200 rows) and with the strength-aware tiles of a wide raster"""
+    from helpers import check_dia25_levels
+    check_dia25_levels(gpu_lib, monkeypatch, shape=(1000, 900), batches=(8, 16, 32))
+    check_dia25_levels(gpu_lib, monkeypatch, shape=(400, 390), batches=(16,), hetero=True)
