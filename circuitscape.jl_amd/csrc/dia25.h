@@ -208,11 +208,162 @@ __global__ __launch_bounds__(256) void dia25_kernel(Dia25Args<T> a) {
       __syncthreads();            // everybody is done with x column j - 2 and the matrix tile of column j
       store_x(j + 3);             // (slot (j + 3) & 7 = that of column j - 5: long since free)
       store_m(j + 1);             // (slot (j + 1) & 1 = that of column j - 1)
-      if (j + 4 <= j1 + 2) load_x(j + 4);
+      if (j + 4 <= j1 + 1) load_x(j + 4);
       if (j + 2 < j1) load_m(j + 2);
       __syncthreads();
     }
   }
+}
+
+// The same product with the 5 x 5 window of x in REGISTERS (25 16-byte vectors per lane): marching one column on, a lane
+// keeps 20 of them and reads the 5 of the new column from LDS -- 5 LDS reads of x per lane and column instead of 25. (With
+// the ring kernel above the LDS pipe is as busy as HBM: per wavefront and column 25 x 8 clocks for x + 25 x 4 for the
+// matrix row against 4 nodes x 968 B of HBM traffic at K = 32 fp64.) The x ring shrinks to two slots (the column being
+// read, the column being written) and one barrier per column is enough. The column loop is unrolled five-fold so the
+// window's slots are compile-time registers.
+template <class T, int K, int EPI>
+__global__ __launch_bounds__(256) void dia25w_kernel(Dia25Args<T> a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CPL = K < VEC ? K : VEC;
+  constexpr int LPR = K / CPL;
+  constexpr int TI = 256 / LPR;
+  constexpr int HR = TI + 4;
+  constexpr int XU = (HR * LPR + 255) / 256;
+  constexpr int MU = (25 * TI + 255) / 256;
+  typedef SpmvVec<T, CPL> XV;
+  __shared__ XV s_x[2][HR * LPR];
+  __shared__ T s_m[2][25 * TI];
+  if (a.skip && *a.skip) return;
+  const int tid = threadIdx.x;
+  const int t = tid / LPR, lq = tid % LPR, c0 = lq * CPL;
+  const int ntiles = a.nstrips * a.nseg;
+  int t_first = blockIdx.x, t_last = ntiles, t_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, chunk = (ntiles + 7) >> 3;
+    t_first = xcd * chunk + (blockIdx.x >> 3);
+    t_last = min(ntiles, (xcd + 1) * chunk);
+    t_step = gridDim.x >> 3;
+  }
+  for (int tile = t_first; tile < t_last; tile += t_step) {
+    const int si = tile % a.nstrips, sj = tile / a.nstrips;
+    const int i0 = si * TI;
+    const int j0 = sj * a.seg, j1 = min(a.C, j0 + a.seg);
+    const bool row_on = i0 + t < a.R;
+    XV xreg[XU];
+    T mreg[MU];
+    XV win[5][5];  // win[s][di]: x(i0 + t + di - 2, column with (column - j0 + 2) % 5 == s)
+    auto load_x = [&](int jc) {
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        const int e = tid + u * 256;
+        XV v;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v.e[q] = T(0);
+        if (e < HR * LPR && jc >= 0 && jc < a.C) {
+          const int row = i0 - 2 + e / LPR;
+          if (row >= 0 && row < a.R) v = *reinterpret_cast<const XV*>(a.x + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
+        }
+        xreg[u] = v;
+      }
+    };
+    auto store_x = [&](int jc) {
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        const int e = tid + u * 256;
+        if (e < HR * LPR) s_x[jc & 1][e] = xreg[u];
+      }
+    };
+    auto load_m = [&](int jc) {
+      const int64_t base = ((int64_t)jc * a.R + i0) * 25;
+      const int nval = 25 * min(TI, a.R - i0);
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * 256;
+        mreg[u] = (e < nval && jc < a.C) ? a.rows[base + e] : T(0);
+      }
+    };
+    auto store_m = [&](int jc) {
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * 256;
+        if (e < 25 * TI) s_m[jc & 1][e] = mreg[u];
+      }
+    };
+    // prologue: columns j0 - 2 .. j0 + 1 through LDS into window slots 0 .. 3
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int jc = j0 - 2 + s;
+      load_x(jc);
+      __syncthreads();  // (previous tile / previous prologue step finished with the slot)
+      store_x(jc);
+      __syncthreads();
+#pragma unroll
+      for (int di = 0; di < 5; ++di) win[s][di] = s_x[jc & 1][(size_t)(t + di) * LPR + lq];
+    }
+    __syncthreads();
+    load_x(j0 + 2);
+    load_m(j0);
+    store_x(j0 + 2);
+    store_m(j0);
+    load_x(j0 + 3);
+    load_m(j0 + 1);
+    __syncthreads();
+    for (int jb = j0; jb < j1; jb += 5) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int j = jb + u;
+        if (j < j1) {  // (uniform over the workgroup)
+          // newest column of the window: j + 2 -> slot (u + 4) % 5
+#pragma unroll
+          for (int di = 0; di < 5; ++di) win[(u + 4) % 5][di] = s_x[(j + 2) & 1][(size_t)(t + di) * LPR + lq];
+          if (row_on) {
+            const T* m = s_m[j & 1] + 25 * t;
+            T acc[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) acc[q] = T(0);
+#pragma unroll
+            for (int dj = 0; dj < 5; ++dj) {
+#pragma unroll
+              for (int di = 0; di < 5; ++di) {
+                const T w = m[dj * 5 + di];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) acc[q] = fma(w, win[(u + dj) % 5][di].e[q], acc[q]);
+              }
+            }
+            const size_t e0 = ((size_t)j * a.R + i0 + t) * K + c0;
+            XV out;
+            if (EPI == D25_PLAIN) {
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) out.e[q] = acc[q];
+            } else {
+              const XV bv = *reinterpret_cast<const XV*>(a.b + e0);
+              if (EPI == D25_RESID) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) out.e[q] = bv.e[q] - acc[q];
+              } else {
+                const T sc = a.omega * a.dinv[(size_t)j * a.R + i0 + t];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) out.e[q] = win[(u + 2) % 5][2].e[q] + sc * (bv.e[q] - acc[q]);
+              }
+            }
+            *reinterpret_cast<XV*>(a.y + e0) = out;
+          }
+          // column j + 3 / matrix j + 1 into the slots nobody reads during this step; next loads in flight
+          store_x(j + 3);
+          store_m(j + 1);
+          if (j + 4 <= j1 + 1) load_x(j + 4);
+          if (j + 2 < j1) load_m(j + 2);
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+// kernel choice (A/B knob CSGPU_DIA25_KERNEL=ring|window)
+inline bool dia25_window() {
+  const char* e = getenv("CSGPU_DIA25_KERNEL");  // (read at every launch: the tests switch it inside one process)
+  return e ? (e[0] == 'w') : true;
 }
 
 template <class T, int K>
@@ -239,6 +390,15 @@ inline void dia25_launch(const Dia25<T>& D, int epi, const T* x, T* y, const T* 
   if (g > 65536) g = 65536;
   if (g >= 64) g &= ~(int64_t)7;
   const dim3 grid((int)std::max<int64_t>(g, 1));
+  if (dia25_window()) {
+    if (epi == D25_PLAIN)
+      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_PLAIN>), grid, dim3(256), 0, st, a);
+    else if (epi == D25_RESID)
+      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_RESID>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_JACOBI>), grid, dim3(256), 0, st, a);
+    return;
+  }
   if (epi == D25_PLAIN)
     hipLaunchKernelGGL((dia25_kernel<T, K, D25_PLAIN>), grid, dim3(256), 0, st, a);
   else if (epi == D25_RESID)

@@ -1622,8 +1622,9 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
     else:
         g = _nodata_raster(shape, 11)
     out = {}
-    for mode in ("csr", "dia25"):
-        monkeypatch.setenv("CSGPU_DIA25", "64" if mode == "dia25" else "0")
+    for mode in ("csr", "dia25", "dia25ring"):
+        monkeypatch.setenv("CSGPU_DIA25", "64" if mode != "csr" else "0")
+        monkeypatch.setenv("CSGPU_DIA25_KERNEL", "ring" if mode == "dia25ring" else "window")
         for pb in (0, 4):
             for K in batches:
                 with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb)) as h:
@@ -1634,7 +1635,7 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                     R, _, _, st = h.solve_pairs([int(v) for v in ids[:K]], [int(v) for v in ids[K:]])
                     assert st["not_converged"] == 0
                     out[(mode, pb, K)] = (R, st["total_iters"])
-                    if mode == "dia25":
+                    if mode != "csr":
                         for lvl in (1, 2):
                             if lvl >= len(info["level_n"]) - 1 or info["level_n"][lvl] < 64:
                                 continue
@@ -1643,11 +1644,14 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                             y, _ = h.level_spmv(lvl, "A", x)
                             ref = A @ x.astype(y.dtype)
                             assert np.abs(y - ref).max() < (1e-13 if y.dtype == np.float64 else 2e-6) * np.abs(ref).max()
-    monkeypatch.delenv("CSGPU_DIA25", raising=False)
-    monkeypatch.delenv("CSGPU_TAIL_ROWS", raising=False)
+    for key in ("CSGPU_DIA25", "CSGPU_DIA25_KERNEL", "CSGPU_TAIL_ROWS"):
+        monkeypatch.delenv(key, raising=False)
     for pb in (0, 4):
         for K in batches:
-            a, b = out[("csr", pb, K)], out[("dia25", pb, K)]
-            assert abs(a[1] - b[1]) <= 1, (a[1], b[1])
-            assert np.max(np.abs(a[0] - b[0]) / a[0]) < 1e-9
+            for mode in ("dia25", "dia25ring"):
+                a, b = out[("csr", pb, K)], out[(mode, pb, K)]
+                diff = np.max(np.abs(a[0] - b[0]) / a[0])
+                # (fp32 hierarchy: another summation order inside the preconditioner moves the iterates at fp32 rounding times
+                # the remaining error -- both answers satisfy the stopping rule)
+                assert abs(a[1] - b[1]) <= 1 and diff < (1e-9 if pb == 0 else 1e-7), (mode, pb, K, a[1], b[1], diff)
     return out

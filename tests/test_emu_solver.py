@@ -1273,5 +1273,5 @@ def test_coarse_levels_in_25_point_lattice_form(emu_lib, monkeypatch, capfd):
     """refined tiles (NODATA cell space): levels >= 1 index-free (dia25.h), same products / iterations / resistances"""
     from helpers import check_dia25_levels
     monkeypatch.setenv("CSGPU_VERBOSE", "1")
-    check_dia25_levels(emu_lib, monkeypatch)
+    check_dia25_levels(emu_lib, monkeypatch, shape=(70, 115))  # level 1: 23 x 38 -- two column segments, 38 = 32 + 6
     assert "in 25-point lattice form" in capfd.readouterr().err
