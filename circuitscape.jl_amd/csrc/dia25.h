@@ -9,9 +9,9 @@
 // Here the operator is stored index-free, 25 values per row (slot (dJ + 2) * 5 + (dI + 2) = A[(i, j), (i + dI, j + dJ)],
 // 0 where absent; the full window, not the symmetric half: the kernel then needs no neighbour's matrix row), and the
 // product marches like the nine-point kernels of stencil.h: a workgroup owns TI rows x SEG columns of the level's lattice,
-// streams a column's x entries (two halo rows above and below) into an 8-slot LDS ring one step ahead and the column's
-// 25 * TI matrix values into a double-buffered LDS tile, and every lane takes its 25 products out of LDS. All HBM accesses
-// are contiguous column segments; matrix bytes per row 200 instead of 304, no column indices, no gathers.
+// streams a column's x entries (two halo rows above and below) through a two-slot LDS ring one step ahead and the column's
+// 25 * TI matrix values into a double-buffered LDS tile; a lane keeps the 5 x 5 window of its row in registers. All HBM
+// accesses are contiguous column segments; matrix bytes per row 200 instead of 304, no column indices, no gathers.
 // GPU counterpart of the smoother / residual products of AlgebraicMultigrid.jl's V-cycle on that level (reference call
 // sites src/core.jl:164-167, 178).
 #pragma once
@@ -88,141 +88,18 @@ struct Dia25Args {
   const int* skip;
 };
 
-// y = A x | b - A x | x + omega dinv (b - A x), A in 25-point lattice form
-template <class T, int K, int EPI>
-__global__ __launch_bounds__(256) void dia25_kernel(Dia25Args<T> a) {
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int CPL = K < VEC ? K : VEC;
-  constexpr int LPR = K / CPL;
-  constexpr int TI = 256 / LPR;
-  constexpr int HR = TI + 4;                       // rows staged per column (two halo rows above / below)
-  constexpr int XU = (HR * LPR + 255) / 256;       // 16-byte loads of x per lane and column
-  constexpr int MU = (25 * TI + 255) / 256;        // matrix values per lane and column
-  typedef SpmvVec<T, CPL> XV;
-  __shared__ XV s_x[8][HR * LPR];
-  __shared__ T s_m[2][25 * TI];
-  if (a.skip && *a.skip) return;
-  const int tid = threadIdx.x;
-  const int t = tid / LPR, lq = tid % LPR, c0 = lq * CPL;
-  const int ntiles = a.nstrips * a.nseg;
-  int t_first = blockIdx.x, t_last = ntiles, t_step = gridDim.x;
-  if ((gridDim.x & 7) == 0) {  // XCD-aware tile walk (see dia_cg_kernel)
-    const int xcd = blockIdx.x & 7, chunk = (ntiles + 7) >> 3;
-    t_first = xcd * chunk + (blockIdx.x >> 3);
-    t_last = min(ntiles, (xcd + 1) * chunk);
-    t_step = gridDim.x >> 3;
-  }
-  for (int tile = t_first; tile < t_last; tile += t_step) {
-    const int si = tile % a.nstrips, sj = tile / a.nstrips;
-    const int i0 = si * TI;
-    const int j0 = sj * a.seg, j1 = min(a.C, j0 + a.seg);
-    const bool row_on = i0 + t < a.R;
-    XV xreg[XU];
-    T mreg[MU];
-    // column jc of x into registers: staged rows i0 - 2 .. i0 + TI + 1, zero outside the lattice
-    auto load_x = [&](int jc) {
-#pragma unroll
-      for (int u = 0; u < XU; ++u) {
-        const int e = tid + u * 256;
-        XV v;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) v.e[q] = T(0);
-        if (e < HR * LPR && jc >= 0 && jc < a.C) {
-          const int row = i0 - 2 + e / LPR;
-          if (row >= 0 && row < a.R) v = *reinterpret_cast<const XV*>(a.x + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
-        }
-        xreg[u] = v;
-      }
-    };
-    auto store_x = [&](int jc) {
-#pragma unroll
-      for (int u = 0; u < XU; ++u) {
-        const int e = tid + u * 256;
-        if (e < HR * LPR) s_x[jc & 7][e] = xreg[u];
-      }
-    };
-    // matrix values of column jc, rows i0 .. i0 + TI - 1 (contiguous: 25 per row)
-    auto load_m = [&](int jc) {
-      const int64_t base = ((int64_t)jc * a.R + i0) * 25;
-      const int nval = 25 * min(TI, a.R - i0);
-#pragma unroll
-      for (int u = 0; u < MU; ++u) {
-        const int e = tid + u * 256;
-        mreg[u] = (e < nval && jc < a.C) ? a.rows[base + e] : T(0);
-      }
-    };
-    auto store_m = [&](int jc) {
-#pragma unroll
-      for (int u = 0; u < MU; ++u) {
-        const int e = tid + u * 256;
-        if (e < 25 * TI) s_m[jc & 1][e] = mreg[u];
-      }
-    };
-    __syncthreads();  // previous tile finished with the ring
-    // prologue: x columns j0 - 2 .. j0 + 2 and the matrix of column j0 into LDS; x column j0 + 3 / matrix j0 + 1 in flight
-    for (int jc = j0 - 2; jc <= j0 + 2; ++jc) {
-      load_x(jc);
-      store_x(jc);
-    }
-    load_m(j0);
-    store_m(j0);
-    load_x(j0 + 3);
-    load_m(j0 + 1);
-    __syncthreads();
-    for (int j = j0; j < j1; ++j) {
-      if (row_on) {
-        const T* m = s_m[j & 1] + 25 * t;
-        T acc[CPL];
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) acc[q] = T(0);
-#pragma unroll
-        for (int dj = 0; dj < 5; ++dj) {
-          const XV* xc = s_x[(j + dj - 2) & 7] + (size_t)t * LPR + lq;  // staged row of lattice row i0 + t - 2
-#pragma unroll
-          for (int di = 0; di < 5; ++di) {
-            const T w = m[dj * 5 + di];
-            const XV xv = xc[di * LPR];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) acc[q] = fma(w, xv.e[q], acc[q]);
-          }
-        }
-        const size_t e0 = ((size_t)j * a.R + i0 + t) * K + c0;
-        XV out;
-        if (EPI == D25_PLAIN) {
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) out.e[q] = acc[q];
-        } else {
-          const XV bv = *reinterpret_cast<const XV*>(a.b + e0);
-          if (EPI == D25_RESID) {
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) out.e[q] = bv.e[q] - acc[q];
-          } else {
-            const XV xs = s_x[j & 7][(size_t)(t + 2) * LPR + lq];
-            const T sc = a.omega * a.dinv[(size_t)j * a.R + i0 + t];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) out.e[q] = xs.e[q] + sc * (bv.e[q] - acc[q]);
-          }
-        }
-        *reinterpret_cast<XV*>(a.y + e0) = out;
-      }
-      __syncthreads();            // everybody is done with x column j - 2 and the matrix tile of column j
-      store_x(j + 3);             // (slot (j + 3) & 7 = that of column j - 5: long since free)
-      store_m(j + 1);             // (slot (j + 1) & 1 = that of column j - 1)
-      if (j + 4 <= j1 + 1) load_x(j + 4);
-      if (j + 2 < j1) load_m(j + 2);
-      __syncthreads();
-    }
-  }
-}
-
-// The same product with the 5 x 5 window of x in REGISTERS (25 16-byte vectors per lane): marching one column on, a lane
-// keeps 20 of them and reads the 5 of the new column from LDS -- 5 LDS reads of x per lane and column instead of 25. (With
-// the ring kernel above the LDS pipe is as busy as HBM: per wavefront and column 25 x 8 clocks for x + 25 x 4 for the
-// matrix row against 4 nodes x 968 B of HBM traffic at K = 32 fp64.) The x ring shrinks to two slots (the column being
-// read, the column being written) and one barrier per column is enough. The column loop is unrolled five-fold so the
-// window's slots are compile-time registers.
-template <class T, int K, int EPI>
-__global__ __launch_bounds__(256) void dia25w_kernel(Dia25Args<T> a) {
+// y = A x | b - A x | x + omega dinv (b - A x), A in 25-point lattice form.
+// The 5 x 5 window of x lives in REGISTERS (25 16-byte vectors per lane): marching one column on, a lane keeps 20 of them
+// and reads the 5 of the new column from LDS. (Round-4 measurement, profiles/r4_dia25_ab_10000_holes15.json: with the
+// whole window read from an LDS ring -- 25 reads of x per lane and column -- the LDS pipe was as busy as HBM, per
+// wavefront and column 25 x 8 clocks for x + 25 x 4 for the matrix row against 4 nodes x 968 B of HBM traffic at K = 32
+// fp64; 486 ms per 16 pairs against 464 with the register window.) The x ring has two slots (the column being read, the
+// column being written) and one barrier per column is enough. The column loop is unrolled five-fold so the window's slots
+// are compile-time registers. PF: the column's b / dinv entries are loaded one column ahead as well (A/B knob
+// CSGPU_DIA25_PF) -- without it every column waits out the latency of its own b load. WV: waves per SIMD the register
+// allocation is held to (3: 168 VGPRs, a few spilled dwords in some instantiations; 1: no limit; A/B knob CSGPU_DIA25_WAVES).
+template <class T, int K, int EPI, bool PF, int WV>
+__global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int CPL = K < VEC ? K : VEC;
   constexpr int LPR = K / CPL;
@@ -307,12 +184,27 @@ __global__ __launch_bounds__(256) void dia25w_kernel(Dia25Args<T> a) {
     store_m(j0);
     load_x(j0 + 3);
     load_m(j0 + 1);
+    XV b_pre;
+    T d_pre = T(0);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) b_pre.e[q] = T(0);
+    auto load_b = [&](int jc) {
+      if (EPI != D25_PLAIN && row_on && jc < j1) {
+        b_pre = *reinterpret_cast<const XV*>(a.b + ((size_t)jc * a.R + i0 + t) * K + c0);
+        if (EPI == D25_JACOBI) d_pre = a.dinv[(size_t)jc * a.R + i0 + t];
+      }
+    };
+    if (PF) load_b(j0);
     __syncthreads();
     for (int jb = j0; jb < j1; jb += 5) {
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
         const int j = jb + u;
         if (j < j1) {  // (uniform over the workgroup)
+          if (!PF) load_b(j);
+          const XV bv = b_pre;
+          const T dv = d_pre;
+          if (PF) load_b(j + 1);
           // newest column of the window: j + 2 -> slot (u + 4) % 5
 #pragma unroll
           for (int di = 0; di < 5; ++di) win[(u + 4) % 5][di] = s_x[(j + 2) & 1][(size_t)(t + di) * LPR + lq];
@@ -336,12 +228,11 @@ __global__ __launch_bounds__(256) void dia25w_kernel(Dia25Args<T> a) {
 #pragma unroll
               for (int q = 0; q < CPL; ++q) out.e[q] = acc[q];
             } else {
-              const XV bv = *reinterpret_cast<const XV*>(a.b + e0);
               if (EPI == D25_RESID) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) out.e[q] = bv.e[q] - acc[q];
               } else {
-                const T sc = a.omega * a.dinv[(size_t)j * a.R + i0 + t];
+                const T sc = a.omega * dv;
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) out.e[q] = win[(u + 2) % 5][2].e[q] + sc * (bv.e[q] - acc[q]);
               }
@@ -360,10 +251,17 @@ __global__ __launch_bounds__(256) void dia25w_kernel(Dia25Args<T> a) {
   }
 }
 
-// kernel choice (A/B knob CSGPU_DIA25_KERNEL=ring|window)
-inline bool dia25_window() {
-  const char* e = getenv("CSGPU_DIA25_KERNEL");  // (read at every launch: the tests switch it inside one process)
-  return e ? (e[0] == 'w') : true;
+inline bool dia25_prefetch_b() {
+  const char* e = getenv("CSGPU_DIA25_PF");  // (read at every launch: the tests switch it inside one process)
+  return e ? atoi(e) != 0 : true;
+}
+
+// Register bound of the launch: 3 waves per SIMD where that costs at most a few spilled dwords (8 or more lanes per node:
+// K = 32, K = 16 fp64; measured at K = 32: 325.3 against 327.7 ms per 16 pairs on the mixed path), no bound for the
+// narrower batches (K = 8 fp64 would spill 52 B per lane under the bound; without it 2 waves per SIMD and no scratch).
+inline int dia25_waves(int lanes_per_node) {
+  const char* e = getenv("CSGPU_DIA25_WAVES");
+  return e ? atoi(e) : (lanes_per_node >= 8 ? 3 : 1);
 }
 
 template <class T, int K>
@@ -390,21 +288,29 @@ inline void dia25_launch(const Dia25<T>& D, int epi, const T* x, T* y, const T* 
   if (g > 65536) g = 65536;
   if (g >= 64) g &= ~(int64_t)7;
   const dim3 grid((int)std::max<int64_t>(g, 1));
-  if (dia25_window()) {
-    if (epi == D25_PLAIN)
-      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_PLAIN>), grid, dim3(256), 0, st, a);
-    else if (epi == D25_RESID)
-      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_RESID>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((dia25w_kernel<T, K, D25_JACOBI>), grid, dim3(256), 0, st, a);
-    return;
+  const bool pf = dia25_prefetch_b(), w3 = dia25_waves(K / CPL) >= 3;
+#define CS_D25_LAUNCH(E, P, W) hipLaunchKernelGGL((dia25w_kernel<T, K, E, P, W>), grid, dim3(256), 0, st, a)
+#define CS_D25_EPI(E)                  \
+  do {                                 \
+    if (pf && w3) {                    \
+      CS_D25_LAUNCH(E, true, 3);       \
+    } else if (pf) {                   \
+      CS_D25_LAUNCH(E, true, 1);       \
+    } else if (w3) {                   \
+      CS_D25_LAUNCH(E, false, 3);      \
+    } else {                           \
+      CS_D25_LAUNCH(E, false, 1);      \
+    }                                  \
+  } while (0)
+  if (epi == D25_PLAIN) {
+    CS_D25_LAUNCH(D25_PLAIN, true, 3);
+  } else if (epi == D25_RESID) {
+    CS_D25_EPI(D25_RESID);
+  } else {
+    CS_D25_EPI(D25_JACOBI);
   }
-  if (epi == D25_PLAIN)
-    hipLaunchKernelGGL((dia25_kernel<T, K, D25_PLAIN>), grid, dim3(256), 0, st, a);
-  else if (epi == D25_RESID)
-    hipLaunchKernelGGL((dia25_kernel<T, K, D25_RESID>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((dia25_kernel<T, K, D25_JACOBI>), grid, dim3(256), 0, st, a);
+#undef CS_D25_EPI
+#undef CS_D25_LAUNCH
 }
 
 }  // namespace csgpu

@@ -1622,9 +1622,9 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
     else:
         g = _nodata_raster(shape, 11)
     out = {}
-    for mode in ("csr", "dia25", "dia25ring"):
+    for mode in ("csr", "dia25", "dia25nopf"):   # (nopf: the kernel variant without the one-column-ahead load of b / dinv)
         monkeypatch.setenv("CSGPU_DIA25", "64" if mode != "csr" else "0")
-        monkeypatch.setenv("CSGPU_DIA25_KERNEL", "ring" if mode == "dia25ring" else "window")
+        monkeypatch.setenv("CSGPU_DIA25_PF", "0" if mode == "dia25nopf" else "1")
         for pb in (0, 4):
             for K in batches:
                 with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb)) as h:
@@ -1644,11 +1644,11 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                             y, _ = h.level_spmv(lvl, "A", x)
                             ref = A @ x.astype(y.dtype)
                             assert np.abs(y - ref).max() < (1e-13 if y.dtype == np.float64 else 2e-6) * np.abs(ref).max()
-    for key in ("CSGPU_DIA25", "CSGPU_DIA25_KERNEL", "CSGPU_TAIL_ROWS"):
+    for key in ("CSGPU_DIA25", "CSGPU_DIA25_PF", "CSGPU_TAIL_ROWS"):
         monkeypatch.delenv(key, raising=False)
     for pb in (0, 4):
         for K in batches:
-            for mode in ("dia25", "dia25ring"):
+            for mode in ("dia25", "dia25nopf"):
                 a, b = out[("csr", pb, K)], out[(mode, pb, K)]
                 diff = np.max(np.abs(a[0] - b[0]) / a[0])
                 # (fp32 hierarchy: another summation order inside the preconditioner moves the iterates at fp32 rounding times
