@@ -231,6 +231,39 @@ def config3_fp32_leg(lib, size, B, dev_index, batch_pairs, sync, one_call):
                     "(core.jl:161), ~4e-3 per entry at n = 1e8 -- a strongly grounded system, hence the low iteration count"}
 
 
+def nodata_leg(lib, g, B, make_opts, precond, sync, frac=0.15, steps=2):
+    """The bench raster with 15 % of its cells NODATA (i.i.d.; construct_node_map drops cells with conductance <= 0,
+    src/raster/pairwise.jl:271-301) -- what a real landscape looks like next to the all-valid headline: cell-space handle
+    (the full lattice on the marching kernels, NODATA cells as weightless rows), 3x3 tiles refined by the piece analysis,
+    coarse levels in 25-point lattice form (csrc/dia25.h). Focal cells: 15 cells of the giant component; 1 warm-up batch +
+    `steps` timed batches of B pairs in one call, on the `value` path's precision. Parity of this path against the tight
+    oracle: tests/test_gpu_parity.py (2000^2)."""
+    rng = np.random.default_rng(2468)
+    gh = np.where(rng.random(g.shape) < frac, g.dtype.type(0), g)
+    h = lib.raster_setup(gh, make_opts(precond))
+    try:
+        del gh
+        info = h.info
+        labels, ncomp = h.components()
+        giant = np.flatnonzero(labels == np.bincount(labels).argmax())
+        pts = np.random.default_rng(97531).choice(giant, size=15, replace=False)
+        pairs = [(int(pts[i]), int(pts[j])) for i in range(15) for j in range(i + 1, 15)]
+
+        def batch_pairs(k):
+            idx = [(k * B + i) % len(pairs) for i in range(B)]
+            return [pairs[i][0] for i in idx], [pairs[i][1] for i in idx]
+        el, res, agg = run_pairs(h, batch_pairs, steps, 1, sync, one_call=True)
+    finally:
+        h.close()
+    sv = (info["setup_ms"] + info["upload_ms"]) / 1e3
+    return {"value": steps * B / (el + sv * steps * B / 100.0), "unit": "pair-solves/s", "nodata_fraction": frac,
+            "nodes": int(info["n"]), "giant_component_nodes": int(giant.size), "components": int(ncomp),
+            "lattice_period": info["lattice_period"], "levels": info["levels"], "steps": steps,
+            "ms_per_16_pairs": el / steps * 1e3 * 16.0 / B, "iters_mean": agg["total_iters"] / float(steps * B),
+            "iters_max": agg["max_iters"], "max_relres": agg["max_relres"], "not_converged": agg["not_converged"],
+            "setup_s": sv, "precond": precond}
+
+
 def random_network(n, seed=424242):
     """BASELINE configs[4] generator (tools/network_bench.py, tests/test_gpu_scale.py): 10 n endpoint pairs, deduplicated,
     giant component, conductances U(0.5, 2)."""
@@ -638,6 +671,11 @@ def main():
                                         "note": "x carried over all n rows + explicit ||Ax-b||/||b|| check; no D2H of voltages"}
             except Exception as e:
                 out["with_voltages"] = {"failed": repr(e)}
+        if world == 1 and args.extra_legs:
+            try:   # the same raster with 15 % NODATA cells (cell space, refined tiles, 25-point coarse levels)
+                out["nodata15"] = nodata_leg(lib, g, B, make_opts, args.precond, sync)
+            except Exception as e:
+                out["nodata15"] = {"failed": repr(e)}
         if world == 1 and args.extra_legs and vb == 8:
             # the two BASELINE configs the headline does not cover, driver-run: configs[3] precision (fp32) on this raster,
             # configs[4] (network, advanced one-to-all) at n = 1e6
