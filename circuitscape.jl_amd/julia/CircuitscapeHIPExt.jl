@@ -139,13 +139,13 @@ laplacian!, regularisation of core.jl:161) and sets up AMG -- no COO / SparseMat
 returns the node map (1-based, 0 = NODATA), `components` the connected components (0-based dense labels).
 `cellmap` is Julia's column-major Matrix; the C side wants row-major, hence the permutedims.
 """
-function raster_factor(cellmap::Matrix{T}, s::HIPAMGSolver; four_neighbors = false, avg_res = false) where {T}
+function raster_factor(cellmap::Matrix{T}, s::HIPAMGSolver; four_neighbors = false, avg_res = false, reg = true) where {T}
     o = default_opts(s.bs)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rm = permutedims(cellmap)                      # row-major [nrows][ncols] as seen from C
     rc = GC.@preserve rm ccall((:csgpu_raster_setup, LIBCSGPU), Cint,
               (Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Cint, Ref{CsgpuOpts}, Ref{Ptr{Cvoid}}),
-              rm, size(cellmap, 1), size(cellmap, 2), sizeof(T), four_neighbors, avg_res, 1, o, h)
+              rm, size(cellmap, 1), size(cellmap, 2), sizeof(T), four_neighbors, avg_res, reg ? 1 : 0, o, h)
     rc == 0 || error("csgpu_raster_setup failed: $(csgpu_error())")
     HIPFactor(h[])
 end
@@ -214,6 +214,87 @@ function solve_grounded(factor::HIPFactor, rhs::Matrix{T}, grounds::Vector{Vecto
     rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
     rc == 0 || error("csgpu_solve_grounded failed: $(csgpu_error())")
     x, cur, st
+end
+
+"""
+One-to-all / all-to-one with ONE graph build and ONE AMG setup for all focal points (scope rows N2 + N4; the Julia twin of
+`solver.py::onetoall_on_device`). `onetoall_kernel` (raster/onetoall.jl:13-162) builds the graph once but calls
+`advanced_kernel` -> `multiple_solver` per focal point, which deletes the grounded rows / columns and factorises again
+(raster/advanced.jl:282-312). Here every focal point is one column of `csgpu_solve_grounded` -- the same reduced systems on
+the hierarchy of the ungrounded Laplacian, `s.bs` points per PCG -- and the node currents come from the device
+(out.jl:178-207). Applies to rasters without polygons, single-cell focal points, no variable strengths, no included pairs
+(`onetoall_on_device_applies`); everything else keeps the reference's driver, which reaches the device through
+`multiple_solve(::HIPAMGSolver, ...)`. Dispatch (INTEGRATION.md section 2): first line of `onetoall_kernel`,
+`s = get_solver(cfg); s isa HIPAMGSolver && onetoall_on_device_applies(data) && return onetoall_on_device(data, flags, cfg, s)`.
+"""
+onetoall_on_device_applies(data) =
+    isempty(data.strengths) && isempty(data.included_pairs) && isempty(data.polymap) &&
+    length(unique(data.points_rc[3])) == length(data.points_rc[3])
+
+function onetoall_on_device(data, flags, cfg, s::HIPAMGSolver)
+    gmap = data.cellmap
+    T = eltype(gmap)
+    hbmeta = data.hbmeta
+    rows, cols, ids = data.points_rc                  # 1-based cells and point ids (raster/onetoall.jl:17)
+    np = length(ids)
+    of = flags.outputflags
+    one_to_all = flags.is_onetoall
+    want_cur = of.write_cur_maps || of.write_cum_cur_map_only
+    res = fill(T(-1), np)
+    cum = initialize_cum_maps(gmap, of.write_max_cur_maps)
+    np == 1 && return hcat(ids, res)                  # (a single point: sum(point_map) == n, onetoall.jl:102-105)
+    # no regularisation shift: the grounded systems are non-singular (advanced.jl never adds one)
+    factor = raster_factor(gmap, s; four_neighbors = flags.four_neighbors, avg_res = flags.avg_res, reg = false)
+    nodemap = raster_nodemap(factor)
+    n = Int(maximum(nodemap))
+    node = Int64[nodemap[rows[i], cols[i]] - 1 for i in 1:np]          # 0-based; -1: the focal cell is NODATA
+    comp, _ = components(factor, n)
+    rhs = zeros(T, n, np)
+    grounds = Vector{Vector{Int64}}(undef, np)
+    solvable = falses(np)
+    gcomps = Vector{Set{Int32}}(undef, np)
+    for i in 1:np
+        others = Int64[node[k] for k in 1:np if k != i && node[k] >= 0]
+        own = node[i] >= 0 ? Int64[node[i]] : Int64[]
+        src, gnd = one_to_all ? (own, others) : (others, own)
+        gcomps[i] = Set{Int32}(comp[g + 1] for g in gnd)
+        for q in src
+            comp[q + 1] in gcomps[i] || continue      # a component without a ground is not solved (advanced.jl:186-191)
+            rhs[q + 1, i] = one(T)
+            solvable[i] = true
+        end
+        grounds[i] = gnd
+    end
+    volt, curr, _ = solve_grounded(factor, rhs, grounds; want_currents = want_cur)
+    finalize(factor)                                  # (releases the device-resident hierarchy now; HIPFactor finalizer)
+    for i in 1:np
+        # a component without a ground is not part of the column's system; the reference has no voltage there
+        outside = Bool[!(comp[k] in gcomps[i]) for k in 1:n]
+        volt[outside, i] .= 0
+        want_cur && (curr[outside, i] .= 0)
+        vmap = zeros(T, size(gmap))
+        cmap = want_cur ? zeros(T, size(gmap)) : zeros(T, 0, 0)
+        for k in eachindex(nodemap)
+            nodemap[k] == 0 && continue
+            vmap[k] = volt[nodemap[k], i]
+            want_cur && (cmap[k] = curr[nodemap[k], i])
+        end
+        if one_to_all
+            v = vmap[rows[i], cols[i]]
+            res[i] = (solvable[i] && v != 0) ? v : T(-1)               # (advanced.jl:252-262: voltage at the source / 1 A)
+        else
+            res[i] = solvable[i] ? T(0) : T(-1)                        # (advanced.jl:263-267)
+        end
+        name = "_$(ids[i])"
+        of.write_volt_maps && write_grid(vmap, name, cfg, hbmeta, gmap, voltage = true)
+        if want_cur
+            !of.write_cum_cur_map_only && of.write_cur_maps && write_grid(cmap, name, cfg, hbmeta, gmap)
+            cum.cum_curr .+= cmap                                      # (onetoall.jl:153-158)
+            of.write_max_cur_maps && (cum.max_curr .= max.(cum.max_curr, cmap))
+        end
+    end
+    want_cur && write_cum_maps(cum, gmap, cfg, hbmeta, of.write_max_cur_maps, of.write_cum_cur_map_only)
+    hcat(ids, res)
 end
 
 """

@@ -134,3 +134,29 @@ def test_reference_dispatch_points_have_methods():
         if (lead or trail) and not re.search(r"\bend$", st):
             openers += 1
     assert openers == ends, (openers, ends)
+
+
+def test_onetoall_hook_runs_all_focal_points_on_one_hierarchy():
+    """VERDICT r3 missing #5: a Julia-side replacement of onetoall_kernel's per-point multiple_solver
+    (src/raster/onetoall.jl:106-151) -- ONE device graph build, ONE hierarchy, the focal points as columns of
+    csgpu_solve_grounded, node currents from the device; the twin of solver.py::onetoall_on_device, which the GPU tests run
+    against the reference's two cases it applies to (oneToAllVerify4 / allToOneVerify4: no polygons, single-cell points)."""
+    m = re.search(r"^function onetoall_on_device\(data, flags, cfg, s::HIPAMGSolver\)(.*?)^end$", JL, re.S | re.M)
+    assert m, "onetoall_on_device is missing"
+    body = m.group(1)
+    assert body.count("raster_factor(") == 1 and "reg = false" in body          # one setup, no regularisation shift
+    assert body.count("solve_grounded(factor, rhs, grounds; want_currents = want_cur)") == 1
+    for needed in ("raster_nodemap(factor)", "components(factor, n)", "flags.is_onetoall", "initialize_cum_maps(gmap, of.write_max_cur_maps)",
+                   "write_grid(vmap, name, cfg, hbmeta, gmap, voltage = true)", "write_grid(cmap, name, cfg, hbmeta, gmap)",
+                   "write_cum_maps(cum, gmap, cfg, hbmeta, of.write_max_cur_maps, of.write_cum_cur_map_only)", "hcat(ids, res)",
+                   "finalize(factor)"):
+        assert needed in body, needed
+    for forbidden in ("multiple_solve(", "construct_cholesky_factor(", "advanced_kernel("):
+        assert forbidden not in body, forbidden
+    assert "onetoall_on_device_applies(data) =" in JL
+    # the same conventions as the Python twin: unsolvable columns -1, all-to-one 0, one-to-all the voltage at the source
+    import inspect
+    from circuitscape_jl_amd import solver as ps
+    py = inspect.getsource(ps.onetoall_on_device)
+    assert "res[i] = v if (solvable[i] and v != 0) else -1" in py and "(solvable[i] && v != 0) ? v : T(-1)" in body
+    assert "res[i] = 0 if solvable[i] else -1" in py and "solvable[i] ? T(0) : T(-1)" in body
