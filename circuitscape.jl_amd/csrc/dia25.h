@@ -90,7 +90,7 @@ struct Dia25Args {
 
 // y = A x | b - A x | x + omega dinv (b - A x), A in 25-point lattice form.
 // The 5 x 5 window of x lives in REGISTERS (25 16-byte vectors per lane): marching one column on, a lane keeps 20 of them
-// and reads the 5 of the new column from LDS. (Round-4 measurement, profiles/r4_dia25_ab_10000_holes15.json: with the
+// and reads the 5 of the new column from LDS. (Round-4 measurement, profiles/r4_nodata_10000_k32_dia25_ab.json: with the
 // whole window read from an LDS ring -- 25 reads of x per lane and column -- the LDS pipe was as busy as HBM, per
 // wavefront and column 25 x 8 clocks for x + 25 x 4 for the matrix row against 4 nodes x 968 B of HBM traffic at K = 32
 // fp64; 486 ms per 16 pairs against 464 with the register window.) The x ring has two slots (the column being read, the
