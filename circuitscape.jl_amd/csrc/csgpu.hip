@@ -18,6 +18,7 @@ static thread_local std::string g_last_error;
 
 struct ISolver {
   virtual ~ISolver() {}
+  bool rebuilt_fp64 = false;  // the C API replaced the fp32 hierarchy the caller asked for by an fp64 one (csgpu_info)
   virtual void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
                            const int64_t* gather, int64_t ngather, void* gathered_out, void* resist_out,
                            csgpu_stats* stats, const int32_t* weights = nullptr, void* curr_out = nullptr,
@@ -1885,8 +1886,18 @@ struct Solver : ISolver {
     info->lattice_period = dia.n > 0 ? dia.R : 0;
     double nnz_sum = 0, n_sum = 0;
     int64_t bytes = (int64_t)(Aouter.device_bytes() + dia.device_bytes() + W.p2.bytes);
+    const int tail_first = tail_first_level_peek(H);
+    info->hierarchy_rebuilt_fp64 = rebuilt_fp64 ? 1 : 0;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
+      if (l < 32) {
+        int form = CSGPU_FORM_CSR;
+        if (l == 0) form = (dia.n > 0 && L.lattice_two_product()) ? CSGPU_FORM_LATTICE9 : CSGPU_FORM_CSR;
+        else if (tail_first >= 1 && (int)l >= tail_first) form = CSGPU_FORM_TAIL;
+        else if (L.lattice_v22()) form = CSGPU_FORM_LATTICE9;
+        else if (L.A25.n > 0 && L.A25.n == L.A.nrows && pick_k(opts.batch) >= 8) form = CSGPU_FORM_LATTICE25;  // (vcycle: K >= 8)
+        info->level_form[l] = form;
+      }
       const int64_t lnnz = l == 0 ? nnz : L.A.nnz;  // (level 0 may hold no CSR form: lattice pipeline)
       nnz_sum += (double)lnnz;
       n_sum += (double)L.A.nrows;
@@ -2347,6 +2358,7 @@ int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_
       o.precond_bytes = 0;
       auto* s2 = new csgpu::Solver<double, double>(o);
       h->solver.reset(s2);
+      s2->rebuilt_fp64 = true;
       s2->setup_from_host(rowptr, colidx, vals, n, nnz, idx_bytes, index_base);
     }
   } else if (val_bytes == 8) {
@@ -2389,6 +2401,7 @@ int csgpu_raster_setup_grounded(const void* cond, const void* ground, int64_t nr
       o.precond_bytes = 0;
       auto* s2 = new csgpu::Solver<double, double>(o);
       h->solver.reset(s2);
+      s2->rebuilt_fp64 = true;
       s2->setup_from_raster(cond, nrows, ncols, four_neighbors, avg_resistances, reg, ground);
     }
   } else if (val_bytes == 8) {
@@ -2431,6 +2444,8 @@ int csgpu_raster_setup_poly(const void* cond, const int32_t* polymap, int64_t nr
     auto* s = new csgpu::Solver<double, float>(o);
     h->solver.reset(s);
     s->setup_from_raster_poly(cond, polymap, nrows, ncols, four_neighbors, avg_resistances, reg);
+    // (no heterogeneity fallback here: on a polygon handle the strength test also counts the cells the STRENGTHENED
+    // polygon interiors cut off at the polygons' rims, so hetero_frac does not measure the raster's heterogeneity)
   } else if (val_bytes == 8) {
     auto* s = new csgpu::Solver<double, double>(o);
     h->solver.reset(s);

@@ -76,6 +76,17 @@ inline int tail_first_level(Hierarchy<T>& H) {
   return H.tail_first;
 }
 
+// what tail_first_level would decide, without deciding it (csgpu_get_info on a handle that has not solved yet)
+template <class T>
+inline int tail_first_level_peek(const Hierarchy<T>& H) {
+  if (H.tail_first != -2) return H.tail_first;
+  const int rows = getenv("CSGPU_TAIL_ROWS") ? atoi(getenv("CSGPU_TAIL_ROWS")) : 4096;
+  const int nl = (int)H.levels.size();
+  for (int l = 1; l + 1 < nl; ++l)
+    if (H.levels[l].A.nrows <= rows && nl - l <= kTailMaxLevels) return l;
+  return -1;
+}
+
 template <class T, int K>
 inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_first, int nu_deep, const int* skip,
                         hipStream_t st) {

@@ -59,7 +59,13 @@ class Info(ctypes.Structure):
         ("setup_ms", ctypes.c_double), ("upload_ms", ctypes.c_double), ("device_bytes", ctypes.c_int64),
         ("level_n", ctypes.c_int64 * 32), ("level_nnz", ctypes.c_int64 * 32),
         ("spmv_bytes_fine", ctypes.c_int64), ("bytes_per_iteration", ctypes.c_int64),
+        ("level_form", ctypes.c_int32 * 32), ("hierarchy_rebuilt_fp64", ctypes.c_int32),
+        ("reserved_info", ctypes.c_int32),
     ]
+
+
+# csgpu_info.level_form (include/csgpu.h, CSGPU_FORM_*)
+FORM_CSR, FORM_LATTICE9, FORM_LATTICE25, FORM_TAIL = 0, 1, 2, 3
 
 
 class Stats(ctypes.Structure):
@@ -201,9 +207,10 @@ class Handle:
     def info(self):
         i = Info()
         _check(lib().csgpu_get_info(self._p, ctypes.byref(i)))
-        d = {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz")}
+        d = {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz", "level_form")}
         d["level_n"] = [i.level_n[l] for l in range(min(i.levels, 32))]
         d["level_nnz"] = [i.level_nnz[l] for l in range(min(i.levels, 32))]
+        d["level_form"] = [i.level_form[l] for l in range(min(i.levels, 32))]
         return d
 
     def solve_pairs(self, src, dst, gather=None, want_voltages=False):
@@ -425,7 +432,7 @@ class MultiHandle:
     def info(self, slot=0):
         i = Info()
         _check(lib().csgpu_get_info(lib().csgpu_multi_handle(self._p, slot), ctypes.byref(i)))
-        return {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz")}
+        return {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("level_n", "level_nnz", "level_form")}
 
     def solve_pairs(self, src, dst, gather=None):
         """As Handle.solve_pairs (no voltages). Returns (resistances, gathered or None, stats dict incl. the per-device

@@ -157,6 +157,13 @@ typedef struct csgpu_opts {
   int32_t reserved3;
 } csgpu_opts;
 
+/* csgpu_info.level_form: CSR = general CSR SpMM; LATTICE9 = index-free nine-point lattice form (level 0: the marching
+ * CG product / two-product level, csrc/stencil.h + lattice.h; level 1: the collapsed four-product form of
+ * lattice_level1_setup); LATTICE25 = A in the 25-point lattice form of csrc/dia25.h (P, R, Q stay CSR; reported for handles
+ * whose full batches are at least 8 columns wide -- narrower calls run such a level through the CSR SpMM); TAIL = the level
+ * runs inside the single-launch coarse tail (csrc/tail.h; the last level there is the dense pseudo-inverse). */
+enum { CSGPU_FORM_CSR = 0, CSGPU_FORM_LATTICE9 = 1, CSGPU_FORM_LATTICE25 = 2, CSGPU_FORM_TAIL = 3 };
+
 typedef struct csgpu_info {
   int64_t n;
   int64_t nnz;
@@ -173,6 +180,12 @@ typedef struct csgpu_info {
   int64_t level_nnz[32];
   int64_t spmv_bytes_fine;      /* algorithmic bytes of one fine-level CSR SpMV (SURVEY.md 8d formula) */
   int64_t bytes_per_iteration;  /* algorithmic bytes of one PCG iteration at batch 1 */
+  int32_t level_form[32];       /* CSGPU_FORM_* of every level: which kernels the V-cycle runs the level's products with A
+                                   through (tests and A/B scripts read the path a handle took from here, not from side
+                                   effects such as device_bytes) */
+  int32_t hierarchy_rebuilt_fp64; /* 1: an fp32 hierarchy was asked for (precond_bytes = 4) and the setup replaced it by an
+                                   fp64 one (strongly heterogeneous raster / off-diagonal contrast above 1e5 in a host CSR) */
+  int32_t reserved_info;
 } csgpu_info;
 
 typedef struct csgpu_stats {

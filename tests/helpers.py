@@ -931,11 +931,13 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
 
 def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4, extra_env=None):
     """lattice_setup.h lattice_level1_setup + the lattice branch of vcycle() (pcg.h): level 1 of a raster hierarchy as four
-    marching products (x = S b, b_c = Q2' b, t = b - A x, out = x + S t + Q2 x_c) against the seven CSR products of the
-    generic branch (CSGPU_NO_LATTICE_L1=1, read once per process -> child processes): the same algebra, so the same
-    iteration counts and resistances equal to rounding; fp64 and fp32 hierarchies, 8- and 4-neighbour, and a raster with
-    NODATA cells (cell space: the level declines the lattice form when the piece analysis refined its tiles, or keeps
-    it -- either way the results must agree)."""
+    marching products (x = S b, b_c = Q2' b, t = b - A x, out = x + S t + Q2 x_c) against its two twins (knobs read once per
+    process -> child processes): the seven CSR products of the generic branch (CSGPU_NO_LATTICE_L1=1 CSGPU_DIA25=0) and the
+    generic branch with A in the 25-point lattice form of dia25.h (CSGPU_NO_LATTICE_L1=1 alone; the form a level takes when
+    it declines the nine-point one). The same algebra three times, so the same iteration counts and resistances equal to
+    rounding; fp64 and fp32 hierarchies, 8- and 4-neighbour, and a raster with NODATA cells (cell space: the level declines
+    the nine-point form when the piece analysis refined its tiles). WHICH form ran is read from csgpu_info.level_form, not
+    from side effects. Reference: the V-cycle AlgebraicMultigrid.jl runs for src/core.jl:164-167."""
     import json, os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent('''
@@ -956,30 +958,46 @@ def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4, extra_en
                         big = np.flatnonzero(labels == np.bincount(labels).argmax())
                         ids = np.random.default_rng(5).choice(big, size=2 * %d, replace=False)
                         Rr, _, _, st = h.solve_pairs([int(v) for v in ids[:%d]], [int(v) for v in ids[%d:]])
+                        info = h.info
                         out.append({"case": name, "pb": pb, "shape": [R, C], "iters": int(st["total_iters"]),
                                     "nc": int(st["not_converged"]), "R": [float(v) for v in Rr],
-                                    "level_n": h.info["level_n"][:h.info["levels"]], "bytes": int(h.info["device_bytes"])})
+                                    "level_n": info["level_n"][:info["levels"]], "form": info["level_form"][:info["levels"]]})
         print("RESULT" + json.dumps(out))
     ''') % (root, L.loaded_path(), tuple(tuple(s) for s in shapes), batch, batch, batch, batch)
     res = {}
-    for tag, extra in (("lattice", {}), ("csr", {"CSGPU_NO_LATTICE_L1": "1"})):
-        env = dict(os.environ, **extra)
-        env.update(extra_env or {})   # (small rasters: CSGPU_LATTICE_L1_MIN_ROWS / CSGPU_TAIL_ROWS let level 1 take the form)
-        if not extra:
-            env.pop("CSGPU_NO_LATTICE_L1", None)
+    twins = (("lattice", {}), ("csr", {"CSGPU_NO_LATTICE_L1": "1", "CSGPU_DIA25": "0"}), ("dia25", {"CSGPU_NO_LATTICE_L1": "1"}))
+    for tag, extra in twins:
+        env = dict(os.environ)
+        env.pop("CSGPU_NO_LATTICE_L1", None)
+        env.pop("CSGPU_DIA25", None)
+        env.update(extra_env or {})   # (small rasters: CSGPU_LATTICE_L1_MIN_ROWS / CSGPU_TAIL_ROWS / CSGPU_DIA25 let level 1 take the forms)
+        env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1800, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
         res[tag] = json.loads(line[len("RESULT"):])
-    used = 0
-    for a, b in zip(res["lattice"], res["csr"]):
-        assert a["case"] == b["case"] and a["pb"] == b["pb"] and a["level_n"] == b["level_n"]
-        assert a["nc"] == 0 and b["nc"] == 0
-        assert abs(a["iters"] - b["iters"]) <= (0 if a["pb"] == 0 else 1), (a["case"], a["pb"], a["iters"], b["iters"])
-        Ra, Rb = np.array(a["R"]), np.array(b["R"])
-        assert np.max(np.abs(Ra - Rb) / Rb) < (1e-10 if a["pb"] == 0 else 1e-8), (a["case"], a["pb"])
-        used += a["bytes"] > b["bytes"]            # (the lattice forms are held in addition to the CSR operators)
-    assert used >= 4, used                         # the all-valid rasters, both precisions, must have taken the lattice form
+    forms = {"lattice": [], "csr": [], "dia25": []}
+    for a, b, c in zip(res["lattice"], res["csr"], res["dia25"]):
+        for t in (b, c):
+            assert a["case"] == t["case"] and a["pb"] == t["pb"] and a["level_n"] == t["level_n"]
+            assert a["nc"] == 0 and t["nc"] == 0
+            assert abs(a["iters"] - t["iters"]) <= (0 if a["pb"] == 0 else 1), (a["case"], a["pb"], a["iters"], t["iters"])
+            Ra, Rt = np.array(a["R"]), np.array(t["R"])
+            assert np.max(np.abs(Ra - Rt) / Rt) < (1e-10 if a["pb"] == 0 else 1e-8), (a["case"], a["pb"])
+        assert a["form"][0] == b["form"][0] == c["form"][0] == L.FORM_LATTICE9      # level 0 marches in all three
+        assert b["form"][1] == L.FORM_CSR, (b["case"], b["form"])                   # the true CSR twin
+        assert c["form"][1] in (L.FORM_LATTICE25, L.FORM_CSR), (c["case"], c["form"])
+        if a["case"].startswith("full"):
+            # the all-valid rasters, both precisions, both neighbourhoods, must have taken the nine-point form on level 1
+            # -- and their twin, which declined it by order, the 25-point one
+            assert a["form"][1] == L.FORM_LATTICE9, (a["case"], a["pb"], a["form"])
+            assert c["form"][1] == L.FORM_LATTICE25, (c["case"], c["pb"], c["form"])
+        else:
+            # refined tiles (NODATA): level 1 declines the nine-point form by itself and runs the 25-point one by default
+            assert a["form"][1] in (L.FORM_LATTICE25, L.FORM_LATTICE9), (a["case"], a["form"])
+        for tag, t in (("lattice", a), ("csr", b), ("dia25", c)):
+            forms[tag].append(t["form"][1])
+    return forms
 
 
 def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
@@ -1635,6 +1653,8 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                     R, _, _, st = h.solve_pairs([int(v) for v in ids[:K]], [int(v) for v in ids[K:]])
                     assert st["not_converged"] == 0
                     out[(mode, pb, K)] = (R, st["total_iters"])
+                    # which kernels served level 1: csgpu_info.level_form, not stderr / device_bytes
+                    assert info["level_form"][1] == (L.FORM_CSR if mode == "csr" else L.FORM_LATTICE25), (mode, info["level_form"])
                     if mode != "csr":
                         for lvl in (1, 2):
                             if lvl >= len(info["level_n"]) - 1 or info["level_n"][lvl] < 64:

@@ -1228,9 +1228,12 @@ def test_omniscape_windows_with_a_block_wider_than_the_disc(emu_lib):
 def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
     """see helpers.check_lattice_level1"""
     from helpers import check_lattice_level1
-    # (small raster: the knobs let its 62 x 64 level 1 take the lattice form instead of running inside the coarse tail)
-    check_lattice_level1(emu_lib, monkeypatch, shapes=((186, 192),),
-                         extra_env={"CSGPU_LATTICE_L1_MIN_ROWS": "1024", "CSGPU_TAIL_ROWS": "1024"})
+    # (small raster: the knobs let its 62 x 64 level 1 take the nine-point / the 25-point form instead of running inside the
+    # coarse tail or staying below dia25_min_rows() = 16384; batch 8: the 25-point kernel serves batches >= 8 columns)
+    forms = check_lattice_level1(emu_lib, monkeypatch, shapes=((186, 192),), batch=8,
+                                 extra_env={"CSGPU_LATTICE_L1_MIN_ROWS": "1024", "CSGPU_TAIL_ROWS": "1024",
+                                            "CSGPU_DIA25": "1024"})
+    assert emu_lib.FORM_LATTICE25 in forms["lattice"]      # the NODATA raster's level 1, by default
 
 
 def test_heterogeneous_rasters_strength_aware_tiles(emu_lib, oracle):
@@ -1272,6 +1275,4 @@ def test_single_level_handles_compute_in_matrix_precision(emu_lib):
 def test_coarse_levels_in_25_point_lattice_form(emu_lib, monkeypatch, capfd):
     """refined tiles (NODATA cell space): levels >= 1 index-free (dia25.h), same products / iterations / resistances"""
     from helpers import check_dia25_levels
-    monkeypatch.setenv("CSGPU_VERBOSE", "1")
     check_dia25_levels(emu_lib, monkeypatch, shape=(70, 115))  # level 1: 23 x 38 -- two column segments, 38 = 32 + 6
-    assert "in 25-point lattice form" in capfd.readouterr().err
