@@ -122,6 +122,62 @@ def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16, single=False)
     return out
 
 
+NODATA_SEED, NODATA_PTS_SEED = 2468, 97531
+
+
+def nodata_raster(g, frac=0.15):
+    """the bench raster with `frac` of its cells NODATA (i.i.d., rng(2468)): construct_node_map drops cells with
+    conductance <= 0 (src/raster/pairwise.jl:271-301)"""
+    rng = np.random.default_rng(NODATA_SEED)
+    return np.where(rng.random(g.shape) < frac, g.dtype.type(0), g)
+
+
+def lexicographic_pairs(pts):
+    return [(int(pts[i]), int(pts[j])) for i in range(len(pts)) for j in range(i + 1, len(pts))]
+
+
+def oracle_leg_nodata(sample_size, npairs=8, frac=0.15):
+    """CHECKER side of the `nodata15` leg's parity figure (runs in the CPU child): the reference's own graph construction
+    restated (oracle/refgraph.py: construct_node_map / construct_graph / laplacian, src/raster/pairwise.jl:271-362,
+    src/core.jl:608-634) on a sample raster of the same generator and the same NODATA mask generator, regularised like
+    core.jl:161, giant component by scipy, 15 focal nodes of it (rng(97531)) -> the first `npairs` lexicographic pairs
+    solved by the TIGHT oracle. Independent of the device: the parent solves the same node pairs on the GPU."""
+    import scipy.sparse.csgraph as csg
+    from oracle import refgraph as rg, refsolve as rs
+    t0 = time.time()
+    g = nodata_raster(make_raster(sample_size), frac)
+    nm = rg.construct_node_map(g, None)
+    A = rs.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+    ncomp, lab = csg.connected_components(A, directed=False)
+    giant = np.flatnonzero(lab == np.bincount(lab).argmax())
+    pts = np.random.default_rng(NODATA_PTS_SEED).choice(giant, size=15, replace=False)
+    pairs = lexicographic_pairs(pts)[:npairs]
+    S = rs.OracleAMG(A)
+    nth = max(1, min(os.cpu_count() or 1, npairs))
+    R, _, res = S.solve_pairs([p[0] for p in pairs], [p[1] for p in pairs], rtol=1e-12, atol=0.0, criterion=1, nthreads=nth)
+    return {"sample_size": sample_size, "n": int(A.shape[0]), "components": int(ncomp), "giant": int(giant.size),
+            "src": [p[0] for p in pairs], "dst": [p[1] for p in pairs], "R": R.tolist(),
+            "max_true_relres": max(r["true_relres"] for r in res), "iters": [r["iters"] for r in res],
+            "wall_s": time.time() - t0}
+
+
+def oracle_leg_fp32(sample_size, npairs=8):
+    """CHECKER side of the `config3_fp32` leg's parity figure (CPU child): the reference's single-precision problem --
+    the Float32 Laplacian with every stored entry shifted by eps(Float32) * norm(nzval) (core.jl:161), built on the host by
+    the oracle's graph code -- solved in double by the TIGHT oracle for the first `npairs` bench pairs of the sample."""
+    from oracle import refgraph as rg, refsolve as rs
+    t0 = time.time()
+    G = rg.raster_laplacian_from_conductance(make_raster(sample_size, dtype=np.float32).astype(np.float64))
+    A = rs.regularize(G, dtype=np.float32).astype(np.float64)
+    _, pairs = focal_pairs(sample_size)
+    pairs = pairs[:npairs]
+    S = rs.OracleAMG(A)
+    nth = max(1, min(os.cpu_count() or 1, npairs))
+    R, _, res = S.solve_pairs([p[0] for p in pairs], [p[1] for p in pairs], rtol=1e-12, atol=0.0, criterion=1, nthreads=nth)
+    return {"sample_size": sample_size, "n": int(A.shape[0]), "src": [p[0] for p in pairs], "dst": [p[1] for p in pairs],
+            "R": R.tolist(), "max_true_relres": max(r["true_relres"] for r in res), "wall_s": time.time() - t0}
+
+
 def cpu_baseline_entry(cb, n_full, size, sample_size):
     """The `cpu_baseline` object of the bench line from a cpu_baseline() measurement."""
     scale = float(n_full) / cb["n"]
@@ -238,16 +294,15 @@ def nodata_leg(lib, g, B, make_opts, precond, sync, frac=0.15, steps=2):
     coarse levels in 25-point lattice form (csrc/dia25.h). Focal cells: 15 cells of the giant component; 1 warm-up batch +
     `steps` timed batches of B pairs in one call, on the `value` path's precision. Parity of this path against the tight
     oracle: tests/test_gpu_parity.py (2000^2)."""
-    rng = np.random.default_rng(2468)
-    gh = np.where(rng.random(g.shape) < frac, g.dtype.type(0), g)
+    gh = nodata_raster(g, frac)
     h = lib.raster_setup(gh, make_opts(precond))
     try:
         del gh
         info = h.info
         labels, ncomp = h.components()
         giant = np.flatnonzero(labels == np.bincount(labels).argmax())
-        pts = np.random.default_rng(97531).choice(giant, size=15, replace=False)
-        pairs = [(int(pts[i]), int(pts[j])) for i in range(15) for j in range(i + 1, 15)]
+        pts = np.random.default_rng(NODATA_PTS_SEED).choice(giant, size=15, replace=False)
+        pairs = lexicographic_pairs(pts)
 
         def batch_pairs(k):
             idx = [(k * B + i) % len(pairs) for i in range(B)]
@@ -258,10 +313,30 @@ def nodata_leg(lib, g, B, make_opts, precond, sync, frac=0.15, steps=2):
     sv = (info["setup_ms"] + info["upload_ms"]) / 1e3
     return {"value": steps * B / (el + sv * steps * B / 100.0), "unit": "pair-solves/s", "nodata_fraction": frac,
             "nodes": int(info["n"]), "giant_component_nodes": int(giant.size), "components": int(ncomp),
-            "lattice_period": info["lattice_period"], "levels": info["levels"], "steps": steps,
+            "lattice_period": info["lattice_period"], "levels": info["levels"], "level_form": info["level_form"], "steps": steps,
             "ms_per_16_pairs": el / steps * 1e3 * 16.0 / B, "iters_mean": agg["total_iters"] / float(steps * B),
             "iters_max": agg["max_iters"], "max_relres": agg["max_relres"], "not_converged": agg["not_converged"],
             "setup_s": sv, "precond": precond}
+
+
+def leg_parity(lib, g, opts, tight, tolerance, what):
+    """GPU side of a leg's parity figure: the leg's own options on the CPU child's sample raster, the child's node pairs,
+    against the TIGHT oracle's resistances (a parity figure accompanies every number)."""
+    h = lib.raster_setup(g, opts)
+    try:
+        info = h.info
+        if info["n"] != tight["n"]:
+            return {"failed": "node count differs: device %d, oracle graph %d" % (info["n"], tight["n"])}
+        R, _, _, st = h.solve_pairs(tight["src"], tight["dst"])
+    finally:
+        h.close()
+    Ro = np.asarray(tight["R"])
+    rel = float(np.max(np.abs(np.asarray(R, dtype=np.float64) - Ro) / np.abs(Ro)))
+    return {"max_rel_err": rel, "tolerance": tolerance, "ok": bool(rel < tolerance), "pairs": len(Ro), "n": int(info["n"]),
+            "sample": what, "oracle": "tight (true-residual rtol 1e-12) on the host-built graph of the same sample",
+            "oracle_max_true_relres": tight["max_true_relres"], "iters_mean": st["total_iters"] / float(len(Ro)),
+            "not_converged": int(st["not_converged"]), "lattice_period": info["lattice_period"],
+            "level_form": info["level_form"]}
 
 
 def random_network(n, seed=424242):
