@@ -339,35 +339,112 @@ def leg_parity(lib, g, opts, tight, tolerance, what):
             "level_form": info["level_form"]}
 
 
-def random_network(n, seed=424242):
-    """BASELINE configs[4] generator (tools/network_bench.py, tests/test_gpu_scale.py): 10 n endpoint pairs, deduplicated,
-    giant component, conductances U(0.5, 2)."""
+def _csr_laplacian_from_edges(lo, hi, w, n, torch=None, dev=None):
+    """CSR Laplacian (sorted rows, diagonal included) of the undirected weighted graph {lo[k], hi[k]}: w[k]. The 2 m + n
+    (key, value) entries are sorted once by key = row * n + col -- on the GPU through torch when one is visible (input
+    GENERATION only, outside every timed region: sorting 1.05e8 keys takes the host ~15 s at BASELINE's 5e6 nodes and the
+    device 0.1 s; both routes give the identical matrix), else by numpy."""
     import scipy.sparse as sp
+    deg = np.bincount(lo, weights=w, minlength=n) + np.bincount(hi, weights=w, minlength=n)
+    ar = np.arange(n, dtype=np.int64)
+    key = np.concatenate([lo * n + hi, hi * n + lo, ar * n + ar])
+    val = np.concatenate([-w, -w, deg])
+    if torch is not None and dev is not None:
+        k = torch.from_numpy(key).to(dev)
+        k, order = torch.sort(k)
+        v = torch.from_numpy(val).to(dev)[order]
+        rows = torch.div(k, n, rounding_mode="floor")
+        cols = (k - rows * n).to(torch.int32).cpu().numpy()
+        counts = torch.bincount(rows, minlength=n)
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indptr[1:] = torch.cumsum(counts, 0).cpu().numpy()
+        val = v.cpu().numpy()
+        del k, order, v, rows, counts
+    else:
+        order = np.argsort(key, kind="stable")
+        key = key[order]
+        val = val[order]
+        rows = key // n
+        cols = (key - rows * n).astype(np.int32)
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    G = sp.csr_matrix((val, cols, indptr.astype(np.int32 if indptr[-1] < 2**31 else np.int64)), shape=(n, n))
+    G.has_sorted_indices = True
+    return G
+
+
+def random_network(n, seed=424242, torch=None, dev=None):
+    """BASELINE configs[4] generator (tools/network_bench.py, tests/test_gpu_scale.py): 10 n endpoint pairs from rng(seed),
+    deduplicated, conductances U(0.5, 2); the giant component is kept (mean degree 20: the graph is connected with
+    probability 1 - 1e-2 at n = 5e6; checked, and cut down to the giant component if it is not)."""
     import scipy.sparse.csgraph as csg
     rng = np.random.default_rng(seed)
     i = rng.integers(0, n, size=10 * n)
     j = rng.integers(0, n, size=10 * n)
     keep = i != j
     lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
-    key = np.unique(lo.astype(np.int64) * n + hi)
+    del i, j, keep
+    key = lo.astype(np.int64) * n + hi
+    if torch is not None and dev is not None:
+        key = torch.unique(torch.from_numpy(key).to(dev), sorted=True).cpu().numpy()
+    else:
+        key = np.unique(key)
     lo, hi = key // n, key % n
+    del key
     w = rng.uniform(0.5, 2.0, size=len(lo))
-    A = sp.coo_matrix((w, (lo, hi)), shape=(n, n)).tocsr()
-    A = (A + A.T).tocsr()
-    _, lab = csg.connected_components(A, directed=False)
+    G = _csr_laplacian_from_edges(lo, hi, w, n, torch, dev)
+    ncomp, lab = csg.connected_components(G, directed=False)
+    if ncomp > 1:
+        giant = np.flatnonzero(lab == np.bincount(lab).argmax())
+        G = G[giant][:, giant].tocsr()
+        G.sort_indices()
+    return G, rng
+
+
+def geometric_network(n, seed=777, torch=None, dev=None):
+    """A network WITH locality (tests/test_gpu_scale.py): random geometric graph in the unit square, mean degree ~10, node
+    ids carry no locality, conductances U(0.5, 2); giant component."""
+    import scipy.sparse.csgraph as csg
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n, 2))
+    pr = cKDTree(pts).query_pairs(np.sqrt(10.0 / (np.pi * n)), output_type="ndarray")
+    lo, hi = np.minimum(pr[:, 0], pr[:, 1]).astype(np.int64), np.maximum(pr[:, 0], pr[:, 1]).astype(np.int64)
+    w = rng.uniform(0.5, 2.0, size=len(lo))
+    G = _csr_laplacian_from_edges(lo, hi, w, n, torch, dev)
+    ncomp, lab = csg.connected_components(G, directed=False)
     giant = np.flatnonzero(lab == np.bincount(lab).argmax())
-    A = A[giant][:, giant]
-    G = (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A).tocsr()
+    G = G[giant][:, giant].tocsr()
     G.sort_indices()
     return G, rng
 
 
-def config4_network_leg(lib, dev_index, n=1000000, nsrc=16):
-    """BASELINE configs[4] at 1/5 of its size on one GPU: network mode, advanced one-to-all (src/raster/advanced.jl:274-312,
-    src/network/advanced.jl:1-51) -- unit current at one focal node, the other focal nodes tied to ground, every source a
-    column of ONE csgpu_solve_grounded on ONE handle. This random graph is an expander: the setup declines to coarsen it,
-    so the preconditioner is JACOBI (levels = 1), not AMG. Every column's residual is checked on the host."""
-    G, rng = random_network(n)
+def _masked_jacobi_cg(G, b, ground, rtol=1e-12, maxiter=2000):
+    """Independent host check of one one-to-all column: scipy's CG with a Jacobi preconditioner on the REDUCED system
+    (rows / columns of the grounded nodes removed, src/raster/advanced.jl:282-288), expressed as a masked operator so that
+    the 1e8-entry matrix is not sliced; true residual driven to rtol."""
+    import scipy.sparse.linalg as spla
+    n = G.shape[0]
+    free = np.ones(n)
+    free[ground] = 0.0
+    dinv = free / G.diagonal()
+    op = spla.LinearOperator((n, n), matvec=lambda v: free * (G @ (free * v)), dtype=np.float64)
+    x, flag = spla.cg(op, free * b, rtol=rtol, atol=0.0, maxiter=maxiter, M=spla.LinearOperator((n, n), matvec=lambda v: dinv * v, dtype=np.float64))
+    res = float(np.linalg.norm(free * (G @ x) - free * b) / np.linalg.norm(free * b))
+    return x, flag, res
+
+
+def config4_network_leg(lib, dev_index, n=5000000, nsrc=16, ncheck=2, torch=None, dev=None):
+    """BASELINE configs[4] at its stated size on one GPU (5e6 nodes, 5e7 undirected edges -> 1.05e8 stored entries):
+    network mode, advanced one-to-all (src/raster/advanced.jl:274-312, src/network/advanced.jl:1-51) -- unit current at one
+    focal node, the other focal nodes tied to ground, every source a column of ONE csgpu_solve_grounded on ONE handle.
+    This random graph is an expander: the setup declines to coarsen it, so the preconditioner is JACOBI (levels = 1), not
+    AMG. Every column's residual is checked on the host, and the first `ncheck` columns against an independent scipy
+    Jacobi-CG solve of the reduced system at true-residual 1e-12 (parity: resistance to the grounded set + whole voltage
+    vector)."""
+    t0 = time.perf_counter()
+    G, rng = random_network(n, torch=torch, dev=dev)
+    t_gen = time.perf_counter() - t0
     n = G.shape[0]
     focal = rng.choice(n, size=nsrc, replace=False)
     t0 = time.perf_counter()
@@ -391,11 +468,71 @@ def config4_network_leg(lib, dev_index, n=1000000, nsrc=16):
         r = G @ X[:, s_] - B[:, s_]
         r[grounds[s_]] = 0.0
         worst = max(worst, float(np.linalg.norm(r)))
+    t0 = time.perf_counter()
+    rerr, verr, cres = 0.0, 0.0, 0.0
+    for s_ in range(min(ncheck, nsrc)):
+        xs, flag, res = _masked_jacobi_cg(G, B[:, s_], grounds[s_])
+        cres = max(cres, res if flag == 0 else float("inf"))
+        rerr = max(rerr, abs(X[focal[s_], s_] - xs[focal[s_]]) / abs(xs[focal[s_]]))
+        verr = max(verr, float(np.max(np.abs(X[:, s_] - xs)) / np.max(np.abs(xs))))
+    parity = {"max_rel_err": float(max(rerr, verr)), "max_rel_err_resistance": float(rerr), "max_rel_err_voltages": float(verr),
+              "tolerance": 1e-6, "ok": bool(max(rerr, verr) < 1e-6), "columns_checked": min(ncheck, nsrc),
+              "checker": "scipy CG + Jacobi on the reduced system (masked operator), true residual %.1e" % cres,
+              "check_s": time.perf_counter() - t0}
     return {"value": nsrc / (t_setup + t_solve), "unit": "one-to-all sources/s (setup + solves)", "n": int(n), "nnz": int(G.nnz),
-            "sources": nsrc, "levels": info["levels"],
+            "undirected_edges": int((G.nnz - n) // 2), "sources": nsrc, "levels": info["levels"],
             "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi (expander: the setup declines to coarsen, amg_setup.h)",
             "setup_s": t_setup, "solve_s_all_sources": t_solve, "iters_mean": st["total_iters"] / float(nsrc),
-            "not_converged": st["not_converged"], "worst_true_residual_norm": worst}
+            "not_converged": st["not_converged"], "worst_true_residual_norm": worst, "generate_s": t_gen, "parity": parity}
+
+
+def network_geometric_leg(lib, dev_index, tight, n=1000000, torch=None, dev=None):
+    """A network that really coarsens, under the driver: random geometric graph (n = 1e6, mean degree 10, shuffled ids),
+    hashed MIS(2) aggregation + CSR kernels (no raster coordinates), pair solves from one anchor as network pairwise mode
+    does (src/network/pairwise.jl:31-65) against the TIGHT oracle's resistances computed by the CPU child on the same
+    graph (same generator, host route)."""
+    from oracle import refsolve as rs
+    G, rng = geometric_network(n, torch=torch, dev=dev)
+    A = rs.regularize(G)
+    if A.shape[0] != tight["n"]:
+        return {"failed": "node count differs: %d vs oracle graph %d" % (A.shape[0], tight["n"])}
+    src, dst = tight["src"], tight["dst"]
+    t0 = time.perf_counter()
+    h = lib.setup(A, lib.default_opts(device=dev_index, batch=8, precond_bytes=0), index_dtype=np.int32, index_base=0)
+    t_setup = time.perf_counter() - t0
+    try:
+        info = h.info
+        h.solve_pairs(src, dst)
+        t0 = time.perf_counter()
+        R, _, _, st = h.solve_pairs(src, dst)
+        t_solve = time.perf_counter() - t0
+    finally:
+        h.close()
+    Ro = np.asarray(tight["R"])
+    rel = float(np.max(np.abs(R - Ro) / np.abs(Ro)))
+    return {"value": len(src) / (t_setup + t_solve), "unit": "pair-solves/s (setup + solves)", "n": int(A.shape[0]), "nnz": int(A.nnz),
+            "levels": info["levels"], "level_n": info["level_n"], "operator_complexity": info["operator_complexity"],
+            "preconditioner": "AMG (hashed MIS(2) aggregation, CSR kernels)", "setup_s": t_setup, "setup_device_s": info["setup_ms"] / 1e3,
+            "solve_s": t_solve, "pairs": len(src), "iters_mean": st["total_iters"] / float(len(src)), "max_relres": st["max_relres"],
+            "not_converged": st["not_converged"],
+            "parity": {"max_rel_err": rel, "tolerance": 1e-6, "ok": bool(rel < 1e-6), "pairs": len(src),
+                       "oracle": "tight (true-residual rtol 1e-12) on the same graph", "oracle_max_true_relres": tight["max_true_relres"]}}
+
+
+def oracle_leg_geometric(n=1000000, npairs=8):
+    """CHECKER side of `network_geometric` (CPU child): the same generator through the host route, regularised like
+    core.jl:161, 8 pairs from one anchor solved by the TIGHT oracle."""
+    from oracle import refsolve as rs
+    t0 = time.time()
+    G, rng = geometric_network(n)
+    A = rs.regularize(G)
+    focal = rng.choice(A.shape[0], size=npairs + 1, replace=False)
+    src = [int(focal[0])] * npairs
+    dst = [int(q) for q in focal[1:]]
+    S = rs.OracleAMG(A)
+    R, _, res = S.solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=max(1, min(os.cpu_count() or 1, npairs)))
+    return {"n": int(A.shape[0]), "src": src, "dst": dst, "R": R.tolist(), "max_true_relres": max(r["true_relres"] for r in res),
+            "iters": [r["iters"] for r in res], "wall_s": time.time() - t0}
 
 
 def rank_identity(torch, rank, dev_index, has_cuda, ms_per_step, pairs_done, agg):
@@ -503,10 +640,30 @@ def main():
                     help="internal: run only the CPU-baseline leg on a --cpu-sample raster, scale to N_FULL nodes, print "
                          "its JSON object and exit (the bench runs this in a child process so that nothing on the host "
                          "side can take the GPU line down)")
+    ap.add_argument("--cpu-legs", default="", help="internal (CPU child): comma list of nodata,fp32,geometric")
+    ap.add_argument("--leg-sample", type=int, default=2000,
+                    help="raster edge of the samples on which the nodata15 / config3_fp32 legs are compared with the tight oracle")
+    ap.add_argument("--network-n", type=int, default=5000000, help="nodes of the config4_network leg (BASELINE: 5e6)")
+    ap.add_argument("--geometric-n", type=int, default=1000000, help="nodes of the network_geometric leg")
     args = ap.parse_args()
     if args.cpu_baseline_only > 0:
-        print(json.dumps(cpu_baseline_entry(cpu_baseline(args.cpu_sample, single=args.precision == "single"),
-                                            args.cpu_baseline_only, args.size, args.cpu_sample)), flush=True)
+        # CPU child: the cpu_baseline object (+ the tight resistances of the headline's parity figure) and, when asked for,
+        # the CHECKER side of the other legs' parity figures -- everything that touches oracle/ lives in this process
+        res = cpu_baseline_entry(cpu_baseline(args.cpu_sample, single=args.precision == "single"),
+                                 args.cpu_baseline_only, args.size, args.cpu_sample)
+        legs = {}
+        for name in [x for x in args.cpu_legs.split(",") if x]:
+            try:
+                if name == "nodata":
+                    legs[name] = oracle_leg_nodata(args.leg_sample)
+                elif name == "fp32":
+                    legs[name] = oracle_leg_fp32(args.leg_sample)
+                elif name == "geometric":
+                    legs[name] = oracle_leg_geometric(args.geometric_n)
+            except Exception as e:
+                legs[name] = {"failed": repr(e)}
+        res["_legs"] = legs
+        print(json.dumps(res), flush=True)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -746,22 +903,30 @@ def main():
                                         "note": "x carried over all n rows + explicit ||Ax-b||/||b|| check; no D2H of voltages"}
             except Exception as e:
                 out["with_voltages"] = {"failed": repr(e)}
+        leg_seconds = {}
         if world == 1 and args.extra_legs:
+            t_leg = time.perf_counter()
             try:   # the same raster with 15 % NODATA cells (cell space, refined tiles, 25-point coarse levels)
                 out["nodata15"] = nodata_leg(lib, g, B, make_opts, args.precond, sync)
             except Exception as e:
                 out["nodata15"] = {"failed": repr(e)}
+            leg_seconds["nodata15"] = time.perf_counter() - t_leg
         if world == 1 and args.extra_legs and vb == 8:
             # the two BASELINE configs the headline does not cover, driver-run: configs[3] precision (fp32) on this raster,
-            # configs[4] (network, advanced one-to-all) at n = 1e6
+            # configs[4] (network, advanced one-to-all) at its stated size
+            t_leg = time.perf_counter()
             try:
                 out["config3_fp32"] = config3_fp32_leg(lib, size, B, dev_index, batch_pairs, sync, one_call)
             except Exception as e:
                 out["config3_fp32"] = {"failed": repr(e)}
+            leg_seconds["config3_fp32"] = time.perf_counter() - t_leg
+            t_leg = time.perf_counter()
             try:
-                out["config4_network"] = config4_network_leg(lib, dev_index)
+                out["config4_network"] = config4_network_leg(lib, dev_index, n=args.network_n, torch=torch if has_cuda else None,
+                                                             dev=dev if has_cuda else None)
             except Exception as e:
                 out["config4_network"] = {"failed": repr(e)}
+            leg_seconds["config4_network"] = time.perf_counter() - t_leg
         if world == 1 and args.host_csr:
             try:
                 out.update(host_csr_setup(lib, g, make_opts(args.precond)))
@@ -772,18 +937,57 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             try:
                 import subprocess
+                want_legs = "nodata,fp32,geometric" if (args.extra_legs and vb == 8) else ""
+                t_leg = time.perf_counter()
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(info["n"]),
                                         "--cpu-sample", str(args.cpu_sample), "--size", str(size), "--precision",
-                                        args.precision],
-                                       capture_output=True, text=True, timeout=900)
+                                        args.precision, "--cpu-legs", want_legs, "--leg-sample", str(args.leg_sample),
+                                        "--geometric-n", str(args.geometric_n)],
+                                       capture_output=True, text=True, timeout=1200)
+                leg_seconds["cpu_child"] = time.perf_counter() - t_leg
                 cb = json.loads(child.stdout.strip().splitlines()[-1])
                 tight = cb.pop("_tight", None)
+                legs = cb.pop("_legs", {})
                 out["cpu_baseline"] = cb
                 if tight:
                     out["parity"] = gpu_parity(lib, args.cpu_sample, tight, make_opts, dtype, vb == 8)
+                # an oracle figure on every leg: the leg's own options on a bounded sample of the leg's
+                # own workload against the tight oracle on the HOST-built graph of that sample
+                t_leg = time.perf_counter()
+                for leg, key, what in (("nodata15", "nodata", "%dx%d raster of the bench generator, 15 %% NODATA (the leg's mask generator)"),
+                                       ("config3_fp32", "fp32", "%dx%d raster of the bench generator in fp32, reference regularisation")):
+                    tl = legs.get(key)
+                    if not tl or leg not in out or "failed" in out[leg]:
+                        continue
+                    if "failed" in tl:
+                        out[leg]["parity"] = {"failed": tl["failed"]}
+                        continue
+                    try:
+                        ns_ = tl["sample_size"]
+                        if key == "nodata":
+                            gs = nodata_raster(make_raster(ns_, dtype=dtype))
+                            out[leg]["parity"] = leg_parity(lib, gs, make_opts(args.precond), tl, 1e-6, what % (ns_, ns_))
+                        else:
+                            gs = make_raster(ns_, dtype=np.float32)
+                            out[leg]["parity"] = leg_parity(lib, gs, lib.default_opts(device=dev_index, batch=B), tl, 1e-4,
+                                                            what % (ns_, ns_))
+                    except Exception as e:
+                        out[leg]["parity"] = {"failed": repr(e)}
+                tl = legs.get("geometric")
+                if tl and "failed" not in tl:
+                    try:
+                        out["network_geometric"] = network_geometric_leg(lib, dev_index, tl, n=args.geometric_n,
+                                                                         torch=torch if has_cuda else None,
+                                                                         dev=dev if has_cuda else None)
+                    except Exception as e:
+                        out["network_geometric"] = {"failed": repr(e)}
+                elif tl:
+                    out["network_geometric"] = {"failed": tl["failed"]}
+                leg_seconds["leg_parity_gpu"] = time.perf_counter() - t_leg
             except Exception as e:  # the GPU line must be printed whatever happens to the host-side leg
                 out.setdefault("cpu_baseline", {"value": None, "unit": "pair-solves/s", "cores": 0, "kind": "port",
                                                 "sample": "failed: %r" % (e,)})
+        out["leg_seconds"] = leg_seconds
         print(json.dumps(out), flush=True)
     try:
         if h is not None:

@@ -24,3 +24,24 @@ def test_bench_line_carries_the_nodata_leg(emu_lib):
     assert leg["not_converged"] == 0 and leg["lattice_period"] == 120 and leg["nodata_fraction"] == 0.15
     assert 0.8 * 120 * 120 < leg["nodes"] < 0.9 * 120 * 120 and leg["value"] > 0
     assert line["value"] > 0 and "shortcut" in line and "with_voltages" in line
+
+
+def test_every_leg_of_the_fp64_line_carries_an_oracle_figure(emu_lib):
+    """nodata15, config3_fp32, config4_network (+ the geometric network that coarsens) each print a
+    `parity` object with max_rel_err / tolerance / ok, computed against the tight oracle (scipy Jacobi-CG for the Jacobi-
+    preconditioned expander) -- here at toy sizes on the emulator build; the driver runs the real sizes."""
+    env = dict(os.environ, CSGPU_LIB=os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so"))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "120", "--steps", "1", "--warmup", "1",
+                          "--batch", "8", "--cpu-sample", "90", "--leg-sample", "96", "--network-n", "4000", "--geometric-n",
+                          "4000", "--host-csr", "0"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["parity"]["ok"] and line["parity"]["max_rel_err_vs_oracle"] < 1e-6
+    for leg, tol in (("nodata15", 1e-6), ("config3_fp32", 1e-4), ("config4_network", 1e-6), ("network_geometric", 1e-6)):
+        assert "failed" not in line[leg], (leg, line[leg])
+        par = line[leg]["parity"]
+        assert "failed" not in par, (leg, par)
+        assert par["tolerance"] == tol and par["ok"] and par["max_rel_err"] < tol, (leg, par)
+    assert line["config4_network"]["levels"] == 1 and line["network_geometric"]["levels"] >= 3
+    assert line["nodata15"]["parity"]["lattice_period"] == 96
+    assert set(line["leg_seconds"]) >= {"nodata15", "config3_fp32", "config4_network", "cpu_child", "leg_parity_gpu"}
