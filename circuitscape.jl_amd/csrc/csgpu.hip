@@ -2895,6 +2895,129 @@ int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* d
   CS_API_END
 }
 
+// csgpu_multi_solve_pairs with the reference's cumulative / maximum current maps (src/out.jl:96-107 merged serially in
+// src/core.jl:262-285): batches are dealt round-robin to the devices (batch b -> slot b % ndevices), every device runs ITS
+// pairs as ONE csgpu_solve_pairs_currents call, so its cumulative / maximum node-current vectors stay in its HBM for the
+// whole job and cross PCIe once; the per-device vectors are then combined on the host in slot order (sum / max of
+// ndevices n-vectors: deterministic).
+int csgpu_multi_solve_pairs_currents(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
+                                     const int32_t* weights, void* cum_curr_inout, void* max_curr_inout, void* resist_out,
+                                     csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!m || npairs < 0 || (npairs > 0 && (!src || !dst))) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  const size_t nd = m->handles.size();
+  std::fill(m->busy_s.begin(), m->busy_s.end(), 0.0);
+  std::fill(m->pairs_done.begin(), m->pairs_done.end(), 0);
+  if (npairs == 0) return CSGPU_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  csgpu_info info;
+  int rc = csgpu_get_info(m->handles[0], &info);
+  if (rc) return rc;
+  const int64_t n = info.n;
+  const size_t vb = (size_t)m->val_bytes;
+  int64_t chunk = m->batch;
+  if ((npairs + chunk - 1) / chunk < (int64_t)nd) chunk = std::max<int64_t>(1, (npairs + (int64_t)nd - 1) / (int64_t)nd);
+  // the pairs of every slot, in the caller's order
+  std::vector<std::vector<int64_t>> idx(nd);
+  for (int64_t p = 0; p < npairs; ++p) idx[(size_t)((p / chunk) % (int64_t)nd)].push_back(p);
+  std::vector<int> codes(nd, CSGPU_OK);
+  std::vector<std::string> msgs(nd);
+  std::vector<csgpu_stats> st(nd);
+  for (auto& x : st) memset(&x, 0, sizeof(x));
+  std::vector<std::vector<char>> cum(nd), mx(nd);
+  auto worker = [&](size_t slot) {
+    auto w0 = std::chrono::steady_clock::now();
+    const std::vector<int64_t>& mine = idx[slot];
+    const int64_t cnt = (int64_t)mine.size();
+    if (cnt > 0) {
+      std::vector<int64_t> s_(cnt), d_(cnt);
+      std::vector<int32_t> w_(cnt);
+      for (int64_t k = 0; k < cnt; ++k) {
+        s_[k] = src[mine[k]];
+        d_[k] = dst[mine[k]];
+        w_[k] = weights ? weights[mine[k]] : 1;
+      }
+      if (cum_curr_inout) cum[slot].assign((size_t)n * vb, 0);
+      if (max_curr_inout) mx[slot].assign((size_t)n * vb, 0);
+      std::vector<char> res((size_t)cnt * vb);
+      codes[slot] = csgpu_solve_pairs_currents(m->handles[slot], s_.data(), d_.data(), cnt, w_.data(), nullptr, nullptr,
+                                               cum_curr_inout ? cum[slot].data() : nullptr,
+                                               max_curr_inout ? mx[slot].data() : nullptr, nullptr, res.data(), &st[slot]);
+      if (codes[slot]) msgs[slot] = csgpu_last_error();
+      if (resist_out && (codes[slot] == CSGPU_OK || codes[slot] == CSGPU_NOT_CONVERGED))
+        for (int64_t k = 0; k < cnt; ++k) memcpy((char*)resist_out + (size_t)mine[k] * vb, res.data() + (size_t)k * vb, vb);
+      m->pairs_done[slot] = cnt;
+    }
+    m->busy_s[slot] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < nd; ++i) th.emplace_back(worker, i);
+  worker(0);
+  for (auto& t : th) t.join();
+  s->nrhs = (int)npairs;
+  int rc_out = CSGPU_OK;
+  for (size_t i = 0; i < nd; ++i) {
+    s->total_iters += st[i].total_iters;
+    s->max_iters = std::max(s->max_iters, st[i].max_iters);
+    s->max_relres = std::max(s->max_relres, st[i].max_relres);
+    s->device_ms = std::max(s->device_ms, st[i].device_ms);
+    s->cg_spmv_ms += st[i].cg_spmv_ms;
+    s->cg_spmv_calls += st[i].cg_spmv_calls;
+    s->not_converged += st[i].not_converged;
+    s->graph_launches += st[i].graph_launches;
+    s->polished_batches += st[i].polished_batches;
+    s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->batch = std::max(s->batch, st[i].batch);
+    if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
+      rc_out = codes[i];
+      g_last_error = "device " + std::to_string(m->devices[i]) + ": " + msgs[i];
+    }
+  }
+  if (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED) {
+    // combine in slot order, the index range split over host threads
+    auto combine = [&](int64_t lo, int64_t hi) {
+      for (size_t i = 0; i < nd; ++i) {
+        if (cum_curr_inout && !cum[i].empty()) {
+          if (vb == 8) {
+            double* o = (double*)cum_curr_inout;
+            const double* a = (const double*)cum[i].data();
+            for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
+          } else {
+            float* o = (float*)cum_curr_inout;
+            const float* a = (const float*)cum[i].data();
+            for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
+          }
+        }
+        if (max_curr_inout && !mx[i].empty()) {
+          if (vb == 8) {
+            double* o = (double*)max_curr_inout;
+            const double* a = (const double*)mx[i].data();
+            for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
+          } else {
+            float* o = (float*)max_curr_inout;
+            const float* a = (const float*)mx[i].data();
+            for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
+          }
+        }
+      }
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(nd, (size_t)(n / 1000000 + 1)));
+    std::vector<std::thread> ct;
+    for (int t = 1; t < nt; ++t) ct.emplace_back(combine, n * t / nt, n * (t + 1) / nt);
+    combine(0, n / nt);
+    for (auto& t : ct) t.join();
+  }
+  s->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc_out;
+  CS_API_END
+}
+
 int csgpu_multi_device_count(const csgpu_multi* m) { return m ? (int)m->handles.size() : 0; }
 
 csgpu_handle* csgpu_multi_handle(csgpu_multi* m, int slot) {

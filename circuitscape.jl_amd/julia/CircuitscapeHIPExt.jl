@@ -374,6 +374,27 @@ function solve_pairs(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst:
 end
 
 """
+csgpu_multi_solve_pairs_currents: the pair list dealt over all GPUs of the node with the cumulative / maximum node-current
+vectors (out.jl:96-107) accumulated per device and combined on return -- the maps-on counterpart of `solve_pairs` above for
+runs that write cumulative / maximum maps only. `cum` / `mx`: length-n vectors updated in place (empty = not wanted).
+"""
+function solve_pairs_currents(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst::Vector{Int64};
+                              weights::Vector{Int32} = Int32[], cum::Vector{T} = T[], mx::Vector{T} = T[]) where {T}
+    np = length(src)
+    res = Vector{T}(undef, np)
+    st = CsgpuStats()
+    rc = GC.@preserve src dst weights cum mx res ccall((:csgpu_multi_solve_pairs_currents, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, src, dst, np, isempty(weights) ? C_NULL : pointer(weights),
+              isempty(cum) ? C_NULL : pointer(cum), isempty(mx) ? C_NULL : pointer(mx), res, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_multi_solve_pairs_currents failed: $(csgpu_error())")
+    res, st
+end
+
+device_count() = Int(ccall((:csgpu_device_count, LIBCSGPU), Cint, ()))
+
+"""
 `node_cell_table(nodemap)`: 0-based raster row / column of the FIRST cell (column-major order) of every node id of the
 node map, built ONCE per problem (one pass over the raster); `node_coords(table, comp)` then picks the entries of a
 connected component (any order of `comp`), or returns `nothing` -- with a warning -- when a node of the component has no
@@ -449,7 +470,17 @@ function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::Spar
         node_cum = linear ? zeros(T, n) : T[]
         node_max = (linear && of.write_max_cur_maps) ? zeros(T, n) : T[]
         ncombos = 0
-        for lo in 1:bs:np
+        # cumulative / maximum maps only, several GPUs, more than one batch: the whole pair list in ONE call over all devices
+        # (csgpu_multi_solve_pairs_currents; the merge of core.jl:262-285 happens inside the library)
+        multi = linear && !per_pair_cur && !of.write_volt_maps && np > bs && device_count() > 1
+        if multi
+            mf = construct_multi_factor(matrix, s)
+            w = Int32[length(fan[p]) for p in 1:np]
+            ncombos = sum(w)
+            res, _ = solve_pairs_currents(mf, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)
+            finalize(mf)
+        end
+        for lo in (multi ? (1:0) : (1:bs:np))
             hi = min(lo + bs - 1, np)
             w = Int32[length(fan[p]) for p in lo:hi]
             ncombos += sum(w)
@@ -503,6 +534,10 @@ function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::Spar
             row = matrix.rowval[k]
             i > row && (push!(I, row); push!(J, V(i)); push!(K, k))
         end
+        coord_index = Dict{Tuple{Int,Int},Int}()                            # (ADVICE r4: was a findfirst scan per branch per pair)
+        for (i, c) in enumerate(cum.coords)
+            coord_index[(Int(c[1]), Int(c[2]))] = i
+        end
         for lo in 1:bs:np
             hi = min(lo + bs - 1, np)
             r, volt, curr, br, _ = solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi];
@@ -519,8 +554,8 @@ function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::Spar
                 lock(cum.lock) do
                     for i in 1:size(branch_currents_array, 1)
                         a1 = (Int(branch_currents_array[i, 1]), Int(branch_currents_array[i, 2]))
-                        idx = findfirst(isequal(a1), cum.coords)
-                        idx === nothing && (idx = findfirst(isequal((a1[2], a1[1])), cum.coords))
+                        idx = get(coord_index, a1, 0)
+                        idx == 0 && (idx = coord_index[(a1[2], a1[1])])
                         cum.cum_branch_curr[idx] += branch_currents_array[i, 3]
                     end
                     for i in 1:size(node_currents_array, 1)

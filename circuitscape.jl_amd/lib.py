@@ -24,7 +24,8 @@ EXPORTS = [
     "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_solve_region_pairs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded", "csgpu_raster_setup_poly",
     "csgpu_solve_raster", "csgpu_dia_product_host",
-    "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_device_count",
+    "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_solve_pairs_currents",
+    "csgpu_multi_device_count",
     "csgpu_multi_handle", "csgpu_multi_last_busy", "csgpu_multi_free",
     "csgpu_free", "csgpu_trim_memory", "csgpu_last_error", "csgpu_version",
 ]
@@ -112,6 +113,8 @@ def _bind(L):
     L.csgpu_multi_setup.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, ctypes.POINTER(Opts), vp, i32, ctypes.POINTER(vp)]
     L.csgpu_multi_raster_setup.argtypes = [vp, i64, i64, i32, i32, i32, i32, ctypes.POINTER(Opts), vp, i32, ctypes.POINTER(vp)]
     L.csgpu_multi_solve_pairs.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_multi_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_multi_solve_pairs_currents.restype = ctypes.c_int
     L.csgpu_multi_device_count.argtypes = [vp]
     L.csgpu_multi_handle.argtypes = [vp, i32]
     L.csgpu_multi_handle.restype = vp
@@ -457,6 +460,34 @@ class MultiHandle:
         d["device_busy_s"] = busy.tolist()
         d["device_pairs"] = done.tolist()
         return res, gathered, d
+
+    def solve_pairs_currents(self, src, dst, weights=None, cum=None, mx=None):
+        """csgpu_multi_solve_pairs_currents: pair solves dealt over the devices with the reference's cumulative / maximum
+        node-current vectors (src/out.jl:96-107) accumulated per device and combined on return. cum / mx: optional length-n
+        arrays of the handle's value type, updated in place. Returns (resistances, stats dict)."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        npairs = len(src)
+        n = self.info(0)["n"]
+        res = np.zeros(npairs, dtype=self.dtype)
+        w = np.ascontiguousarray(weights, dtype=np.int32) if weights is not None else None
+        for a in (cum, mx):
+            assert a is None or (a.dtype == self.dtype and a.flags["C_CONTIGUOUS"] and a.shape == (n,))
+        st = Stats()
+        rc = lib().csgpu_multi_solve_pairs_currents(self._p, src.ctypes.data, dst.ctypes.data, npairs,
+                                                    w.ctypes.data if w is not None else None,
+                                                    cum.ctypes.data if cum is not None else None,
+                                                    mx.ctypes.data if mx is not None else None, res.ctypes.data,
+                                                    ctypes.byref(st))
+        _check(rc)
+        nd = self.ndevices
+        busy = np.zeros(nd)
+        done = np.zeros(nd, dtype=np.int64)
+        lib().csgpu_multi_last_busy(self._p, busy.ctypes.data, done.ctypes.data)
+        d = st.as_dict()
+        d["device_busy_s"] = busy.tolist()
+        d["device_pairs"] = done.tolist()
+        return res, d
 
 
 def _device_list(devices):

@@ -24,7 +24,7 @@
  *                              ground sets, one hierarchy
  *   csgpu_solve_pairs_currents <-> the same plus postprocess() -> write_cur_maps -> _create_current_maps
  *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
- *   csgpu_multi_setup, csgpu_multi_raster_setup, csgpu_multi_solve_pairs, csgpu_multi_free
+ *   csgpu_multi_setup, csgpu_multi_raster_setup, csgpu_multi_solve_pairs, csgpu_multi_solve_pairs_currents, csgpu_multi_free
  *                          <-> the task fan-out and serial result merge of solve(prob, ::AMGSolver, ...)
  *                              (Threads.@spawn per source point, src/core.jl:262-285), as one host thread per GPU
  *   csgpu_free             <-> GC finalizer of the factor object (PardisoFactorize, Pardiso ext :8-13)
@@ -390,6 +390,17 @@ int csgpu_multi_raster_setup(const void* cond, int64_t nrows, int64_t ncols, int
 int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
                             const int64_t* gather_idx, int64_t ngather, void* gathered_out, void* resist_out,
                             csgpu_stats* stats);
+/* The same with the reference's cumulative / maximum current maps (write_cum_maps / accum_currents!, src/out.jl:96-107,
+ * merged serially after the task fan-out in src/core.jl:262-285): batches are dealt round-robin to the devices and every
+ * device runs its pairs as ONE csgpu_solve_pairs_currents call, so its cumulative / maximum node-current vectors stay in its
+ * HBM for the whole job; the ndevices n-vectors are combined on the host in slot order (sum / max: deterministic -- this
+ * is the one place where the path moves n-sized data between devices: 0.8 GB per vector at n = 1e8, once per job).
+ *   cum_curr_inout[i] += sum_p weights[p] * curr_p[i]   (weights NULL => 1)    may be NULL
+ *   max_curr_inout[i]  = max(max_curr_inout[i], max_p curr_p[i])               may be NULL
+ *   resist_out[p] as in csgpu_solve_pairs (may be NULL). Host arrays of the handle's value type, n = csgpu_get_info().n. */
+int csgpu_multi_solve_pairs_currents(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
+                                     const int32_t* weights, void* cum_curr_inout, void* max_curr_inout, void* resist_out,
+                                     csgpu_stats* stats);
 /* number of devices of the set; handle of device slot i (for csgpu_get_info etc.; owned by the set); per-slot wall
  * seconds spent inside the last csgpu_multi_solve_pairs (busy_s: ndevices doubles, may be NULL) */
 int csgpu_multi_device_count(const csgpu_multi* m);

@@ -929,6 +929,62 @@ def test_multi_device_handle_matches_single_device(emu_lib, oracle):
     assert np.max(np.abs(np.array(d["R"]) - Ro) / Ro) < 1e-6
 
 
+def test_multi_device_cumulative_current_maps(emu_lib):
+    """csgpu_multi_solve_pairs_currents: the pair list dealt over three (emulated) devices, cumulative
+    and maximum node-current vectors accumulated per device and combined on return == the single-handle accumulation of
+    csgpu_solve_pairs_currents (src/out.jl:96-107 merged serially in src/core.jl:262-285), weights included; the in/out
+    semantics (+= / max with what the caller passes in) and fewer batches than devices."""
+    import subprocess, sys, json, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        lib.load(%r)
+        assert lib.device_count() == 3
+        N = 36
+        rng = np.random.default_rng(8)
+        g = np.exp(rng.standard_normal((N, N + 2)))
+        g[rng.random(g.shape) < 0.1] = 0.0
+        out = {}
+        with lib.raster_setup(g, lib.default_opts(batch=4)) as h:
+            n = h.info["n"]
+            labels, _ = h.components()
+            big = np.flatnonzero(labels == np.bincount(labels).argmax())
+            pts = np.random.default_rng(9).choice(big, size=7, replace=False)
+            src = [int(pts[i]) for i in range(7) for j in range(i + 1, 7)]
+            dst = [int(pts[j]) for i in range(7) for j in range(i + 1, 7)]
+            w = (1 + np.arange(len(src)) %% 3).astype(np.int32)
+            cum1 = np.full(n, 0.5); mx1 = np.full(n, 0.01)
+            R1, _, _, st1 = h.solve_pairs_currents(src, dst, weights=w, want_currents=False, cum=cum1, mx=mx1)
+        with lib.multi_raster_setup(g, lib.default_opts(batch=4)) as m:
+            cumm = np.full(n, 0.5); mxm = np.full(n, 0.01)
+            Rm, stm = m.solve_pairs_currents(src, dst, weights=w, cum=cumm, mx=mxm)
+            out["pairs"] = stm["device_pairs"]
+            cum5 = np.zeros(n)
+            R5, st5 = m.solve_pairs_currents(src[:5], dst[:5], cum=cum5)
+            out["pairs5"] = st5["device_pairs"]
+            R0, st0 = m.solve_pairs_currents([], [])
+        with lib.raster_setup(g, lib.default_opts(batch=4)) as h:
+            cum5s = np.zeros(n)
+            h.solve_pairs_currents(src[:5], dst[:5], want_currents=False, cum=cum5s)
+        out.update(relR=float(np.max(np.abs(R1 - Rm) / R1)), relcum=float(np.max(np.abs(cum1 - cumm)) / np.max(cum1)),
+                   relmax=float(np.max(np.abs(mx1 - mxm)) / np.max(mx1)), relcum5=float(np.max(np.abs(cum5 - cum5s)) / np.max(cum5s)),
+                   floor=bool(np.min(cumm) >= 0.5 and np.min(mxm) >= 0.01), n0=len(R0), nc=stm["not_converged"],
+                   iters=[st1["total_iters"], stm["total_iters"]])
+        print(json.dumps(out))
+    ''') % (root, os.path.join(root, "tests", "emu", "libcsgpu_emu.so"))
+    env = dict(os.environ, HIPEMU_DEVICES="3", HIPEMU_THREADS="2")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["relR"] < 1e-10 and d["relcum"] < 1e-10 and d["relmax"] < 1e-10 and d["relcum5"] < 1e-10, d
+    assert d["floor"] and d["n0"] == 0 and d["nc"] == 0 and d["iters"][0] == d["iters"][1]
+    assert sum(d["pairs"]) == 21 and all(p > 0 for p in d["pairs"])
+    assert sum(d["pairs5"]) == 5 and all(p > 0 for p in d["pairs5"])
+
+
 def test_direct_tentative_product_matches_general_spgemm(emu_lib):
     """setup: A * T by the one-thread-per-row kernel == the general SpGEMM (see helpers.check_direct_tentative_product)."""
     from helpers import check_direct_tentative_product

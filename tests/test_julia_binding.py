@@ -109,7 +109,10 @@ def test_reference_dispatch_points_have_methods():
     assert mm, "solve_pairs_with_maps! is missing"
     mbody = mm.group(1)
     assert mbody.count("solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi]") == 2   # raster, network
-    assert mbody.count("for lo in 1:bs:np") == 2
+    assert mbody.count("1:bs:np") == 2
+    # round 5: cumulative / maximum maps only on several GPUs -> ONE csgpu_multi_solve_pairs_currents call for the list
+    assert "solve_pairs_currents(mf, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)" in mbody
+    assert "device_count() > 1" in mbody and "findfirst(isequal(a1), cum.coords)" not in mbody
     for needed in ("cum = node_cum, mx = node_max", "want_voltages = of.write_volt_maps", "want_currents = per_pair_cur",
                    "write_volt_maps(name, out, component_data, flags, cfg)", "write_grid(cmap, name, cfg, hbmeta)",
                    "process_grid!(cmap, cellmap, hbmeta", "write_currents(node_currents_array, branch_currents_array, name, cfg)",
