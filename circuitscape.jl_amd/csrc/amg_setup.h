@@ -973,6 +973,26 @@ struct Level {
   DBuf xa, rb, b, qs;
 };
 
+// Spectral enrichment of the level-0 coarse space (enrich.h): a second coarse function on the aggregates of a perforated /
+// refined-tile raster lattice whose local Fiedler value is small, handled multiplicatively around the V-cycle.
+struct Enrich {
+  int nvec = 0, nmem = 0, nhalo = 0, R = 0, ntiles = 0;
+  int64_t n = 0;
+  DBuf agg;          // [n] int: level-0 aggregate (tile) of every cell
+  DBuf phi;          // [n] hierarchy precision: the enrichment vectors side by side (disjoint supports), 0 elsewhere
+  int phi_bytes = 0;
+  DBuf vec_of_tile;  // [ntiles] int: vector index of an enriched aggregate, -1 otherwise
+  DBuf vptr, vcell;  // members of every vector (cell ids, window order)
+  DBuf binv;         // [nvec] double: 1 / (G_vv + sum_w |G_vw|)
+  DBuf hcell;        // cells whose residual the pre-correction changes (members and their coupled neighbours), ascending
+  DBuf t, c, c2, save;  // work: [nvec][K] doubles x 3, [nhalo][K] saved residual entries
+  int work_k = 0, work_bytes = 0;
+  size_t device_bytes() const {
+    return agg.bytes + phi.bytes + vec_of_tile.bytes + vptr.bytes + vcell.bytes + binv.bytes + hcell.bytes + t.bytes + c.bytes +
+           c2.bytes + save.bytes;
+  }
+};
+
 static const int kMaxDirComp = 256;  // components of the coarsest graph the Dirichlet correction handles (pcg.h)
 
 template <class T>
@@ -1002,6 +1022,7 @@ struct Hierarchy {
   double* dir_coef = nullptr;
   int dir_mode = 0;
   double cand_norm2 = 0;       // |candidate|^2 (= number of fine nodes: the same on every level)
+  Enrich enr;                  // level 0 of a cell-space / refined-tile raster lattice (enrich.h); nvec == 0: none
   int tail_first = -2;
   DBuf tail_ws;
   int64_t tail_stride = 0;

@@ -1909,6 +1909,7 @@ struct Solver : ISolver {
                          L.xa.bytes + L.rb.bytes + L.b.bytes + L.qs.bytes + L.orderA.bytes + L.QT.device_bytes() +
                          L.M.device_bytes() + L.orderQT.bytes + L.Sdia.device_bytes() + L.Ql.device_bytes() + L.Adia.device_bytes() + L.A25.device_bytes());
     }
+    bytes += (int64_t)H.enr.device_bytes();
     bytes += (int64_t)(H.coarse_inv.bytes + W.x.bytes + W.r.bytes + W.z.bytes + W.rp.bytes + W.p.bytes + W.Ap.bytes + W.b.bytes);
     info->operator_complexity = nnz_sum / std::max(1.0, (double)nnz);
     info->grid_complexity = n_sum / std::max(1.0, (double)H.levels[0].A.nrows);

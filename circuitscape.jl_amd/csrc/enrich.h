@@ -1,0 +1,476 @@
+// enrich.h -- spectral enrichment of the level-0 coarse space on perforated / refined-tile raster lattices (round 5).
+//
+// Why. On a raster with NODATA cells the 3x3 tiles stay the aggregates of level 0 (that is what keeps the transfer
+// operators index-free), and the piece analysis keeps every aggregate CONNECTED. Connected is not enough: a short wall of
+// NODATA cells inside a tile leaves a C- or U-shaped aggregate whose two arms hang together through a one-cell neck, a
+// bare diagonal bridge, a corridor along the raster's edge. The smoothed-aggregation coarse space carries ONE function per
+// aggregate -- (smoothed) constants -- and cannot represent the low-energy mode "one arm up, the other down"; Jacobi
+// damps it slowly because the neck makes it smooth. Measured with a scipy reconstruction of this very hierarchy (400^2 and
+// 1000^2, 15 % i.i.d. NODATA): the spectrum of M^-1 A has the same bulk edge as on the all-valid raster (0.29-0.30) and
+// below it a tail of LOCALISED eigenvectors (10-40 cells each, lambda 0.15 ... 0.29), every one of them a jump across such
+// a wall inside one aggregate; the tail is what costs the iterations (12.3 against 10.0 at 400^2; it fills up as the raster
+// grows: 13.8-16.3 at 10000^2) -- the reference's own hierarchy (greedy aggregation + Gauss-Seidel, oracle/) needs 16.9 at
+// 400^2. Re-dealing the cells over the tiles (splitting the pieces along their Fiedler vectors) only moves the defects.
+//
+// What. Every aggregate whose local generalised eigenproblem  L_agg phi = lambda D phi  (L_agg: the couplings INSIDE the
+// aggregate, D: the full diagonal) has a second eigenvalue below tau gets a SECOND coarse function: an approximation phi_t
+// of that Fiedler vector (start: the coordinate direction with the smallest Rayleigh quotient, then a few power steps),
+// supported on the aggregate's cells. The vectors E = [phi_t] form an auxiliary coarse space handled OUTSIDE the lattice
+// hierarchy, multiplicatively and symmetrically around the V-cycle:
+//
+//     c  = B E'r,   r1 = r - A E c,   z = V(r1),   c2 = B E'(r1 - A z),   z += E (c + c2),       B = diag(E'AE)^-1 (row-
+//                                                                              abs-sum scaled: B^-1 >= E'AE)
+//
+// i.e. M^-1 = E(2B - B G B)E' + (I - E B E'A) V (I - A E B E'): symmetric positive definite for any symmetric A used in
+// it. All of it touches only the members of the enriched aggregates and their neighbours (2-5 % of the cells): gathers /
+// scatters over compact lists, no atomics, fixed summation orders -- bit-reproducible. The r'z partials of the V-cycle's
+// last product are corrected by the scalars the passes produce anyway (r'z = r1'z_V + c'(AE)'z_V + t'(c + c2)).
+// Prototype (two-grid, exact coarse solve, 400^2 / 15 % NODATA): 12.5 -> 10.6 iterations with 4 % of the tiles enriched
+// (tau = 0.08), 9.75 with 23 % (tau = 0.15; the all-valid raster: 9.9).
+//
+// GPU counterpart of nothing in the reference: AlgebraicMultigrid.jl has no such step (its unstructured aggregates adapt
+// to the holes instead; call site of the hierarchy src/core.jl:164-167). Parity is solution-level, as for the rest of
+// the preconditioner.
+#pragma once
+#include "amg_setup.h"
+
+namespace csgpu {
+
+static const int kEnrichMaxM = 20;   // members of an aggregate the local analysis handles (more: not enriched)
+static const int kEnrichWin = 8;     // window edge: a tile (<= 4 cells) and two cells around it
+
+// k-th entry (k = 0..8, ascending column order) of row i of a lattice matrix: column j and value (0 where absent)
+template <class U>
+__device__ __forceinline__ U enr_entry(const U* __restrict__ rows, int64_t n, int R, int64_t i, int k, int64_t& j) {
+  switch (k) {
+    case 0: j = i - R - 1; return j >= 0 ? rows[j * 5 + 4] : U(0);
+    case 1: j = i - R; return j >= 0 ? rows[j * 5 + 3] : U(0);
+    case 2: j = i - R + 1; return j >= 0 ? rows[j * 5 + 2] : U(0);
+    case 3: j = i - 1; return j >= 0 ? rows[j * 5 + 1] : U(0);
+    case 4: j = i; return rows[i * 5 + 0];
+    case 5: j = i + 1; return j < n ? rows[i * 5 + 1] : U(0);
+    case 6: j = i + R - 1; return j < n ? rows[i * 5 + 2] : U(0);
+    case 7: j = i + R; return j < n ? rows[i * 5 + 3] : U(0);
+    default: j = i + R + 1; return j < n ? rows[i * 5 + 4] : U(0);
+  }
+}
+
+// Pass A, one thread per tile: members of the aggregate (window scan), local Fiedler approximation, decision.
+// phi (dense, pre-zeroed) receives the vector of an enriched aggregate; flag[t] = 1, mcount[t] = members.
+template <class U, class T>
+__global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
+                                                        const long long* __restrict__ size0, const int* __restrict__ agg,
+                                                        const unsigned long long* __restrict__ size_c, double tau,
+                                                        int psteps, T* __restrict__ phi, int* __restrict__ flag,
+                                                        int* __restrict__ mcount) {
+  const int64_t n = (int64_t)R * C;
+  const int ntiles = Rc * Cc;
+  for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
+    flag[t] = 0;
+    mcount[t] = 0;
+    const int want = (int)size_c[t];
+    if (want < 3 || want > kEnrichMaxM) continue;
+    const int I = t % Rc, J = t / Rc;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const int wr0 = max(r0 - 2, 0), wr1 = min(r1 + 2, R), wc0 = max(c0 - 2, 0), wc1 = min(c1 + 2, C);
+    signed char widx[kEnrichWin * kEnrichWin];
+    int mr[kEnrichMaxM], mc[kEnrichMaxM];
+    int m = 0;
+    bool full = r1 - r0 == 3 && c1 - c0 == 3 && want == 9;  // a complete regular tile (checked below) is never enriched
+    for (int c = wc0; c < wc1; ++c)
+      for (int r = wr0; r < wr1; ++r) {
+        const int64_t cell = (int64_t)c * R + r;
+        const bool mem = agg[cell] == t && (!size0 || size0[cell] != 0);
+        widx[(c - wc0) * kEnrichWin + (r - wr0)] = (signed char)(mem && m < kEnrichMaxM ? m : -1);
+        if (mem) {
+          if (m < kEnrichMaxM) {
+            mr[m] = r;
+            mc[m] = c;
+          }
+          ++m;
+          if (r < r0 || r >= r1 || c < c0 || c >= c1) full = false;
+        }
+      }
+    if (m != want || full) continue;  // (members outside the window: the aggregate is left alone)
+    // local graph: couplings between members
+    double d[kEnrichMaxM], w[kEnrichMaxM][8];
+    signed char nb[kEnrichMaxM][8];
+    double dsum = 0.0;
+    for (int a = 0; a < m; ++a) {
+      const int64_t cell = (int64_t)mc[a] * R + mr[a];
+      d[a] = (double)rows[cell * 5];
+      dsum += d[a];
+      int q = 0;
+      for (int k = 0; k < 9; ++k) {
+        if (k == 4) continue;
+        int64_t j;
+        const double v = (double)enr_entry(rows, n, R, cell, k, j);
+        int b = -1;
+        if (v != 0.0) {
+          const int jr = (int)(j % R), jc = (int)(j / R);
+          if (jr >= wr0 && jr < wr1 && jc >= wc0 && jc < wc1) b = widx[(jc - wc0) * kEnrichWin + (jr - wr0)];
+        }
+        nb[a][q] = (signed char)b;
+        w[a][q] = b >= 0 ? (v < 0.0 ? -v : v) : 0.0;
+        ++q;
+      }
+    }
+    if (!(dsum > 0.0)) continue;
+    double v[kEnrichMaxM], lv[kEnrichMaxM];
+    auto center = [&](double* x) {
+      double s = 0.0;
+      for (int a = 0; a < m; ++a) s += d[a] * x[a];
+      s /= dsum;
+      for (int a = 0; a < m; ++a) x[a] -= s;
+    };
+    auto apply = [&](const double* x, double* y) {  // y = L_agg x
+      for (int a = 0; a < m; ++a) {
+        double s = 0.0;
+        for (int q = 0; q < 8; ++q)
+          if (nb[a][q] >= 0) s += w[a][q] * (x[a] - x[nb[a][q]]);
+        y[a] = s;
+      }
+    };
+    auto rayleigh = [&](const double* x, const double* y) {
+      double num = 0.0, den = 0.0;
+      for (int a = 0; a < m; ++a) {
+        num += x[a] * y[a];
+        den += d[a] * x[a] * x[a];
+      }
+      return den > 0.0 ? num / den : 1e300;
+    };
+    // start: the coordinate direction (row, column, the two diagonals) with the smallest Rayleigh quotient
+    double best = 1e300;
+    int bestdir = -1;
+    for (int dir = 0; dir < 4; ++dir) {
+      for (int a = 0; a < m; ++a)
+        v[a] = dir == 0 ? (double)mr[a] : dir == 1 ? (double)mc[a] : dir == 2 ? (double)(mr[a] + mc[a]) : (double)(mr[a] - mc[a]);
+      center(v);
+      apply(v, lv);
+      const double q = rayleigh(v, lv);
+      if (q < best) {
+        best = q;
+        bestdir = dir;
+      }
+    }
+    if (bestdir < 0 || best > 1e299) continue;
+    for (int a = 0; a < m; ++a)
+      v[a] = bestdir == 0 ? (double)mr[a] : bestdir == 1 ? (double)mc[a] : bestdir == 2 ? (double)(mr[a] + mc[a]) : (double)(mr[a] - mc[a]);
+    center(v);
+    for (int s = 0; s < psteps; ++s) {  // power steps on I - 0.6 D^-1 L_agg (deflated against the constant)
+      apply(v, lv);
+      for (int a = 0; a < m; ++a) v[a] -= 0.6 * lv[a] / d[a];
+      center(v);
+    }
+    apply(v, lv);
+    const double lam = rayleigh(v, lv);
+    if (!(lam < tau)) continue;
+    double den = 0.0;
+    for (int a = 0; a < m; ++a) den += d[a] * v[a] * v[a];
+    if (!(den > 0.0)) continue;
+    const double sc = 1.0 / sqrt(den);
+    for (int a = 0; a < m; ++a) phi[(int64_t)mc[a] * R + mr[a]] = (T)(v[a] * sc);
+    flag[t] = 1;
+    mcount[t] = m;
+  }
+}
+
+// Pass B, one thread per tile (enriched ones work): member list in window order; G_vv = phi'A phi and the sum of
+// |phi_i A_ij phi_j| over the couplings into OTHER enriched aggregates (row-abs-sum scaling of B)
+template <class U, class T>
+__global__ __launch_bounds__(64) void enrich_lists_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
+                                                          const int* __restrict__ agg, const T* __restrict__ phi,
+                                                          const int* __restrict__ vec_of_tile, const int* __restrict__ moff,
+                                                          int* __restrict__ vptr, int* __restrict__ vcell,
+                                                          double* __restrict__ binv) {
+  const int64_t n = (int64_t)R * C;
+  const int ntiles = Rc * Cc;
+  for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
+    const int v = vec_of_tile[t];
+    if (v < 0) continue;
+    const int I = t % Rc, J = t / Rc;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const int wr0 = max(r0 - 2, 0), wr1 = min(r1 + 2, R), wc0 = max(c0 - 2, 0), wc1 = min(c1 + 2, C);
+    int o = moff[t];
+    vptr[v] = o;
+    double gvv = 0.0, off = 0.0;
+    for (int c = wc0; c < wc1; ++c)
+      for (int r = wr0; r < wr1; ++r) {
+        const int64_t cell = (int64_t)c * R + r;
+        const double pi = (double)phi[cell];
+        if (agg[cell] != t || pi == 0.0) continue;   // (phi is non-zero exactly at the members of enriched aggregates ...
+        vcell[o++] = (int)cell;
+        for (int k = 0; k < 9; ++k) {
+          int64_t j;
+          const double a = (double)enr_entry(rows, n, R, cell, k, j);
+          if (a == 0.0) continue;
+          const double pj = (double)phi[j];
+          if (pj == 0.0) continue;
+          if (agg[j] == t) gvv += pi * a * pj;
+          else off += fabs(pi * a * pj);
+        }
+      }
+    binv[v] = gvv + off > 0.0 ? 1.0 / (gvv + off) : 0.0;
+  }
+}
+// ... a member whose phi rounds to exactly 0 is dropped from the list; it would contribute nothing anywhere.)
+
+// halo flag of a cell: the cell or one of its coupled neighbours belongs to an enriched aggregate
+template <class U, class T>
+__global__ __launch_bounds__(256) void enrich_halo_flag_kernel(int64_t n, int R, const U* __restrict__ rows,
+                                                               const T* __restrict__ phi, int* __restrict__ hflag) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (int64_t)gridDim.x * 256) {
+    int f = 0;
+    if (i < n) {
+      for (int k = 0; k < 9 && !f; ++k) {
+        int64_t j;
+        const U a = enr_entry(rows, n, R, i, k, j);
+        if (a != U(0) && phi[j] != T(0)) f = 1;
+      }
+    }
+    hflag[i] = f;
+  }
+}
+
+__global__ __launch_bounds__(256) void enrich_halo_fill_kernel(int64_t n, const int* __restrict__ hoff, int* __restrict__ hcell) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (hoff[i + 1] != hoff[i]) hcell[hoff[i]] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void enrich_vec_of_tile_kernel(int ntiles, const int* __restrict__ flag,
+                                                                 const int* __restrict__ voff, int* __restrict__ vec_of_tile) {
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) vec_of_tile[t] = flag[t] ? voff[t] : -1;
+}
+
+// ---- set-up ---------------------------------------------------------------------------------------------------------
+// A/B knobs: CSGPU_ENRICH=0 switches the enrichment off, CSGPU_ENRICH_TAU (default 0.1), CSGPU_ENRICH_STEPS (default 6).
+inline double enrich_tau() {
+  const char* e = getenv("CSGPU_ENRICH");
+  if (e && atof(e) <= 0.0) return 0.0;
+  const char* t = getenv("CSGPU_ENRICH_TAU");
+  return t ? atof(t) : 0.1;
+}
+
+template <class U, class T>
+inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc, const long long* size0, const int* agg,
+                         const unsigned long long* size_c, hipStream_t st) {
+  E = Enrich();
+  const double tau = enrich_tau();
+  if (!(tau > 0.0)) return;
+  const int psteps = getenv("CSGPU_ENRICH_STEPS") ? atoi(getenv("CSGPU_ENRICH_STEPS")) : 6;
+  const int64_t n = (int64_t)R * C;
+  const int ntiles = Rc * Cc;
+  DBuf phi((size_t)n * sizeof(T)), flag = dalloc<int>((size_t)ntiles + 1), mcount = dalloc<int>((size_t)ntiles + 1);
+  CS_HIP(hipMemsetAsync(phi.p, 0, phi.bytes, st));
+  CS_HIP(hipMemsetAsync(flag.p, 0, flag.bytes, st));
+  CS_HIP(hipMemsetAsync(mcount.p, 0, mcount.bytes, st));
+  const int gt = std::min(ceil_div(ntiles, 64), 65536);
+  hipLaunchKernelGGL((enrich_phi_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, size0, agg, size_c, tau, psteps,
+                     dptr<T>(phi), dptr<int>(flag), dptr<int>(mcount));
+  check_launch("enrichment vectors");
+  DBuf voff = dalloc<int>((size_t)ntiles + 1), tot = dalloc<int>(2);
+  CS_HIP(hipMemcpyAsync(voff.p, flag.p, ((size_t)ntiles + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+  exclusive_scan_i32(dptr<int>(voff), (int64_t)ntiles + 1, st, dptr<int>(tot));
+  const int nvec = read_int(dptr<int>(tot), st);
+  if (nvec <= 0) return;
+  exclusive_scan_i32(dptr<int>(mcount), (int64_t)ntiles + 1, st, dptr<int>(tot) + 1);
+  const int nmem = read_int(dptr<int>(tot) + 1, st);
+  E.vec_of_tile = dalloc<int>((size_t)ntiles);
+  hipLaunchKernelGGL(enrich_vec_of_tile_kernel, dim3(grid_for(ntiles)), dim3(256), 0, st, ntiles, (const int*)dptr<int>(flag),
+                     (const int*)dptr<int>(voff), dptr<int>(E.vec_of_tile));
+  E.vptr = dalloc<int>((size_t)nvec + 1);
+  E.vcell = dalloc<int>((size_t)std::max(nmem, 1));
+  E.binv = dalloc<double>((size_t)nvec);
+  hipLaunchKernelGGL((enrich_lists_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(E.vec_of_tile), (const int*)dptr<int>(mcount), dptr<int>(E.vptr), dptr<int>(E.vcell),
+                     dptr<double>(E.binv));
+  CS_HIP(hipMemcpyAsync(dptr<int>(E.vptr) + nvec, &nmem, sizeof(int), hipMemcpyHostToDevice, st));
+  // halo list: the cells whose residual the pre-correction changes
+  DBuf hoff = dalloc<int>((size_t)n + 1);
+  hipLaunchKernelGGL((enrich_halo_flag_kernel<U, T>), dim3(grid_for(n + 1)), dim3(256), 0, st, n, R, rows, (const T*)dptr<T>(phi),
+                     dptr<int>(hoff));
+  exclusive_scan_i32(dptr<int>(hoff), n + 1, st, dptr<int>(tot));
+  const int nhalo = read_int(dptr<int>(tot), st);
+  E.hcell = dalloc<int>((size_t)std::max(nhalo, 1));
+  hipLaunchKernelGGL(enrich_halo_fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, (const int*)dptr<int>(hoff), dptr<int>(E.hcell));
+  check_launch("enrichment lists");
+  CS_HIP(hipStreamSynchronize(st));
+  E.agg = dalloc<int>((size_t)n);
+  CS_HIP(hipMemcpyAsync(E.agg.p, agg, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
+  E.phi = std::move(phi);
+  E.phi_bytes = (int)sizeof(T);
+  E.nvec = nvec;
+  E.nmem = nmem;
+  E.nhalo = nhalo;
+  E.R = R;
+  E.n = n;
+  E.ntiles = ntiles;
+  if (getenv("CSGPU_VERBOSE"))
+    fprintf(stderr, "csgpu: coarse-space enrichment: %d of %d aggregates get a second function (tau %.3g), %d members, %d halo cells\n",
+            nvec, ntiles, tau, nmem, nhalo);
+}
+
+// ---- application (K interleaved columns) ------------------------------------------------------------------------------
+// t[v][c] = sum_members phi_i r_i ; cc[v][c] = binv_v t   (one thread per (vector, column))
+template <class T, int K>
+__global__ __launch_bounds__(256) void enrich_gather_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
+                                                            const T* __restrict__ phi, const double* __restrict__ binv,
+                                                            const T* __restrict__ r, double* __restrict__ t,
+                                                            double* __restrict__ cc, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nvec * K; id += (int64_t)gridDim.x * 256) {
+    const int v = (int)(id / K), c = (int)(id % K);
+    double s = 0.0;
+    for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
+      const int64_t cell = vcell[m];
+      s += (double)phi[cell] * (double)r[cell * K + c];
+    }
+    t[id] = s;
+    cc[id] = binv[v] * s;
+  }
+}
+
+// halo cells: save r, then r -= (A E c)   (one thread per (halo cell, column))
+template <class U, class T, int K>
+__global__ __launch_bounds__(256) void enrich_pre_kernel(int nhalo, const int* __restrict__ hcell, int64_t n, int R,
+                                                         const U* __restrict__ rows, const int* __restrict__ agg,
+                                                         const int* __restrict__ vec_of_tile, const T* __restrict__ phi,
+                                                         const double* __restrict__ cc, T* __restrict__ r,
+                                                         T* __restrict__ save, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nhalo * K; id += (int64_t)gridDim.x * 256) {
+    const int h = (int)(id / K), c = (int)(id % K);
+    const int64_t i = hcell[h];
+    double s = 0.0;
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      const double a = (double)enr_entry(rows, n, R, i, k, j);
+      if (a == 0.0) continue;
+      const double pj = (double)phi[j];
+      if (pj == 0.0) continue;
+      s += a * pj * cc[(int64_t)vec_of_tile[agg[j]] * K + c];
+    }
+    const T old = r[i * K + c];
+    save[id] = old;
+    r[i * K + c] = (T)((double)old - s);
+  }
+}
+
+// c2 = binv (t - E'A(E c + z)) ; cc += c2 ; corr[v][c] = c s_z + t (c + c2) -> block partial rows of the r'z correction
+template <class U, class T, int K>
+__global__ __launch_bounds__(256) void enrich_post_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
+                                                          int64_t n, int R, const U* __restrict__ rows,
+                                                          const int* __restrict__ agg, const int* __restrict__ vec_of_tile,
+                                                          const T* __restrict__ phi, const double* __restrict__ binv,
+                                                          const T* __restrict__ z, const double* __restrict__ t,
+                                                          const double* __restrict__ cc, double* __restrict__ cnew,
+                                                          double* __restrict__ part, const int* __restrict__ skip) {
+  __shared__ double sm[256];
+  if (skip && *skip) return;
+  double acc = 0.0;   // this thread's column is (threadIdx.x % K) for every id it visits (256 % K == 0, grid stride % K == 0)
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nvec * K; id += (int64_t)gridDim.x * 256) {
+    const int v = (int)(id / K), c = (int)(id % K);
+    double sz = 0.0, sy = 0.0;
+    for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
+      const int64_t i = vcell[m];
+      double az = 0.0, ay = 0.0;
+      for (int k = 0; k < 9; ++k) {
+        int64_t j;
+        const double a = (double)enr_entry(rows, n, R, i, k, j);
+        if (a == 0.0) continue;
+        az += a * (double)z[j * K + c];
+        const double pj = (double)phi[j];
+        if (pj != 0.0) ay += a * pj * cc[(int64_t)vec_of_tile[agg[j]] * K + c];
+      }
+      const double pi = (double)phi[i];
+      sz += pi * az;
+      sy += pi * ay;
+    }
+    const double c1 = cc[id], tv = t[id];
+    const double c2 = binv[v] * (tv - sy - sz);
+    cnew[id] = c1 + c2;
+    acc += c1 * sz + tv * (c1 + c2);
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0.0;
+    for (int q = threadIdx.x; q < 256; q += K) s += sm[q];
+    part[(int64_t)blockIdx.x * K + threadIdx.x] = s;
+  }
+}
+
+// z += E cnew at the members ; r restored at the halo cells
+template <class T, int K>
+__global__ __launch_bounds__(256) void enrich_finish_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
+                                                            const T* __restrict__ phi, const double* __restrict__ cnew,
+                                                            T* __restrict__ z, int nhalo, const int* __restrict__ hcell,
+                                                            const T* __restrict__ save, T* __restrict__ r,
+                                                            const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int64_t nv = (int64_t)nvec * K, nh = (int64_t)nhalo * K;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nv + nh; id += (int64_t)gridDim.x * 256) {
+    if (id < nv) {
+      const int v = (int)(id / K), c = (int)(id % K);
+      const double x = cnew[id];
+      for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
+        const int64_t cell = vcell[m];
+        z[cell * K + c] = (T)((double)z[cell * K + c] + (double)phi[cell] * x);
+      }
+    } else {
+      const int64_t q = id - nv;
+      r[(int64_t)hcell[q / K] * K + (q % K)] = save[q];
+    }
+  }
+}
+
+static const int kEnrichParts = 256;  // rows of r'z correction partials (appended to the V-cycle's own rows)
+
+template <class T, int K>
+inline void enrich_ensure_work(Enrich& E) {
+  if (E.work_k == K && E.work_bytes == (int)sizeof(T)) return;
+  E.t = dalloc<double>((size_t)E.nvec * K);
+  E.c = dalloc<double>((size_t)E.nvec * K);
+  E.c2 = dalloc<double>((size_t)E.nvec * K);
+  E.save.alloc((size_t)std::max(E.nhalo, 1) * K * sizeof(T));
+  E.work_k = K;
+  E.work_bytes = (int)sizeof(T);
+}
+
+// before the V-cycle: r (the V-cycle's input, modified in place at the halo cells and restored by enrich_post)
+template <class U, class T, int K>
+inline void enrich_pre(Enrich& E, const U* rows, T* r, const int* skip, hipStream_t st) {
+  enrich_ensure_work<T, K>(E);
+  const int64_t n = E.n;
+  hipLaunchKernelGGL((enrich_gather_kernel<T, K>), dim3(grid_for((int64_t)E.nvec * K)), dim3(256), 0, st, E.nvec,
+                     (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.phi),
+                     (const double*)dptr<double>(E.binv), (const T*)r, dptr<double>(E.t), dptr<double>(E.c), skip);
+  hipLaunchKernelGGL((enrich_pre_kernel<U, T, K>), dim3(grid_for((int64_t)E.nhalo * K)), dim3(256), 0, st, E.nhalo,
+                     (const int*)dptr<int>(E.hcell), n, E.R, rows, (const int*)dptr<int>(E.agg),
+                     (const int*)dptr<int>(E.vec_of_tile), (const T*)dptr<T>(E.phi), (const double*)dptr<double>(E.c), r,
+                     dptr<T>(E.save), skip);
+}
+
+// after the V-cycle: z corrected, r restored, kEnrichParts rows of r'z correction partials written to `part`
+template <class U, class T, int K>
+inline void enrich_post(Enrich& E, const U* rows, T* r, T* z, double* part, const int* skip, hipStream_t st) {
+  const int64_t n = E.n;
+  int g = grid_for((int64_t)E.nvec * K);
+  if (g > kEnrichParts) g = kEnrichParts;
+  if (g < kEnrichParts) CS_HIP(hipMemsetAsync(part, 0, (size_t)kEnrichParts * K * sizeof(double), st));
+  hipLaunchKernelGGL((enrich_post_kernel<U, T, K>), dim3(g), dim3(256), 0, st, E.nvec, (const int*)dptr<int>(E.vptr),
+                     (const int*)dptr<int>(E.vcell), n, E.R, rows, (const int*)dptr<int>(E.agg),
+                     (const int*)dptr<int>(E.vec_of_tile), (const T*)dptr<T>(E.phi), (const double*)dptr<double>(E.binv),
+                     (const T*)z, (const double*)dptr<double>(E.t), (const double*)dptr<double>(E.c), dptr<double>(E.c2), part,
+                     skip);
+  hipLaunchKernelGGL((enrich_finish_kernel<T, K>), dim3(grid_for((int64_t)(E.nvec + E.nhalo) * K)), dim3(256), 0, st, E.nvec,
+                     (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.phi),
+                     (const double*)dptr<double>(E.c2), z, E.nhalo, (const int*)dptr<int>(E.hcell), (const T*)dptr<T>(E.save), r,
+                     skip);
+}
+
+}  // namespace csgpu

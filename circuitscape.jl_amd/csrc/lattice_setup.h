@@ -25,6 +25,7 @@
 #include "amg_setup.h"
 #include "lattice.h"
 #include "raster.h"
+#include "enrich.h"
 
 namespace csgpu {
 
@@ -847,6 +848,11 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   if (read_int(dptr<int>(bad), st) != 0) return false;  // (cannot happen for tile aggregates; the CSR pipeline takes over)
   tv.release();
   labs.release();
+  // refined tiles (NODATA cells, strength-aware tiles): a second coarse function on the badly shaped aggregates (enrich.h)
+  H.enr = Enrich();
+  if (size0 && n < 0x7fffffffLL)
+    enrich_setup<U, T>(H.enr, A0.data(), R, C, Rc, Cc, (const long long*)size0, (const int*)dptr<int>(agg),
+                       (const unsigned long long*)dptr<unsigned long long>(size_c), st);
   agg.release();
   // Galerkin operator of level 1
   Csr<T> Ac;

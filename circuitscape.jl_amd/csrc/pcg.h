@@ -19,6 +19,7 @@
 #include "tail.h"
 #include "raster.h"
 #include "poly.h"
+#include "enrich.h"
 
 namespace csgpu {
 
@@ -613,6 +614,21 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   fuse.b_has_tail = two_product;
   fuse.dotw = rp;
   fuse.partials = pa;
+  // second coarse function on the badly shaped aggregates of a perforated raster lattice (enrich.h): a symmetric
+  // multiplicative correction around the V-cycle; its r'z terms travel as kEnrichParts extra rows behind the V-cycle's own
+  Enrich& EN = H.enr;
+  const bool enrich = use_dia && EN.nvec > 0 && EN.n == n && two_product && L0.lattice_two_product() && !grounded &&
+                      !projected && EN.phi_bytes == (int)sizeof(TP);
+  if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
+    W.drop_graphs();  // (captured chunks hold the old work pointers)
+    enrich_ensure_work<TP, K>(EN);
+  }
+  const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
+  auto precondition = [&](const int* skip_flag) {   // z = M^-1 r (r in its V-cycle precision: rp), partials of r'z in pa
+    if (enrich) enrich_pre<T, TP, K>(EN, dia->data(), rp, skip_flag, st);
+    vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    if (enrich) enrich_post<T, TP, K>(EN, dia->data(), rp, z, pa + (size_t)spmv_gp * K, skip_flag, st);
+  };
 
   if (dirichlet) {
     const size_t cbytes = (size_t)kMaxDirComp * kMaxK * sizeof(double);
@@ -644,7 +660,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // polygons: r0 = Pi b (a unit current into a polygon node is spread evenly over the polygon's cells)
   if (projected) poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)nullptr, st);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
-  vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+  precondition(nullptr);
   // (the fused r'z partials are those of the projected z too: r is in the subspace, r'z = r'(Pi z))
   if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)nullptr, st);
   // (the fused r'z partials are unaffected by masking z afterwards: r is zero at the grounded entries)
@@ -672,7 +688,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     return {dst, kCollapsedParts};
   };
   {
-    auto rz = collapsed(pa, spmv_gp, pac);
+    auto rz = collapsed(pa, rz_rows, pac);
     hipLaunchKernelGGL((cg_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, (const double*)pb, rr_rows,
                        crit0, pp.rtol, atol, 1, ncols_active);
   }
@@ -776,13 +792,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     if (nf > 0)
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
-    vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    precondition((const int*)&S->all_done);
     if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)&S->all_done, st);
     if (grounded)
       hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
                          (const int*)&S->all_done);
     {
-      auto rz = collapsed(pa, spmv_gp, pac);
+      auto rz = collapsed(pa, rz_rows, pac);
       // r'r partials (true-residual criterion): one row per workgroup of whichever kernel updated r
       const double* prr = pb;
       int nrr = gv;
@@ -1111,6 +1127,13 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   fuse.b_has_tail = true;
   fuse.dotw = rp;
   fuse.partials = pa;
+  Enrich& EN = H.enr;  // (enrich.h; as in pcg_solve)
+  const bool enrich = EN.nvec > 0 && EN.n == n && EN.phi_bytes == (int)sizeof(TP);
+  if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
+    W.drop_graphs();
+    enrich_ensure_work<TP, K>(EN);
+  }
+  const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
   static const int max_timed = getenv("CSGPU_TIMED_LAUNCHES") ? atoi(getenv("CSGPU_TIMED_LAUNCHES")) : 512;
   int timed = 0;
   int parity = 0;
@@ -1146,9 +1169,11 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
                          fnode, nf, (const TP*)pcur, xf);
     hipLaunchKernelGGL((stream_restart_kernel<T, TP, K>), dim3(1), dim3(256), 0, st, (const CgScalars*)S, r,
                        MIXED ? rp : (TP*)nullptr, nf, xf);
+    if (enrich) enrich_pre<T, TP, K>(EN, dia.data(), rp, (const int*)nullptr, st);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
+    if (enrich) enrich_post<T, TP, K>(EN, dia.data(), rp, z, pa + (size_t)spmv_gp * K, (const int*)nullptr, st);
     {
-      auto rz = collapsed(pa, spmv_gp, pac);
+      auto rz = collapsed(pa, rz_rows, pac);
       auto rr = collapsed(pb, spmv_g, pbc);
       hipLaunchKernelGGL((cg_stream_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, rr.first, rr.second,
                          pp.criterion, pp.rtol, atol, pp.itmax);
