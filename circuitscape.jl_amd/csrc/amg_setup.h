@@ -978,18 +978,18 @@ struct Level {
 struct Enrich {
   int nvec = 0, nmem = 0, nhalo = 0, R = 0, ntiles = 0;
   int64_t n = 0;
-  DBuf agg;          // [n] int: level-0 aggregate (tile) of every cell
-  DBuf phi;          // [n] hierarchy precision: the enrichment vectors side by side (disjoint supports), 0 elsewhere
-  int phi_bytes = 0;
-  DBuf vec_of_tile;  // [ntiles] int: vector index of an enriched aggregate, -1 otherwise
-  DBuf vptr, vcell;  // members of every vector (cell ids, window order)
-  DBuf binv;         // [nvec] double: 1 / (G_vv + sum_w |G_vw|)
-  DBuf hcell;        // cells whose residual the pre-correction changes (members and their coupled neighbours), ascending
-  DBuf t, c, c2, save;  // work: [nvec][K] doubles x 3, [nhalo][K] saved residual entries
+  int phi_bytes = 0;        // precision of vphi (= the hierarchy's)
+  DBuf vptr, vcell, vphi;   // the vectors: members of every vector (cell ids in window order) and their values
+  DBuf vhalo;               // position of every member's cell in hcell
+  DBuf binv;                // [nvec] double: 1 / (G_vv + sum_w |G_vw|)
+  DBuf aptr, acell, acoef;  // A E by columns: (cell, coefficient) per vector
+  DBuf hcell;               // the non-empty rows of A E (members and their coupled neighbours), ascending cell ids
+  DBuf hptr, hvec, hcoef;   // A E by rows: (vector, coefficient) per halo cell
+  DBuf t, c, c2, sbuf, save;  // work: [nvec][K] doubles x 3, [nhalo][K] (A E c) and saved residual entries
   int work_k = 0, work_bytes = 0;
   size_t device_bytes() const {
-    return agg.bytes + phi.bytes + vec_of_tile.bytes + vptr.bytes + vcell.bytes + binv.bytes + hcell.bytes + t.bytes + c.bytes +
-           c2.bytes + save.bytes;
+    return vptr.bytes + vcell.bytes + vphi.bytes + vhalo.bytes + binv.bytes + aptr.bytes + acell.bytes + acoef.bytes +
+           hcell.bytes + hptr.bytes + hvec.bytes + hcoef.bytes + t.bytes + c.bytes + c2.bytes + sbuf.bytes + save.bytes;
   }
 };
 

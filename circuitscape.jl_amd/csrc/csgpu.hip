@@ -1888,6 +1888,7 @@ struct Solver : ISolver {
     int64_t bytes = (int64_t)(Aouter.device_bytes() + dia.device_bytes() + W.p2.bytes);
     const int tail_first = tail_first_level_peek(H);
     info->hierarchy_rebuilt_fp64 = rebuilt_fp64 ? 1 : 0;
+    info->enrich_vectors = H.enr.nvec;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
       if (l < 32) {

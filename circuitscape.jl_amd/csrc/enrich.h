@@ -26,7 +26,9 @@
 // scatters over compact lists, no atomics, fixed summation orders -- bit-reproducible. The r'z partials of the V-cycle's
 // last product are corrected by the scalars the passes produce anyway (r'z = r1'z_V + c'(AE)'z_V + t'(c + c2)).
 // Prototype (two-grid, exact coarse solve, 400^2 / 15 % NODATA): 12.5 -> 10.6 iterations with 4 % of the tiles enriched
-// (tau = 0.08), 9.75 with 23 % (tau = 0.15; the all-valid raster: 9.9).
+// (tau = 0.08), 9.75 with 23 % (tau = 0.15; the all-valid raster: 9.9). The solve-phase passes run from PRECOMPUTED sparse
+// forms of E and A E (by columns for the gathers, by rows over the halo cells for the residual update): the first version
+// searched the lattice neighbourhoods in every pass and cost 25 ms per iteration at 10000^2 -- more than it saved.
 //
 // GPU counterpart of nothing in the reference: AlgebraicMultigrid.jl has no such step (its unstructured aggregates adapt
 // to the holes instead; call site of the hierarchy src/core.jl:164-167). Parity is solution-level, as for the rest of
@@ -177,14 +179,15 @@ __global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, in
   }
 }
 
-// Pass B, one thread per tile (enriched ones work): member list in window order; G_vv = phi'A phi and the sum of
-// |phi_i A_ij phi_j| over the couplings into OTHER enriched aggregates (row-abs-sum scaling of B)
+// Pass B, one thread per tile (enriched ones work): member list in window order (cell, phi); G_vv = phi'A phi and the sum
+// of |phi_i A_ij phi_j| over the couplings into OTHER enriched aggregates (row-abs-sum scaling of B); number of entries of
+// the vector's column of A E (cells of the window whose row of A meets the members)
 template <class U, class T>
 __global__ __launch_bounds__(64) void enrich_lists_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                           const int* __restrict__ agg, const T* __restrict__ phi,
                                                           const int* __restrict__ vec_of_tile, const int* __restrict__ moff,
-                                                          int* __restrict__ vptr, int* __restrict__ vcell,
-                                                          double* __restrict__ binv) {
+                                                          int* __restrict__ vptr, int* __restrict__ vcell, T* __restrict__ vphi,
+                                                          double* __restrict__ binv, int* __restrict__ acount) {
   const int64_t n = (int64_t)R * C;
   const int ntiles = Rc * Cc;
   for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
@@ -194,45 +197,137 @@ __global__ __launch_bounds__(64) void enrich_lists_kernel(int R, int C, int Rc, 
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
     tile_extent(J, Cc, C, c0, c1);
-    const int wr0 = max(r0 - 2, 0), wr1 = min(r1 + 2, R), wc0 = max(c0 - 2, 0), wc1 = min(c1 + 2, C);
+    const int wr0 = max(r0 - 3, 0), wr1 = min(r1 + 3, R), wc0 = max(c0 - 3, 0), wc1 = min(c1 + 3, C);
     int o = moff[t];
     vptr[v] = o;
     double gvv = 0.0, off = 0.0;
+    int na = 0;
     for (int c = wc0; c < wc1; ++c)
       for (int r = wr0; r < wr1; ++r) {
         const int64_t cell = (int64_t)c * R + r;
         const double pi = (double)phi[cell];
-        if (agg[cell] != t || pi == 0.0) continue;   // (phi is non-zero exactly at the members of enriched aggregates ...
-        vcell[o++] = (int)cell;
+        const bool mem = agg[cell] == t && pi != 0.0;   // (phi is non-zero exactly at the members of enriched aggregates;
+        if (mem) {                                        //  a member whose phi rounds to 0 contributes nothing anywhere)
+          vcell[o] = (int)cell;
+          vphi[o] = (T)pi;
+          ++o;
+        }
+        double coef = 0.0;
         for (int k = 0; k < 9; ++k) {
           int64_t j;
           const double a = (double)enr_entry(rows, n, R, cell, k, j);
           if (a == 0.0) continue;
           const double pj = (double)phi[j];
           if (pj == 0.0) continue;
-          if (agg[j] == t) gvv += pi * a * pj;
-          else off += fabs(pi * a * pj);
+          if (agg[j] == t) {
+            coef += a * pj;
+            if (mem) gvv += pi * a * pj;
+          } else if (mem) {
+            off += fabs(pi * a * pj);
+          }
         }
+        if (coef != 0.0) ++na;
       }
+    for (const int mend = moff[t + 1]; o < mend; ++o) {  // (a member whose phi rounded to 0: padding entries without weight)
+      vcell[o] = vcell[moff[t]];
+      vphi[o] = T(0);
+    }
     binv[v] = gvv + off > 0.0 ? 1.0 / (gvv + off) : 0.0;
+    acount[v] = na;
   }
 }
-// ... a member whose phi rounds to exactly 0 is dropped from the list; it would contribute nothing anywhere.)
 
-// halo flag of a cell: the cell or one of its coupled neighbours belongs to an enriched aggregate
+// column v of A E: (cell, coefficient) in window order -- the same arithmetic as the count above
 template <class U, class T>
-__global__ __launch_bounds__(256) void enrich_halo_flag_kernel(int64_t n, int R, const U* __restrict__ rows,
-                                                               const T* __restrict__ phi, int* __restrict__ hflag) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (int64_t)gridDim.x * 256) {
-    int f = 0;
+__global__ __launch_bounds__(64) void enrich_ae_fill_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
+                                                            const int* __restrict__ agg, const T* __restrict__ phi,
+                                                            const int* __restrict__ vec_of_tile, const int* __restrict__ aptr,
+                                                            int* __restrict__ acell, double* __restrict__ acoef) {
+  const int64_t n = (int64_t)R * C;
+  const int ntiles = Rc * Cc;
+  for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
+    const int v = vec_of_tile[t];
+    if (v < 0) continue;
+    const int I = t % Rc, J = t / Rc;
+    int r0, r1, c0, c1;
+    tile_extent(I, Rc, R, r0, r1);
+    tile_extent(J, Cc, C, c0, c1);
+    const int wr0 = max(r0 - 3, 0), wr1 = min(r1 + 3, R), wc0 = max(c0 - 3, 0), wc1 = min(c1 + 3, C);
+    int o = aptr[v];
+    for (int c = wc0; c < wc1; ++c)
+      for (int r = wr0; r < wr1; ++r) {
+        const int64_t cell = (int64_t)c * R + r;
+        double coef = 0.0;
+        for (int k = 0; k < 9; ++k) {
+          int64_t j;
+          const double a = (double)enr_entry(rows, n, R, cell, k, j);
+          if (a == 0.0) continue;
+          const double pj = (double)phi[j];
+          if (pj != 0.0 && agg[j] == t) coef += a * pj;
+        }
+        if (coef != 0.0) {
+          acell[o] = (int)cell;
+          acoef[o] = coef;
+          ++o;
+        }
+      }
+  }
+}
+
+// halo cells (rows of A E that are not empty): flag; then per halo cell the (vector, coefficient) entries of its row, in
+// the order the vectors first appear among the cell's neighbours (at most kEnrichRowMax distinct ones)
+static const int kEnrichRowMax = 6;
+
+template <class U, class T, int PASS>
+__global__ __launch_bounds__(256) void enrich_halo_kernel(int64_t n, int R, const U* __restrict__ rows, const int* __restrict__ agg,
+                                                          const T* __restrict__ phi, const int* __restrict__ vec_of_tile,
+                                                          int* __restrict__ hflag, const int* __restrict__ hcell, int nhalo,
+                                                          int* __restrict__ hcount, const int* __restrict__ hptr,
+                                                          int* __restrict__ hvec, double* __restrict__ hcoef,
+                                                          int* __restrict__ overflow) {
+  const int64_t total = PASS == 0 ? n + 1 : (int64_t)nhalo;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = PASS == 0 ? q : (int64_t)hcell[q];
+    int vs[kEnrichRowMax];
+    double cs[kEnrichRowMax];
+    int nv = 0;
     if (i < n) {
-      for (int k = 0; k < 9 && !f; ++k) {
+      for (int k = 0; k < 9; ++k) {
         int64_t j;
-        const U a = enr_entry(rows, n, R, i, k, j);
-        if (a != U(0) && phi[j] != T(0)) f = 1;
+        const double a = (double)enr_entry(rows, n, R, i, k, j);
+        if (a == 0.0) continue;
+        const double pj = (double)phi[j];
+        if (pj == 0.0) continue;
+        const int v = vec_of_tile[agg[j]];
+        int s = 0;
+        while (s < nv && vs[s] != v) ++s;
+        if (s == nv) {
+          if (nv == kEnrichRowMax) {
+            atomicOr(overflow, 1);
+            continue;
+          }
+          vs[nv] = v;
+          cs[nv] = 0.0;
+          ++nv;
+        }
+        cs[s] += a * pj;
       }
     }
-    hflag[i] = f;
+    if (PASS == 0) {
+      hflag[q] = nv > 0 ? 1 : 0;
+    } else if (PASS == 1) {
+      int cnt = 0;
+      for (int s = 0; s < nv; ++s) cnt += cs[s] != 0.0 ? 1 : 0;
+      hcount[q] = cnt;
+    } else {
+      int o = hptr[q];
+      for (int s = 0; s < nv; ++s)
+        if (cs[s] != 0.0) {
+          hvec[o] = vs[s];
+          hcoef[o] = cs[s];
+          ++o;
+        }
+    }
   }
 }
 
@@ -241,18 +336,41 @@ __global__ __launch_bounds__(256) void enrich_halo_fill_kernel(int64_t n, const 
     if (hoff[i + 1] != hoff[i]) hcell[hoff[i]] = (int)i;
 }
 
+// position of every member's cell in the (ascending) halo list
+__global__ __launch_bounds__(256) void enrich_vhalo_kernel(int nmem, const int* __restrict__ vcell, const int* __restrict__ hcell,
+                                                           int nhalo, int* __restrict__ vhalo, int* __restrict__ bad) {
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < nmem; m += gridDim.x * 256) {
+    const int cell = vcell[m];
+    int lo = 0, hi = nhalo - 1, pos = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const int hc = hcell[mid];
+      if (hc == cell) {
+        pos = mid;
+        break;
+      }
+      if (hc < cell) lo = mid + 1; else hi = mid - 1;
+    }
+    if (pos < 0) {
+      atomicOr(bad, 1);
+      pos = 0;
+    }
+    vhalo[m] = pos;
+  }
+}
+
 __global__ __launch_bounds__(256) void enrich_vec_of_tile_kernel(int ntiles, const int* __restrict__ flag,
                                                                  const int* __restrict__ voff, int* __restrict__ vec_of_tile) {
   for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) vec_of_tile[t] = flag[t] ? voff[t] : -1;
 }
 
 // ---- set-up ---------------------------------------------------------------------------------------------------------
-// A/B knobs: CSGPU_ENRICH=0 switches the enrichment off, CSGPU_ENRICH_TAU (default 0.1), CSGPU_ENRICH_STEPS (default 6).
+// A/B knobs: CSGPU_ENRICH=0 switches the enrichment off, CSGPU_ENRICH_TAU (default below), CSGPU_ENRICH_STEPS (default 6).
 inline double enrich_tau() {
   const char* e = getenv("CSGPU_ENRICH");
   if (e && atof(e) <= 0.0) return 0.0;
   const char* t = getenv("CSGPU_ENRICH_TAU");
-  return t ? atof(t) : 0.1;
+  return t ? atof(t) : 0.06;
 }
 
 template <class U, class T>
@@ -272,36 +390,67 @@ inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc,
   hipLaunchKernelGGL((enrich_phi_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, size0, agg, size_c, tau, psteps,
                      dptr<T>(phi), dptr<int>(flag), dptr<int>(mcount));
   check_launch("enrichment vectors");
-  DBuf voff = dalloc<int>((size_t)ntiles + 1), tot = dalloc<int>(2);
+  DBuf voff = dalloc<int>((size_t)ntiles + 1), tot = dalloc<int>(4);
   CS_HIP(hipMemcpyAsync(voff.p, flag.p, ((size_t)ntiles + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
   exclusive_scan_i32(dptr<int>(voff), (int64_t)ntiles + 1, st, dptr<int>(tot));
   const int nvec = read_int(dptr<int>(tot), st);
   if (nvec <= 0) return;
   exclusive_scan_i32(dptr<int>(mcount), (int64_t)ntiles + 1, st, dptr<int>(tot) + 1);
   const int nmem = read_int(dptr<int>(tot) + 1, st);
-  E.vec_of_tile = dalloc<int>((size_t)ntiles);
+  DBuf vec_of_tile = dalloc<int>((size_t)ntiles);
   hipLaunchKernelGGL(enrich_vec_of_tile_kernel, dim3(grid_for(ntiles)), dim3(256), 0, st, ntiles, (const int*)dptr<int>(flag),
-                     (const int*)dptr<int>(voff), dptr<int>(E.vec_of_tile));
+                     (const int*)dptr<int>(voff), dptr<int>(vec_of_tile));
   E.vptr = dalloc<int>((size_t)nvec + 1);
   E.vcell = dalloc<int>((size_t)std::max(nmem, 1));
+  E.vphi.alloc((size_t)std::max(nmem, 1) * sizeof(T));
   E.binv = dalloc<double>((size_t)nvec);
+  E.aptr = dalloc<int>((size_t)nvec + 1);
+  CS_HIP(hipMemsetAsync(E.aptr.p, 0, E.aptr.bytes, st));
   hipLaunchKernelGGL((enrich_lists_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
-                     (const int*)dptr<int>(E.vec_of_tile), (const int*)dptr<int>(mcount), dptr<int>(E.vptr), dptr<int>(E.vcell),
-                     dptr<double>(E.binv));
+                     (const int*)dptr<int>(vec_of_tile), (const int*)dptr<int>(mcount), dptr<int>(E.vptr), dptr<int>(E.vcell),
+                     dptr<T>(E.vphi), dptr<double>(E.binv), dptr<int>(E.aptr));
   CS_HIP(hipMemcpyAsync(dptr<int>(E.vptr) + nvec, &nmem, sizeof(int), hipMemcpyHostToDevice, st));
-  // halo list: the cells whose residual the pre-correction changes
-  DBuf hoff = dalloc<int>((size_t)n + 1);
-  hipLaunchKernelGGL((enrich_halo_flag_kernel<U, T>), dim3(grid_for(n + 1)), dim3(256), 0, st, n, R, rows, (const T*)dptr<T>(phi),
-                     dptr<int>(hoff));
+  exclusive_scan_i32(dptr<int>(E.aptr), (int64_t)nvec + 1, st, dptr<int>(tot) + 2);
+  const int nae = read_int(dptr<int>(tot) + 2, st);
+  E.acell = dalloc<int>((size_t)std::max(nae, 1));
+  E.acoef = dalloc<double>((size_t)std::max(nae, 1));
+  hipLaunchKernelGGL((enrich_ae_fill_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(vec_of_tile), (const int*)dptr<int>(E.aptr), dptr<int>(E.acell), dptr<double>(E.acoef));
+  // halo list: the cells whose residual the pre-correction changes, and their rows of A E
+  DBuf hoff = dalloc<int>((size_t)n + 1), ovf = dalloc<int>(2);
+  CS_HIP(hipMemsetAsync(ovf.p, 0, ovf.bytes, st));
+  hipLaunchKernelGGL((enrich_halo_kernel<U, T, 0>), dim3(grid_for(n + 1)), dim3(256), 0, st, n, R, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(vec_of_tile), dptr<int>(hoff), (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr,
+                     (int*)nullptr, (double*)nullptr, dptr<int>(ovf));
   exclusive_scan_i32(dptr<int>(hoff), n + 1, st, dptr<int>(tot));
   const int nhalo = read_int(dptr<int>(tot), st);
-  E.hcell = dalloc<int>((size_t)std::max(nhalo, 1));
+  if (nhalo <= 0 || read_int(dptr<int>(ovf), st) != 0) {  // (a row of A E with more than kEnrichRowMax vectors: no enrichment)
+    E = Enrich();
+    return;
+  }
+  E.hcell = dalloc<int>((size_t)nhalo);
   hipLaunchKernelGGL(enrich_halo_fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, (const int*)dptr<int>(hoff), dptr<int>(E.hcell));
+  hoff.release();
+  E.hptr = dalloc<int>((size_t)nhalo + 1);
+  CS_HIP(hipMemsetAsync(E.hptr.p, 0, E.hptr.bytes, st));
+  hipLaunchKernelGGL((enrich_halo_kernel<U, T, 1>), dim3(grid_for(nhalo)), dim3(256), 0, st, n, R, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(vec_of_tile), (int*)nullptr, (const int*)dptr<int>(E.hcell), nhalo, dptr<int>(E.hptr),
+                     (const int*)nullptr, (int*)nullptr, (double*)nullptr, dptr<int>(ovf));
+  exclusive_scan_i32(dptr<int>(E.hptr), (int64_t)nhalo + 1, st, dptr<int>(tot) + 3);
+  const int nhe = read_int(dptr<int>(tot) + 3, st);
+  E.hvec = dalloc<int>((size_t)std::max(nhe, 1));
+  E.hcoef = dalloc<double>((size_t)std::max(nhe, 1));
+  hipLaunchKernelGGL((enrich_halo_kernel<U, T, 2>), dim3(grid_for(nhalo)), dim3(256), 0, st, n, R, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(vec_of_tile), (int*)nullptr, (const int*)dptr<int>(E.hcell), nhalo, (int*)nullptr,
+                     (const int*)dptr<int>(E.hptr), dptr<int>(E.hvec), dptr<double>(E.hcoef), dptr<int>(ovf));
+  E.vhalo = dalloc<int>((size_t)std::max(nmem, 1));
+  hipLaunchKernelGGL(enrich_vhalo_kernel, dim3(grid_for(nmem)), dim3(256), 0, st, nmem, (const int*)dptr<int>(E.vcell),
+                     (const int*)dptr<int>(E.hcell), nhalo, dptr<int>(E.vhalo), dptr<int>(ovf) + 1);
   check_launch("enrichment lists");
-  CS_HIP(hipStreamSynchronize(st));
-  E.agg = dalloc<int>((size_t)n);
-  CS_HIP(hipMemcpyAsync(E.agg.p, agg, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
-  E.phi = std::move(phi);
+  if (read_int(dptr<int>(ovf) + 1, st) != 0) {  // (cannot happen: every member with phi != 0 has a non-empty row of A E ...
+    E = Enrich();                               //  unless its row cancels exactly; then the correction is simply not used)
+    return;
+  }
   E.phi_bytes = (int)sizeof(T);
   E.nvec = nvec;
   E.nmem = nmem;
@@ -310,63 +459,54 @@ inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc,
   E.n = n;
   E.ntiles = ntiles;
   if (getenv("CSGPU_VERBOSE"))
-    fprintf(stderr, "csgpu: coarse-space enrichment: %d of %d aggregates get a second function (tau %.3g), %d members, %d halo cells\n",
-            nvec, ntiles, tau, nmem, nhalo);
+    fprintf(stderr, "csgpu: coarse-space enrichment: %d of %d aggregates get a second function (tau %.3g), %d members, %d halo cells, %d + %d entries of A E\n",
+            nvec, ntiles, tau, nmem, nhalo, nae, nhe);
 }
 
 // ---- application (K interleaved columns) ------------------------------------------------------------------------------
 // t[v][c] = sum_members phi_i r_i ; cc[v][c] = binv_v t   (one thread per (vector, column))
 template <class T, int K>
 __global__ __launch_bounds__(256) void enrich_gather_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
-                                                            const T* __restrict__ phi, const double* __restrict__ binv,
+                                                            const T* __restrict__ vphi, const double* __restrict__ binv,
                                                             const T* __restrict__ r, double* __restrict__ t,
                                                             double* __restrict__ cc, const int* __restrict__ skip) {
   if (skip && *skip) return;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nvec * K; id += (int64_t)gridDim.x * 256) {
     const int v = (int)(id / K), c = (int)(id % K);
     double s = 0.0;
-    for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
-      const int64_t cell = vcell[m];
-      s += (double)phi[cell] * (double)r[cell * K + c];
-    }
+    for (int m = vptr[v]; m < vptr[v + 1]; ++m) s += (double)vphi[m] * (double)r[(int64_t)vcell[m] * K + c];
     t[id] = s;
     cc[id] = binv[v] * s;
   }
 }
 
-// halo cells: save r, then r -= (A E c)   (one thread per (halo cell, column))
-template <class U, class T, int K>
-__global__ __launch_bounds__(256) void enrich_pre_kernel(int nhalo, const int* __restrict__ hcell, int64_t n, int R,
-                                                         const U* __restrict__ rows, const int* __restrict__ agg,
-                                                         const int* __restrict__ vec_of_tile, const T* __restrict__ phi,
+// halo cells: s = (A E c)_i kept for the post pass, r saved (SAVE: when r is the CG residual itself) and r -= s
+template <class T, int K, bool SAVE>
+__global__ __launch_bounds__(256) void enrich_pre_kernel(int nhalo, const int* __restrict__ hcell, const int* __restrict__ hptr,
+                                                         const int* __restrict__ hvec, const double* __restrict__ hcoef,
                                                          const double* __restrict__ cc, T* __restrict__ r,
-                                                         T* __restrict__ save, const int* __restrict__ skip) {
+                                                         double* __restrict__ sbuf, T* __restrict__ save,
+                                                         const int* __restrict__ skip) {
   if (skip && *skip) return;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nhalo * K; id += (int64_t)gridDim.x * 256) {
     const int h = (int)(id / K), c = (int)(id % K);
-    const int64_t i = hcell[h];
     double s = 0.0;
-    for (int k = 0; k < 9; ++k) {
-      int64_t j;
-      const double a = (double)enr_entry(rows, n, R, i, k, j);
-      if (a == 0.0) continue;
-      const double pj = (double)phi[j];
-      if (pj == 0.0) continue;
-      s += a * pj * cc[(int64_t)vec_of_tile[agg[j]] * K + c];
-    }
-    const T old = r[i * K + c];
-    save[id] = old;
-    r[i * K + c] = (T)((double)old - s);
+    for (int e = hptr[h]; e < hptr[h + 1]; ++e) s += hcoef[e] * cc[(int64_t)hvec[e] * K + c];
+    sbuf[id] = s;
+    const int64_t at = (int64_t)hcell[h] * K + c;
+    const T old = r[at];
+    if (SAVE) save[id] = old;
+    r[at] = (T)((double)old - s);
   }
 }
 
-// c2 = binv (t - E'A(E c + z)) ; cc += c2 ; corr[v][c] = c s_z + t (c + c2) -> block partial rows of the r'z correction
-template <class U, class T, int K>
-__global__ __launch_bounds__(256) void enrich_post_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
-                                                          int64_t n, int R, const U* __restrict__ rows,
-                                                          const int* __restrict__ agg, const int* __restrict__ vec_of_tile,
-                                                          const T* __restrict__ phi, const double* __restrict__ binv,
-                                                          const T* __restrict__ z, const double* __restrict__ t,
+// c2 = binv (t - E'A(E c) - E'A z) ; cnew = c + c2 ; corr[v][c] = c s_z + t (c + c2) -> block partial rows of the r'z correction
+template <class T, int K>
+__global__ __launch_bounds__(256) void enrich_post_kernel(int nvec, const int* __restrict__ vptr, const T* __restrict__ vphi,
+                                                          const int* __restrict__ vhalo, const int* __restrict__ aptr,
+                                                          const int* __restrict__ acell, const double* __restrict__ acoef,
+                                                          const double* __restrict__ binv, const T* __restrict__ z,
+                                                          const double* __restrict__ sbuf, const double* __restrict__ t,
                                                           const double* __restrict__ cc, double* __restrict__ cnew,
                                                           double* __restrict__ part, const int* __restrict__ skip) {
   __shared__ double sm[256];
@@ -375,21 +515,8 @@ __global__ __launch_bounds__(256) void enrich_post_kernel(int nvec, const int* _
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nvec * K; id += (int64_t)gridDim.x * 256) {
     const int v = (int)(id / K), c = (int)(id % K);
     double sz = 0.0, sy = 0.0;
-    for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
-      const int64_t i = vcell[m];
-      double az = 0.0, ay = 0.0;
-      for (int k = 0; k < 9; ++k) {
-        int64_t j;
-        const double a = (double)enr_entry(rows, n, R, i, k, j);
-        if (a == 0.0) continue;
-        az += a * (double)z[j * K + c];
-        const double pj = (double)phi[j];
-        if (pj != 0.0) ay += a * pj * cc[(int64_t)vec_of_tile[agg[j]] * K + c];
-      }
-      const double pi = (double)phi[i];
-      sz += pi * az;
-      sy += pi * ay;
-    }
+    for (int e = aptr[v]; e < aptr[v + 1]; ++e) sz += acoef[e] * (double)z[(int64_t)acell[e] * K + c];
+    for (int m = vptr[v]; m < vptr[v + 1]; ++m) sy += (double)vphi[m] * sbuf[(int64_t)vhalo[m] * K + c];
     const double c1 = cc[id], tv = t[id];
     const double c2 = binv[v] * (tv - sy - sz);
     cnew[id] = c1 + c2;
@@ -404,22 +531,22 @@ __global__ __launch_bounds__(256) void enrich_post_kernel(int nvec, const int* _
   }
 }
 
-// z += E cnew at the members ; r restored at the halo cells
-template <class T, int K>
+// z += E cnew at the members ; r restored at the halo cells (SAVE)
+template <class T, int K, bool SAVE>
 __global__ __launch_bounds__(256) void enrich_finish_kernel(int nvec, const int* __restrict__ vptr, const int* __restrict__ vcell,
-                                                            const T* __restrict__ phi, const double* __restrict__ cnew,
+                                                            const T* __restrict__ vphi, const double* __restrict__ cnew,
                                                             T* __restrict__ z, int nhalo, const int* __restrict__ hcell,
                                                             const T* __restrict__ save, T* __restrict__ r,
                                                             const int* __restrict__ skip) {
   if (skip && *skip) return;
-  const int64_t nv = (int64_t)nvec * K, nh = (int64_t)nhalo * K;
+  const int64_t nv = (int64_t)nvec * K, nh = SAVE ? (int64_t)nhalo * K : 0;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nv + nh; id += (int64_t)gridDim.x * 256) {
     if (id < nv) {
       const int v = (int)(id / K), c = (int)(id % K);
       const double x = cnew[id];
       for (int m = vptr[v]; m < vptr[v + 1]; ++m) {
-        const int64_t cell = vcell[m];
-        z[cell * K + c] = (T)((double)z[cell * K + c] + (double)phi[cell] * x);
+        const int64_t at = (int64_t)vcell[m] * K + c;
+        z[at] = (T)((double)z[at] + (double)vphi[m] * x);
       }
     } else {
       const int64_t q = id - nv;
@@ -428,7 +555,7 @@ __global__ __launch_bounds__(256) void enrich_finish_kernel(int nvec, const int*
   }
 }
 
-static const int kEnrichParts = 256;  // rows of r'z correction partials (appended to the V-cycle's own rows)
+static const int kEnrichParts = 256;  // rows of r'z correction partials (appended to the V-cycle's own rows; pcg.h: kEnrichRows)
 
 template <class T, int K>
 inline void enrich_ensure_work(Enrich& E) {
@@ -436,39 +563,40 @@ inline void enrich_ensure_work(Enrich& E) {
   E.t = dalloc<double>((size_t)E.nvec * K);
   E.c = dalloc<double>((size_t)E.nvec * K);
   E.c2 = dalloc<double>((size_t)E.nvec * K);
+  E.sbuf = dalloc<double>((size_t)E.nhalo * K);
   E.save.alloc((size_t)std::max(E.nhalo, 1) * K * sizeof(T));
   E.work_k = K;
   E.work_bytes = (int)sizeof(T);
 }
 
-// before the V-cycle: r (the V-cycle's input, modified in place at the halo cells and restored by enrich_post)
-template <class U, class T, int K>
-inline void enrich_pre(Enrich& E, const U* rows, T* r, const int* skip, hipStream_t st) {
+// before the V-cycle: r = the V-cycle's input, modified in place at the halo cells. SAVE: r is the CG residual itself (the
+// hierarchy computes in the CG precision) and enrich_post puts the saved entries back, bit for bit; otherwise r is the
+// preconditioner-precision copy the next residual update rewrites anyway.
+template <class T, int K, bool SAVE>
+inline void enrich_pre(Enrich& E, T* r, const int* skip, hipStream_t st) {
   enrich_ensure_work<T, K>(E);
-  const int64_t n = E.n;
   hipLaunchKernelGGL((enrich_gather_kernel<T, K>), dim3(grid_for((int64_t)E.nvec * K)), dim3(256), 0, st, E.nvec,
-                     (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.phi),
+                     (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.vphi),
                      (const double*)dptr<double>(E.binv), (const T*)r, dptr<double>(E.t), dptr<double>(E.c), skip);
-  hipLaunchKernelGGL((enrich_pre_kernel<U, T, K>), dim3(grid_for((int64_t)E.nhalo * K)), dim3(256), 0, st, E.nhalo,
-                     (const int*)dptr<int>(E.hcell), n, E.R, rows, (const int*)dptr<int>(E.agg),
-                     (const int*)dptr<int>(E.vec_of_tile), (const T*)dptr<T>(E.phi), (const double*)dptr<double>(E.c), r,
+  hipLaunchKernelGGL((enrich_pre_kernel<T, K, SAVE>), dim3(grid_for((int64_t)E.nhalo * K)), dim3(256), 0, st, E.nhalo,
+                     (const int*)dptr<int>(E.hcell), (const int*)dptr<int>(E.hptr), (const int*)dptr<int>(E.hvec),
+                     (const double*)dptr<double>(E.hcoef), (const double*)dptr<double>(E.c), r, dptr<double>(E.sbuf),
                      dptr<T>(E.save), skip);
 }
 
 // after the V-cycle: z corrected, r restored, kEnrichParts rows of r'z correction partials written to `part`
-template <class U, class T, int K>
-inline void enrich_post(Enrich& E, const U* rows, T* r, T* z, double* part, const int* skip, hipStream_t st) {
-  const int64_t n = E.n;
+template <class T, int K, bool SAVE>
+inline void enrich_post(Enrich& E, T* r, T* z, double* part, const int* skip, hipStream_t st) {
   int g = grid_for((int64_t)E.nvec * K);
   if (g > kEnrichParts) g = kEnrichParts;
   if (g < kEnrichParts) CS_HIP(hipMemsetAsync(part, 0, (size_t)kEnrichParts * K * sizeof(double), st));
-  hipLaunchKernelGGL((enrich_post_kernel<U, T, K>), dim3(g), dim3(256), 0, st, E.nvec, (const int*)dptr<int>(E.vptr),
-                     (const int*)dptr<int>(E.vcell), n, E.R, rows, (const int*)dptr<int>(E.agg),
-                     (const int*)dptr<int>(E.vec_of_tile), (const T*)dptr<T>(E.phi), (const double*)dptr<double>(E.binv),
-                     (const T*)z, (const double*)dptr<double>(E.t), (const double*)dptr<double>(E.c), dptr<double>(E.c2), part,
-                     skip);
-  hipLaunchKernelGGL((enrich_finish_kernel<T, K>), dim3(grid_for((int64_t)(E.nvec + E.nhalo) * K)), dim3(256), 0, st, E.nvec,
-                     (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.phi),
+  hipLaunchKernelGGL((enrich_post_kernel<T, K>), dim3(g), dim3(256), 0, st, E.nvec, (const int*)dptr<int>(E.vptr),
+                     (const T*)dptr<T>(E.vphi), (const int*)dptr<int>(E.vhalo), (const int*)dptr<int>(E.aptr),
+                     (const int*)dptr<int>(E.acell), (const double*)dptr<double>(E.acoef), (const double*)dptr<double>(E.binv),
+                     (const T*)z, (const double*)dptr<double>(E.sbuf), (const double*)dptr<double>(E.t),
+                     (const double*)dptr<double>(E.c), dptr<double>(E.c2), part, skip);
+  hipLaunchKernelGGL((enrich_finish_kernel<T, K, SAVE>), dim3(grid_for((int64_t)(E.nvec + (SAVE ? E.nhalo : 0)) * K)), dim3(256), 0,
+                     st, E.nvec, (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.vphi),
                      (const double*)dptr<double>(E.c2), z, E.nhalo, (const int*)dptr<int>(E.hcell), (const T*)dptr<T>(E.save), r,
                      skip);
 }

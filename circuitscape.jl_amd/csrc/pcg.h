@@ -422,6 +422,8 @@ struct PcgGraphKey {
   }
 };
 
+static const int kEnrichRows = 256;  // = kEnrichParts of enrich.h: extra rows of part_a
+
 // T = precision of the CG iteration (matrix seen by CG, x, r, p, Ap); TP = precision of the AMG hierarchy and of
 // everything inside the V-cycle (TP == T, or TP = float under T = double: "fp32 preconditioner").
 template <class T, class TP>
@@ -470,7 +472,8 @@ struct PcgWork {
     if (!SAME) rp.alloc((size_t)(n + tail) * K * sizeof(TP));
     scalars.alloc(sizeof(CgScalars));
     // one row of kMaxK partials per workgroup of the largest launch: spmv_grid() and grid_for() (<= kMaxGrid)
-    const size_t pb = std::max<size_t>(16384, spmv_grid_upper(n)) * kMaxK * sizeof(double);
+    // (+ kEnrichRows: the r'z correction rows of enrich.h sit behind the V-cycle's own in part_a)
+    const size_t pb = (std::max<size_t>(16384, spmv_grid_upper(n)) + kEnrichRows) * kMaxK * sizeof(double);
     part_a.alloc(pb);
     part_b.alloc(pb);
     part_c.alloc(pb);
@@ -625,9 +628,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   }
   const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
   auto precondition = [&](const int* skip_flag) {   // z = M^-1 r (r in its V-cycle precision: rp), partials of r'z in pa
-    if (enrich) enrich_pre<T, TP, K>(EN, dia->data(), rp, skip_flag, st);
+    if (enrich) enrich_pre<TP, K, !MIXED>(EN, rp, skip_flag, st);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
-    if (enrich) enrich_post<T, TP, K>(EN, dia->data(), rp, z, pa + (size_t)spmv_gp * K, skip_flag, st);
+    if (enrich) enrich_post<TP, K, !MIXED>(EN, rp, z, pa + (size_t)spmv_gp * K, skip_flag, st);
   };
 
   if (dirichlet) {
@@ -1169,9 +1172,9 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
                          fnode, nf, (const TP*)pcur, xf);
     hipLaunchKernelGGL((stream_restart_kernel<T, TP, K>), dim3(1), dim3(256), 0, st, (const CgScalars*)S, r,
                        MIXED ? rp : (TP*)nullptr, nf, xf);
-    if (enrich) enrich_pre<T, TP, K>(EN, dia.data(), rp, (const int*)nullptr, st);
+    if (enrich) enrich_pre<TP, K, !MIXED>(EN, rp, (const int*)nullptr, st);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
-    if (enrich) enrich_post<T, TP, K>(EN, dia.data(), rp, z, pa + (size_t)spmv_gp * K, (const int*)nullptr, st);
+    if (enrich) enrich_post<TP, K, !MIXED>(EN, rp, z, pa + (size_t)spmv_gp * K, (const int*)nullptr, st);
     {
       auto rz = collapsed(pa, rz_rows, pac);
       auto rr = collapsed(pb, spmv_g, pbc);

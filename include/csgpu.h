@@ -185,7 +185,8 @@ typedef struct csgpu_info {
                                    effects such as device_bytes) */
   int32_t hierarchy_rebuilt_fp64; /* 1: an fp32 hierarchy was asked for (precond_bytes = 4) and the setup replaced it by an
                                    fp64 one (strongly heterogeneous raster / off-diagonal contrast above 1e5 in a host CSR) */
-  int32_t reserved_info;
+  int32_t enrich_vectors;       /* aggregates of level 0 that carry a SECOND coarse function (csrc/enrich.h: badly shaped aggregates
+                                   of a raster with NODATA cells / strength-refined tiles); 0 = none */
 } csgpu_info;
 
 typedef struct csgpu_stats {

@@ -1004,6 +1004,57 @@ def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4, extra_en
     return forms
 
 
+def check_enrichment(L, oracle, monkeypatch, shape=(150, 141), batch=8, frac=0.15):
+    """csrc/enrich.h: on a raster with NODATA cells the badly shaped aggregates of level 0 (C- / U-shapes around short walls
+    of NODATA cells, bare diagonal bridges) get a second coarse function, applied as a symmetric multiplicative correction
+    around the V-cycle. Checked against the same handle without it (CSGPU_ENRICH=0, read at every set-up) and against the
+    tight oracle on the reference's own graph (src/raster/pairwise.jl:271-362 restated in oracle/refgraph.py): the
+    resistances are the oracle's (1e-6; the preconditioner changes, the solution must not), no column needs more iterations
+    and the batch needs clearly fewer, the result is bit-reproducible, a general right-hand side (whole solution carried,
+    explicit residual check) and the K = 1 path agree too; fp64 and fp32 hierarchy. An all-valid raster sets up none."""
+    from oracle import refgraph as rg
+    rng = np.random.default_rng(17)
+    base = np.exp(rng.standard_normal(shape))
+    g = np.where(rng.random(shape) < frac, 0.0, base)
+    nm = rg.construct_node_map(g, None)
+    A = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+    out = {}
+    for pb in (0, 4):
+        for on in (False, True):
+            monkeypatch.setenv("CSGPU_ENRICH", "1" if on else "0")
+            monkeypatch.setenv("CSGPU_ENRICH_TAU", "0.1")     # (the default threshold is chosen for cost at 10000^2; the
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:   # mechanism is tested at 0.1)
+                info = h.info
+                assert info["n"] == A.shape[0] and info["lattice_period"] == shape[0]
+                assert (info["enrich_vectors"] > 0) == on, info["enrich_vectors"]
+                labels, _ = h.components()
+                big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                ids = np.random.default_rng(5).choice(big, size=2 * batch, replace=False)
+                src, dst = [int(v) for v in ids[:batch]], [int(v) for v in ids[batch:]]
+                R, _, _, st = h.solve_pairs(src, dst)
+                R2, _, _, st2 = h.solve_pairs(src, dst)
+                assert st["not_converged"] == 0 and np.array_equal(R, R2) and st["total_iters"] == st2["total_iters"]
+                R1 = np.array([h.solve_pairs([s_], [d_])[0][0] for s_, d_ in zip(src[:3], dst[:3])])      # K = 1
+                Rv, _, volt, stv = h.solve_pairs(src[:2], dst[:2], want_voltages=True)                     # x carried
+                assert stv["not_converged"] == 0
+                b = np.zeros(info["n"]); b[dst[0]] = 1.0; b[src[0]] = -1.0
+                assert np.linalg.norm(A @ volt[:, 0] - b) < 1e-4 * np.linalg.norm(b)
+                out[(pb, on)] = (R, st["total_iters"], st["max_iters"], R1, Rv, src, dst, info["enrich_vectors"])
+    monkeypatch.delenv("CSGPU_ENRICH", raising=False)
+    monkeypatch.delenv("CSGPU_ENRICH_TAU", raising=False)
+    src, dst = out[(0, True)][5], out[(0, True)][6]
+    Ro, _, res = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=min(8, batch))
+    for pb in (0, 4):
+        off, on = out[(pb, False)], out[(pb, True)]
+        for R, _, _, R1, Rv, _, _, _ in (off, on):
+            assert np.max(np.abs(R - Ro) / Ro) < 1e-6
+            assert np.max(np.abs(R1 - Ro[:3]) / Ro[:3]) < 1e-6 and np.max(np.abs(Rv - Ro[:2]) / Ro[:2]) < 1e-6
+        assert on[1] < off[1] and on[2] <= off[2], (pb, on[1], off[1], on[2], off[2])
+    with L.raster_setup(base, L.default_opts(batch=batch)) as h:
+        assert h.info["enrich_vectors"] == 0
+    return {pb: (out[(pb, False)][1] / float(batch), out[(pb, True)][1] / float(batch), out[(pb, True)][7]) for pb in (0, 4)}
+
+
 def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
     """strongly heterogeneous conductances (log-normal sigma = 2, 3: cell-to-cell ratios up to e^+-9).
     The reference copes through symmetric Gauss-Seidel (src/core.jl:166-167); here the regular tiles are refined by the

@@ -1292,6 +1292,13 @@ def test_lattice_level1_matches_csr_level1(emu_lib, monkeypatch):
     assert emu_lib.FORM_LATTICE25 in forms["lattice"]      # the NODATA raster's level 1, by default
 
 
+def test_coarse_space_enrichment_on_nodata_rasters(emu_lib, oracle, monkeypatch):
+    """see helpers.check_enrichment"""
+    from helpers import check_enrichment
+    r = check_enrichment(emu_lib, oracle, monkeypatch)
+    assert r[0][1] <= r[0][0] - 0.5, r         # at least half an iteration per pair at 150 x 141 / 15 % NODATA
+
+
 def test_heterogeneous_rasters_strength_aware_tiles(emu_lib, oracle):
     """see helpers.check_heterogeneous_rasters"""
     from helpers import check_heterogeneous_rasters

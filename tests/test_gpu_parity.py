@@ -673,3 +673,11 @@ def test_coarse_levels_in_25_point_lattice_form_gpu(gpu_lib, monkeypatch):
     from helpers import check_dia25_levels
     check_dia25_levels(gpu_lib, monkeypatch, shape=(1000, 900), batches=(8, 16, 32))
     check_dia25_levels(gpu_lib, monkeypatch, shape=(400, 390), batches=(16,), hetero=True)
+
+
+def test_coarse_space_enrichment_on_nodata_rasters_gpu(gpu_lib, oracle, monkeypatch):
+    """csrc/enrich.h on the device: twin of the emulator test at 900 x 870 with batches of 16 (helpers.check_enrichment)"""
+    from helpers import check_enrichment
+    r = check_enrichment(gpu_lib, oracle, monkeypatch, shape=(900, 870), batch=16)
+    print("enrichment 900 x 870: iterations per pair off / on, vectors:", r)
+    assert r[0][1] <= r[0][0] - 0.75, r
