@@ -985,11 +985,11 @@ struct Enrich {
   DBuf aptr, acell, acoef;  // A E by columns: (cell, coefficient) per vector
   DBuf hcell;               // the non-empty rows of A E (members and their coupled neighbours), ascending cell ids
   DBuf hptr, hvec, hcoef;   // A E by rows: (vector, coefficient) per halo cell
-  DBuf t, c, c2, sbuf, save;  // work: [nvec][K] doubles x 3, [nhalo][K] (A E c) and saved residual entries
+  DBuf t, c, c2, sbuf, save, ppart;  // work: [nvec][K] doubles x 3, [nhalo][K] (A E c) and saved residual entries, block partials
   int work_k = 0, work_bytes = 0;
   size_t device_bytes() const {
     return vptr.bytes + vcell.bytes + vphi.bytes + vhalo.bytes + binv.bytes + aptr.bytes + acell.bytes + acoef.bytes +
-           hcell.bytes + hptr.bytes + hvec.bytes + hcoef.bytes + t.bytes + c.bytes + c2.bytes + sbuf.bytes + save.bytes;
+           hcell.bytes + hptr.bytes + hvec.bytes + hcoef.bytes + t.bytes + c.bytes + c2.bytes + sbuf.bytes + save.bytes + ppart.bytes;
   }
 };
 

@@ -59,6 +59,9 @@ __device__ __forceinline__ U enr_entry(const U* __restrict__ rows, int64_t n, in
 
 // Pass A, one thread per tile: members of the aggregate (window scan), local Fiedler approximation, decision.
 // phi (dense, pre-zeroed) receives the vector of an enriched aggregate; flag[t] = 1, mcount[t] = members.
+// (55 ms at 10000^2 in its first form -- as much as the rest of the set-up's level 0; now: tiles that hold exactly their own
+// cells with at most one hole leave after nine loads, neighbours by coordinate offsets instead of j % R, j / R, fp32
+// weights in the thread's scratch.)
 template <class U, class T>
 __global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                         const long long* __restrict__ size0, const int* __restrict__ agg,
@@ -76,11 +79,23 @@ __global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, in
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
     tile_extent(J, Cc, C, c0, c1);
+    {
+      // a tile that holds exactly its own cells and has at most one hole is compact: not enriched, and most tiles are such
+      int own = 0, validc = 0;
+      for (int c = c0; c < c1; ++c)
+        for (int r = r0; r < r1; ++r) {
+          const int64_t cell = (int64_t)c * R + r;
+          const bool v = !size0 || size0[cell] != 0;
+          validc += v ? 1 : 0;
+          own += (v && agg[cell] == t) ? 1 : 0;
+        }
+      // (one hole: the local Fiedler value of such a tile stays above 0.075 -- measured; a larger tau looks at them)
+      if (own == want && validc == own && (r1 - r0) * (c1 - c0) - validc <= (tau < 0.075 ? 1 : 0)) continue;
+    }
     const int wr0 = max(r0 - 2, 0), wr1 = min(r1 + 2, R), wc0 = max(c0 - 2, 0), wc1 = min(c1 + 2, C);
     signed char widx[kEnrichWin * kEnrichWin];
-    int mr[kEnrichMaxM], mc[kEnrichMaxM];
+    signed char mr[kEnrichMaxM], mc[kEnrichMaxM];   // window coordinates of the members
     int m = 0;
-    bool full = r1 - r0 == 3 && c1 - c0 == 3 && want == 9;  // a complete regular tile (checked below) is never enriched
     for (int c = wc0; c < wc1; ++c)
       for (int r = wr0; r < wr1; ++r) {
         const int64_t cell = (int64_t)c * R + r;
@@ -88,92 +103,98 @@ __global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, in
         widx[(c - wc0) * kEnrichWin + (r - wr0)] = (signed char)(mem && m < kEnrichMaxM ? m : -1);
         if (mem) {
           if (m < kEnrichMaxM) {
-            mr[m] = r;
-            mc[m] = c;
+            mr[m] = (signed char)(r - wr0);
+            mc[m] = (signed char)(c - wc0);
           }
           ++m;
-          if (r < r0 || r >= r1 || c < c0 || c >= c1) full = false;
         }
       }
-    if (m != want || full) continue;  // (members outside the window: the aggregate is left alone)
-    // local graph: couplings between members
-    double d[kEnrichMaxM], w[kEnrichMaxM][8];
+    if (m != want) continue;  // (members outside the window: the aggregate is left alone)
+    // local graph: couplings between members (k-th neighbour of a cell: column offset k / 3 - 1, row offset k % 3 - 1)
+    float d[kEnrichMaxM], w[kEnrichMaxM][8];
     signed char nb[kEnrichMaxM][8];
-    double dsum = 0.0;
+    float dsum = 0.f;
+    const int wh = wr1 - wr0, ww = wc1 - wc0;
     for (int a = 0; a < m; ++a) {
-      const int64_t cell = (int64_t)mc[a] * R + mr[a];
-      d[a] = (double)rows[cell * 5];
+      const int64_t cell = (int64_t)(wc0 + mc[a]) * R + wr0 + mr[a];
+      d[a] = (float)rows[cell * 5];
       dsum += d[a];
       int q = 0;
       for (int k = 0; k < 9; ++k) {
         if (k == 4) continue;
-        int64_t j;
-        const double v = (double)enr_entry(rows, n, R, cell, k, j);
+        const int jr = mr[a] + (k % 3) - 1, jc = mc[a] + (k / 3) - 1;
         int b = -1;
-        if (v != 0.0) {
-          const int jr = (int)(j % R), jc = (int)(j / R);
-          if (jr >= wr0 && jr < wr1 && jc >= wc0 && jc < wc1) b = widx[(jc - wc0) * kEnrichWin + (jr - wr0)];
+        float v = 0.f;
+        if (jr >= 0 && jr < wh && jc >= 0 && jc < ww) {
+          b = widx[jc * kEnrichWin + jr];
+          if (b >= 0) {
+            int64_t j;
+            v = (float)enr_entry(rows, n, R, cell, k, j);
+            if (v == 0.f) b = -1;
+          }
         }
         nb[a][q] = (signed char)b;
-        w[a][q] = b >= 0 ? (v < 0.0 ? -v : v) : 0.0;
+        w[a][q] = v < 0.f ? -v : v;
         ++q;
       }
     }
-    if (!(dsum > 0.0)) continue;
-    double v[kEnrichMaxM], lv[kEnrichMaxM];
-    auto center = [&](double* x) {
-      double s = 0.0;
+    if (!(dsum > 0.f)) continue;
+    float v[kEnrichMaxM], lv[kEnrichMaxM];
+    auto center = [&](float* x) {
+      float s = 0.f;
       for (int a = 0; a < m; ++a) s += d[a] * x[a];
       s /= dsum;
       for (int a = 0; a < m; ++a) x[a] -= s;
     };
-    auto apply = [&](const double* x, double* y) {  // y = L_agg x
+    auto apply = [&](const float* x, float* y) {  // y = L_agg x
       for (int a = 0; a < m; ++a) {
-        double s = 0.0;
+        float s = 0.f;
         for (int q = 0; q < 8; ++q)
           if (nb[a][q] >= 0) s += w[a][q] * (x[a] - x[nb[a][q]]);
         y[a] = s;
       }
     };
-    auto rayleigh = [&](const double* x, const double* y) {
-      double num = 0.0, den = 0.0;
+    auto rayleigh = [&](const float* x, const float* y) {
+      float num = 0.f, den = 0.f;
       for (int a = 0; a < m; ++a) {
         num += x[a] * y[a];
         den += d[a] * x[a] * x[a];
       }
-      return den > 0.0 ? num / den : 1e300;
+      return den > 0.f ? num / den : 1e30f;
+    };
+    auto direction = [&](int dir, int a) {
+      return dir == 0 ? (float)mr[a] : dir == 1 ? (float)mc[a] : dir == 2 ? (float)(mr[a] + mc[a]) : (float)(mr[a] - mc[a]);
     };
     // start: the coordinate direction (row, column, the two diagonals) with the smallest Rayleigh quotient
-    double best = 1e300;
+    float best = 1e30f;
     int bestdir = -1;
     for (int dir = 0; dir < 4; ++dir) {
-      for (int a = 0; a < m; ++a)
-        v[a] = dir == 0 ? (double)mr[a] : dir == 1 ? (double)mc[a] : dir == 2 ? (double)(mr[a] + mc[a]) : (double)(mr[a] - mc[a]);
+      for (int a = 0; a < m; ++a) v[a] = direction(dir, a);
       center(v);
       apply(v, lv);
-      const double q = rayleigh(v, lv);
+      const float q = rayleigh(v, lv);
       if (q < best) {
         best = q;
         bestdir = dir;
       }
     }
-    if (bestdir < 0 || best > 1e299) continue;
-    for (int a = 0; a < m; ++a)
-      v[a] = bestdir == 0 ? (double)mr[a] : bestdir == 1 ? (double)mc[a] : bestdir == 2 ? (double)(mr[a] + mc[a]) : (double)(mr[a] - mc[a]);
+    if (bestdir < 0 || best > 1e29f) continue;
+    if (best > 7.0f * (float)tau) continue;   // (the power steps below lower the quotient, but not by this much)
+    for (int a = 0; a < m; ++a) v[a] = direction(bestdir, a);
     center(v);
     for (int s = 0; s < psteps; ++s) {  // power steps on I - 0.6 D^-1 L_agg (deflated against the constant)
       apply(v, lv);
-      for (int a = 0; a < m; ++a) v[a] -= 0.6 * lv[a] / d[a];
+      for (int a = 0; a < m; ++a) v[a] -= 0.6f * lv[a] / d[a];
       center(v);
     }
     apply(v, lv);
-    const double lam = rayleigh(v, lv);
-    if (!(lam < tau)) continue;
-    double den = 0.0;
+    const float lam = rayleigh(v, lv);
+    if (!(lam < (float)tau)) continue;
+    float den = 0.f;
     for (int a = 0; a < m; ++a) den += d[a] * v[a] * v[a];
-    if (!(den > 0.0)) continue;
-    const double sc = 1.0 / sqrt(den);
-    for (int a = 0; a < m; ++a) phi[(int64_t)mc[a] * R + mr[a]] = (T)(v[a] * sc);
+    if (!(den > 0.f)) continue;
+    const float sc = 1.0f / sqrtf(den);
+    for (int a = 0; a < m; ++a) phi[(int64_t)(wc0 + mc[a]) * R + wr0 + mr[a]] = (T)(v[a] * sc);
     flag[t] = 1;
     mcount[t] = m;
   }
@@ -185,14 +206,12 @@ __global__ __launch_bounds__(64) void enrich_phi_kernel(int R, int C, int Rc, in
 template <class U, class T>
 __global__ __launch_bounds__(64) void enrich_lists_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                           const int* __restrict__ agg, const T* __restrict__ phi,
-                                                          const int* __restrict__ vec_of_tile, const int* __restrict__ moff,
+                                                          const int* __restrict__ tile_of_vec, int nvec, const int* __restrict__ moff,
                                                           int* __restrict__ vptr, int* __restrict__ vcell, T* __restrict__ vphi,
                                                           double* __restrict__ binv, int* __restrict__ acount) {
   const int64_t n = (int64_t)R * C;
-  const int ntiles = Rc * Cc;
-  for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
-    const int v = vec_of_tile[t];
-    if (v < 0) continue;
+  for (int v = blockIdx.x * 64 + threadIdx.x; v < nvec; v += gridDim.x * 64) {
+    const int t = tile_of_vec[v];
     const int I = t % Rc, J = t / Rc;
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
@@ -241,13 +260,11 @@ __global__ __launch_bounds__(64) void enrich_lists_kernel(int R, int C, int Rc, 
 template <class U, class T>
 __global__ __launch_bounds__(64) void enrich_ae_fill_kernel(int R, int C, int Rc, int Cc, const U* __restrict__ rows,
                                                             const int* __restrict__ agg, const T* __restrict__ phi,
-                                                            const int* __restrict__ vec_of_tile, const int* __restrict__ aptr,
+                                                            const int* __restrict__ tile_of_vec, int nvec, const int* __restrict__ aptr,
                                                             int* __restrict__ acell, double* __restrict__ acoef) {
   const int64_t n = (int64_t)R * C;
-  const int ntiles = Rc * Cc;
-  for (int t = blockIdx.x * 64 + threadIdx.x; t < ntiles; t += gridDim.x * 64) {
-    const int v = vec_of_tile[t];
-    if (v < 0) continue;
+  for (int v = blockIdx.x * 64 + threadIdx.x; v < nvec; v += gridDim.x * 64) {
+    const int t = tile_of_vec[v];
     const int I = t % Rc, J = t / Rc;
     int r0, r1, c0, c1;
     tile_extent(I, Rc, R, r0, r1);
@@ -360,8 +377,12 @@ __global__ __launch_bounds__(256) void enrich_vhalo_kernel(int nmem, const int* 
 }
 
 __global__ __launch_bounds__(256) void enrich_vec_of_tile_kernel(int ntiles, const int* __restrict__ flag,
-                                                                 const int* __restrict__ voff, int* __restrict__ vec_of_tile) {
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) vec_of_tile[t] = flag[t] ? voff[t] : -1;
+                                                                 const int* __restrict__ voff, int* __restrict__ vec_of_tile,
+                                                                 int* __restrict__ tile_of_vec) {
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+    vec_of_tile[t] = flag[t] ? voff[t] : -1;
+    if (flag[t]) tile_of_vec[voff[t]] = t;
+  }
 }
 
 // ---- set-up ---------------------------------------------------------------------------------------------------------
@@ -397,25 +418,26 @@ inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc,
   if (nvec <= 0) return;
   exclusive_scan_i32(dptr<int>(mcount), (int64_t)ntiles + 1, st, dptr<int>(tot) + 1);
   const int nmem = read_int(dptr<int>(tot) + 1, st);
-  DBuf vec_of_tile = dalloc<int>((size_t)ntiles);
+  DBuf vec_of_tile = dalloc<int>((size_t)ntiles), tile_of_vec = dalloc<int>((size_t)nvec);
   hipLaunchKernelGGL(enrich_vec_of_tile_kernel, dim3(grid_for(ntiles)), dim3(256), 0, st, ntiles, (const int*)dptr<int>(flag),
-                     (const int*)dptr<int>(voff), dptr<int>(vec_of_tile));
+                     (const int*)dptr<int>(voff), dptr<int>(vec_of_tile), dptr<int>(tile_of_vec));
+  const int gv = std::min(ceil_div(nvec, 64), 65536);
   E.vptr = dalloc<int>((size_t)nvec + 1);
   E.vcell = dalloc<int>((size_t)std::max(nmem, 1));
   E.vphi.alloc((size_t)std::max(nmem, 1) * sizeof(T));
   E.binv = dalloc<double>((size_t)nvec);
   E.aptr = dalloc<int>((size_t)nvec + 1);
   CS_HIP(hipMemsetAsync(E.aptr.p, 0, E.aptr.bytes, st));
-  hipLaunchKernelGGL((enrich_lists_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
-                     (const int*)dptr<int>(vec_of_tile), (const int*)dptr<int>(mcount), dptr<int>(E.vptr), dptr<int>(E.vcell),
+  hipLaunchKernelGGL((enrich_lists_kernel<U, T>), dim3(gv), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(tile_of_vec), nvec, (const int*)dptr<int>(mcount), dptr<int>(E.vptr), dptr<int>(E.vcell),
                      dptr<T>(E.vphi), dptr<double>(E.binv), dptr<int>(E.aptr));
   CS_HIP(hipMemcpyAsync(dptr<int>(E.vptr) + nvec, &nmem, sizeof(int), hipMemcpyHostToDevice, st));
   exclusive_scan_i32(dptr<int>(E.aptr), (int64_t)nvec + 1, st, dptr<int>(tot) + 2);
   const int nae = read_int(dptr<int>(tot) + 2, st);
   E.acell = dalloc<int>((size_t)std::max(nae, 1));
   E.acoef = dalloc<double>((size_t)std::max(nae, 1));
-  hipLaunchKernelGGL((enrich_ae_fill_kernel<U, T>), dim3(gt), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
-                     (const int*)dptr<int>(vec_of_tile), (const int*)dptr<int>(E.aptr), dptr<int>(E.acell), dptr<double>(E.acoef));
+  hipLaunchKernelGGL((enrich_ae_fill_kernel<U, T>), dim3(gv), dim3(64), 0, st, R, C, Rc, Cc, rows, agg, (const T*)dptr<T>(phi),
+                     (const int*)dptr<int>(tile_of_vec), nvec, (const int*)dptr<int>(E.aptr), dptr<int>(E.acell), dptr<double>(E.acoef));
   // halo list: the cells whose residual the pre-correction changes, and their rows of A E
   DBuf hoff = dalloc<int>((size_t)n + 1), ovf = dalloc<int>(2);
   CS_HIP(hipMemsetAsync(ovf.p, 0, ovf.bytes, st));
@@ -555,6 +577,21 @@ __global__ __launch_bounds__(256) void enrich_finish_kernel(int nvec, const int*
   }
 }
 
+// block partials of the post pass -> kEnrichParts rows (the chunked sum of collapse_partials_kernel, blas1.h)
+template <int K>
+__global__ __launch_bounds__(256) void enrich_collapse_kernel(const double* __restrict__ in, int nparts, double* __restrict__ out,
+                                                              const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 256 * K) return;
+  const int r = t / K, c = t % K;
+  const int chunk = (nparts + 255) / 256;
+  const int lo = r * chunk, hi = min(nparts, lo + chunk);
+  double s = 0.0;
+  for (int i = lo; i < hi; ++i) s += in[(size_t)i * K + c];
+  out[(size_t)r * K + c] = s;
+}
+
 static const int kEnrichParts = 256;  // rows of r'z correction partials (appended to the V-cycle's own rows; pcg.h: kEnrichRows)
 
 template <class T, int K>
@@ -564,6 +601,7 @@ inline void enrich_ensure_work(Enrich& E) {
   E.c = dalloc<double>((size_t)E.nvec * K);
   E.c2 = dalloc<double>((size_t)E.nvec * K);
   E.sbuf = dalloc<double>((size_t)E.nhalo * K);
+  E.ppart = dalloc<double>((size_t)kMaxGrid * K);
   E.save.alloc((size_t)std::max(E.nhalo, 1) * K * sizeof(T));
   E.work_k = K;
   E.work_bytes = (int)sizeof(T);
@@ -587,14 +625,16 @@ inline void enrich_pre(Enrich& E, T* r, const int* skip, hipStream_t st) {
 // after the V-cycle: z corrected, r restored, kEnrichParts rows of r'z correction partials written to `part`
 template <class T, int K, bool SAVE>
 inline void enrich_post(Enrich& E, T* r, T* z, double* part, const int* skip, hipStream_t st) {
-  int g = grid_for((int64_t)E.nvec * K);
-  if (g > kEnrichParts) g = kEnrichParts;
-  if (g < kEnrichParts) CS_HIP(hipMemsetAsync(part, 0, (size_t)kEnrichParts * K * sizeof(double), st));
+  // one workgroup per 256 (vector, column) items up to kMaxGrid: the block partials go to a scratch array and are collapsed
+  // into the kEnrichParts rows behind the V-cycle's own (a grid of kEnrichParts workgroups ran 5 ms per pass at 10000^2)
+  const int g = grid_for((int64_t)E.nvec * K);
   hipLaunchKernelGGL((enrich_post_kernel<T, K>), dim3(g), dim3(256), 0, st, E.nvec, (const int*)dptr<int>(E.vptr),
                      (const T*)dptr<T>(E.vphi), (const int*)dptr<int>(E.vhalo), (const int*)dptr<int>(E.aptr),
                      (const int*)dptr<int>(E.acell), (const double*)dptr<double>(E.acoef), (const double*)dptr<double>(E.binv),
                      (const T*)z, (const double*)dptr<double>(E.sbuf), (const double*)dptr<double>(E.t),
-                     (const double*)dptr<double>(E.c), dptr<double>(E.c2), part, skip);
+                     (const double*)dptr<double>(E.c), dptr<double>(E.c2), dptr<double>(E.ppart), skip);
+  hipLaunchKernelGGL((enrich_collapse_kernel<K>), dim3(ceil_div(kEnrichParts * K, 256)), dim3(256), 0, st,
+                     (const double*)dptr<double>(E.ppart), g, part, skip);
   hipLaunchKernelGGL((enrich_finish_kernel<T, K, SAVE>), dim3(grid_for((int64_t)(E.nvec + (SAVE ? E.nhalo : 0)) * K)), dim3(256), 0,
                      st, E.nvec, (const int*)dptr<int>(E.vptr), (const int*)dptr<int>(E.vcell), (const T*)dptr<T>(E.vphi),
                      (const double*)dptr<double>(E.c2), z, E.nhalo, (const int*)dptr<int>(E.hcell), (const T*)dptr<T>(E.save), r,

@@ -24,6 +24,7 @@ PB = int(os.environ.get("PB", "0"))
 B = int(os.environ.get("BATCH", "32"))
 FRAC = float(os.environ.get("FRAC", "0.15"))
 P = int(os.environ.get("PAIRS", "64"))
+EXTRA = {k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv)}
 base = bench.make_raster(N)
 for seed in seeds:
     if FRAC > 0:
@@ -35,7 +36,7 @@ for seed in seeds:
         os.environ["CSGPU_ENRICH_TAU"] = str(tau)
         os.environ["CSGPU_ENRICH"] = "1" if tau > 0 else "0"
         t0 = time.perf_counter()
-        with L.raster_setup(g, L.default_opts(batch=B, precond_bytes=PB)) as h:
+        with L.raster_setup(g, L.default_opts(batch=B, precond_bytes=PB, **EXTRA)) as h:
             t_setup = time.perf_counter() - t0
             info = h.info
             if FRAC > 0:
@@ -52,7 +53,7 @@ for seed in seeds:
             t0 = time.perf_counter()
             R, _, _, st = h.solve_pairs(src, dst)
             ms = (time.perf_counter() - t0) * 1e3
-            print(json.dumps({"N": N, "frac": FRAC, "mask_seed": seed, "tau": tau, "precond_bytes": info["precond_bytes"], "batch": B,
+            print(json.dumps({"N": N, "frac": FRAC, "mask_seed": seed, "tau": tau, "opts": EXTRA, "precond_bytes": info["precond_bytes"], "batch": B,
                               "pairs": len(src), "iters_mean": st["total_iters"] / float(len(src)), "iters_max": st["max_iters"],
                               "ms_per_16_pairs": ms * 16.0 / len(src), "setup_device_ms": info["setup_ms"], "setup_wall_s": t_setup,
                               "not_converged": st["not_converged"], "max_relres": st["max_relres"],
