@@ -163,3 +163,24 @@ def test_onetoall_hook_runs_all_focal_points_on_one_hierarchy():
     py = inspect.getsource(ps.onetoall_on_device)
     assert "res[i] = v if (solvable[i] and v != 0) else -1" in py and "(solvable[i] && v != 0) ? v : T(-1)" in body
     assert "res[i] = 0 if solvable[i] else -1" in py and "solvable[i] ? T(0) : T(-1)" in body
+
+
+def test_reference_suite_script_names_real_reference_files():
+    """julia/run_reference_suite.jl is the defined first test of the Julia binding on a machine with
+    Julia: statically, every reference file it includes exists in the reference checkout (when that is present -- it is not
+    on the GPU box), the solver alias it passes is one of the INTEGRATION.md patch's, and the struct size it asserts for
+    csgpu_stats is the ctypes mirror's."""
+    path = os.path.join(ROOT, "circuitscape.jl_amd", "julia", "run_reference_suite.jl")
+    src = open(path).read()
+    assert 'runtests(solver = "hip", parallel = false)' in src and '"issue341.jl"' in src and '"test_utils.jl"' in src
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert 'const HIP = ["hip"' in integ
+    assert "sizeof(st) == %d" % ctypes.sizeof(lib.Stats) in src
+    for fn in ("default_opts", "device_count", "CsgpuStats", "CsgpuOpts", "HIPAMGSolver"):
+        assert re.search(r"\b%s\b" % fn, JL), fn
+    ref = "/root/reference/test"
+    if os.path.isdir(ref):
+        for f in ("test_utils.jl", "issue341.jl", "runtests.jl"):
+            assert os.path.exists(os.path.join(ref, f)), f
+        tu = open(os.path.join(ref, "test_utils.jl")).read()
+        assert "function runtests(; solver::String" in tu and "function compute_with(" in tu and "function clean_output()" in tu
