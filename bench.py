@@ -197,6 +197,19 @@ def cpu_baseline_entry(cb, n_full, size, sample_size):
         entry["sample"] = sample + ("; then %d pairs on %d threads (one pair per thread) in %.2fs"
                                     % (cb["mt_pairs"], cb["mt_threads"], cb["mt_wall_s"]))
     entry["sample_n"] = cb["n"]
+    # the same oracle MEASURED at the full size on a GPU box's host cores (tools/cpu_full_size.py; minutes of CPU work, so
+    # not part of the default run): committed with its provenance, cited here beside the live bounded-sample figure
+    try:
+        with open(os.path.join(ROOT, "profiles", "r5_cpu_baseline_full_size.json")) as f:
+            m = json.load(f)
+        if m.get("size") == size:
+            entry["measured_full_size"] = {
+                "value": m["value_pair_solves_per_s"], "unit": "pair-solves/s", "cores": m["threads"], "kind": "port, measured at full size",
+                "setup_s": m["setup_s"], "pairs": m["pairs"], "pairs_wall_s": m["pairs_wall_s"], "iters": m["iters"],
+                "single_thread_value": m["single_thread_value"], "host_cores": m["host_cores"],
+                "source": "profiles/r5_cpu_baseline_full_size.json (tools/cpu_full_size.py on a GPU box of this round)"}
+    except Exception:
+        pass
     if "tight_R" in cb:  # consumed by the parent (parity), not part of the published object
         entry["_tight"] = {"R": cb["tight_R"], "pairs": cb["tight_pairs"], "max_true_relres": cb["tight_max_true_relres"],
                            "wall_s": cb["tight_wall_s"]}

@@ -72,7 +72,10 @@ inline bool dia25_from_csr(const Csr<T>& A, int R, Dia25<T>& out, hipStream_t st
   return true;
 }
 
-enum Dia25Epi { D25_PLAIN = 0, D25_RESID = 1, D25_JACOBI = 2 };
+// JACOBI0: the first TWO sweeps of a level from a zero guess in one pass -- x1 = omega0 D^-1 b is formed while b is staged
+// into the window (never written), y = x1 + omega D^-1 (b - A x1). Replaces scale_dinv_kernel + the first JACOBI pass of the
+// V-cycle's pre-smoothing: three n x K vector passes less per level and cycle (write x1, read x1, read b twice -> once).
+enum Dia25Epi { D25_PLAIN = 0, D25_RESID = 1, D25_JACOBI = 2, D25_JACOBI0 = 3 };
 
 template <class T>
 struct Dia25Args {
@@ -85,6 +88,7 @@ struct Dia25Args {
   const T* b;      // RESID / JACOBI
   const T* dinv;   // JACOBI
   T omega;         // JACOBI: y = x + omega dinv (b - A x)
+  T omega0;        // JACOBI0: weight of the sweep from zero that is folded into the load of the window
   const int* skip;
 };
 
@@ -138,7 +142,17 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
         for (int q = 0; q < CPL; ++q) v.e[q] = T(0);
         if (e < HR * LPR && jc >= 0 && jc < a.C) {
           const int row = i0 - 2 + e / LPR;
-          if (row >= 0 && row < a.R) v = *reinterpret_cast<const XV*>(a.x + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
+          if (row >= 0 && row < a.R) {
+            if (EPI == D25_JACOBI0) {
+              // x1 = (omega0 * dinv) * b: the arithmetic of scale_dinv_kernel, bit for bit
+              v = *reinterpret_cast<const XV*>(a.b + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
+              const T sc = a.omega0 * a.dinv[(size_t)jc * a.R + row];
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) v.e[q] = sc * v.e[q];
+            } else {
+              v = *reinterpret_cast<const XV*>(a.x + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
+            }
+          }
         }
         xreg[u] = v;
       }
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
     auto load_b = [&](int jc) {
       if (EPI != D25_PLAIN && row_on && jc < j1) {
         b_pre = *reinterpret_cast<const XV*>(a.b + ((size_t)jc * a.R + i0 + t) * K + c0);
-        if (EPI == D25_JACOBI) d_pre = a.dinv[(size_t)jc * a.R + i0 + t];
+        if (EPI == D25_JACOBI || EPI == D25_JACOBI0) d_pre = a.dinv[(size_t)jc * a.R + i0 + t];
       }
     };
     if (PF) load_b(j0);
@@ -266,7 +280,7 @@ inline int dia25_waves(int lanes_per_node) {
 
 template <class T, int K>
 inline void dia25_launch(const Dia25<T>& D, int epi, const T* x, T* y, const T* b, const T* dinv, T omega, const int* skip,
-                         hipStream_t st) {
+                         hipStream_t st, T omega0 = T(0)) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int CPL = K < VEC ? K : VEC;
   constexpr int TI = 256 / (K / CPL);
@@ -283,6 +297,7 @@ inline void dia25_launch(const Dia25<T>& D, int epi, const T* x, T* y, const T* 
   a.b = b;
   a.dinv = dinv;
   a.omega = omega;
+  a.omega0 = omega0;
   a.skip = skip;
   int64_t g = (int64_t)a.nstrips * a.nseg;
   if (g > 65536) g = 65536;
@@ -306,6 +321,8 @@ inline void dia25_launch(const Dia25<T>& D, int epi, const T* x, T* y, const T* 
     CS_D25_LAUNCH(D25_PLAIN, true, 3);
   } else if (epi == D25_RESID) {
     CS_D25_EPI(D25_RESID);
+  } else if (epi == D25_JACOBI0) {
+    CS_D25_EPI(D25_JACOBI0);
   } else {
     CS_D25_EPI(D25_JACOBI);
   }

@@ -278,9 +278,18 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   }
   // pre-smoothing (first sweep from x = 0 is a scaling)
   if (nu_pre >= 1) {
-    if (!(fuse && fuse->xa_ready && l == 0))
+    int s_first = 1;
+    static const bool no_j0 = getenv("CSGPU_DIA25_NO_J0") != nullptr;  // A/B knob
+    if (use25 && nu_pre >= 2 && !no_j0 && !(fuse && fuse->xa_ready && l == 0)) {
+      // 25-point lattice level: the sweep from zero and the first real sweep in one marching pass (dia25.h, JACOBI0)
+      dia25_launch<T, (K >= 8 ? K : 8)>(L.A25, D25_JACOBI0, (const T*)nullptr, oth, b, (const T*)dptr<T>(L.dinv), weight(1), skip, st,
+                                        omega);
+      std::swap(cur, oth);
+      s_first = 2;
+    } else if (!(fuse && fuse->xa_ready && l == 0)) {
       hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega, skip);
-    for (int s = 1; s < nu_pre; ++s) {
+    }
+    for (int s = s_first; s < nu_pre; ++s) {
       jacobi_sweep(cur, oth, false, s);
       std::swap(cur, oth);
     }
@@ -620,8 +629,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // second coarse function on the badly shaped aggregates of a perforated raster lattice (enrich.h): a symmetric
   // multiplicative correction around the V-cycle; its r'z terms travel as kEnrichParts extra rows behind the V-cycle's own
   Enrich& EN = H.enr;
-  const bool enrich = use_dia && EN.nvec > 0 && EN.n == n && two_product && L0.lattice_two_product() && !grounded &&
-                      !projected && EN.phi_bytes == (int)sizeof(TP);
+  // (Dirichlet-masked solves keep it: with Pm the mask, the preconditioner in effect is Pm M Pm -- r is zero at the grounded
+  // entries and z is masked after the correction, so symmetry and the r'z terms hold; polygon handles -- `projected` -- do
+  // not use it: their hierarchy's matrix carries the strengthened interiors)
+  const bool enrich = use_dia && EN.nvec > 0 && EN.n == n && two_product && L0.lattice_two_product() && !projected &&
+                      EN.phi_bytes == (int)sizeof(TP);
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();  // (captured chunks hold the old work pointers)
     enrich_ensure_work<TP, K>(EN);
