@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-KERNEL_SOURCES = ("stencil.h", "lattice.h", "spmv.h", "blas1.h", "prims.h", "common.h")
+KERNEL_SOURCES = ("stencil.h", "lattice.h", "spmv.h", "blas1.h", "prims.h", "common.h", "pcg.h", "dia25.h", "amg_setup.h",
+                  "lattice_setup.h", "enrich.h")
 
 
 def kernel_source_hash():
@@ -68,6 +69,52 @@ def pmc_traffic(size, batch, vb, lattice=False, pb=4):
         return e["traffic_bytes_per_launch"], "PMC pass %s (kernel sources %s)" % (key, cur)
     except Exception as ex:
         return None, "pmc_traffic.json unreadable: %r" % (ex,)
+
+
+def live_pmc_traffic(args, precond, kernel_prefix, timeout_s=170):
+    """`roofline.traffic` measured in THIS run: two rocprofv3 passes -- `--pmc FETCH_SIZE` and `--pmc
+    WRITE_SIZE`, separately, with `--kernel-trace` only, as MI355X_MICROARCH.md's HBM section prescribes -- over a child
+    process that runs one warm-up and one timed batch of the same workload on the same path, nothing else. HBM bytes per
+    launch of the roofline kernel = FETCH_SIZE x 2 (the counter's unit is 64 B on gfx950 while rocprofv3 scales it as 32 B;
+    verified on streaming kernels of known size, profiles/pmc_traffic.json) + WRITE_SIZE, both KiB, averaged over the
+    full-size launches (the warm-up problem launches the same kernel on a 768^2 raster). Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="csgpu_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--compare-steps", "0",
+               "--extra-legs", "0", "--host-csr", "0", "--pmc-live", "0", "--size", str(args.size), "--batch", str(args.batch),
+               "--precond", precond, "--precision", args.precision, "--calls", args.calls]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and row.get("Kernel_Name", "").startswith(kernel_prefix):
+                            got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "live PMC pass %s: no launches of %s in the counter file" % (counter, kernel_prefix)
+            full = [v for v in got if v >= 0.5 * max(got)]
+            vals[counter] = (sum(full) / len(full), len(full))
+        except Exception as e:
+            return None, "live PMC pass %s failed: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    note = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a "
+            "one-batch child run; FETCH x2 (gfx950 unit) + WRITE, KiB; mean over %d / %d full-size launches of %s; %.0f s"
+            % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1], kernel_prefix, time.perf_counter() - t0))
+    return traffic, note
 
 
 def make_raster(size, seed=12345, sigma=1.0, dtype=np.float64):
@@ -326,7 +373,8 @@ def nodata_leg(lib, g, B, make_opts, precond, sync, frac=0.15, steps=2):
     sv = (info["setup_ms"] + info["upload_ms"]) / 1e3
     return {"value": steps * B / (el + sv * steps * B / 100.0), "unit": "pair-solves/s", "nodata_fraction": frac,
             "nodes": int(info["n"]), "giant_component_nodes": int(giant.size), "components": int(ncomp),
-            "lattice_period": info["lattice_period"], "levels": info["levels"], "level_form": info["level_form"], "steps": steps,
+            "lattice_period": info["lattice_period"], "levels": info["levels"], "level_form": info["level_form"],
+            "enrich_vectors": info.get("enrich_vectors", 0), "steps": steps,
             "ms_per_16_pairs": el / steps * 1e3 * 16.0 / B, "iters_mean": agg["total_iters"] / float(steps * B),
             "iters_max": agg["max_iters"], "max_relres": agg["max_relres"], "not_converged": agg["not_converged"],
             "setup_s": sv, "precond": precond}
@@ -653,6 +701,10 @@ def main():
                     help="internal: run only the CPU-baseline leg on a --cpu-sample raster, scale to N_FULL nodes, print "
                          "its JSON object and exit (the bench runs this in a child process so that nothing on the host "
                          "side can take the GPU line down)")
+    ap.add_argument("--pmc-live", type=int, default=1,
+                    help="N=1 only: measure roofline.traffic in this run with two rocprofv3 --pmc passes over a one-batch child "
+                         "process (~1 min); 0 = report the committed PMC pass of profiles/pmc_traffic.json when its kernel-source "
+                         "hash matches this build")
     ap.add_argument("--cpu-legs", default="", help="internal (CPU child): comma list of nodata,fp32,geometric")
     ap.add_argument("--leg-sample", type=int, default=2000,
                     help="raster edge of the samples on which the nodata15 / config3_fp32 legs are compared with the tight oracle")
@@ -947,6 +999,26 @@ def main():
                 out["setup_host_csr_s"] = None
                 out["setup_host_csr"] = {"failed": repr(e)}
         del g
+        if world == 1 and args.pmc_live and has_cuda and info["lattice_period"] > 0:
+            # live HBM traffic of the roofline kernel (the handles of this process are closed; its pooled blocks go back to
+            # the driver first so that the child finds the device empty)
+            t_leg = time.perf_counter()
+            try:
+                lib.trim_memory()
+                tn = {8: "double", 4: "float"}
+                xb = info["precond_bytes"] or vb
+                prefix = "void csgpu::dia_cg_kernel<%s, %s, %d, 1>" % (tn[vb], tn[xb], B)
+                traffic, note = live_pmc_traffic(args, args.precond, prefix)
+                if traffic is not None:
+                    out["roofline"]["traffic_committed_pass"] = out["roofline"]["traffic"]
+                    out["roofline"]["traffic"] = traffic
+                    out["roofline"]["traffic_source"] = note
+                    out["roofline"]["traffic_over_algorithmic"] = traffic / max(out["roofline"]["algorithmic_bytes_per_launch"], 1)
+                else:
+                    out["roofline"]["traffic_live_failed"] = note
+            except Exception as e:
+                out["roofline"]["traffic_live_failed"] = repr(e)
+            leg_seconds["pmc_live"] = time.perf_counter() - t_leg
         if args.cpu_sample > 0 and world == 1:
             try:
                 import subprocess
