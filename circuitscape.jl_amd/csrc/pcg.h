@@ -613,7 +613,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   } dirichlet_guard;
   const bool dirichlet = grounded && H.dir_ncomp > 0 && H.coarse_dense && H.coarse_cand.p && A.nnz > 0 && !pp.rhs_in_r;
   const int gm = grounded ? ceil_div(pp.gtotal, 256) : 1;
-  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product && !grounded;
+  // (not with a projection either -- ADVICE r4: r is replaced after the update wrote xa = omega D^-1 r, so the fused first
+  // sweep would start the V-cycle from the unprojected residual)
+  const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product && !grounded && !projected;
   // lattice path: the residual update recomputes A p from the lattice form (one read of p, 5 matrix values per row)
   // instead of the product kernel writing A p and the update reading it back (2 x sizeof(T) per vector element)
   static const bool no_recompute = getenv("CSGPU_NO_RECOMPUTE") != nullptr;  // A/B knob
