@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
     const int j0 = sj * a.seg, j1 = min(a.C, j0 + a.seg);
     const bool row_on = i0 + t < a.R;
     XV xreg[XU];
+    T dreg[XU];   // JACOBI0: D^-1 of the staged entries
     T mreg[MU];
     XV win[5][5];  // win[s][di]: x(i0 + t + di - 2, column with (column - j0 + 2) % 5 == s)
     auto load_x = [&](int jc) {
@@ -140,15 +141,16 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
         XV v;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) v.e[q] = T(0);
+        if (EPI == D25_JACOBI0) dreg[u] = T(0);
         if (e < HR * LPR && jc >= 0 && jc < a.C) {
           const int row = i0 - 2 + e / LPR;
           if (row >= 0 && row < a.R) {
             if (EPI == D25_JACOBI0) {
-              // x1 = (omega0 * dinv) * b: the arithmetic of scale_dinv_kernel, bit for bit
+              // (b and D^-1 only LOADED here; scaled when the registers go to LDS one column later -- scaling here would wait
+              // for both loads on the spot and take the prefetch out of the pipeline: 1.00 instead of 0.72 ms per launch
+              // at 4.0 M rows, profiles/r5_dia25_level1_6000.txt)
               v = *reinterpret_cast<const XV*>(a.b + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
-              const T sc = a.omega0 * a.dinv[(size_t)jc * a.R + row];
-#pragma unroll
-              for (int q = 0; q < CPL; ++q) v.e[q] = sc * v.e[q];
+              dreg[u] = a.dinv[(size_t)jc * a.R + row];
             } else {
               v = *reinterpret_cast<const XV*>(a.x + ((size_t)jc * a.R + row) * K + (e % LPR) * CPL);
             }
@@ -161,7 +163,18 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
 #pragma unroll
       for (int u = 0; u < XU; ++u) {
         const int e = tid + u * 256;
-        if (e < HR * LPR) s_x[jc & 1][e] = xreg[u];
+        if (e < HR * LPR) {
+          if (EPI == D25_JACOBI0) {
+            // x1 = (omega0 * dinv) * b: the arithmetic of scale_dinv_kernel, bit for bit
+            const T sc = a.omega0 * dreg[u];
+            XV v = xreg[u];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v.e[q] = sc * v.e[q];
+            s_x[jc & 1][e] = v;
+          } else {
+            s_x[jc & 1][e] = xreg[u];
+          }
+        }
       }
     };
     auto load_m = [&](int jc) {
