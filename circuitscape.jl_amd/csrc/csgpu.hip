@@ -1313,7 +1313,10 @@ struct Solver : ISolver {
       s->total_iters += r.s.iters[c];
       s->max_iters = std::max(s->max_iters, r.s.iters[c]);
       s->max_relres = std::max(s->max_relres, r.s.relres[c]);
-      const bool bad = (r.s.done[c] != 1) || !(r.s.relres[c] < 1e-4);
+      // the reference's ONLY acceptance test is the residual (src/core.jl:639-641: Krylov.cg's stats are not looked at): a
+      // column that stopped on itmax or on a breakdown of the recurrence with ||Ax-b||/||b|| < 1e-4 is a success there, and
+      // here (fuzz finding of round 5: ten-decade mazes at rtol 1e-10 stagnate at 1e-7 and were reported as failures)
+      const bool bad = !(r.s.relres[c] < 1e-4);
       if (bad) s->not_converged += 1;
     }
     s->device_ms += r.device_ms;
@@ -1424,7 +1427,7 @@ struct Solver : ISolver {
           stats->total_iters += sr.iters[p];
           stats->max_iters = std::max(stats->max_iters, sr.iters[p]);
           stats->max_relres = std::max(stats->max_relres, sr.relres[p]);
-          if (sr.status[p] != 1 || !(sr.relres[p] < 1e-4)) stats->not_converged += 1;
+          if (!(sr.relres[p] < 1e-4)) stats->not_converged += 1;   // (as in accumulate(): the residual decides)
         }
         stats->device_ms += sr.device_ms;
         stats->cg_spmv_ms += sr.spmv_ms;

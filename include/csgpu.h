@@ -56,8 +56,10 @@
  *     at 21000 x 21000 = 441 M cells, 3.97e9 stored entries); calls that need the CSR form of such a raster (voltage /
  *     current maps, explicit_check) return status 4, resistance-only csgpu_solve_pairs does not.
  *   - All calls are blocking; a handle is serialised internally (one caller at a time per handle).
- *   - Return value: 0 ok, 1 not converged (some right-hand side hit itmax or failed the reference's
- *     1e-4 true-residual check), 2 HIP runtime error, 3 out of memory, 4 bad arguments, 5 internal error.
+ *   - Return value: 0 ok, 1 not converged (some right-hand side failed the reference's 1e-4 true-residual check,
+ *     src/core.jl:640-641 -- the reference's only acceptance test: how the iteration stopped (rule met, itmax, breakdown of
+ *     the recurrence) is not looked at there and does not decide here), 2 HIP runtime error, 3 out of memory, 4 bad arguments,
+ *     5 internal error.
  *     csgpu_last_error() returns a thread-local human-readable message for the last non-zero status.
  * ============================================================================= */
 #ifndef CSGPU_H
@@ -199,7 +201,7 @@ typedef struct csgpu_stats {
   double cg_spmv_ms;            /* sum of HIP-event durations of the fine-level CG SpMV/SpMM launches */
   int64_t cg_spmv_calls;        /* number of those launches */
   int32_t batch;                /* batch width actually used */
-  int32_t not_converged;        /* number of rhs that hit itmax / broke down / failed the 1e-4 check */
+  int32_t not_converged;        /* number of rhs whose ||Ax-b||/||b|| is not below 1e-4 (core.jl:640), whatever stopped them */
   int64_t graph_launches;       /* hipGraph replays issued (each = check_every PCG iterations) */
   int64_t polished_batches;     /* batches that were re-opened on the true residual because a column stopped on the
                                    configured rule with ||Ax-b||/||b|| >= 1e-4 (the reference would have errored) */

@@ -1339,3 +1339,24 @@ def test_coarse_levels_in_25_point_lattice_form(emu_lib, monkeypatch, capfd):
     """refined tiles (NODATA cell space): levels >= 1 index-free (dia25.h), same products / iterations / resistances"""
     from helpers import check_dia25_levels
     check_dia25_levels(emu_lib, monkeypatch, shape=(70, 115))  # level 1: 23 x 38 -- two column segments, 38 = 32 + 6
+
+
+def test_the_residual_alone_decides_convergence_like_the_reference(emu_lib):
+    """src/core.jl:639-641: the reference runs Krylov.cg and then accepts the solve iff ||Ax - b|| / ||b|| < 1e-4 -- how the
+    iteration stopped is not looked at. A column that ran into itmax (an unreachable rtol) with a tiny residual is a
+    success (round-5 fuzz finding: ten-decade mazes at rtol 1e-10 stagnate at 1e-7 and used to be reported as failures);
+    one that is stopped while the residual is still large raises with the reference's wording."""
+    from oracle import refgraph as rg
+    N = 40
+    _, g = rg.synthetic_raster_problem(N, N, seed=3)
+    with emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, itmax=60, rtol=1e-30, atol=0.0)) as h:
+        R, _, _, st = h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
+        # (stopped by itmax or -- once the recurrence has reached machine precision -- by its breakdown test; never by the rule)
+        assert 20 <= st["max_iters"] <= 60 and st["not_converged"] == 0 and st["max_relres"] < 1e-8
+    with emu_lib.raster_setup(g, emu_lib.default_opts(batch=2)) as h:
+        R0, _, _, st0 = h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
+    assert np.max(np.abs(R - R0) / R0) < 1e-6
+    with emu_lib.raster_setup(g, emu_lib.default_opts(batch=2, itmax=1)) as h:
+        with pytest.raises(emu_lib.CsgpuError) as e:
+            h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
+        assert e.value.code == emu_lib.CSGPU_NOT_CONVERGED and "exceeds tolerance 1e-4" in str(e.value)
