@@ -1,3 +1,4 @@
+import gzip
 import json
 import os
 import subprocess
@@ -26,9 +27,16 @@ def advanced_cases():
     return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgNetwork"))
 
 
+def _stem(f):
+    return f[:-8] if f.endswith(".json.gz") else f[:-5]
+
+
 def raster_advanced_cases():
-    """raster advanced-mode cases (mgVerify1..6: voltage / current map goldens)"""
-    return sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f.startswith("mgVerify"))
+    """raster advanced-mode cases (mgVerify1..6: voltage / current map goldens; mgVerify7, a 355 x 481 landscape with
+    5574 finite grounds whose golden current map the reference ships but its own suite does not run
+    (test/test_utils.jl:117 stops at 6), is stored gzipped)"""
+    return sorted(_stem(f) for f in os.listdir(GOLDEN)
+                  if (f.endswith(".json") or f.endswith(".json.gz")) and f.startswith("mgVerify"))
 
 
 def onetoall_cases():
@@ -43,7 +51,11 @@ def compare_aagrid(expected, got, tol=1e-6):
 
 
 def load_case(name):
-    with open(os.path.join(GOLDEN, name + ".json")) as f:
+    path = os.path.join(GOLDEN, name + ".json")
+    if not os.path.exists(path):
+        with gzip.open(path + ".gz", "rt") as f:
+            return json.load(f)
+    with open(path) as f:
         return json.load(f)
 
 
