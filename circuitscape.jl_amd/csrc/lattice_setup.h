@@ -199,6 +199,46 @@ __global__ __launch_bounds__(256) void csr_to_cell_dia_kernel(int n, int R, cons
   }
 }
 
+// The same scatter for a BLOCK of CSR rows (nodes i0 .. i0 + nloc) whose row pointers were rebased to the block (rp[0] = 0):
+// the streamed set-up of host matrices with 2^31 stored entries and more (csgpu.hip, setup_from_host_streamed), which never
+// holds the whole CSR form on the device. Node ids, coordinates and node2cell are global.
+template <class T>
+__global__ __launch_bounds__(256) void csr_block_to_cell_dia_kernel(int i0, int nloc, int R, const int* __restrict__ rp,
+                                                                    const int* __restrict__ ci, const T* __restrict__ va,
+                                                                    const int* __restrict__ row, const int* __restrict__ col,
+                                                                    const int* __restrict__ node2cell, T* __restrict__ rows,
+                                                                    int* __restrict__ bad) {
+  for (int il = blockIdx.x * 256 + threadIdx.x; il < nloc; il += gridDim.x * 256) {
+    const int i = i0 + il;
+    const int64_t c = node2cell[i];
+    bool diag = false;
+    for (int k = rp[il]; k < rp[il + 1]; ++k) {
+      const int j = ci[k];
+      if (j == i) {
+        rows[c * 5] = va[k];
+        diag = true;
+        continue;
+      }
+      const int dr = row[j] - row[i], dc = col[j] - col[i];
+      if (dr < -1 || dr > 1 || dc < -1 || dc > 1) {
+        atomicOr(bad, 4);
+        continue;
+      }
+      const int d = dc * R + dr;
+      if (d < 0) continue;
+      const int slot = d == 1 ? 1 : (d == R - 1 ? 2 : (d == R ? 3 : 4));
+      rows[c * 5 + slot] = va[k];
+    }
+    if (!diag) atomicOr(bad, 16);  // (a Laplacian row without its diagonal: not a matrix this path can take)
+  }
+}
+
+// all-valid raster handed over as a matrix: the handle keeps the caller's numbering only if it IS the column-major one
+__global__ __launch_bounds__(256) void identity_numbering_kernel(int n, const int* __restrict__ node2cell, int* __restrict__ bad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (node2cell[i] != i) atomicOr(bad, 8);
+}
+
 // cells without a node: identity rows; size0 = 1 for a cell with a node
 template <class T>
 __global__ __launch_bounds__(256) void cell_identity_kernel(int64_t ncells, const int* __restrict__ cell2node, T* __restrict__ rows,

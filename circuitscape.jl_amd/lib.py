@@ -61,7 +61,7 @@ class Info(ctypes.Structure):
         ("level_n", ctypes.c_int64 * 32), ("level_nnz", ctypes.c_int64 * 32),
         ("spmv_bytes_fine", ctypes.c_int64), ("bytes_per_iteration", ctypes.c_int64),
         ("level_form", ctypes.c_int32 * 32), ("hierarchy_rebuilt_fp64", ctypes.c_int32),
-        ("enrich_vectors", ctypes.c_int32),
+        ("enrich_vectors", ctypes.c_int32), ("host_blocks", ctypes.c_int32), ("reserved_info", ctypes.c_int32),
     ]
 
 

@@ -50,11 +50,15 @@
  *     column/row form (identical by symmetry) exactly as Julia's SparseMatrixCSC stores it:
  *     rowptr[n+1], colidx[nnz] (sorted within a row), vals[nnz]; idx_bytes in {4,8}, val_bytes in {4,8},
  *     index_base in {0,1}. The library COPIES it to the device; host pointers are never retained.
- *   - On device everything is int32 / 0-based; nnz < 2^31 (and n < 2^31 - 1) are required of matrices handed over in
- *     CSR form (status 4 otherwise); vector element indices (node * batch + column) are 64-bit. csgpu_raster_setup builds
- *     the fine level of a raster without a CSR matrix, so rasters are limited by n = rows * cols < 2^31 - 1 only (tested
- *     at 21000 x 21000 = 441 M cells, 3.97e9 stored entries); calls that need the CSR form of such a raster (voltage /
- *     current maps, explicit_check) return status 4, resistance-only csgpu_solve_pairs does not.
+ *   - On device everything is int32 / 0-based and n < 2^31 - 1 is required (status 4 otherwise); vector element indices
+ *     (node * batch + column) are 64-bit. A device CSR form exists only for nnz < 2^31. csgpu_raster_setup builds the fine
+ *     level of a raster without a CSR matrix, so rasters are limited by n = rows * cols < 2^31 - 1 only (tested at
+ *     21000 x 21000 = 441 M cells, 3.97e9 stored entries). A HOST matrix with nnz >= 2^31 (the reference's
+ *     use_64bit_indexing, src/run.jl:34: Int64 colptr / rowval) is accepted by csgpu_setup when it is the graph of a raster
+ *     without polygons and comes with csgpu_opts.node_row / node_col: it is streamed to the device in blocks of rows and
+ *     scattered straight into the same lattice form (csgpu_get_info().host_blocks tells; status 4 with the reason when the
+ *     matrix does not qualify). Calls that need the CSR form of such a handle (voltage / current maps, explicit_check)
+ *     return status 4, resistance-only csgpu_solve_pairs does not.
  *   - All calls are blocking; a handle is serialised internally (one caller at a time per handle).
  *   - Return value: 0 ok, 1 not converged (some right-hand side failed the reference's 1e-4 true-residual check,
  *     src/core.jl:640-641 -- the reference's only acceptance test: how the iteration stopped (rule met, itmax, breakdown of
@@ -189,6 +193,10 @@ typedef struct csgpu_info {
                                    fp64 one (strongly heterogeneous raster / off-diagonal contrast above 1e5 in a host CSR) */
   int32_t enrich_vectors;       /* aggregates of level 0 that carry a SECOND coarse function (csrc/enrich.h: badly shaped aggregates
                                    of a raster with NODATA cells / strength-refined tiles); 0 = none */
+  int32_t host_blocks;          /* > 0: the host matrix of csgpu_setup was streamed to the device in this many blocks of rows and
+                                   scattered straight into the lattice form (matrices with 2^31 stored entries and more; the
+                                   device holds no CSR form of it); 0 = any other set-up */
+  int32_t reserved_info;
 } csgpu_info;
 
 typedef struct csgpu_stats {
@@ -217,7 +225,8 @@ typedef struct csgpu_stats {
 int csgpu_device_count(void);
 void csgpu_default_opts(csgpu_opts* opts);
 
-/* Copy a host CSR/CSC symmetric matrix to the device and build the AMG hierarchy there. */
+/* Copy a host CSR/CSC symmetric matrix to the device and build the AMG hierarchy there (construct_cholesky_factor's place,
+ * src/core.jl:519-523; the AMG set-up site src/core.jl:164-167). nnz >= 2^31: see "Conventions" above (streamed set-up). */
 int csgpu_setup(const void* rowptr, const void* colidx, const void* vals, int64_t n, int64_t nnz, int idx_bytes,
                 int val_bytes, int index_base, const csgpu_opts* opts, csgpu_handle** out);
 

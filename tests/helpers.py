@@ -1730,3 +1730,99 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                 # the remaining error -- both answers satisfy the stopping rule)
                 assert abs(a[1] - b[1]) <= 1 and diff < (1e-9 if pb == 0 else 1e-7), (mode, pb, K, a[1], b[1], diff)
     return out
+
+
+def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4):
+    """Host matrices with 2^31 stored entries and more (use_64bit_indexing, src/run.jl:34: raster pairwise problems above
+    238 M cells) cannot be held in CSR form on the device; csgpu_setup streams them in blocks of rows into the lattice
+    form (csgpu.hip, setup_from_host_streamed). CSGPU_STREAM_HOST_CSR=<entries per block> sends a small matrix down the
+    same code. Such a handle must be indistinguishable from the one the ordinary path builds from the same arrays:
+    (1) a raster with NODATA cells (ordinary twin: setup_cellspace_from_csr -- the same lattice form, so bit-identical
+    resistances and iteration counts), Int64 / 1-based and Int32 / 0-based arrays, one block and many; (2) an all-valid
+    raster (ordinary twin: lattice detected from the matrix + CSR pipeline); (3) both against the tight oracle; (4) a
+    matrix the path cannot take (polygon: a coupling between cells that are not neighbours; no coordinates; a numbering
+    that is not column-major) declines and takes the ordinary path when it is small enough to have one. Which path a
+    handle took is read from csgpu_info.host_blocks."""
+    import scipy.sparse as sp
+    from circuitscape_jl_amd import solver as ps
+
+    def both(A, row, col, src, dst, pb, block, **kw):
+        os.environ.pop("CSGPU_STREAM_HOST_CSR", None)
+        with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb), node_row=row, node_col=col, **kw) as h:
+            assert h.info["host_blocks"] == 0
+            base = (h.solve_pairs(src, dst), h.info)
+        os.environ["CSGPU_STREAM_HOST_CSR"] = str(block)
+        try:
+            with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb), node_row=row, node_col=col, **kw) as h:
+                info = h.info
+                out = h.solve_pairs(src, dst)
+                x = np.random.default_rng(1).standard_normal(A.shape[0])
+                assert np.allclose(h.spmv(x.copy()), A @ x, rtol=1e-12, atol=1e-12)   # (CSR form rebuilt from the lattice form)
+        finally:
+            os.environ.pop("CSGPU_STREAM_HOST_CSR", None)
+        return base, (out, info)
+
+    # (1) NODATA raster, a connected component with an offset bounding box
+    g = _nodata_raster(shape, 17, frac=0.12, wall=False)
+    g[:, :3] = 0.0
+    g[:2, :] = 0.0
+    nm = rg.construct_node_map(g, None)
+    G = rg.construct_graph(g, nm, False, False)
+    comp = np.asarray(max(rg.connected_components(G), key=len), dtype=np.int64)
+    A = oracle.regularize(sp.csr_matrix(rg.laplacian(G))[comp - 1][:, comp - 1])
+    row, col = ps._node_coords(nm, comp)
+    ids = np.random.default_rng(5).choice(len(comp), size=2 * batch, replace=False)
+    src, dst = [int(v) for v in ids[:batch]], [int(v) for v in ids[batch:]]
+    Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
+    R0, C0 = int(row.max() - row.min() + 1), int(col.max() - col.min() + 1)
+    for pb in (0, 4):
+        for block, kw in ((997, {}), (10 ** 9, {}), (640, {"index_dtype": np.int32, "index_base": 0})):
+            ((Rb, _, _, stb), ib), ((Rs, _, _, sts), is_) = both(A, row, col, src, dst, pb, block, **kw)
+            want_blocks = 1 if block >= A.nnz else None
+            assert is_["host_blocks"] >= (want_blocks or 2), is_["host_blocks"]
+            if want_blocks:
+                assert is_["host_blocks"] == 1
+            assert is_["n"] == len(comp) and is_["nnz"] == A.nnz and is_["lattice_period"] == R0, is_
+            assert is_["level_n"] == ib["level_n"] and is_["level_form"] == ib["level_form"], (is_, ib)
+            assert sts["not_converged"] == 0 and np.max(np.abs(Rs - Ro) / Ro) < 1e-6
+            assert np.array_equal(Rs, Rb) and sts["total_iters"] == stb["total_iters"], (Rs - Rb, sts, stb)
+    # (2) all-valid raster in the reference's column-major numbering
+    ga = np.exp(np.random.default_rng(23).standard_normal((41, 38)))
+    nma = rg.construct_node_map(ga, None)
+    Aa = oracle.regularize(rg.laplacian(rg.construct_graph(ga, nma, False, False)))
+    rowa, cola = ps._node_coords(nma, np.arange(1, ga.size + 1))
+    idsa = np.random.default_rng(6).choice(ga.size, size=2 * batch, replace=False)
+    srca, dsta = [int(v) for v in idsa[:batch]], [int(v) for v in idsa[batch:]]
+    Roa, _, _ = oracle.OracleAMG(Aa).solve_pairs(srca, dsta, rtol=1e-12, atol=0.0, criterion=1)
+    for pb in (0, 4):
+        ((Rb, _, _, stb), ib), ((Rs, _, _, sts), is_) = both(Aa, rowa, cola, srca, dsta, pb, 1500)
+        assert is_["host_blocks"] >= 2 and is_["lattice_period"] == 41 and is_["level_n"][0] == ga.size, is_
+        assert is_["level_form"][0] == L.FORM_LATTICE9 and ib["level_form"][0] == L.FORM_LATTICE9
+        assert sts["not_converged"] == 0 and np.max(np.abs(Rs - Roa) / Roa) < 1e-6
+        assert np.max(np.abs(Rs - Rb) / Rb) < 1e-8 and abs(sts["total_iters"] - stb["total_iters"]) <= batch
+    # (4) declines: polygon coupling, missing coordinates, permuted numbering -> the ordinary path, same answers as ever
+    B = sp.lil_matrix(A)
+    far = len(comp) - 1
+    B[0, far] -= 0.5
+    B[far, 0] -= 0.5
+    B[0, 0] += 0.5
+    B[far, far] += 0.5
+    B = sp.csr_matrix(B)
+    perm = np.random.default_rng(9).permutation(ga.size)
+    Ap = sp.csr_matrix(Aa)[perm][:, perm]
+    os.environ["CSGPU_STREAM_HOST_CSR"] = "500"
+    try:
+        with L.setup(B, L.default_opts(batch=batch), node_row=row, node_col=col) as h:
+            assert h.info["host_blocks"] == 0 and h.info["lattice_period"] == 0
+            assert h.solve_pairs(src[:2], dst[:2])[3]["not_converged"] == 0
+        with L.setup(A, L.default_opts(batch=batch)) as h:
+            assert h.info["host_blocks"] == 0
+            Rn, _, _, stn = h.solve_pairs(src, dst)
+            assert stn["not_converged"] == 0 and np.max(np.abs(Rn - Ro) / Ro) < 1e-6
+        with L.setup(Ap, L.default_opts(batch=batch), node_row=rowa[perm], node_col=cola[perm]) as h:
+            assert h.info["host_blocks"] == 0
+            inv = np.argsort(perm)
+            Rp, _, _, stp = h.solve_pairs([int(inv[s]) for s in srca], [int(inv[d]) for d in dsta])
+            assert stp["not_converged"] == 0 and np.max(np.abs(Rp - Roa) / Roa) < 1e-6
+    finally:
+        os.environ.pop("CSGPU_STREAM_HOST_CSR", None)

@@ -77,9 +77,10 @@ def main():
       i2 = h2.info
       R2, _, _, st2 = h2.solve_pairs(src, dst)
       h2.close()
+      host_bytes = int(rp.nbytes + ci.nbytes + va.nbytes)   # (before the arrays go: ADVICE r4)
       del rp, ci, va
       out["host_csr"] = {"setup_wall_s": wall, "upload_convert_s": i2["upload_ms"] / 1e3, "device_setup_s": i2["setup_ms"] / 1e3,
-                       "host_bytes": int(rp.nbytes + ci.nbytes + va.nbytes), "lattice_period_detected": i2["lattice_period"],
+                       "host_bytes": host_bytes, "lattice_period_detected": i2["lattice_period"],
                        "levels": i2["levels"], "iters_mean": st2["total_iters"] / 16.0,
                        "max_rel_diff_R_vs_raster_entry_point": float(np.max(np.abs(R2 - res["mixed"]) / res["mixed"])),
                        "note": "no raster coordinates are handed over on this path: the lattice period detected from the "
