@@ -9,6 +9,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import circuitscape_jl_amd  # noqa: F401
 from circuitscape_jl_amd import lib
 
@@ -184,3 +186,173 @@ def test_reference_suite_script_names_real_reference_files():
             assert os.path.exists(os.path.join(ref, f)), f
         tu = open(os.path.join(ref, "test_utils.jl")).read()
         assert "function runtests(; solver::String" in tu and "function compute_with(" in tu and "function clean_output()" in tu
+
+
+# ---- a structural lint of the Julia sources ("a typo in any of 363 code lines survives") ------------------
+# No Julia parser here; what a tokenizer can hold the files to: brackets balance; every block opener has its `end`; every
+# function the binding calls is defined in the binding, in the reference's src/ (when the checkout is present) or is one of
+# the Base / SparseArrays / LinearAlgebra names listed below; calls of the binding's own and of the reference's functions
+# pass a number of positional arguments some method accepts.
+JL_DIR = os.path.join(ROOT, "circuitscape.jl_amd", "julia")
+JL_BASE = set("""Int Int32 Int64 Float32 Float64 Cint axes ccall clamp cumsum deepcopy eachindex eltype enumerate eps error falses
+fill filter finalize finalizer findall findfirst first get hcat isempty isequal length lock max maximum min new nextpow nnz norm
+nzrange one ones permutedims pointer push! reduce searchsortedfirst searchsortedlast similar size sizeof sparse sum unique
+unsafe_string vcat view zeros include println exit isfile joinpath abspath dirname get! haskey Dict Set Vector Matrix string
+Symbol parse map collect sort sort! any all abs sqrt count in setdiff union last reverse copy copyto! fill! resize! append!
+isnothing something convert reshape vec Ref Ptr unsafe_load cd mktempdir rm mkpath normpath pathof isdefined Module replace read""".split())
+
+
+def _jl_strip(src):
+    """comments and string contents removed (quotes and newlines kept)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("#=", i):
+            j = src.find("=#", i + 2)
+            j = n if j < 0 else j
+            out.append("\n" * src[i:j].count("\n"))
+            i = j + 2
+        elif c == "#":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith('"""', i):
+            j = src.find('"""', i + 3)
+            j = n if j < 0 else j
+            out.append('""' + "\n" * src[i:j].count("\n"))
+            i = j + 3
+        elif c == '"':
+            j = i + 1
+            while j < n and src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""' + "\n" * src[i:j].count("\n"))
+            i = j + 1
+        elif c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and i + 3 < n and src[i + 3] == "'")):
+            out.append("' '")
+            i += 3 if src[i + 2] == "'" else 4
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _jl_args(text, start):
+    """(argument text, end) of the parenthesis opened just before `start`"""
+    d, j = 1, start
+    while j < len(text) and d > 0:
+        d += text[j] in "([{"
+        d -= text[j] in ")]}"
+        j += 1
+    return text[start:j - 1], j
+
+
+def _jl_positional(args):
+    pos = [a for a in split_top(args.split(";")[0]) if a.strip()]
+    return [a for a in pos if not re.match(r"\s*[A-Za-z_]\w*\s*=(?!=)", a)], [a for a in pos if re.match(r"\s*[A-Za-z_]\w*\s*=(?!=)", a)]
+
+
+def _jl_defs(text):
+    """{name: set of (min, max) positional arities} of the functions `text` defines; struct names with arity None"""
+    defs = {}
+    for m in re.finditer(r"(?:\bfunction\s+(?:[A-Za-z_]\w*\.)?|^[ \t]*)([A-Za-z_][A-Za-z0-9_!]*)\(", text, re.M):
+        args, j = _jl_args(text, m.end())
+        if not (m.group(0).lstrip().startswith("function") or re.match(r"\s*(where[^=\n]*)?=(?!=)", text[j:j + 60])):
+            continue
+        pos, opt = _jl_positional(args)
+        var = any(a.strip().endswith("...") for a in pos)
+        defs.setdefault(m.group(1), set()).add((len(pos), 10 ** 6 if var else len(pos) + len(opt)))
+    for name in re.findall(r"\bstruct\s+([A-Za-z_]\w*)", text):
+        defs.setdefault(name, set())
+    for name in re.findall(r"\b([A-Za-z_][A-Za-z0-9_!]*)\s*=\s*(?:\([^)\n]*\)|[A-Za-z_]\w*)\s*->", text):   # closures
+        defs.setdefault(name, set())
+    return defs
+
+
+@pytest.mark.parametrize("fname", sorted(f for f in os.listdir(JL_DIR) if f.endswith(".jl")))
+def test_julia_sources_are_structurally_sound(fname):
+    s = _jl_strip(open(os.path.join(JL_DIR, fname)).read())
+    # brackets
+    stack, line = [], 1
+    for ch in s:
+        line += ch == "\n"
+        if ch in "([{":
+            stack.append((ch, line))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == {")": "(", "]": "[", "}": "{"}[ch], (fname, "bracket mismatch at line", line)
+            stack.pop()
+    assert not stack, (fname, "unclosed", stack[-3:])
+    # blocks: openers and `end` outside any bracket (inside: generators, comprehensions, a[end])
+    depth, opens, ends = 0, [], 0
+    line = 1
+    for m in re.finditer(r"[()\[\]{}]|\b[A-Za-z_][A-Za-z0-9_!]*\b|\n", s):
+        t = m.group(0)
+        if t == "\n":
+            line += 1
+        elif t in "([{":
+            depth += 1
+        elif t in ")]}":
+            depth -= 1
+        elif depth == 0 and t in ("function", "if", "for", "while", "let", "try", "begin", "do", "struct", "module", "quote",
+                                  "macro"):
+            opens.append((t, line))
+        elif depth == 0 and t == "end":
+            ends += 1
+            assert len(opens) >= ends, (fname, "`end` without an opener at line", line)
+    assert len(opens) == ends, (fname, "block openers", len(opens), "ends", ends)
+    # names and arities
+    own = _jl_defs(s)
+    ref = {}
+    if os.path.isdir("/root/reference/src"):
+        for root, _, files in os.walk("/root/reference/src"):
+            for f in files:
+                if f.endswith(".jl"):
+                    for k, v in _jl_defs(_jl_strip(open(os.path.join(root, f)).read())).items():
+                        ref.setdefault(k, set()).update(v)
+        for f in ("test_utils.jl",):
+            for k, v in _jl_defs(_jl_strip(open(os.path.join("/root/reference/test", f)).read())).items():
+                ref.setdefault(k, set()).update(v)
+    if fname != "CircuitscapeHIPExt.jl":   # the suite script includes the binding
+        for k, v in _jl_defs(_jl_strip(JL)).items():
+            own.setdefault(k, set()).update(v)
+    for m in re.finditer(r"(?<![\.\w@:])([A-Za-z_][A-Za-z0-9_!]*)\(", s):
+        name = m.group(1)
+        ln = s[:m.start()].count("\n") + 1
+        known = own.get(name, ref.get(name))
+        if known is None:
+            if re.fullmatch(r"[A-Z]", name):
+                continue                                    # T(x), V(i): conversion to a type parameter
+            assert name in JL_BASE or not ref, (fname, ln, "call of an unknown function", name)
+            continue
+        if re.search(r"\bfunction\s+(?:[A-Za-z_]\w*\.)?$", s[:m.start()]) or not known:
+            continue                                        # the definition itself / a struct constructor / a closure
+        args, j = _jl_args(s, m.end())
+        if re.match(r"\s*(where[^=\n]*)?=(?!=)", s[j:j + 60]) or any(a.strip().endswith("...") for a in split_top(args)):
+            continue                                        # a short-form definition / a splatted call
+        k = len(_jl_positional(args)[0])
+        assert any(lo <= k <= hi for lo, hi in known), (fname, ln, name, "called with", k, "positional arguments; methods:",
+                                                        sorted(known))
+
+
+def _jl_fields(text):
+    out = set()
+    for m in re.finditer(r"\bstruct\s+[^\n]*\n(.*?)\n\s*end\b", text, re.S):
+        for part in re.split(r"[;\n]", m.group(1)):
+            mm = re.match(r"([A-Za-z_]\w*)\s*(::|$)", part.strip())
+            if mm and mm.group(1) not in ("function", "end", "new"):
+                out.add(mm.group(1))
+    return out
+
+
+def test_julia_binding_reads_only_fields_that_exist():
+    """every `x.field` the binding reads or writes is a field of one of its own structs, of a struct of the reference's src/
+    (GraphProblem, ComponentData, OutputFlags, CSConfig, Cumulative ... -- checked when the checkout is present), or of
+    SparseMatrixCSC"""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference checkout not present")
+    s = _jl_strip(JL)
+    known = _jl_fields(s) | {"colptr", "rowval", "nzval"}
+    for root, _, files in os.walk("/root/reference/src"):
+        for f in files:
+            if f.endswith(".jl"):
+                known |= _jl_fields(_jl_strip(open(os.path.join(root, f)).read()))
+    used = set(re.findall(r"(?<=[\w\)\]])\.([A-Za-z_]\w*)\b(?!\s*\()", s))
+    assert len(used) > 40 and not (used - known), sorted(used - known)
