@@ -356,3 +356,14 @@ def test_julia_binding_reads_only_fields_that_exist():
                 known |= _jl_fields(_jl_strip(open(os.path.join(root, f)).read()))
     used = set(re.findall(r"(?<=[\w\)\]])\.([A-Za-z_]\w*)\b(?!\s*\()", s))
     assert len(used) > 40 and not (used - known), sorted(used - known)
+
+
+def test_julia_opts_are_only_built_through_default_opts():
+    """`CsgpuOpts() = new()` leaves the fields undefined until csgpu_default_opts has filled them: the bare
+    constructor is called in one place, default_opts, right before that ccall; every other site goes through default_opts."""
+    s = _jl_strip(JL)
+    sites = [m.start() for m in re.finditer(r"(?<![\w.])CsgpuOpts\(\)(?!\s*=)", s)]
+    assert len(sites) == 1, sites
+    body = s[sites[0]:sites[0] + 200]
+    assert "csgpu_default_opts" in body and s[:sites[0]].rstrip().endswith("o =") and "function default_opts" in s[:sites[0]][-80:]
+    assert len(re.findall(r"\bdefault_opts\(", s)) >= 5
