@@ -1732,7 +1732,7 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
     return out
 
 
-def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4):
+def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4, exact=True):
     """Host matrices with 2^31 stored entries and more (use_64bit_indexing, src/run.jl:34: raster pairwise problems above
     238 M cells) cannot be held in CSR form on the device; csgpu_setup streams them in blocks of rows into the lattice
     form (csgpu.hip, setup_from_host_streamed). CSGPU_STREAM_HOST_CSR=<entries per block> sends a small matrix down the
@@ -1742,7 +1742,8 @@ def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4):
     raster (ordinary twin: lattice detected from the matrix + CSR pipeline); (3) both against the tight oracle; (4) a
     matrix the path cannot take (polygon: a coupling between cells that are not neighbours; no coordinates; a numbering
     that is not column-major) declines and takes the ordinary path when it is small enough to have one. Which path a
-    handle took is read from csgpu_info.host_blocks."""
+    handle took is read from csgpu_info.host_blocks. exact=False (the device twin, written when no device time was left to
+    try it): 1e-9 / one iteration per column instead of bit-identity between the two handles of (1)."""
     import scipy.sparse as sp
     from circuitscape_jl_amd import solver as ps
 
@@ -1785,7 +1786,10 @@ def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4):
             assert is_["n"] == len(comp) and is_["nnz"] == A.nnz and is_["lattice_period"] == R0, is_
             assert is_["level_n"] == ib["level_n"] and is_["level_form"] == ib["level_form"], (is_, ib)
             assert sts["not_converged"] == 0 and np.max(np.abs(Rs - Ro) / Ro) < 1e-6
-            assert np.array_equal(Rs, Rb) and sts["total_iters"] == stb["total_iters"], (Rs - Rb, sts, stb)
+            if exact:
+                assert np.array_equal(Rs, Rb) and sts["total_iters"] == stb["total_iters"], (Rs - Rb, sts, stb)
+            else:
+                assert np.max(np.abs(Rs - Rb) / Rb) < 1e-9 and abs(sts["total_iters"] - stb["total_iters"]) <= batch
     # (2) all-valid raster in the reference's column-major numbering
     ga = np.exp(np.random.default_rng(23).standard_normal((41, 38)))
     nma = rg.construct_node_map(ga, None)

@@ -35,4 +35,4 @@ def test_matrices_above_2_31_entries_are_admitted_only_with_coordinates(emu_lib)
 @pytest.mark.gpu
 def test_streamed_host_csr_matches_ordinary_path_gpu(gpu_lib, oracle):
     from helpers import check_streamed_host_csr
-    check_streamed_host_csr(gpu_lib, oracle)
+    check_streamed_host_csr(gpu_lib, oracle, exact=False)
