@@ -1360,3 +1360,10 @@ def test_the_residual_alone_decides_convergence_like_the_reference(emu_lib):
         with pytest.raises(emu_lib.CsgpuError) as e:
             h.solve_pairs([0, 5], [N * N - 1, N * N - 7])
         assert e.value.code == emu_lib.CSGPU_NOT_CONVERGED and "exceeds tolerance 1e-4" in str(e.value)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixtures_in_single_precision(emu_lib, name):
+    """see helpers.check_golden_single_precision: runtests(precision = "single") of test/test_utils.jl through the product path"""
+    from helpers import check_golden_single_precision
+    check_golden_single_precision(emu_lib, name)

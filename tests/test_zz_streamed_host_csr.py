@@ -36,3 +36,12 @@ def test_matrices_above_2_31_entries_are_admitted_only_with_coordinates(emu_lib)
 def test_streamed_host_csr_matches_ordinary_path_gpu(gpu_lib, oracle):
     from helpers import check_streamed_host_csr
     check_streamed_host_csr(gpu_lib, oracle, exact=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("conftest").golden_cases())
+def test_golden_fixtures_in_single_precision_gpu(gpu_lib, name):
+    """runtests(precision = "single") of test/test_utils.jl through the product path on the device (helpers.
+    check_golden_single_precision; emulator twin in test_emu_solver.py: worst case 1.8e-3 against the reference's 1e-2)"""
+    from helpers import check_golden_single_precision
+    check_golden_single_precision(gpu_lib, name)
