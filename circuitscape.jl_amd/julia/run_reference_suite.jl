@@ -10,7 +10,9 @@
 #      advanced, raster pairwise 1-17, raster advanced 1-6, one-to-all 1-13, all-to-one 1-12: resistances, voltage and
 #      current maps, at the reference's tolerances 1e-6 / 1e-4),
 #   3. the include / exclude-pairs scenarios of test/issue341.jl with the solver line of every generated INI rewritten,
-#   4. (--single) the suite once more with `precision = single`.
+#   4. (--single) the suite once more with `precision = single` (expect sgVerify17 to miss the helper's 1e-2 criterion with ANY
+#      solver: the Float32 regularisation shift of core.jl:161 moves that case's exact solution by 1.0e-2 relative, DESIGN.md
+#      section 2 "the fp32 contract"; the Python mirror of this run is tests/helpers.py::check_golden_single_precision).
 # The build image of this repository has no Julia (INTEGRATION.md), so this file has never been executed; what it calls is
 # mirrored line by line by tests/ (Python host mirror + ctypes) -- tests/test_gpu_golden.py runs the same 54 cases and
 # tests/test_issue341.py the same scenarios on the device. tests/test_julia_binding.py checks this script statically
