@@ -10,7 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so")
+# (CSGPU_EMU_LIB: another build of the same emulator library, e.g. one compiled with -fsanitize=address -- tools/README.md)
+EMU_LIB = os.environ.get("CSGPU_EMU_LIB", os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so"))
 
 
 def pytest_configure(config):
