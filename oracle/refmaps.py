@@ -246,7 +246,9 @@ def _maps_from_fixture(case):
 
 
 def raster_advanced_from_fixture(case, mode="direct", solve=None):
-    """raster_advanced (raster/advanced.jl:17-34) on a tests/golden mgVerify fixture.
+    """raster_advanced (raster/advanced.jl:17-34) on a tests/golden mgVerify fixture. Pinned on the reference's mgVerify1..6
+    voltage / current map goldens and on mgVerify7_curmap.asc (355 x 481 cells, 5574 finite grounds: the largest golden the
+    reference ships; its own suite stops at 6) with the reference's criterion sum(abs2, x - r) < 1e-6 (tests/test_oracle_golden.py).
     Returns {'voltmap': processed voltage map, 'curmap': processed current map, 'volt': raw per-cell voltages}."""
     o = case["options"]
     gmap = np.asarray(case["cellmap"], dtype=np.float64)
