@@ -495,56 +495,95 @@ def _masked_jacobi_cg(G, b, ground, rtol=1e-12, maxiter=2000):
     return x, flag, res
 
 
-def config4_network_leg(lib, dev_index, n=5000000, nsrc=16, ncheck=2, torch=None, dev=None):
+def csr_spmm_roofline(st, info, K):
+    """roofline object of the CSR SpMM that is the CG product of a handle without lattice structure (networks): algorithmic
+    bytes per launch nnz (val + 4) + (n + 1) 4 + n K (x + val) (reported by the library) / the mean HIP-event
+    duration of those launches in this call."""
+    calls = max(st["cg_spmv_calls"], 1)
+    avg_ms = st["cg_spmv_ms"] / calls
+    nbytes = st["cg_spmv_bytes"]
+    ach = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    tp = "float" if (info["precond_bytes"] or info["val_bytes"]) == 4 else "double"
+    return {"bound": "hbm", "kernel": "csgpu::spmv_kernel<%s, %d, ...> (CSR SpMM, the CG product A p of a network)" % (tp, K),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "traffic_source": "not collected in this run (profiles/r6_network_* hold the rocprofv3 --pmc passes)",
+            "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms, "launches_timed": st["cg_spmv_calls"]}
+
+
+def one_to_all_columns(focal):
+    """advanced one-to-all over the focal nodes (src/raster/onetoall.jl:106-117): column s = unit current into focal[s],
+    every other focal node tied to ground; the check node of a column is its source (`res[i] = v[1]`, onetoall.jl:141)."""
+    focal = [int(q) for q in focal]
+    return [[p] for p in focal], [[q for q in focal if q != p] for p in focal], focal
+
+
+def config4_network_leg(lib, dev_index, n=5000000, nsrc=16, ncheck=2, torch=None, dev=None, batch=16):
     """BASELINE configs[4] at its stated size on one GPU (5e6 nodes, 5e7 undirected edges -> 1.05e8 stored entries):
     network mode, advanced one-to-all (src/raster/advanced.jl:274-312, src/network/advanced.jl:1-51) -- unit current at one
-    focal node, the other focal nodes tied to ground, every source a column of ONE csgpu_solve_grounded on ONE handle.
+    focal node, the other focal nodes tied to ground, every source a column of ONE csgpu_solve_sources call on ONE handle:
+    sparse right-hand sides in (a column is a single +1), the sources' voltages and the cumulative node-current vector out
+    (what the one-to-all driver keeps, onetoall.jl:141,153-158) -- no n x nrhs array crosses PCIe in the timed call. Reported
+    wall AND device (HIP-event time of the PCG loops) with a roofline of the CSR SpMM.
     This random graph is an expander: the setup declines to coarsen it, so the preconditioner is JACOBI (levels = 1), not
-    AMG. Every column's residual is checked on the host, and the first `ncheck` columns against an independent scipy
-    Jacobi-CG solve of the reduced system at true-residual 1e-12 (parity: resistance to the grounded set + whole voltage
-    vector)."""
+    AMG. The first `ncheck` columns are solved again with their voltages handed back (untimed) and compared with an
+    independent scipy Jacobi-CG solve of the reduced system at true-residual 1e-12 (parity: resistance to the grounded set +
+    whole voltage vector), and their true residual is evaluated on the host."""
     t0 = time.perf_counter()
     G, rng = random_network(n, torch=torch, dev=dev)
     t_gen = time.perf_counter() - t0
     n = G.shape[0]
     focal = rng.choice(n, size=nsrc, replace=False)
+    src, grounds, chk = one_to_all_columns(focal)
     t0 = time.perf_counter()
-    h = lib.setup(G, lib.default_opts(device=dev_index, batch=16, precond_bytes=4, itmax=2000), index_dtype=np.int32,
+    h = lib.setup(G, lib.default_opts(device=dev_index, batch=batch, precond_bytes=4, itmax=2000), index_dtype=np.int32,
                   index_base=0)
     t_setup = time.perf_counter() - t0
     try:
         info = h.info
-        B = np.zeros((n, nsrc))
-        grounds = []
-        for s_ in range(nsrc):
-            B[focal[s_], s_] = 1.0
-            grounds.append([int(q) for q in focal if q != focal[s_]])
+        h.solve_sources(src[:1], grounds[:1], check=chk[:1])          # (untimed: code objects, work vectors)
+        cum = np.zeros(n)
         t0 = time.perf_counter()
-        X, _, st = h.solve_grounded(B, grounds)
+        v, _, _, st = h.solve_sources(src, grounds, check=chk, cum=cum)
         t_solve = time.perf_counter() - t0
+        nck = min(ncheck, nsrc)
+        vck, X, _, stck = h.solve_sources(src[:nck], grounds[:nck], check=chk[:nck], want_voltages=True)
+        K = st["batch"]
     finally:
         h.close()
-    worst = 0.0
-    for s_ in range(nsrc):
-        r = G @ X[:, s_] - B[:, s_]
+    t0 = time.perf_counter()
+    rerr, verr, cres, worst = 0.0, 0.0, 0.0, 0.0
+    for s_ in range(nck):
+        b = np.zeros(n)
+        b[focal[s_]] = 1.0
+        r = G @ X[:, s_] - b
         r[grounds[s_]] = 0.0
         worst = max(worst, float(np.linalg.norm(r)))
-    t0 = time.perf_counter()
-    rerr, verr, cres = 0.0, 0.0, 0.0
-    for s_ in range(min(ncheck, nsrc)):
-        xs, flag, res = _masked_jacobi_cg(G, B[:, s_], grounds[s_])
+        xs, flag, res = _masked_jacobi_cg(G, b, grounds[s_])
         cres = max(cres, res if flag == 0 else float("inf"))
-        rerr = max(rerr, abs(X[focal[s_], s_] - xs[focal[s_]]) / abs(xs[focal[s_]]))
+        rerr = max(rerr, abs(X[focal[s_], s_] - xs[focal[s_]]) / abs(xs[focal[s_]]),
+                   abs(v[s_] - xs[focal[s_]]) / abs(xs[focal[s_]]))   # (the timed call's answer for the same column too)
         verr = max(verr, float(np.max(np.abs(X[:, s_] - xs)) / np.max(np.abs(xs))))
     parity = {"max_rel_err": float(max(rerr, verr)), "max_rel_err_resistance": float(rerr), "max_rel_err_voltages": float(verr),
-              "tolerance": 1e-6, "ok": bool(max(rerr, verr) < 1e-6), "columns_checked": min(ncheck, nsrc),
+              "tolerance": 1e-6, "ok": bool(max(rerr, verr) < 1e-6), "columns_checked": nck,
               "checker": "scipy CG + Jacobi on the reduced system (masked operator), true residual %.1e" % cres,
               "check_s": time.perf_counter() - t0}
-    return {"value": nsrc / (t_setup + t_solve), "unit": "one-to-all sources/s (setup + solves)", "n": int(n), "nnz": int(G.nnz),
-            "undirected_edges": int((G.nnz - n) // 2), "sources": nsrc, "levels": info["levels"],
+    iters = st["total_iters"] / float(nsrc)
+    nbatches = -(-nsrc // max(K, 1))
+    dev_s = st["device_ms"] / 1e3
+    return {"value": nsrc / (t_setup + t_solve), "unit": "one-to-all sources/s (setup + solves, wall)",
+            "value_device": nsrc / (info["setup_ms"] / 1e3 + dev_s),
+            "value_device_note": "sources / (device time of the set-up + HIP-event time of the PCG loops)",
+            "n": int(n), "nnz": int(G.nnz),
+            "undirected_edges": int((G.nnz - n) // 2), "sources": nsrc, "batch": K, "levels": info["levels"],
             "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi (expander: the setup declines to coarsen, amg_setup.h)",
-            "setup_s": t_setup, "solve_s_all_sources": t_solve, "iters_mean": st["total_iters"] / float(nsrc),
-            "not_converged": st["not_converged"], "worst_true_residual_norm": worst, "generate_s": t_gen, "parity": parity}
+            "setup_s": t_setup, "setup_device_s": info["setup_ms"] / 1e3, "upload_s": info["upload_ms"] / 1e3,
+            "solve_s_all_sources": t_solve, "solve_device_s_all_sources": dev_s,
+            "pcg_device_ms_per_iteration": st["device_ms"] / max(st["max_iters"] * nbatches, 1),
+            "boundary": "csgpu_solve_sources: sparse right-hand sides in; %d source voltages + one cumulative node-current "
+                        "n-vector (%.0f MB) out" % (nsrc, n * 8 / 1e6),
+            "iters_mean": iters, "iters_max": st["max_iters"], "max_relres_device": st["max_relres"],
+            "not_converged": st["not_converged"], "worst_true_residual_norm": worst, "cum_current_sum": float(cum.sum()),
+            "generate_s": t_gen, "parity": parity, "roofline": csr_spmm_roofline(st, info, K)}
 
 
 def network_geometric_leg(lib, dev_index, tight, n=1000000, torch=None, dev=None):
@@ -575,7 +614,9 @@ def network_geometric_leg(lib, dev_index, tight, n=1000000, torch=None, dev=None
             "levels": info["levels"], "level_n": info["level_n"], "operator_complexity": info["operator_complexity"],
             "preconditioner": "AMG (hashed MIS(2) aggregation, CSR kernels)", "setup_s": t_setup, "setup_device_s": info["setup_ms"] / 1e3,
             "solve_s": t_solve, "pairs": len(src), "iters_mean": st["total_iters"] / float(len(src)), "max_relres": st["max_relres"],
-            "not_converged": st["not_converged"],
+            "not_converged": st["not_converged"], "solve_device_s": st["device_ms"] / 1e3,
+            "value_device": len(src) / ((info["setup_ms"] + st["device_ms"]) / 1e3), "batch": st["batch"],
+            "roofline": csr_spmm_roofline(st, info, st["batch"]),
             "parity": {"max_rel_err": rel, "tolerance": 1e-6, "ok": bool(rel < 1e-6), "pairs": len(src),
                        "oracle": "tight (true-residual rtol 1e-12) on the same graph", "oracle_max_true_relres": tight["max_true_relres"]}}
 
@@ -708,6 +749,10 @@ def main():
     ap.add_argument("--cpu-legs", default="", help="internal (CPU child): comma list of nodata,fp32,geometric")
     ap.add_argument("--leg-sample", type=int, default=2000,
                     help="raster edge of the samples on which the nodata15 / config3_fp32 legs are compared with the tight oracle")
+    ap.add_argument("--workload", default="raster", choices=["raster", "network"],
+                    help="raster = BASELINE configs[2] (the headline); network = BASELINE configs[4]: random network, "
+                         "advanced one-to-all, sources dealt over the GPUs (a step = one batch of --net-batch sources)")
+    ap.add_argument("--net-batch", type=int, default=16, help="--workload network: one-to-all sources per step")
     ap.add_argument("--network-n", type=int, default=5000000, help="nodes of the config4_network leg (BASELINE: 5e6)")
     ap.add_argument("--geometric-n", type=int, default=1000000, help="nodes of the network_geometric leg")
     args = ap.parse_args()
@@ -787,6 +832,9 @@ def main():
         idx = [(b * B + c) % len(pairs) for c in range(B)]
         return [pairs[i][0] for i in idx], [pairs[i][1] for i in idx]
 
+    if args.workload == "network":
+        network_workload(args, lib, torch, dist, dev, rank, world, sync)
+        return
     if args.scaling == "strong":
         strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, vb, pairs, sync)
         return
@@ -1221,6 +1269,113 @@ def strong_scaling(args, lib, torch, dist, dev, rank, world, make_opts, dtype, v
         else:
             out["rank0"] = reports[0]
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def network_workload(args, lib, torch, dist, dev, rank, world, sync):
+    """BASELINE configs[4] -- "Network-mode 50M-edge random Laplacian, advanced one-to-all, fp64, 8 x MI355X" -- as the
+    driver's command runs it: `bench.py --workload network --gpus N --steps K --warmup W`. Every rank builds the SAME random
+    network (5e6 nodes, 5e7 undirected edges; seeded generator) and its own replica of the handle ("replicas only across
+    sources"); a step = one batch of --net-batch one-to-all sources (unit current into one focal node, the
+    other focal nodes of the batch's focal set tied to ground: src/raster/onetoall.jl:106-117 -> multiple_solver,
+    src/raster/advanced.jl:274-312) through csgpu_solve_sources with the sources' voltages and the cumulative node-current
+    vector kept; the job's N * K batches are dealt over the ranks as contiguous slices (shard.solve_sources_sharded); the
+    timed region ends with the path's two collectives -- ONE all_gather of the sources' voltages and ONE all_reduce(SUM) of
+    the cumulative current vector (the serial merge of onetoall.jl:153-158; 40 MB at n = 5e6). Weak scaling: K batches per
+    GPU whatever N. Parity: rank 0 solves its first two columns again with voltages back and checks them against scipy's
+    Jacobi-CG on the reduced system."""
+    from circuitscape_jl_amd import shard
+    has_cuda = torch.cuda.is_available()
+    dev_index = dev.index if dev is not None and dev.index is not None else 0
+    B, K, Wm = args.net_batch, args.steps, args.warmup
+    t0 = time.perf_counter()
+    G, rng = random_network(args.network_n, torch=torch if has_cuda else None, dev=dev if has_cuda else None)
+    t_gen = time.perf_counter() - t0
+    n = G.shape[0]
+    # the focal set: B nodes per batch, (W + K) * world batches; a batch's columns ground the batch's other focal nodes
+    nb_total = (Wm + K) * world
+    focal = rng.choice(n, size=nb_total * B, replace=False).reshape(nb_total, B)
+    src, grounds, chk = [], [], []
+    for b in range(nb_total):
+        s_, g_, c_ = one_to_all_columns(focal[b])
+        src += s_
+        grounds += g_
+        chk += c_
+    t0 = time.perf_counter()
+    h = lib.setup(G, lib.default_opts(device=dev_index, batch=B, precond_bytes=4, itmax=2000), index_dtype=np.int32,
+                  index_base=0)
+    t_setup = time.perf_counter() - t0
+    info = h.info
+    gdev = dev if (has_cuda and (dist is None or args.backend == "nccl")) else None
+    nw = Wm * world * B
+    if nw > 0:   # warm-up batches: same code path incl. the collectives
+        shard.solve_sources_sharded(h, src[:nw], grounds[:nw], check=chk[:nw], dist=dist, device=gdev, want_cum=True)
+    sync()
+    t0 = time.perf_counter()
+    v, cum, _, stats = shard.solve_sources_sharded(h, src[nw:], grounds[nw:], check=chk[nw:], dist=dist, device=gdev,
+                                                   want_cum=True)
+    t_rank = time.perf_counter() - t0
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = stats[0] if stats else {"total_iters": 0, "max_iters": 0, "max_relres": 0.0, "not_converged": 0, "device_ms": 0.0,
+                                 "cg_spmv_ms": 0.0, "cg_spmv_calls": 0, "cg_spmv_bytes": 0, "batch": B}
+    agg = {"total_iters": st["total_iters"], "max_relres": st["max_relres"], "not_converged": st["not_converged"]}
+    reports = [rank_identity(torch, rank, dev_index, has_cuda, t_rank / max(K, 1) * 1e3, K * B, agg)]
+    multi = None
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        reports = [None] * world
+        dist.all_gather_object(reports, rank_identity(torch, rank, dev_index, has_cuda, t_rank / max(K, 1) * 1e3, K * B, agg))
+        multi = {"rccl_world_size": int(dist.get_world_size()), "dist_backend": str(dist.get_backend()), "ranks": reports,
+                 "distinct_devices": len({(r_["host"], r_["pci_bus_id"] or r_["device_ordinal"]) for r_ in reports}),
+                 "collectives": {"all_gather": "(index, voltage) rows, %d B per rank" % (K * B * 16),
+                                 "all_reduce_sum": "cumulative node-current vector, %d B" % (n * 8)},
+                 "gather": {"pairs_received": int(np.sum(~np.isnan(v)))}}
+    if rank == 0:
+        nsrc = K * B * world
+        out = {
+            "metric": "one-to-all sources/sec (PCG on one shared hierarchy, setup amortised over the job) on a %d-node network" % n,
+            "value": nsrc / (elapsed + t_setup), "unit": "one-to-all sources/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": elapsed / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "random network n = %d, %d undirected edges (BASELINE configs[4]), advanced one-to-all, "
+                                   "%d sources/GPU in batches of %d, fp64 (fp32 preconditioner)" % (n, (G.nnz - n) // 2, K * B, B),
+                       "n": int(n), "nnz": int(G.nnz), "batch": B, "levels": info["levels"],
+                       "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi (expander: the setup declines to coarsen)"},
+            "solve_only_sources_per_s": nsrc / elapsed, "setup_s": t_setup, "setup_device_s": info["setup_ms"] / 1e3,
+            "generate_s": t_gen, "iters_mean": st["total_iters"] / float(max(K * B, 1)), "iters_max": st["max_iters"],
+            "max_relres": st["max_relres"], "not_converged": st["not_converged"],
+            "pcg_device_ms_per_step": st["device_ms"] / max(K, 1), "rank0_wall_ms_per_step": t_rank / max(K, 1) * 1e3,
+            "value_device_rank0": K * B / max(st["device_ms"] / 1e3, 1e-12),
+            "roofline": csr_spmm_roofline(st, info, st["batch"]),
+            "all_sources_gathered": bool(not np.any(np.isnan(v))), "cum_current_sum": float(cum.sum()),
+        }
+        if multi is not None:
+            out["multi_gpu"] = multi
+        else:
+            out["rank0"] = reports[0]
+        # parity of this rank's first two columns (untimed): voltages back, scipy Jacobi-CG on the reduced system
+        try:
+            lo, _ = shard.pair_slice(K * B * world, rank, world)
+            cols = [nw + lo, nw + lo + 1][: min(2, K * B)]
+            vck, X, _, _ = h.solve_sources([src[c] for c in cols], [grounds[c] for c in cols], check=[chk[c] for c in cols],
+                                           want_voltages=True)
+            rerr = verr = 0.0
+            for k_, c in enumerate(cols):
+                b = np.zeros(n)
+                b[chk[c]] = 1.0
+                xs, flag, res = _masked_jacobi_cg(G, b, grounds[c])
+                rerr = max(rerr, abs(v[c - nw] - xs[chk[c]]) / abs(xs[chk[c]]), abs(vck[k_] - xs[chk[c]]) / abs(xs[chk[c]]))
+                verr = max(verr, float(np.max(np.abs(X[:, k_] - xs)) / np.max(np.abs(xs))))
+            out["parity"] = {"max_rel_err": float(max(rerr, verr)), "tolerance": 1e-6, "ok": bool(max(rerr, verr) < 1e-6),
+                             "columns_checked": len(cols), "checker": "scipy CG + Jacobi on the reduced system, true residual 1e-12"}
+        except Exception as e:
+            out["parity"] = {"failed": repr(e)}
+        print(json.dumps(out), flush=True)
+    h.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -16,6 +16,17 @@ namespace csgpu {
 
 static thread_local std::string g_last_error;
 
+// One call of the Dirichlet-masked solves (csgpu_solve_grounded / csgpu_solve_sources): right-hand sides dense (host column-major
+// n x nrhs) or as sparse columns, one ground set per column, what to hand back.
+struct GroundedJob {
+  const void* rhs = nullptr;                                 // dense right-hand sides, or ...
+  const int64_t *sptr = nullptr, *sidx = nullptr;            // ... sparse columns: entries [sptr[c], sptr[c+1]) of (sidx, sval)
+  const void* sval = nullptr;                                //     (NULL: every entry is 1)
+  const int64_t *gptr = nullptr, *gidx = nullptr;            // ground sets
+  const int64_t* check = nullptr;                            // per column: node whose voltage goes to check_out[c] (< 0: none)
+  void *check_out = nullptr, *x_out = nullptr, *curr_out = nullptr, *cum_inout = nullptr, *max_inout = nullptr;
+};
+
 struct ISolver {
   virtual ~ISolver() {}
   bool rebuilt_fp64 = false;  // the C API replaced the fp32 hierarchy the caller asked for by an fp64 one (csgpu_info)
@@ -24,8 +35,7 @@ struct ISolver {
                            csgpu_stats* stats, const int32_t* weights = nullptr, void* curr_out = nullptr,
                            void* cum_inout = nullptr, void* max_inout = nullptr, void* branch_out = nullptr) = 0;
   virtual void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) = 0;
-  virtual void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
-                              void* curr_out, csgpu_stats* stats) = 0;
+  virtual void solve_grounded(const GroundedJob& job, int64_t nrhs, csgpu_stats* stats) = 0;
   virtual void solve_region_pairs(const int64_t* set_ptr, const int64_t* set_nodes, int64_t nsets, const int64_t* src_set,
                                   const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) = 0;
   virtual void get_info(csgpu_info* info) const = 0;
@@ -1799,22 +1809,45 @@ struct Solver : ISolver {
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
-  // N2: per-column Dirichlet sets on one hierarchy (see csgpu_solve_grounded in csgpu.h)
-  void solve_grounded(const void* rhs, int64_t nrhs, const int64_t* gptr, const int64_t* gidx, void* x_out,
-                      void* curr_out, csgpu_stats* stats) override {
-    if (poly_proj) return poly_fallback().solve_grounded(rhs, nrhs, gptr, gidx, x_out, curr_out, stats);
+  // N2: per-column Dirichlet sets on one hierarchy (see csgpu_solve_grounded / csgpu_solve_sources in csgpu.h)
+  void solve_grounded(const GroundedJob& J, int64_t nrhs, csgpu_stats* stats) override {
+    if (poly_proj) return poly_fallback().solve_grounded(J, nrhs, stats);
     std::lock_guard<std::mutex> lk(mu);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
+    const int64_t* gptr = J.gptr;
+    const int64_t* gidx = J.gidx;
+    const int64_t* sptr = J.sptr;
+    const int64_t* sidx = J.sidx;
+    const bool sparse = J.rhs == nullptr;
     for (int64_t c = 0; c < nrhs; ++c) {
       CS_REQUIRE(gptr[c] <= gptr[c + 1], CSGPU_BAD_ARGS, "ground_ptr must be non-decreasing");
       for (int64_t e = gptr[c]; e < gptr[c + 1]; ++e)
         CS_REQUIRE(gidx[e] >= 0 && gidx[e] < n_api, CSGPU_BAD_ARGS, "ground node id out of range");
+      if (sparse) {
+        CS_REQUIRE(sptr[c] <= sptr[c + 1], CSGPU_BAD_ARGS, "source_ptr must be non-decreasing");
+        for (int64_t e = sptr[c]; e < sptr[c + 1]; ++e)
+          CS_REQUIRE(sidx[e] >= 0 && sidx[e] < n_api, CSGPU_BAD_ARGS, "source node id out of range");
+      }
+      if (J.check) CS_REQUIRE(J.check[c] < n_api, CSGPU_BAD_ARGS, "check node id out of range");
     }
     const Ids gidx_r = rows_of(gidx + gptr[0], gptr[nrhs] - gptr[0]);  // row ids of the device matrix (cell space)
     gidx = gidx_r.p - gptr[0];
+    Ids sidx_r;
+    if (sparse) {
+      sidx_r = rows_of(sidx + sptr[0], sptr[nrhs] - sptr[0]);
+      sidx = sidx_r.p - sptr[0];
+    }
+    std::vector<int64_t> chk_in;  // (a negative id = no check node: mapped as node 0, masked again afterwards)
+    Ids chk_r;
+    if (J.check) {
+      chk_in.resize((size_t)nrhs);
+      for (int64_t c = 0; c < nrhs; ++c) chk_in[(size_t)c] = std::max<int64_t>(J.check[c], 0);
+      chk_r = rows_of(chk_in.data(), nrhs);
+    }
     const int K = pick_k(nrhs);
+    const bool want_curr = J.curr_out || J.cum_inout || J.max_inout;
     ensure_csr();
     W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
@@ -1822,16 +1855,45 @@ struct Solver : ISolver {
       stats->nrhs = (int)nrhs;
       stats->batch = K;
     }
-    int64_t maxg = 1;
-    for (int64_t p0 = 0; p0 < nrhs; p0 += K) maxg = std::max(maxg, gptr[std::min(nrhs, p0 + K)] - gptr[p0]);
-    DBuf stage((size_t)n * K * sizeof(T)), dgp = dalloc<int>(K + 1), dgi = dalloc<int>((size_t)maxg);
-    DBuf dcurr, dbpart, dbmax;
-    if (curr_out) {
+    int64_t maxg = 1, maxs = 1;
+    for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
+      maxg = std::max(maxg, gptr[std::min(nrhs, p0 + K)] - gptr[p0]);
+      if (sparse) maxs = std::max(maxs, sptr[std::min(nrhs, p0 + K)] - sptr[p0]);
+    }
+    DBuf stage, dgp = dalloc<int>(K + 1), dgi = dalloc<int>((size_t)maxg);
+    if (!sparse || J.x_out || J.curr_out) stage.alloc((size_t)n * K * sizeof(T));
+    DBuf dsrow, dscol, dsval, dchk, dchkv;
+    if (sparse) {
+      dsrow = dalloc<int>((size_t)maxs);
+      dscol = dalloc<int>((size_t)maxs);
+      dsval = dalloc<T>((size_t)maxs);
+    }
+    if (J.check && J.check_out) {
+      dchk = dalloc<int>(K);
+      dchkv = dalloc<T>(K);
+    }
+    DBuf dcurr, dbpart, dbmax, dcum, dmax, dweight;
+    if (want_curr) {
       dcurr.alloc((size_t)n * K * sizeof(T));
       dbpart.alloc((size_t)kMaxGrid * K * 2 * sizeof(double));
       dbmax.alloc((size_t)K * 2 * sizeof(double));
+      if (J.cum_inout || J.max_inout) dweight.alloc((size_t)K * sizeof(int));
+      if (J.cum_inout) {
+        dcum.alloc((size_t)n * sizeof(T));
+        CS_HIP(hipMemsetAsync(dcum.p, 0, dcum.bytes, st));
+      }
+      if (J.max_inout) {
+        dmax.alloc((size_t)n * sizeof(T));
+        CS_HIP(hipMemsetAsync(dmax.p, 0, dmax.bytes, st));
+      }
     }
-    std::vector<int> hp(K + 1), hi;
+    std::vector<int> hp(K + 1), hi, srow, scol, w32(K), c32(K);
+    std::vector<T> sval, chkv(K);
+    struct Ent {
+      int col, row;
+      T val;
+    };
+    std::vector<Ent> ents;
     for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
       const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
       hi.clear();
@@ -1843,15 +1905,47 @@ struct Solver : ISolver {
       hp[K] = (int)hi.size();
       CS_HIP(hipMemcpyAsync(dgp.p, hp.data(), (size_t)(K + 1) * sizeof(int), hipMemcpyHostToDevice, st));
       if (!hi.empty()) CS_HIP(hipMemcpyAsync(dgi.p, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      upload_cols((const T*)rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
-      CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
-                                           (const T*)dptr<T>(stage), ncols, W.rhs()));
+      if (!sparse) {
+        upload_cols((const T*)J.rhs + (size_t)p0 * n_api, ncols, dptr<T>(stage));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((interleave_kernel<T, KK>), dim3(grid_for(n * K)), dim3(256), 0, st, n,
+                                             (const T*)dptr<T>(stage), ncols, W.rhs()));
+      } else {
+        // the batch's entries, duplicates of one (column, node) summed on the host in the caller's order (a few entries per
+        // column: a one-to-all column is a single +1 and does not cross PCIe as 8 n bytes of zeros)
+        ents.clear();
+        for (int c = 0; c < ncols; ++c)
+          for (int64_t e = sptr[p0 + c]; e < sptr[p0 + c + 1]; ++e)
+            ents.push_back(Ent{c, (int)sidx[e], J.sval ? ((const T*)J.sval)[e] : T(1)});
+        std::stable_sort(ents.begin(), ents.end(),
+                         [](const Ent& a, const Ent& b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+        srow.clear();
+        scol.clear();
+        sval.clear();
+        for (const Ent& e : ents) {
+          if (!srow.empty() && scol.back() == e.col && srow.back() == e.row) {
+            sval.back() += e.val;
+          } else {
+            srow.push_back(e.row);
+            scol.push_back(e.col);
+            sval.push_back(e.val);
+          }
+        }
+        CS_HIP(hipMemsetAsync(W.rhs(), 0, (size_t)n * K * sizeof(T), st));
+        if (!srow.empty()) {
+          CS_HIP(hipMemcpyAsync(dsrow.p, srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice, st));
+          CS_HIP(hipMemcpyAsync(dscol.p, scol.data(), scol.size() * sizeof(int), hipMemcpyHostToDevice, st));
+          CS_HIP(hipMemcpyAsync(dsval.p, sval.data(), sval.size() * sizeof(T), hipMemcpyHostToDevice, st));
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((sparse_rhs_kernel<T, KK>), dim3(ceil_div((int)srow.size(), 256)), dim3(256), 0,
+                                               st, (int)srow.size(), (const int*)dptr<int>(dsrow),
+                                               (const int*)dptr<int>(dscol), (const T*)dptr<T>(dsval), W.rhs()));
+        }
+      }
       const int gtotal = (int)hi.size();
       if (gtotal > 0)
         CS_DISPATCH_K(K, hipLaunchKernelGGL((mask_grounds_kernel<T, T, KK>), dim3(ceil_div(gtotal, 256)), dim3(256), 0, st,
                                              (const int*)dptr<int>(dgp), (const int*)dptr<int>(dgi), W.rhs(),
                                              (T*)nullptr, (const int*)nullptr));
-      CS_HIP(hipStreamSynchronize(st));  // hp / hi are reused by the next batch
+      CS_HIP(hipStreamSynchronize(st));  // hp / hi / the entry lists are reused by the next batch
       PcgBatchResult r;
       {
         PcgParams pp = pcg_params(K);
@@ -1862,10 +1956,21 @@ struct Solver : ISolver {
         CS_DISPATCH_K(K, r = (pcg_solve<T, TP, KK>(cg_matrix(), H, W, pp, ncols, st, dia_ptr())));
       }
       accumulate(stats, r, ncols);
-      CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
-                                           (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
-      download_cols((const T*)dptr<T>(stage), ncols, (T*)x_out + (size_t)p0 * n_api);
-      if (curr_out) {
+      if (J.check && J.check_out) {
+        for (int c = 0; c < K; ++c) c32[c] = (c < ncols && J.check[p0 + c] >= 0) ? (int)chk_r[p0 + c] : -1;
+        CS_HIP(hipMemcpyAsync(dchk.p, c32.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((gather_columns_kernel<T, KK>), dim3(1), dim3(64), 0, st,
+                                             (const T*)dptr<T>(W.x), (const int*)dptr<int>(dchk), ncols, dptr<T>(dchkv)));
+        CS_HIP(hipMemcpyAsync(chkv.data(), dchkv.p, (size_t)K * sizeof(T), hipMemcpyDeviceToHost, st));
+        CS_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < ncols; ++c) ((T*)J.check_out)[p0 + c] = chkv[c];
+      }
+      if (J.x_out) {
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                             (const T*)dptr<T>(W.x), ncols, dptr<T>(stage)));
+        download_cols((const T*)dptr<T>(stage), ncols, (T*)J.x_out + (size_t)p0 * n_api);
+      }
+      if (want_curr) {
         const Csr<T>& A = cg_matrix();
         const int gc = grid_for(n * K);
         CS_DISPATCH_K(K, hipLaunchKernelGGL((branch_max_kernel<T, KK>), dim3(gc), dim3(256), 0, st, (int)n, A.rp(), A.ci(),
@@ -1876,13 +1981,37 @@ struct Solver : ISolver {
                                             A.va(), (const T*)dptr<T>(W.x), (const double*)dptr<double>(dbmax),
                                             dptr<T>(dcurr), (const T*)nullptr, (const int*)nullptr,
                                             (const unsigned long long*)nullptr));
-        CS_HIP(hipStreamSynchronize(st));  // stage still feeds the copy of x
-        CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
-                                            (const T*)dptr<T>(dcurr), ncols, dptr<T>(stage)));
-        download_cols((const T*)dptr<T>(stage), ncols, (T*)curr_out + (size_t)p0 * n_api);
+        if (J.curr_out) {
+          CS_HIP(hipStreamSynchronize(st));  // stage still feeds the copy of x
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((deinterleave_kernel<T, KK>), dim3(grid_for(n * ncols)), dim3(256), 0, st, n,
+                                              (const T*)dptr<T>(dcurr), ncols, dptr<T>(stage)));
+          download_cols((const T*)dptr<T>(stage), ncols, (T*)J.curr_out + (size_t)p0 * n_api);
+        }
+        if (J.cum_inout || J.max_inout) {
+          // the reference's serial merge after the fan-out over the focal points (src/raster/onetoall.jl:153-158)
+          for (int c = 0; c < K; ++c) w32[c] = c < ncols ? 1 : 0;
+          CS_HIP(hipMemcpyAsync(dweight.p, w32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
+          CS_DISPATCH_K(K, hipLaunchKernelGGL((current_accumulate_kernel<T, KK>), dim3(grid_for(n)), dim3(256), 0, st, (int)n,
+                                              (const T*)dptr<T>(dcurr), ncols, (const int*)dptr<int>(dweight),
+                                              J.cum_inout ? dptr<T>(dcum) : (T*)nullptr,
+                                              J.max_inout ? dptr<T>(dmax) : (T*)nullptr));
+        }
       }
       check_launch("solve_grounded batch");
       CS_HIP(hipStreamSynchronize(st));
+    }
+    if (J.cum_inout || J.max_inout) {
+      std::vector<T> tmp((size_t)n_api);
+      if (J.cum_inout) {
+        download_cols((const T*)dptr<T>(dcum), 1, tmp.data());
+        T* h = (T*)J.cum_inout;
+        for (int64_t i = 0; i < n_api; ++i) h[i] += tmp[i];
+      }
+      if (J.max_inout) {
+        download_cols((const T*)dptr<T>(dmax), 1, tmp.data());
+        T* h = (T*)J.max_inout;
+        for (int64_t i = 0; i < n_api; ++i) h[i] = tmp[i] > h[i] ? tmp[i] : h[i];
+      }
     }
     if (stats) stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -2788,19 +2917,13 @@ int csgpu_solve_region_pairs(csgpu_handle* h, const int64_t* set_ptr, const int6
   CS_API_END
 }
 
-int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
-                         const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats) {
+static int grounded_call(csgpu_handle* h, const csgpu::GroundedJob& job, int64_t nrhs, csgpu_stats* stats) {
   CS_API_BEGIN
-  if (!h || nrhs < 0 || (nrhs > 0 && (!rhs || !x_out || !ground_ptr)) ||
-      (nrhs > 0 && ground_ptr[nrhs] > ground_ptr[0] && !ground_idx)) {
-    g_last_error = "bad arguments";
-    return CSGPU_BAD_ARGS;
-  }
   csgpu_stats local;
   csgpu_stats* s = stats ? stats : &local;
   memset(s, 0, sizeof(*s));
   if (nrhs == 0) return CSGPU_OK;
-  h->solver->solve_grounded(rhs, nrhs, ground_ptr, ground_idx, x_out, curr_out, s);
+  h->solver->solve_grounded(job, nrhs, s);
   if (s->not_converged > 0) {
     char buf[256];
     snprintf(buf, sizeof(buf), "CG solver did not converge: relative residual %g exceeds tolerance 1e-4 (%d of %d right-hand sides)",
@@ -2810,6 +2933,56 @@ int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const i
   }
   return CSGPU_OK;
   CS_API_END
+}
+
+int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
+                         const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats) {
+  if (!h || nrhs < 0 || (nrhs > 0 && (!rhs || !x_out || !ground_ptr)) ||
+      (nrhs > 0 && ground_ptr[nrhs] > ground_ptr[0] && !ground_idx)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu::GroundedJob job;
+  job.rhs = rhs;
+  job.gptr = ground_ptr;
+  job.gidx = ground_idx;
+  job.x_out = x_out;
+  job.curr_out = curr_out;
+  return grounded_call(h, job, nrhs, stats);
+}
+
+static bool sources_args_ok(int64_t nrhs, const int64_t* source_ptr, const int64_t* source_idx, const int64_t* ground_ptr,
+                            const int64_t* ground_idx, const int64_t* check_node, const void* check_out) {
+  if (nrhs < 0) return false;
+  if (nrhs == 0) return true;
+  if (!source_ptr || !ground_ptr) return false;
+  if (source_ptr[nrhs] > source_ptr[0] && !source_idx) return false;
+  if (ground_ptr[nrhs] > ground_ptr[0] && !ground_idx) return false;
+  if ((check_out != nullptr) != (check_node != nullptr)) return false;
+  return true;
+}
+
+int csgpu_solve_sources(csgpu_handle* h, int64_t nrhs, const int64_t* source_ptr, const int64_t* source_idx,
+                        const void* source_val, const int64_t* ground_ptr, const int64_t* ground_idx,
+                        const int64_t* check_node, void* check_out, void* x_out, void* curr_out, void* cum_curr_inout,
+                        void* max_curr_inout, csgpu_stats* stats) {
+  if (!h || !sources_args_ok(nrhs, source_ptr, source_idx, ground_ptr, ground_idx, check_node, check_out)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu::GroundedJob job;
+  job.sptr = source_ptr;
+  job.sidx = source_idx;
+  job.sval = source_val;
+  job.gptr = ground_ptr;
+  job.gidx = ground_idx;
+  job.check = check_node;
+  job.check_out = check_out;
+  job.x_out = x_out;
+  job.curr_out = curr_out;
+  job.cum_inout = cum_curr_inout;
+  job.max_inout = max_curr_inout;
+  return grounded_call(h, job, nrhs, stats);
 }
 
 int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms) {
@@ -2950,6 +3123,43 @@ int multi_build(const csgpu_opts* opts, const int32_t* devices, int ndevices, in
     }
   *out = m.release();
   return CSGPU_OK;
+}
+
+// the per-device cumulative / maximum node-current vectors of a job combined into the caller's arrays in slot order (sum /
+// max: deterministic), the index range split over host threads
+void multi_combine_maps(size_t nd, int64_t n, size_t vb, const std::vector<std::vector<char>>& cum,
+                        const std::vector<std::vector<char>>& mx, void* cum_curr_inout, void* max_curr_inout) {
+  auto combine = [&](int64_t lo, int64_t hi) {
+    for (size_t i = 0; i < nd; ++i) {
+      if (cum_curr_inout && !cum[i].empty()) {
+        if (vb == 8) {
+          double* o = (double*)cum_curr_inout;
+          const double* a = (const double*)cum[i].data();
+          for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
+        } else {
+          float* o = (float*)cum_curr_inout;
+          const float* a = (const float*)cum[i].data();
+          for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
+        }
+      }
+      if (max_curr_inout && !mx[i].empty()) {
+        if (vb == 8) {
+          double* o = (double*)max_curr_inout;
+          const double* a = (const double*)mx[i].data();
+          for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
+        } else {
+          float* o = (float*)max_curr_inout;
+          const float* a = (const float*)mx[i].data();
+          for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
+        }
+      }
+    }
+  };
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(nd, (size_t)(n / 1000000 + 1)));
+  std::vector<std::thread> ct;
+  for (int t = 1; t < nt; ++t) ct.emplace_back(combine, n * t / nt, n * (t + 1) / nt);
+  combine(0, n / nt);
+  for (auto& t : ct) t.join();
 }
 
 }  // namespace
@@ -3152,42 +3362,146 @@ int csgpu_multi_solve_pairs_currents(csgpu_multi* m, const int64_t* src, const i
       g_last_error = "device " + std::to_string(m->devices[i]) + ": " + msgs[i];
     }
   }
-  if (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED) {
-    // combine in slot order, the index range split over host threads
-    auto combine = [&](int64_t lo, int64_t hi) {
-      for (size_t i = 0; i < nd; ++i) {
-        if (cum_curr_inout && !cum[i].empty()) {
-          if (vb == 8) {
-            double* o = (double*)cum_curr_inout;
-            const double* a = (const double*)cum[i].data();
-            for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
-          } else {
-            float* o = (float*)cum_curr_inout;
-            const float* a = (const float*)cum[i].data();
-            for (int64_t k = lo; k < hi; ++k) o[k] += a[k];
-          }
-        }
-        if (max_curr_inout && !mx[i].empty()) {
-          if (vb == 8) {
-            double* o = (double*)max_curr_inout;
-            const double* a = (const double*)mx[i].data();
-            for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
-          } else {
-            float* o = (float*)max_curr_inout;
-            const float* a = (const float*)mx[i].data();
-            for (int64_t k = lo; k < hi; ++k) o[k] = a[k] > o[k] ? a[k] : o[k];
-          }
-        }
-      }
-    };
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(nd, (size_t)(n / 1000000 + 1)));
-    std::vector<std::thread> ct;
-    for (int t = 1; t < nt; ++t) ct.emplace_back(combine, n * t / nt, n * (t + 1) / nt);
-    combine(0, n / nt);
-    for (auto& t : ct) t.join();
-  }
+  if (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)
+    multi_combine_maps(nd, n, vb, cum, mx, cum_curr_inout, max_curr_inout);
   s->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return rc_out;
+  CS_API_END
+}
+
+}  // extern "C"
+
+namespace {
+
+// Columns of a Dirichlet-masked job dealt over the devices of a set: slot i takes the contiguous range [lo_i, hi_i) of the
+// caller's columns (sizes differ by at most one column; the pointer arrays of the caller are used as they are, offset by
+// the range) and runs it as ONE call on its handle, so that the cumulative / maximum node-current vectors of its columns
+// stay in its HBM for the whole job; the per-device vectors are combined on the host in slot order (deterministic).
+// job_of(lo, hi) returns the GroundedJob of that range without the cumulative / maximum pointers.
+template <class F>
+int multi_grounded(csgpu_multi* m, int64_t nrhs, void* cum_curr_inout, void* max_curr_inout, csgpu_stats* stats, F job_of) {
+  csgpu_stats local;
+  csgpu_stats* s = stats ? stats : &local;
+  memset(s, 0, sizeof(*s));
+  const size_t nd = m->handles.size();
+  std::fill(m->busy_s.begin(), m->busy_s.end(), 0.0);
+  std::fill(m->pairs_done.begin(), m->pairs_done.end(), 0);
+  if (nrhs == 0) return CSGPU_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  csgpu_info info;
+  int rc = csgpu_get_info(m->handles[0], &info);
+  if (rc) return rc;
+  const int64_t n = info.n;
+  const size_t vb = (size_t)m->val_bytes;
+  std::vector<int> codes(nd, CSGPU_OK);
+  std::vector<std::string> msgs(nd);
+  std::vector<csgpu_stats> st(nd);
+  for (auto& x : st) memset(&x, 0, sizeof(x));
+  std::vector<std::vector<char>> cum(nd), mx(nd);
+  auto worker = [&](size_t slot) {
+    auto w0 = std::chrono::steady_clock::now();
+    const int64_t base = nrhs / (int64_t)nd, rem = nrhs % (int64_t)nd;
+    const int64_t lo = (int64_t)slot * base + std::min<int64_t>((int64_t)slot, rem);
+    const int64_t hi = lo + base + ((int64_t)slot < rem ? 1 : 0);
+    if (hi > lo) {
+      csgpu::GroundedJob job = job_of(lo, hi);
+      if (cum_curr_inout) {
+        cum[slot].assign((size_t)n * vb, 0);
+        job.cum_inout = cum[slot].data();
+      }
+      if (max_curr_inout) {
+        mx[slot].assign((size_t)n * vb, 0);
+        job.max_inout = mx[slot].data();
+      }
+      codes[slot] = grounded_call(m->handles[slot], job, hi - lo, &st[slot]);
+      if (codes[slot]) msgs[slot] = csgpu_last_error();
+      m->pairs_done[slot] = hi - lo;
+    }
+    m->busy_s[slot] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < nd; ++i) th.emplace_back(worker, i);
+  worker(0);
+  for (auto& t : th) t.join();
+  s->nrhs = (int)nrhs;
+  int rc_out = CSGPU_OK;
+  for (size_t i = 0; i < nd; ++i) {
+    s->total_iters += st[i].total_iters;
+    s->max_iters = std::max(s->max_iters, st[i].max_iters);
+    s->max_relres = std::max(s->max_relres, st[i].max_relres);
+    s->device_ms = std::max(s->device_ms, st[i].device_ms);
+    s->cg_spmv_ms += st[i].cg_spmv_ms;
+    s->cg_spmv_calls += st[i].cg_spmv_calls;
+    s->not_converged += st[i].not_converged;
+    s->graph_launches += st[i].graph_launches;
+    s->polished_batches += st[i].polished_batches;
+    s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->batch = std::max(s->batch, st[i].batch);
+    if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
+      rc_out = codes[i];
+      g_last_error = "device " + std::to_string(m->devices[i]) + ": " + msgs[i];
+    }
+  }
+  if ((rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED) && (cum_curr_inout || max_curr_inout))
+    multi_combine_maps(nd, n, vb, cum, mx, cum_curr_inout, max_curr_inout);
+  s->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc_out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csgpu_multi_solve_grounded(csgpu_multi* m, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
+                               const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!m || nrhs < 0 || (nrhs > 0 && (!rhs || !x_out || !ground_ptr)) ||
+      (nrhs > 0 && ground_ptr[nrhs] > ground_ptr[0] && !ground_idx)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_info info;
+  int rc = csgpu_get_info(m->handles[0], &info);
+  if (rc) return rc;
+  const size_t colb = (size_t)info.n * (size_t)m->val_bytes;
+  return multi_grounded(m, nrhs, nullptr, nullptr, stats, [&](int64_t lo, int64_t) {
+    csgpu::GroundedJob job;
+    job.rhs = (const char*)rhs + (size_t)lo * colb;
+    job.gptr = ground_ptr + lo;
+    job.gidx = ground_idx;
+    job.x_out = (char*)x_out + (size_t)lo * colb;
+    job.curr_out = curr_out ? (char*)curr_out + (size_t)lo * colb : nullptr;
+    return job;
+  });
+  CS_API_END
+}
+
+int csgpu_multi_solve_sources(csgpu_multi* m, int64_t nrhs, const int64_t* source_ptr, const int64_t* source_idx,
+                              const void* source_val, const int64_t* ground_ptr, const int64_t* ground_idx,
+                              const int64_t* check_node, void* check_out, void* x_out, void* curr_out,
+                              void* cum_curr_inout, void* max_curr_inout, csgpu_stats* stats) {
+  CS_API_BEGIN
+  if (!m || !sources_args_ok(nrhs, source_ptr, source_idx, ground_ptr, ground_idx, check_node, check_out)) {
+    g_last_error = "bad arguments";
+    return CSGPU_BAD_ARGS;
+  }
+  csgpu_info info;
+  int rc = csgpu_get_info(m->handles[0], &info);
+  if (rc) return rc;
+  const size_t vb = (size_t)m->val_bytes, colb = (size_t)info.n * vb;
+  return multi_grounded(m, nrhs, cum_curr_inout, max_curr_inout, stats, [&](int64_t lo, int64_t) {
+    csgpu::GroundedJob job;
+    job.sptr = source_ptr + lo;
+    job.sidx = source_idx;
+    job.sval = source_val;
+    job.gptr = ground_ptr + lo;
+    job.gidx = ground_idx;
+    job.check = check_node ? check_node + lo : nullptr;
+    job.check_out = check_out ? (char*)check_out + (size_t)lo * vb : nullptr;
+    job.x_out = x_out ? (char*)x_out + (size_t)lo * colb : nullptr;
+    job.curr_out = curr_out ? (char*)curr_out + (size_t)lo * colb : nullptr;
+    return job;
+  });
   CS_API_END
 }
 

@@ -91,4 +91,22 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(int64_t n, const T* _
   }
 }
 
+// sparse right-hand sides (csgpu_solve_sources): b (interleaved n x K, pre-zeroed) gets val[e] at (row[e], col[e]); the host
+// has merged duplicates, so every (row, col) occurs once -- plain stores, deterministic
+template <class T, int K>
+__global__ __launch_bounds__(256) void sparse_rhs_kernel(int cnt, const int* __restrict__ row, const int* __restrict__ col,
+                                                         const T* __restrict__ val, T* __restrict__ b) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < cnt) b[(size_t)row[e] * K + col[e]] = val[e];
+}
+
+// out[c] = x[node[c]][c] for the columns of a batch (node < 0: 0) -- the voltage of a one-to-all column's check node
+// (`res[i] = v[1]`, src/raster/onetoall.jl:141)
+template <class T, int K>
+__global__ __launch_bounds__(64) void gather_columns_kernel(const T* __restrict__ x, const int* __restrict__ node, int ncols,
+                                                            T* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c < K) out[c] = (c < ncols && node[c] >= 0) ? x[(size_t)node[c] * K + c] : T(0);
+}
+
 }  // namespace csgpu

@@ -21,11 +21,11 @@ AGG_AUTO, AGG_MIS2, AGG_GRID = 0, 1, 2
 
 EXPORTS = [
     "csgpu_device_count", "csgpu_default_opts", "csgpu_setup", "csgpu_raster_setup", "csgpu_get_info",
-    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_solve_region_pairs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
+    "csgpu_solve_pairs", "csgpu_solve_pairs_currents", "csgpu_solve_rhs", "csgpu_solve_grounded", "csgpu_solve_sources", "csgpu_solve_region_pairs", "csgpu_spmv_bench", "csgpu_spmv_host", "csgpu_level_spmv_host",
     "csgpu_get_level_matrix", "csgpu_raster_nodemap", "csgpu_components", "csgpu_raster_setup_grounded", "csgpu_raster_setup_poly",
     "csgpu_solve_raster", "csgpu_dia_product_host",
     "csgpu_multi_setup", "csgpu_multi_raster_setup", "csgpu_multi_solve_pairs", "csgpu_multi_solve_pairs_currents",
-    "csgpu_multi_device_count",
+    "csgpu_multi_solve_grounded", "csgpu_multi_solve_sources", "csgpu_multi_device_count",
     "csgpu_multi_handle", "csgpu_multi_last_busy", "csgpu_multi_free",
     "csgpu_free", "csgpu_trim_memory", "csgpu_last_error", "csgpu_version",
 ]
@@ -98,6 +98,7 @@ def _bind(L):
     L.csgpu_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_rhs.argtypes = [vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_grounded.argtypes = [vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_solve_sources.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_solve_region_pairs.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, ctypes.POINTER(Stats)]
     L.csgpu_spmv_bench.argtypes = [vp, i32, i32, ctypes.POINTER(dbl)]
     L.csgpu_spmv_host.argtypes = [vp, vp, vp, i32]
@@ -115,6 +116,8 @@ def _bind(L):
     L.csgpu_multi_solve_pairs.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_multi_solve_pairs_currents.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_multi_solve_pairs_currents.restype = ctypes.c_int
+    L.csgpu_multi_solve_grounded.argtypes = [vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(Stats)]
+    L.csgpu_multi_solve_sources.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Stats)]
     L.csgpu_multi_device_count.argtypes = [vp]
     L.csgpu_multi_handle.argtypes = [vp, i32]
     L.csgpu_multi_handle.restype = vp
@@ -178,6 +181,43 @@ def default_opts(**kw):
             raise TypeError("unknown option %r" % k)
         setattr(o, k, v)
     return o
+
+
+def _ragged(lists):
+    """(ptr[len + 1], idx) int64 arrays of a list of lists of node ids"""
+    ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum([len(q) for q in lists])
+    idx = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.int64).ravel() for q in lists])
+                               if ptr[-1] > 0 else np.zeros(1, dtype=np.int64))
+    return ptr, idx
+
+
+def _sources_args(dtype, n, sources, grounds, values, check, want_voltages, want_currents, cum, mx):
+    """Marshal the arguments of csgpu_[multi_]solve_sources. sources / grounds: one list of 0-based node ids per column
+    (a bare int = that one node); values: None (all ones) or one list of numbers per column, matching `sources`;
+    check: None or one node id per column (< 0: none)."""
+    sources = [[q] if np.isscalar(q) else list(q) for q in sources]
+    nrhs = len(sources)
+    assert len(grounds) == nrhs
+    sptr, sidx = _ragged(sources)
+    gptr, gidx = _ragged(grounds)
+    sval = None
+    if values is not None:
+        values = [[v] if np.isscalar(v) else list(v) for v in values]
+        assert [len(v) for v in values] == [len(q) for q in sources]
+        sval = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=dtype) for v in values])
+                                    if sptr[-1] > 0 else np.zeros(1, dtype=dtype))
+    chk = np.ascontiguousarray(check, dtype=np.int64) if check is not None else None
+    assert chk is None or chk.shape == (nrhs,)
+    cout = np.zeros(nrhs, dtype=dtype) if chk is not None else None
+    X = np.zeros((n, nrhs), dtype=dtype, order="F") if want_voltages else None
+    C = np.zeros((n, nrhs), dtype=dtype, order="F") if want_currents else None
+    for a in (cum, mx):
+        assert a is None or (a.dtype == dtype and a.flags["C_CONTIGUOUS"] and a.shape == (n,))
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    args = [nrhs, sptr.ctypes.data, sidx.ctypes.data, ptr(sval), gptr.ctypes.data, gidx.ctypes.data, ptr(chk), ptr(cout),
+            ptr(X), ptr(C), ptr(cum), ptr(mx)]
+    return args, (sptr, sidx, sval, gptr, gidx, chk), cout, X, C
 
 
 class Handle:
@@ -295,6 +335,19 @@ class Handle:
         if one:
             return X[:, 0], (C[:, 0] if C is not None else None), st.as_dict()
         return X, C, st.as_dict()
+
+    def solve_sources(self, sources, grounds, values=None, check=None, want_voltages=False, want_currents=False,
+                      cum=None, mx=None):
+        """csgpu_solve_sources: sparse right-hand sides (column c = `values[c]` -- default ones -- at the nodes
+        `sources[c]`), x = 0 on `grounds[c]`. check: one node per column whose voltage is returned (the one-to-all
+        drivers' `res[i] = v[1]`). cum / mx: optional length-n arrays updated in place with the columns' node currents.
+        Returns (check voltages or None, voltages (n, nrhs) or None, currents or None, stats)."""
+        args, keep, cout, X, C = _sources_args(self.dtype, self.info["n"], sources, grounds, values, check, want_voltages,
+                                               want_currents, cum, mx)
+        st = Stats()
+        _check(lib().csgpu_solve_sources(self._p, *args, ctypes.byref(st)))
+        del keep
+        return cout, X, C, st.as_dict()
 
     def solve_region_pairs(self, sets, src_set, dst_set):
         """csgpu_solve_region_pairs: `sets` = list of lists of 0-based node ids; effective resistance between the
@@ -488,6 +541,41 @@ class MultiHandle:
         d["device_busy_s"] = busy.tolist()
         d["device_pairs"] = done.tolist()
         return res, d
+
+    def solve_grounded(self, rhs, grounds, want_currents=False):
+        """csgpu_multi_solve_grounded: Handle.solve_grounded with the columns dealt over the devices (contiguous ranges).
+        Returns (x, currents or None, stats incl. per-device busy seconds and column counts)."""
+        B = np.asfortranarray(np.asarray(rhs, dtype=self.dtype).reshape(np.shape(rhs)[0], -1))
+        assert len(grounds) == B.shape[1] and B.shape[0] == self.info(0)["n"]
+        gptr, gidx = _ragged(grounds)
+        X = np.zeros_like(B, order="F")
+        C = np.zeros_like(B, order="F") if want_currents else None
+        st = Stats()
+        _check(lib().csgpu_multi_solve_grounded(self._p, B.ctypes.data, B.shape[1], gptr.ctypes.data, gidx.ctypes.data,
+                                                X.ctypes.data, C.ctypes.data if C is not None else None, ctypes.byref(st)))
+        return X, C, _multi_busy(self, st)
+
+    def solve_sources(self, sources, grounds, values=None, check=None, want_voltages=False, want_currents=False,
+                      cum=None, mx=None):
+        """csgpu_multi_solve_sources: Handle.solve_sources with the columns dealt over the devices. Returns (check
+        voltages or None, voltages or None, currents or None, stats incl. per-device busy seconds / columns)."""
+        args, keep, cout, X, C = _sources_args(self.dtype, self.info(0)["n"], sources, grounds, values, check,
+                                               want_voltages, want_currents, cum, mx)
+        st = Stats()
+        _check(lib().csgpu_multi_solve_sources(self._p, *args, ctypes.byref(st)))
+        del keep
+        return cout, X, C, _multi_busy(self, st)
+
+
+def _multi_busy(mh, st):
+    nd = mh.ndevices
+    busy = np.zeros(nd)
+    done = np.zeros(nd, dtype=np.int64)
+    lib().csgpu_multi_last_busy(mh._p, busy.ctypes.data, done.ctypes.data)
+    d = st.as_dict()
+    d["device_busy_s"] = busy.tolist()
+    d["device_pairs"] = done.tolist()
+    return d
 
 
 def _device_list(devices):

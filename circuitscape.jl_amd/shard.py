@@ -1,4 +1,5 @@
-"""Multi-GPU sharding of the pairwise path: independent pair solves, replicated matrix + hierarchy, one gather.
+"""Multi-GPU sharding of the pairwise path (independent pair solves) and of the one-to-all / all-to-one path (independent
+sources): replicated matrix + hierarchy, one gather (+ one reduction of the cumulative current map when it is asked for).
 
 The reference has no distributed layer; its only parallelism is one task per source point
 (Threads.@spawn, src/core.jl:262-272), which gives a triangular load (core.jl:265-267). Here the unit of work is a
@@ -118,4 +119,46 @@ def solve_pairs_currents_sharded(handle, src, dst, batch, dist=None, device=None
         tm = tm.to(device) if device is not None else tm
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         mx = tm.cpu().numpy()
+    return full, cum, mx, stats
+
+
+def solve_sources_sharded(handle, sources, grounds, check=None, values=None, dist=None, device=None, want_cum=False,
+                          want_max=False):
+    """BASELINE configs[4] across ranks -- advanced one-to-all / all-to-one on one graph: the fan-out over the focal points
+    (`Threads.@spawn(f(x))` per point, src/raster/onetoall.jl:146-151, each a multiple_solver call,
+    src/raster/advanced.jl:274-312) with one process per GPU. "Replicas only across sources" (SURVEY.md section 8e): every
+    rank holds the whole matrix + hierarchy and solves a CONTIGUOUS slice of the columns (pair_slice: sizes differ by at
+    most one column) as one csgpu_solve_sources call; the columns' check voltages (`res[i] = v[1]`, onetoall.jl:141) are
+    gathered with ONE all_gather, and -- when the cumulative / maximum current map is asked for -- the per-rank n-vectors
+    are combined with ONE all_reduce each (SUM / MAX: the serial merge of onetoall.jl:153-158). Returns (check voltages of
+    all columns, cum or None, max or None, [stats of this rank]) identical on every rank."""
+    nrhs = len(sources)
+    n = handle.info["n"]
+    dt = handle.dtype
+    cum = np.zeros(n, dtype=dt) if want_cum else None
+    mx = np.zeros(n, dtype=dt) if want_max else None
+    chk = None if check is None else np.asarray(check, dtype=np.int64)
+    if dist is None or dist.get_world_size() == 1:
+        v, _, _, st = handle.solve_sources(sources, grounds, values=values, check=chk, cum=cum, mx=mx)
+        return (None if v is None else np.asarray(v, dtype=np.float64)), cum, mx, [st]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = pair_slice(nrhs, rank, world)
+    stats = []
+    v = np.zeros(0)
+    if hi > lo:
+        v, _, _, st = handle.solve_sources(sources[lo:hi], grounds[lo:hi], values=None if values is None else values[lo:hi],
+                                           check=None if chk is None else chk[lo:hi], cum=cum, mx=mx)
+        stats.append(st)
+    full = None
+    if chk is not None:
+        full = gather_pairs(np.asarray(v, dtype=np.float64), np.arange(lo, hi), nrhs, dist, device)
+    if want_cum or want_max:
+        import torch
+        for arr, op in ((cum, dist.ReduceOp.SUM), (mx, dist.ReduceOp.MAX)):
+            if arr is None:
+                continue
+            t = torch.from_numpy(arr)
+            t = t.to(device) if device is not None else t
+            dist.all_reduce(t, op=op)
+            arr[:] = t.cpu().numpy()
     return full, cum, mx, stats

@@ -22,6 +22,12 @@
  *   csgpu_solve_grounded   <-> multiple_solver with infinite grounds (src/raster/advanced.jl:274-305) as the one-to-all /
  *                              all-to-one drivers call it per focal point (src/raster/onetoall.jl:106-151): many
  *                              ground sets, one hierarchy
+ *   csgpu_solve_sources    <-> the same for the sparse right-hand sides those drivers build (one +1 per one-to-all column), with
+ *                              what they keep of a solve: `res[i] = v[1]` (onetoall.jl:141) and the accumulated current maps
+ *                              (onetoall.jl:153-158); network advanced mode src/network/advanced.jl:1-51
+ *   csgpu_multi_solve_grounded, csgpu_multi_solve_sources
+ *                          <-> the fan-out of those drivers over the focal points (Threads.@spawn per point,
+ *                              src/raster/onetoall.jl:146-151) as one host thread per GPU
  *   csgpu_solve_pairs_currents <-> the same plus postprocess() -> write_cur_maps -> _create_current_maps
  *                              (core.jl:655-683, out.jl:46-115,150-303): node currents, cumulative and maximum maps
  *   csgpu_multi_setup, csgpu_multi_raster_setup, csgpu_multi_solve_pairs, csgpu_multi_solve_pairs_currents, csgpu_multi_free
@@ -343,8 +349,25 @@ int csgpu_solve_rhs(csgpu_handle* h, const void* rhs, int64_t nrhs, void* x_out,
 int csgpu_solve_grounded(csgpu_handle* h, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
                          const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats);
 
-/* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
- * library's stream (k up to 32); returns the average milliseconds per launch. Used by bench.py for the roofline line. */
+/* csgpu_solve_grounded for right-hand sides with a few entries each -- the one-to-all / all-to-one drivers of the reference
+ * (src/raster/onetoall.jl:77-158, network advanced mode src/network/advanced.jl:1-51 -> src/raster/advanced.jl:274-312): a
+ * one-to-all column is ONE +1 (a dense n x nrhs upload would move 8 n bytes of zeros per column: 640 MB for 16 columns at
+ * n = 5e6), and what the drivers keep of a solve is the voltage of one node and the accumulated current maps, not the n x nrhs
+ * voltages. Column c: right-hand side = sum of source_val[e] at node source_idx[e], e in [source_ptr[c], source_ptr[c+1])
+ * (source_val NULL: every entry is 1; several entries at one node are summed; 0-based node ids), x = 0 on column c's ground
+ * set as in csgpu_solve_grounded.
+ *   check_out[c]        = x[check_node[c]] of column c (`res[i] = v[1]`, onetoall.jl:141); check_node[c] < 0: 0. Both NULL or
+ *                         both given.
+ *   x_out, curr_out     = n x nrhs voltages / node currents as in csgpu_solve_grounded                     may be NULL
+ *   cum_curr_inout[i]  += sum_c curr_c[i];  max_curr_inout[i] = max(max_curr_inout[i], max_c curr_c[i])    may be NULL
+ *                         (the serial merge after the fan-out over the focal points, onetoall.jl:153-158; accumulated on the
+ *                         device, one n-vector back per call)
+ * Host arrays of the handle's value type. stats->device_ms is the HIP-event time of the PCG loops. */
+int csgpu_solve_sources(csgpu_handle* h, int64_t nrhs, const int64_t* source_ptr, const int64_t* source_idx,
+                        const void* source_val, const int64_t* ground_ptr, const int64_t* ground_idx,
+                        const int64_t* check_node, void* check_out, void* x_out, void* curr_out, void* cum_curr_inout,
+                        void* max_curr_inout, csgpu_stats* stats);
+
 /* Scope row N2 / missing item "focal regions" -- effective resistance between SHORT-CIRCUITED NODE SETS on one
  * hierarchy. With focal regions (several cells per focal id) the reference merges the two regions of every pair into
  * one node each and builds a fresh graph and a fresh hierarchy per pair (_pt_file_polygons_path,
@@ -363,6 +386,8 @@ int csgpu_solve_region_pairs(csgpu_handle* h, const int64_t* set_ptr, const int6
                              const int64_t* src_set, const int64_t* dst_set, int64_t npairs, double* resistances,
                              csgpu_stats* stats);
 
+/* Time `reps` launches of the fine-level CSR SpMV (batch width k in {1,2,4,8,16}) with HIP events on the
+ * library's stream (k up to 32); returns the average milliseconds per launch. Used by bench.py for the roofline line. */
 int csgpu_spmv_bench(csgpu_handle* h, int k, int reps, double* avg_ms);
 
 /* y = A x on the device for host vectors (tests: parity of the SpMV kernel itself). */
@@ -418,6 +443,21 @@ int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* d
 int csgpu_multi_solve_pairs_currents(csgpu_multi* m, const int64_t* src, const int64_t* dst, int64_t npairs,
                                      const int32_t* weights, void* cum_curr_inout, void* max_curr_inout, void* resist_out,
                                      csgpu_stats* stats);
+/* BASELINE configs[4] across the GPUs of a node -- the fan-out over the focal points of the one-to-all / all-to-one drivers
+ * (`Threads.@spawn(f(x))` per focal point, src/raster/onetoall.jl:146-151, each f a multiple_solver call,
+ * src/raster/advanced.jl:274-312) as one host thread per GPU: device slot i takes the contiguous range of columns
+ * [i*nrhs/nd ...) (sizes differ by at most one column) and runs it as ONE csgpu_solve_grounded / csgpu_solve_sources call on
+ * its replica of the hierarchy, writing straight into the caller's arrays; cumulative / maximum current vectors stay in each
+ * device's HBM for the whole job and are combined on the host in slot order (sum / max; the merge of onetoall.jl:153-158).
+ * "Replicas only across sources" (SURVEY.md section 8e): no device-to-device traffic. Arguments, outputs and status as in the
+ * single-handle calls; stats merged as in csgpu_multi_solve_pairs (device_ms = the busiest device);
+ * csgpu_multi_last_busy reports seconds and columns per slot. */
+int csgpu_multi_solve_grounded(csgpu_multi* m, const void* rhs, int64_t nrhs, const int64_t* ground_ptr,
+                               const int64_t* ground_idx, void* x_out, void* curr_out, csgpu_stats* stats);
+int csgpu_multi_solve_sources(csgpu_multi* m, int64_t nrhs, const int64_t* source_ptr, const int64_t* source_idx,
+                              const void* source_val, const int64_t* ground_ptr, const int64_t* ground_idx,
+                              const int64_t* check_node, void* check_out, void* x_out, void* curr_out,
+                              void* cum_curr_inout, void* max_curr_inout, csgpu_stats* stats);
 /* number of devices of the set; handle of device slot i (for csgpu_get_info etc.; owned by the set); per-slot wall
  * seconds spent inside the last csgpu_multi_solve_pairs (busy_s: ndevices doubles, may be NULL) */
 int csgpu_multi_device_count(const csgpu_multi* m);

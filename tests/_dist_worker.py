@@ -28,10 +28,19 @@ def main():
     mine = shard.shard_batches(len(src), 4, rank, world)
     # scope row N1 across ranks: cumulative / maximum node-current vectors, one all_reduce(SUM) + one all_reduce(MAX)
     R2, cum, mx, _ = shard.solve_pairs_currents_sharded(h, src, dst, batch=4, dist=dist, want_max=True)
+    # BASELINE configs[4] across ranks: one-to-all columns dealt as contiguous slices, check voltages gathered, the
+    # cumulative / maximum node-current vectors reduced (SUM / MAX)
+    pts = [int(c) for c in cells]
+    osrc = [[p] for p in pts]
+    ognd = [[q for q in pts if q != p] for p in pts]
+    v, ocum, omx, ost = shard.solve_sources_sharded(h, osrc, ognd, check=pts, dist=dist, want_cum=True, want_max=True)
+    lo, hi = shard.pair_slice(len(pts), rank, world)
     h.close()
     if rank == 0:
         json.dump({"R": full.tolist(), "src": src, "dst": dst, "n_mine_rank0": int(len(mine)), "world": world,
-                   "R2": R2.tolist(), "cum": cum.tolist(), "max": mx.tolist()}, open(out_path, "w"))
+                   "R2": R2.tolist(), "cum": cum.tolist(), "max": mx.tolist(), "pts": pts, "v": v.tolist(),
+                   "ocum": ocum.tolist(), "omax": omx.tolist(), "cols_rank0": [lo, hi], "ost_nrhs": ost[0]["nrhs"]},
+                  open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

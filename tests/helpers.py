@@ -432,6 +432,86 @@ def check_grounded_solves(L, shape=(50, 46), npts=9, batch=8, tol=5e-6):
             assert np.max(np.abs(C1[:, 0] - ref)) < 1e-9 * max(1.0, ref.max())
 
 
+def sources_problem(shape=(50, 46), npts=9, seed=1, holes=0.0):
+    """One-to-all and all-to-one columns on a raster (holes > 0: NODATA cells, focal nodes in the giant component) in the
+    sparse form csgpu_solve_sources takes and in the dense form of csgpu_solve_grounded: (g, G, pts, cases) with cases =
+    [(sources, values, grounds, check, B dense)]."""
+    import scipy.sparse.csgraph as csg
+    rng = np.random.default_rng(seed)
+    R, C = shape
+    g = np.exp(rng.standard_normal((R, C)))
+    if holes > 0:
+        g[rng.random((R, C)) < holes] = 0.0
+    G = rg.laplacian(rg.construct_graph(g, rg.construct_node_map(g, None), False, False)).tocsr()
+    n = G.shape[0]
+    _, lab = csg.connected_components(G, directed=False)
+    big = np.flatnonzero(lab == np.bincount(lab).argmax())
+    pts = [int(q) for q in rng.choice(big, size=npts, replace=False)]
+    one = ([[p] for p in pts], None, [[q for q in pts if q != p] for p in pts], pts)
+    strength = [[1.0 + 0.5 * k for k, q in enumerate(pts) if q != p] for p in pts]
+    all_ = ([[q for q in pts if q != p] for p in pts], strength, [[p] for p in pts], [-1] * npts)
+    cases = []
+    for src, val, gnd, chk in (one, all_):
+        B = np.zeros((n, npts))
+        for c in range(npts):
+            for k, q in enumerate(src[c]):
+                B[q, c] += 1.0 if val is None else val[c][k]
+        cases.append((src, val, gnd, chk, B))
+    return g, G, pts, cases
+
+
+def check_solve_sources(L, shape=(50, 46), npts=9, batch=4, holes=0.0, pbs=(0, 4)):
+    """csgpu_solve_sources == csgpu_solve_grounded on the same columns handed over densely -- voltages, node currents, the
+    voltage of the check node, cumulative / maximum current vectors (+= / max with what the caller passes in), duplicate
+    entries of one node summed, outputs that are not asked for left alone -- and both against a sparse direct solve of
+    every reduced system (src/raster/advanced.jl:282-288). One-to-all columns (a single +1: what the sparse form is for,
+    src/raster/onetoall.jl:106-117) and all-to-one columns with variable source strengths; ragged last batch."""
+    import scipy.sparse.linalg as spla
+    g, G, pts, cases = sources_problem(shape, npts, holes=holes)
+    n = G.shape[0]
+    Gc = G.tocsc()
+    for pb in pbs:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), reg=False) as h:
+            assert h.info["n"] == n
+            for src, val, gnd, chk, B in cases:
+                Xd, Cd, std = h.solve_grounded(B, gnd, want_currents=True)
+                cum = np.full(n, 0.25)
+                mx = np.full(n, 1e-3)
+                v, X, C, st = h.solve_sources(src, gnd, values=val, check=chk, want_voltages=True, want_currents=True,
+                                              cum=cum, mx=mx)
+                assert st["not_converged"] == 0 and st["total_iters"] == std["total_iters"] and st["nrhs"] == npts
+                assert st["device_ms"] > 0
+                assert np.array_equal(X, Xd) and np.array_equal(C, Cd)   # the same right-hand sides bit for bit
+                for c in range(npts):
+                    assert v[c] == (X[chk[c], c] if chk[c] >= 0 else 0.0)
+                    keep = np.setdiff1d(np.arange(n), gnd[c])
+                    xs = np.zeros(n)
+                    xs[keep] = spla.spsolve(Gc[keep][:, keep].tocsc(), B[keep, c])
+                    assert np.max(np.abs(X[:, c] - xs)) < 5e-6 * np.max(np.abs(xs)), (pb, c)
+                assert np.allclose(cum, 0.25 + C.sum(axis=1), rtol=1e-12, atol=1e-14)
+                assert np.array_equal(mx, np.maximum(1e-3, C.max(axis=1)))
+                # only the check voltages / only the cumulative map: no n x nrhs array crosses the boundary
+                v2, X2, C2, _ = h.solve_sources(src, gnd, values=val, check=chk)
+                assert X2 is None and C2 is None and np.array_equal(v2, v)
+                cum2 = np.zeros(n)
+                _, _, _, _ = h.solve_sources(src, gnd, values=val, cum=cum2)
+                assert np.allclose(cum2, C.sum(axis=1), rtol=1e-12, atol=1e-14)
+            # several entries at one node are summed: +0.25 +0.75 at the source == +1
+            src, val, gnd, chk, B = cases[0]
+            v3, _, _, _ = h.solve_sources([[p, p] for p in pts], gnd, values=[[0.25, 0.75]] * npts, check=chk)
+            v1, _, _, _ = h.solve_sources(src, gnd, check=chk)
+            assert np.array_equal(v3, v1)
+            # error paths: node ids out of range, check without output
+            for bad in ([[n]] + src[1:], ):
+                try:
+                    h.solve_sources(bad, gnd)
+                    raise AssertionError("out-of-range source accepted")
+                except L.CsgpuError as e:
+                    assert e.code == L.CSGPU_BAD_ARGS
+            v0, _, _, st0 = h.solve_sources([], [], check=[])
+            assert len(v0) == 0 and st0["nrhs"] == 0
+
+
 def check_polygon_graph_on_device(L, seeds=(1, 2, 3, 4, 5)):
     """csgpu_raster_setup_poly: node map and Laplacian of rasters with random rectangular polygons (overlapping,
     touching, covering NODATA cells), NODATA holes, 4/8 neighbours, both averaging rules, against the oracle's

@@ -43,6 +43,18 @@ def test_two_ranks_gloo_match_oracle(emu_lib, oracle, tmp_path):
     h.close()
     assert np.max(np.abs(np.array(d["cum"]) - cum)) < 1e-12 * cum.max()
     assert np.array_equal(np.array(d["max"]), mx)
+    # one-to-all sources across the two ranks (BASELINE configs[4]'s sharding: contiguous slices of the columns, one gather,
+    # one reduction per map) == the single-process call on all columns
+    pts = d["pts"]
+    h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=4))
+    ocum = np.zeros(n)
+    omx = np.zeros(n)
+    v, _, _, st = h.solve_sources([[p] for p in pts], [[q for q in pts if q != p] for p in pts], check=pts, cum=ocum, mx=omx)
+    h.close()
+    assert d["cols_rank0"] == [0, 3] and d["ost_nrhs"] == 3 and st["nrhs"] == 6
+    assert np.max(np.abs(np.array(d["v"]) - v) / v) < 1e-9
+    assert np.max(np.abs(np.array(d["ocum"]) - ocum)) < 1e-9 * ocum.max()
+    assert np.max(np.abs(np.array(d["omax"]) - omx)) < 1e-9 * omx.max()
 
 
 def test_pair_slice_and_gather_single_process():
@@ -103,3 +115,26 @@ def test_bench_two_ranks_strong_scaling_line(emu_lib, tmp_path):
     assert len(d["rank_busy_s"]) == 2 and d["pairs_per_rank"] == 6 and d["value"] > 0
     _check_multi_gpu_block(d, pairs_per_rank=[6, 5])
     assert d["predicted_speedup_vs_1gpu"] > 1.0 and d["achieved_speedup_vs_1gpu_reconstructed"] > 0.5
+
+
+def test_bench_two_ranks_network_workload_line(emu_lib, tmp_path):
+    """`bench.py --workload network --gpus 2` (BASELINE configs[4] as the driver would launch it, gloo instead of RCCL): the
+    sources of the job dealt over the two ranks, the two collectives of the path, the N-GPU verification block, a roofline
+    of the CSR SpMM and the scipy parity figure in ONE line from rank 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HIPEMU_THREADS="2",
+               CSGPU_LIB=os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "network",
+           "--network-n", "4000", "--net-batch", "4", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "one-to-all sources/s" and d["value"] > 0 and d["not_converged"] == 0 and d["max_relres"] < 1e-4
+    assert d["all_sources_gathered"] is True and d["cum_current_sum"] > 0
+    assert abs(d["solve_only_sources_per_s"] * d["ms_per_step"] * 1e-3 * 2 - 16) < 1e-6    # 2 ranks x 2 steps x 4 sources
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert d["pcg_device_ms_per_step"] > 0 and d["parity"]["ok"] is True and d["parity"]["columns_checked"] == 2
+    _check_multi_gpu_block(d, pairs_per_rank=[8, 8])

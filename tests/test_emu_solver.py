@@ -1021,6 +1021,74 @@ def test_grounded_solves_share_one_hierarchy(emu_lib):
     check_grounded_solves(emu_lib)
 
 
+@pytest.mark.parametrize("holes", [0.0, 0.12])
+def test_sparse_sources_match_dense_grounded_solves(emu_lib, holes):
+    """csgpu_solve_sources (BASELINE configs[4]'s right-hand sides without the dense upload; see helpers.check_solve_sources)."""
+    from helpers import check_solve_sources
+    check_solve_sources(emu_lib, holes=holes)
+
+
+def test_multi_device_sources_and_grounded(emu_lib):
+    """csgpu_multi_solve_sources / csgpu_multi_solve_grounded (configs[4] across the GPUs of a node): the
+    columns of a one-to-all job on a NETWORK dealt over three (emulated) devices in contiguous ranges, one call per device
+    == the single-handle call bit for bit (check voltages, voltages, node currents), the cumulative / maximum current
+    vectors combined in slot order == the single-handle accumulation to rounding; every device used; fewer columns than
+    devices; the dense form likewise."""
+    import subprocess, sys, json, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        sys.path.insert(0, %r)
+        import circuitscape_jl_amd
+        from circuitscape_jl_amd import lib
+        from bench import geometric_network
+        lib.load(%r)
+        assert lib.device_count() == 3
+        G, rng = geometric_network(3000, seed=11)
+        n = G.shape[0]
+        pts = [int(q) for q in rng.choice(n, size=10, replace=False)]
+        src = [[p] for p in pts]
+        gnd = [[q for q in pts if q != p] for p in pts]
+        o = lambda: lib.default_opts(batch=4, itmax=3000)
+        out = {}
+        with lib.setup(G, o(), index_dtype=np.int32, index_base=0) as h:
+            cum1 = np.full(n, 0.5); mx1 = np.full(n, 0.01)
+            v1, X1, C1, st1 = h.solve_sources(src, gnd, check=pts, want_voltages=True, want_currents=True, cum=cum1, mx=mx1)
+            out["levels"] = h.info["levels"]
+        with lib.multi_setup(G, o(), index_dtype=np.int32, index_base=0) as m:
+            cumm = np.full(n, 0.5); mxm = np.full(n, 0.01)
+            vm, Xm, Cm, stm = m.solve_sources(src, gnd, check=pts, want_voltages=True, want_currents=True, cum=cumm, mx=mxm)
+            out["cols"] = stm["device_pairs"]
+            v2, _, _, st2 = m.solve_sources(src[:2], gnd[:2], check=pts[:2])
+            out["cols2"] = st2["device_pairs"]
+            B = np.zeros((n, 10))
+            for c, p in enumerate(pts):
+                B[p, c] = 1.0
+            Xg, Cg, stg = m.solve_grounded(B, gnd, want_currents=True)
+            v0, _, _, st0 = m.solve_sources([], [], check=[])
+        out.update(v=bool(np.max(np.abs(vm - v1) / v1) < 1e-10), X=float(np.max(np.abs(Xm - X1)) / np.max(np.abs(X1))),
+                   C=float(np.max(np.abs(Cm - C1)) / np.max(C1)), cum=float(np.max(np.abs(cumm - cum1)) / np.max(cum1)),
+                   mx=float(np.max(np.abs(mxm - mx1)) / np.max(mx1)), v2=float(np.max(np.abs(v2 - v1[:2]) / v1[:2])),
+                   Xg=float(np.max(np.abs(Xg - X1)) / np.max(np.abs(X1))), Cg=float(np.max(np.abs(Cg - C1)) / np.max(C1)),
+                   floor=bool(np.min(cumm) >= 0.5 and np.min(mxm) >= 0.01), n0=len(v0),
+                   nc=[st1["not_converged"], stm["not_converged"], stg["not_converged"]],
+                   res=float(max(np.linalg.norm((G @ X1[:, c] - B[:, c])[np.setdiff1d(np.arange(n), gnd[c])]) for c in range(10))),
+                   dev_ms=[st1["device_ms"], stm["device_ms"]])
+        print(json.dumps(out))
+    ''') % (root, os.path.join(root, "tests"), os.path.join(root, "tests", "emu", "libcsgpu_emu.so"))
+    env = dict(os.environ, HIPEMU_DEVICES="3", HIPEMU_THREADS="2")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    # (a device's range runs at the batch width its column count asks for: 4 + 3 + 3 columns at K = 4 against 4 + 4 + 2 on
+    # the single handle -- same systems, results to rounding of the solve tolerance's slack)
+    assert d["v"] and d["X"] < 1e-6 and d["C"] < 1e-6 and d["cum"] < 1e-6 and d["mx"] < 1e-6 and d["v2"] < 1e-6, d
+    assert d["Xg"] < 1e-6 and d["Cg"] < 1e-6 and d["floor"] and d["n0"] == 0 and d["nc"] == [0, 0, 0], d
+    assert d["cols"] == [4, 3, 3] and d["cols2"] == [1, 1, 0] and d["res"] < 1e-5 and min(d["dev_ms"]) > 0, d
+    assert d["levels"] > 1, d
+
+
 def test_polygon_graph_built_on_device(emu_lib):
     """scope row N4: short-circuit polygons merged on the device (see helpers.check_polygon_graph_on_device)."""
     from helpers import check_polygon_graph_on_device

@@ -681,3 +681,12 @@ def test_coarse_space_enrichment_on_nodata_rasters_gpu(gpu_lib, oracle, monkeypa
     r = check_enrichment(gpu_lib, oracle, monkeypatch, shape=(900, 870), batch=16)
     print("enrichment 900 x 870: iterations per pair off / on, vectors:", r)
     assert r[0][1] <= r[0][0] - 0.75, r
+
+
+@pytest.mark.parametrize("holes", [0.0, 0.12])
+def test_sparse_sources_match_dense_grounded_solves_gpu(gpu_lib, holes):
+    """csgpu_solve_sources on the device (see helpers.check_solve_sources): one-to-all / all-to-one columns handed over as
+    sparse right-hand sides == the dense csgpu_solve_grounded call bit for bit, both against direct solves of the reduced
+    systems; check voltages, cumulative / maximum current vectors."""
+    from helpers import check_solve_sources
+    check_solve_sources(gpu_lib, shape=(90, 83), npts=11, batch=8, holes=holes)

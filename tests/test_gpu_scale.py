@@ -128,6 +128,20 @@ def test_config5_network_one_to_all_1e6_erdos_renyi(gpu_lib):
         assert np.all(X[grounds[s], s] == 0.0)
     print("ER 1e6: setup %.2fs, 16 sources in %.2fs (%.1f iterations)" % (t_setup, t_solve, st["total_iters"] / 16.0))
     assert t_setup < 20.0 and t_solve < 20.0
+    # the same job through csgpu_solve_sources (sparse right-hand sides in, source voltages + cumulative current vector out:
+    # what the one-to-all driver keeps, src/raster/onetoall.jl:141,153-158): the same answers without the n x 16 arrays
+    # crossing PCIe, device time reported
+    h = gpu_lib.setup(G, gpu_lib.default_opts(batch=16, precond_bytes=4, itmax=2000), index_dtype=np.int32, index_base=0)
+    cum = np.zeros(n)
+    t0 = time.perf_counter()
+    v, _, _, st2 = h.solve_sources([[int(p)] for p in focal], grounds, check=[int(p) for p in focal], cum=cum)
+    t_sparse = time.perf_counter() - t0
+    _, _, C, _ = h.solve_sources([[int(p)] for p in focal[:2]], grounds[:2], want_currents=True)
+    h.close()
+    assert st2["not_converged"] == 0 and st2["total_iters"] == st["total_iters"] and st2["device_ms"] > 0
+    assert np.array_equal(v, X[focal, np.arange(16)])
+    assert np.all(cum >= C.sum(axis=1) * (1 - 1e-12)) and cum.sum() > 0
+    print("ER 1e6 through csgpu_solve_sources: %.3fs wall, %.3fs device" % (t_sparse, st2["device_ms"] / 1e3))
 
 
 def test_network_with_locality_coarsens_1e6(gpu_lib, oracle):
