@@ -1002,7 +1002,8 @@ struct Hierarchy {
   int coarse_n = 0;
   bool coarse_dense = false;
   double setup_ms = 0;
-  int work_k = 0;       // batch width the work vectors are allocated for
+  int work_k = 0;       // batch width the work vectors are laid out for
+  int work_kcap = 0;    // batch width they were allocated for (>= work_k)
   // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
   // per-column scratch area and the batch width it is allocated for
   bool near_singular = false;  // the coarsest operator's near-kernel eigenpair was dropped (fp32 hierarchy of a Laplacian)

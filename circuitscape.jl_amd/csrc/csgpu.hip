@@ -1567,11 +1567,17 @@ struct Solver : ISolver {
       for (int64_t p = 0; p < npairs; ++p)
         CS_REQUIRE(lab[p] == lab[npairs + p], CSGPU_BAD_ARGS, "pair spans two connected components");
     }
-    const int K = pick_k(npairs);
-    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
+    // Kmax: the width of the call's full batches; the work arena is sized for it. The batch width is then picked PER BATCH:
+    // the ragged tail of a pair list runs at the width ITS column count asks for (100 pairs at batch 32 = 32 + 32 + 32 + 4:
+    // the last four pairs run through the K = 4 kernels in the same buffers, instead of dragging 28 idle columns through
+    // every K = 32 pass -- 0.6 s of the 2.66 s job at 10000^2; the reference's batched driver handles a
+    // short last batch too, src/core.jl:448-463).
+    const int Kmax = pick_k(npairs);
+    const int64_t tail_rows = H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0;
+    W.ensure(n, Kmax, tail_rows);
     if (stats) {
       stats->nrhs = (int)npairs;
-      stats->batch = K;
+      stats->batch = Kmax;
     }
     // Streaming ("continuous batching", pcg.h): a resistance-only call with more pairs than columns on the lattice path
     // can keep every column busy -- a column takes the next pair of the list when its own has converged -- instead of
@@ -1584,16 +1590,16 @@ struct Solver : ISolver {
     // milliseconds (the host looks at the slots after every iteration): CSGPU_STREAM_MIN (vector elements n * K, default
     // 2^25) moves that bound; CSGPU_STREAM=1 streams from the first pair on (tests, A/B), CSGPU_NO_STREAM=1 never.
     bool stream_eligible = false, stream_now = false;
-    if (!(volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0) && dia_ptr() && npairs > K &&
-        K >= 8 && !poly_proj && !getenv("CSGPU_NO_STREAM")) {
+    if (!(volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0) && dia_ptr() && npairs > Kmax &&
+        Kmax >= 8 && !poly_proj && !getenv("CSGPU_NO_STREAM")) {
       const char* sm = getenv("CSGPU_STREAM_MIN");
-      stream_eligible = (int64_t)n * K >= (sm ? atoll(sm) : ((int64_t)1 << 25));
+      stream_eligible = (int64_t)n * Kmax >= (sm ? atoll(sm) : ((int64_t)1 << 25));
       const char* fs = getenv("CSGPU_STREAM");
       stream_now = stream_eligible && fs && atoi(fs) > 0;
     }
     // the rest of the list [p0, npairs) as a stream; false when the stream declined (the batches go on)
     auto stream_rest = [&](int64_t p0) -> bool {
-      PcgStreamResult sr = run_stream_k(K, src + p0, dst + p0, npairs - p0, gather, ngather,
+      PcgStreamResult sr = run_stream_k(Kmax, src + p0, dst + p0, npairs - p0, gather, ngather,
                                         resist_out ? (T*)resist_out + p0 : (T*)nullptr,
                                         gathered_out ? (T*)gathered_out + (size_t)p0 * ngather : (T*)nullptr);
       if (!sr.applicable) return false;
@@ -1613,7 +1619,7 @@ struct Solver : ISolver {
       }
       return true;
     };
-    DBuf dsrc = dalloc<int>(K), ddst = dalloc<int>(K);
+    DBuf dsrc = dalloc<int>(Kmax), ddst = dalloc<int>(Kmax);
     DBuf dgather = dalloc<int>((size_t)std::max<int64_t>(ngather, 1));
     if (ngather > 0) {
       std::vector<int> g32(ngather);
@@ -1621,9 +1627,9 @@ struct Solver : ISolver {
       CS_HIP(hipMemcpyAsync(dgather.p, g32.data(), (size_t)ngather * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipStreamSynchronize(st));
     }
-    DBuf dres = dalloc<T>(K), dgath = dalloc<T>((size_t)std::max<int64_t>(ngather, 1) * K);
+    DBuf dres = dalloc<T>(Kmax), dgath = dalloc<T>((size_t)std::max<int64_t>(ngather, 1) * Kmax);
     DBuf dvolt;
-    if (volt_out || curr_out) dvolt.alloc((size_t)n * K * sizeof(T));
+    if (volt_out || curr_out) dvolt.alloc((size_t)n * Kmax * sizeof(T));
     // N1: node currents of every pair, optional cumulative / maximum accumulation over the pairs of this call
     const bool want_curr = curr_out || cum_inout || max_inout || branch_out;
     // resistance-only calls consume x at the pairs' nodes and the gathered focal nodes only (core.jl:231-232,
@@ -1631,17 +1637,17 @@ struct Solver : ISolver {
     const bool need_x = volt_out || want_curr || opts.explicit_check > 0;
     if (need_x) ensure_csr();  // (the explicit residual check and the current kernels walk the CSR form)
     std::vector<int> focal;
-    if (!need_x) focal.resize((size_t)ngather + 2 * K);
+    if (!need_x) focal.resize((size_t)ngather + 2 * Kmax);
     DBuf dcurr, dcum, dmax, dweight, dbpart, dbmax, dbranch, dbranch2;
     if (branch_out) {
-      dbranch.alloc((size_t)std::max<int64_t>(nnz, 1) * K * sizeof(T));
-      dbranch2.alloc((size_t)std::max<int64_t>(nnz, 1) * K * sizeof(T));
+      dbranch.alloc((size_t)std::max<int64_t>(nnz, 1) * Kmax * sizeof(T));
+      dbranch2.alloc((size_t)std::max<int64_t>(nnz, 1) * Kmax * sizeof(T));
     }
     if (want_curr) {
-      dcurr.alloc((size_t)n * K * sizeof(T));
-      dweight.alloc((size_t)K * sizeof(int));
-      dbpart.alloc((size_t)kMaxGrid * K * 2 * sizeof(double));
-      dbmax.alloc((size_t)K * 2 * sizeof(double));
+      dcurr.alloc((size_t)n * Kmax * sizeof(T));
+      dweight.alloc((size_t)Kmax * sizeof(int));
+      dbpart.alloc((size_t)kMaxGrid * Kmax * 2 * sizeof(double));
+      dbmax.alloc((size_t)Kmax * 2 * sizeof(double));
       if (cum_inout) {
         dcum.alloc((size_t)n * sizeof(T));
         CS_HIP(hipMemsetAsync(dcum.p, 0, dcum.bytes, st));
@@ -1651,12 +1657,16 @@ struct Solver : ISolver {
         CS_HIP(hipMemsetAsync(dmax.p, 0, dmax.bytes, st));
       }
     }
-    std::vector<int> s32(K), d32(K), w32(K);
+    std::vector<int> s32(Kmax), d32(Kmax), w32(Kmax);
+    static const bool fixed_k = getenv("CSGPU_FIXED_K") != nullptr;  // A/B knob: every batch at the call's width (round 5)
+    int K = Kmax;
     for (int64_t p0 = 0; p0 < npairs; p0 += K) {
-      if (stream_now && npairs - p0 > K) {
+      if (stream_now && npairs - p0 > Kmax) {
         if (stream_rest(p0)) break;
         stream_now = stream_eligible = false;  // (declined: not asked again in this call)
       }
+      K = fixed_k ? Kmax : pick_k(npairs - p0);
+      W.ensure(n, K, tail_rows);  // (a narrower batch: same buffers, laid out for its own width)
       const int ncols = (int)std::min<int64_t>(K, npairs - p0);
       for (int c = 0; c < K; ++c) {
         s32[c] = (int)src[p0 + std::min(c, ncols - 1)];
@@ -1685,6 +1695,7 @@ struct Solver : ISolver {
                                              dptr<int>(dsrc), dptr<int>(ddst), ncols));
       }
       if (!need_x) {  // focal list: [gathered nodes..., src of every column..., dst of every column...]
+        focal.resize((size_t)ngather + 2 * K);
         for (int64_t g = 0; g < ngather; ++g) focal[g] = (int)gather[g];
         for (int c = 0; c < K; ++c) {
           focal[ngather + c] = s32[c];
@@ -1846,22 +1857,23 @@ struct Solver : ISolver {
       for (int64_t c = 0; c < nrhs; ++c) chk_in[(size_t)c] = std::max<int64_t>(J.check[c], 0);
       chk_r = rows_of(chk_in.data(), nrhs);
     }
-    const int K = pick_k(nrhs);
+    const int Kmax = pick_k(nrhs);  // (the arena's width; the ragged last batch runs at its own, as in solve_pairs)
     const bool want_curr = J.curr_out || J.cum_inout || J.max_inout;
     ensure_csr();
-    W.ensure(n, K, H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0);
+    const int64_t tail_rows = H.levels.size() > 1 && H.levels[0].two_product() ? H.levels[1].A.nrows : 0;
+    W.ensure(n, Kmax, tail_rows);
     W.drop_graphs();  // captured chunks hold the ground-set buffers of an earlier call
     if (stats) {
       stats->nrhs = (int)nrhs;
-      stats->batch = K;
+      stats->batch = Kmax;
     }
     int64_t maxg = 1, maxs = 1;
-    for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
-      maxg = std::max(maxg, gptr[std::min(nrhs, p0 + K)] - gptr[p0]);
-      if (sparse) maxs = std::max(maxs, sptr[std::min(nrhs, p0 + K)] - sptr[p0]);
+    for (int64_t p0 = 0; p0 < nrhs; p0 += Kmax) {
+      maxg = std::max(maxg, gptr[std::min(nrhs, p0 + Kmax)] - gptr[p0]);
+      if (sparse) maxs = std::max(maxs, sptr[std::min(nrhs, p0 + Kmax)] - sptr[p0]);
     }
-    DBuf stage, dgp = dalloc<int>(K + 1), dgi = dalloc<int>((size_t)maxg);
-    if (!sparse || J.x_out || J.curr_out) stage.alloc((size_t)n * K * sizeof(T));
+    DBuf stage, dgp = dalloc<int>(Kmax + 1), dgi = dalloc<int>((size_t)maxg);
+    if (!sparse || J.x_out || J.curr_out) stage.alloc((size_t)n * Kmax * sizeof(T));
     DBuf dsrow, dscol, dsval, dchk, dchkv;
     if (sparse) {
       dsrow = dalloc<int>((size_t)maxs);
@@ -1869,15 +1881,15 @@ struct Solver : ISolver {
       dsval = dalloc<T>((size_t)maxs);
     }
     if (J.check && J.check_out) {
-      dchk = dalloc<int>(K);
-      dchkv = dalloc<T>(K);
+      dchk = dalloc<int>(Kmax);
+      dchkv = dalloc<T>(Kmax);
     }
     DBuf dcurr, dbpart, dbmax, dcum, dmax, dweight;
     if (want_curr) {
-      dcurr.alloc((size_t)n * K * sizeof(T));
-      dbpart.alloc((size_t)kMaxGrid * K * 2 * sizeof(double));
-      dbmax.alloc((size_t)K * 2 * sizeof(double));
-      if (J.cum_inout || J.max_inout) dweight.alloc((size_t)K * sizeof(int));
+      dcurr.alloc((size_t)n * Kmax * sizeof(T));
+      dbpart.alloc((size_t)kMaxGrid * Kmax * 2 * sizeof(double));
+      dbmax.alloc((size_t)Kmax * 2 * sizeof(double));
+      if (J.cum_inout || J.max_inout) dweight.alloc((size_t)Kmax * sizeof(int));
       if (J.cum_inout) {
         dcum.alloc((size_t)n * sizeof(T));
         CS_HIP(hipMemsetAsync(dcum.p, 0, dcum.bytes, st));
@@ -1887,14 +1899,21 @@ struct Solver : ISolver {
         CS_HIP(hipMemsetAsync(dmax.p, 0, dmax.bytes, st));
       }
     }
-    std::vector<int> hp(K + 1), hi, srow, scol, w32(K), c32(K);
-    std::vector<T> sval, chkv(K);
+    std::vector<int> hp(Kmax + 1), hi, srow, scol, w32(Kmax), c32(Kmax);
+    std::vector<T> sval, chkv(Kmax);
     struct Ent {
       int col, row;
       T val;
     };
     std::vector<Ent> ents;
+    static const bool fixed_k = getenv("CSGPU_FIXED_K") != nullptr;  // A/B knob, as in solve_pairs
+    int K = Kmax;
     for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
+      K = fixed_k ? Kmax : pick_k(nrhs - p0);
+      if (K != W.K) {
+        W.ensure(n, K, tail_rows);
+        W.drop_graphs();
+      }
       const int ncols = (int)std::min<int64_t>(K, nrhs - p0);
       hi.clear();
       for (int c = 0; c < K; ++c) {

@@ -26,6 +26,10 @@ namespace csgpu {
 template <class T>
 inline void ensure_level_work(Hierarchy<T>& H, int K) {
   if (H.work_k == K) return;
+  if (K <= H.work_kcap) {  // a narrower batch (the ragged tail of a pair list) runs in the buffers of the widest one: every
+    H.work_k = K;          // offset inside them is computed from the K of the launch
+    return;
+  }
   for (size_t l = 0; l < H.levels.size(); ++l) {
     Level<T>& L = H.levels[l];
     const size_t elems = (size_t)std::max(L.A.nrows, 1) * K;
@@ -45,6 +49,7 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
       L.b.release();
   }
   H.work_k = K;
+  H.work_kcap = K;
 }
 
 // Optional fusions at level 0 of the V-cycle.
@@ -438,6 +443,7 @@ static const int kEnrichRows = 256;  // = kEnrichParts of enrich.h: extra rows o
 template <class T, class TP>
 struct PcgWork {
   int K = 0;
+  int Kcap = 0;               // batch width the buffers were allocated for (>= K: a narrower batch reuses them, see ensure)
   int64_t n = 0;
   DBuf x, r, Ap, b;           // T
   DBuf p;                     // TP: search direction (x and r are updated with exactly these stored values, so the
@@ -465,8 +471,15 @@ struct PcgWork {
   void ensure(int64_t n_, int K_, int64_t tail_rows = 0) {
     if (n == n_ && K == K_ && tail == tail_rows) return;
     drop_graphs();
+    if (n == n_ && tail == tail_rows && K_ <= Kcap) {
+      // the arena of the widest batch serves a narrower one as it is (sizes are monotone in K, offsets are computed from
+      // the K of the launch): the short last batch of a pair list runs at ITS width without an allocation
+      K = K_;
+      return;
+    }
     n = n_;
     K = K_;
+    Kcap = K_;
     tail = tail_rows;
     const size_t bytes = (size_t)n * K * sizeof(T);
     constexpr bool SAME = std::is_same<T, TP>::value;

@@ -348,15 +348,39 @@ mutable struct HIPMultiFactor
     end
 end
 
-function construct_multi_factor(matrix::SparseMatrixCSC{T,V}, s::HIPAMGSolver; ndevices::Int = 0) where {T,V}
+# `coords` as in construct_cholesky_factor: with the raster cell of every node each device builds the cell-space lattice
+# hierarchy a raster with NODATA cells gets from the single-device factor (csgpu_multi_setup forwards the options to every
+# device; ADVICE r5: without them every device fell back to the general CSR hierarchy).
+function construct_multi_factor(matrix::SparseMatrixCSC{T,V}, s::HIPAMGSolver; coords = nothing, ndevices::Int = 0) where {T,V}
     o = default_opts(s.bs)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = GC.@preserve matrix ccall((:csgpu_multi_setup, LIBCSGPU), Cint,
+    rc = GC.@preserve matrix coords begin
+        if coords !== nothing
+            o.node_row = pointer(coords[1]); o.node_col = pointer(coords[2])
+        end
+        ccall((:csgpu_multi_setup, LIBCSGPU), Cint,
               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Cint, Cint, Ref{CsgpuOpts}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
               matrix.colptr, matrix.rowval, matrix.nzval, size(matrix, 1), nnz(matrix), sizeof(V), sizeof(T), 1, o,
               C_NULL, ndevices, h)
+    end
     rc == 0 || error("csgpu_multi_setup failed: $(csgpu_error())")
     HIPMultiFactor(h[])
+end
+
+"""
+`maps_on_all_devices(flags, s, np)`: whether a maps-on pair list goes to ALL GPUs of the node in one call
+(csgpu_multi_solve_pairs_currents) instead of through the single-device factor: only cumulative / maximum maps are written
+(linear accumulation, nothing per pair to bring back), more than one device is visible, and the list holds at least two
+batches per device -- a replicated hierarchy per device is not worth building for less. The caller then builds the
+multi-device factor INSTEAD of the single-device one (two hierarchies of one matrix never share device 0).
+"""
+function maps_on_all_devices(flags, s::HIPAMGSolver, np::Int)
+    of = flags.outputflags
+    flags.is_raster || return false
+    (of.log_transform_maps || of.write_volt_maps) && return false
+    (of.write_cur_maps && !of.write_cum_cur_map_only) && return false
+    nd = device_count()
+    nd > 1 && np >= 2 * max(1, s.bs) * nd
 end
 
 function solve_pairs(factor::HIPMultiFactor, ::Type{T}, src::Vector{Int64}, dst::Vector{Int64};
@@ -453,8 +477,9 @@ list of ONE connected component, in chunks of `s.bs` pairs through `solve_pairs_
 Host memory is O(n * bs) (O(nnz * bs) in network mode), as in the reference's batched driver (core.jl:448-493).
 Returns the resistance of every pair of `src0` / `dst0`.
 """
-function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::SparseMatrixCSC{T,V}, component_data,
-                                src0::Vector{Int64}, dst0::Vector{Int64}, fan, points, orig_pts, cum, flags, cfg) where {T,V}
+function solve_pairs_with_maps!(factor::Union{HIPFactor,HIPMultiFactor}, s::HIPAMGSolver, matrix::SparseMatrixCSC{T,V},
+                                component_data, src0::Vector{Int64}, dst0::Vector{Int64}, fan, points, orig_pts, cum,
+                                flags, cfg) where {T,V}
     of = flags.outputflags
     n = size(matrix, 1)
     np = length(src0)
@@ -470,15 +495,13 @@ function solve_pairs_with_maps!(factor::HIPFactor, s::HIPAMGSolver, matrix::Spar
         node_cum = linear ? zeros(T, n) : T[]
         node_max = (linear && of.write_max_cur_maps) ? zeros(T, n) : T[]
         ncombos = 0
-        # cumulative / maximum maps only, several GPUs, more than one batch: the whole pair list in ONE call over all devices
+        # a multi-device factor (the caller decided: maps_on_all_devices): the whole pair list in ONE call over all devices
         # (csgpu_multi_solve_pairs_currents; the merge of core.jl:262-285 happens inside the library)
-        multi = linear && !per_pair_cur && !of.write_volt_maps && np > bs && device_count() > 1
+        multi = factor isa HIPMultiFactor
         if multi
-            mf = construct_multi_factor(matrix, s)
             w = Int32[length(fan[p]) for p in 1:np]
             ncombos = sum(w)
-            res, _ = solve_pairs_currents(mf, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)
-            finalize(mf)
+            res, _ = solve_pairs_currents(factor, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)
         end
         for lo in (multi ? (1:0) : (1:bs:np))
             hi = min(lo + bs - 1, np)
@@ -651,7 +674,10 @@ function solve(prob::GraphProblem{T,V}, s::HIPAMGSolver, flags, cfg, log)::Matri
         if !isempty(src0)
             # raster coordinates of the component's nodes seed the aggregation with 3 x 3 tiles (csgpu_opts.node_row/col)
             coords = cell_table === nothing ? nothing : node_coords(cell_table, comp)
-            factor = @timeit CSTIMER "construct preconditioner" construct_cholesky_factor(matrix, s; coords = coords)
+            all_devices = want_maps && maps_on_all_devices(flags, s, length(src0))
+            factor = @timeit CSTIMER "construct preconditioner" (all_devices ?
+                         construct_multi_factor(matrix, s; coords = coords) :
+                         construct_cholesky_factor(matrix, s; coords = coords))
             if want_maps
                 # maps on: chunks of s.bs pairs, currents on the device (see the doc string)
                 component_data = ComponentData(comp, matrix, construct_local_node_map(prob.nodemap, comp, prob.polymap),

@@ -512,6 +512,40 @@ def check_solve_sources(L, shape=(50, 46), npts=9, batch=4, holes=0.0, pbs=(0, 4
             assert len(v0) == 0 and st0["nrhs"] == 0
 
 
+def check_ragged_tail_batches(L, shape=(64, 57), batch=8, npairs=11, pbs=(0, 4), holes=0.0):
+    """The batch width is picked per batch: the short last batch of a pair list runs at the width ITS
+    column count asks for, in the work arena of the full batches. Every pair's result equals, bit for bit, what a call
+    holding only that batch returns (11 pairs at batch 8 = 8 at K = 8 + 3 at K = 4), iteration counts included; the same
+    for one-to-all columns through csgpu_solve_sources; a second call on the same handle (arena now laid out for the
+    narrow width) gives the first call's answers again."""
+    g, G, pts, cases = sources_problem(shape, 12, seed=5, holes=holes)
+    rng = np.random.default_rng(3)
+    src = [int(pts[i]) for i in rng.integers(0, 12, npairs)]
+    dst = [int(pts[(pts.index(s_) + 1 + int(k)) % 12]) for s_, k in zip(src, rng.integers(0, 10, npairs))]
+    nfull = npairs // batch * batch
+    for pb in pbs:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+            R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
+            assert st["batch"] == batch and st["not_converged"] == 0
+            Rh, gh, _, sth = h.solve_pairs(src[:nfull], dst[:nfull], gather=pts[:3])
+            Rt, gt, _, stt = h.solve_pairs(src[nfull:], dst[nfull:], gather=pts[:3])
+            assert stt["batch"] < batch
+            assert np.array_equal(R[:nfull], Rh) and np.array_equal(R[nfull:], Rt), pb
+            assert np.array_equal(ga[:nfull], gh) and np.array_equal(ga[nfull:], gt)
+            assert st["total_iters"] == sth["total_iters"] + stt["total_iters"]
+            R2, _, _, _ = h.solve_pairs(src, dst)
+            assert np.array_equal(R2, R)
+            # voltages carried (x in the arena too)
+            Rv, _, V, _ = h.solve_pairs(src, dst, want_voltages=True)
+            assert np.max(np.abs(Rv - R) / R) < 1e-9
+            for p_ in range(npairs):
+                assert abs(V[dst[p_], p_] - Rv[p_]) < 1e-12 * max(1.0, abs(Rv[p_]))
+            osrc, oval, ognd, ochk, B = cases[0]
+            v, X, _, so = h.solve_sources(osrc[:npairs], ognd[:npairs], check=ochk[:npairs], want_voltages=True)
+            vt, Xt, _, sot = h.solve_sources(osrc[nfull:npairs], ognd[nfull:npairs], check=ochk[nfull:npairs], want_voltages=True)
+            assert np.array_equal(v[nfull:], vt) and np.array_equal(X[:, nfull:], Xt) and sot["batch"] < batch
+
+
 def check_polygon_graph_on_device(L, seeds=(1, 2, 3, 4, 5)):
     """csgpu_raster_setup_poly: node map and Laplacian of rasters with random rectangular polygons (overlapping,
     touching, covering NODATA cells), NODATA holes, 4/8 neighbours, both averaging rules, against the oracle's

@@ -24,6 +24,11 @@ def test_bench_line_carries_the_nodata_leg(emu_lib):
     assert leg["not_converged"] == 0 and leg["lattice_period"] == 120 and leg["nodata_fraction"] == 0.15
     assert 0.8 * 120 * 120 < leg["nodes"] < 0.9 * 120 * 120 and leg["value"] > 0
     assert line["value"] > 0 and "shortcut" in line and "with_voltages" in line
+    # BASELINE configs[2] as a job: the 100-pair list in one call, 12 full batches of 8 + 4
+    job = line["job_100_pairs"]
+    assert "failed" not in job, job
+    assert job["pairs"] == 100 and job["batches"] == "12 x 8 + 4" and job["not_converged"] == 0
+    assert abs(line["value_job"] - 100 / job["job_s"]) < 1e-9 and line["job_100_pairs_s"] == job["job_s"]
 
 
 def test_every_leg_of_the_fp64_line_carries_an_oracle_figure(emu_lib):
@@ -43,5 +48,11 @@ def test_every_leg_of_the_fp64_line_carries_an_oracle_figure(emu_lib):
         assert "failed" not in par, (leg, par)
         assert par["tolerance"] == tol and par["ok"] and par["max_rel_err"] < tol, (leg, par)
     assert line["config4_network"]["levels"] == 1 and line["network_geometric"]["levels"] >= 3
+    # device time and a CSR-SpMM roofline in both network legs
+    for leg in ("config4_network", "network_geometric"):
+        roof = line[leg]["roofline"]
+        assert roof["bound"] == "hbm" and roof["algorithmic_bytes_per_launch"] > 0 and roof["launches_timed"] > 0, (leg, roof)
+        assert line[leg]["value_device"] > 0
+    assert line["config4_network"]["solve_device_s_all_sources"] > 0 and line["config4_network"]["cum_current_sum"] > 0
     assert line["nodata15"]["parity"]["lattice_period"] == 96
     assert set(line["leg_seconds"]) >= {"nodata15", "config3_fp32", "config4_network", "cpu_child", "leg_parity_gpu"}

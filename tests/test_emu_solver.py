@@ -1028,6 +1028,13 @@ def test_sparse_sources_match_dense_grounded_solves(emu_lib, holes):
     check_solve_sources(emu_lib, holes=holes)
 
 
+@pytest.mark.parametrize("holes", [0.0, 0.12])
+def test_ragged_tail_batch_runs_at_its_own_width(emu_lib, holes):
+    """K picked per batch (see helpers.check_ragged_tail_batches)."""
+    from helpers import check_ragged_tail_batches
+    check_ragged_tail_batches(emu_lib, holes=holes)
+
+
 def test_multi_device_sources_and_grounded(emu_lib):
     """csgpu_multi_solve_sources / csgpu_multi_solve_grounded (configs[4] across the GPUs of a node): the
     columns of a one-to-all job on a NETWORK dealt over three (emulated) devices in contiguous ranges, one call per device

@@ -690,3 +690,10 @@ def test_sparse_sources_match_dense_grounded_solves_gpu(gpu_lib, holes):
     systems; check voltages, cumulative / maximum current vectors."""
     from helpers import check_solve_sources
     check_solve_sources(gpu_lib, shape=(90, 83), npts=11, batch=8, holes=holes)
+
+
+@pytest.mark.parametrize("holes,batch,npairs", [(0.0, 32, 37), (0.12, 16, 21)])
+def test_ragged_tail_batch_runs_at_its_own_width_gpu(gpu_lib, holes, batch, npairs):
+    """K picked per batch on the device (see helpers.check_ragged_tail_batches): 37 pairs at batch 32 = 32 + 5 at K = 8."""
+    from helpers import check_ragged_tail_batches
+    check_ragged_tail_batches(gpu_lib, shape=(130, 121), batch=batch, npairs=npairs, holes=holes)

@@ -112,9 +112,19 @@ def test_reference_dispatch_points_have_methods():
     mbody = mm.group(1)
     assert mbody.count("solve_pairs_currents(factor, T, n, nnz(matrix), src0[lo:hi], dst0[lo:hi]") == 2   # raster, network
     assert mbody.count("1:bs:np") == 2
-    # round 5: cumulative / maximum maps only on several GPUs -> ONE csgpu_multi_solve_pairs_currents call for the list
-    assert "solve_pairs_currents(mf, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)" in mbody
-    assert "device_count() > 1" in mbody and "findfirst(isequal(a1), cum.coords)" not in mbody
+    # round 5: cumulative / maximum maps only on several GPUs -> ONE csgpu_multi_solve_pairs_currents call for the list.
+    # Round 6: the CALLER decides (maps_on_all_devices: cumulative / maximum maps only, > 1 device, at
+    # least two batches per device) and builds the multi-device factor INSTEAD of the single-device one, with the nodes'
+    # raster cells (coords) so that every device gets the cell-space lattice hierarchy; the maps routine only dispatches.
+    assert "multi = factor isa HIPMultiFactor" in mbody and "construct_multi_factor(" not in mbody
+    assert "solve_pairs_currents(factor, T, src0, dst0; weights = w, cum = node_cum, mx = node_max)" in mbody
+    assert "findfirst(isequal(a1), cum.coords)" not in mbody
+    assert "all_devices = want_maps && maps_on_all_devices(flags, s, length(src0))" in body
+    assert "construct_multi_factor(matrix, s; coords = coords)" in body
+    mo = re.search(r"^function maps_on_all_devices\(flags, s::HIPAMGSolver, np::Int\)(.*?)^end$", JL, re.S | re.M)
+    assert mo and "device_count()" in mo.group(1) and "np >= 2 * max(1, s.bs) * nd" in mo.group(1)
+    mc = re.search(r"^function construct_multi_factor\((.*?)^end$", JL, re.S | re.M)
+    assert mc and "coords = nothing" in mc.group(1) and "o.node_row = pointer(coords[1]); o.node_col = pointer(coords[2])" in mc.group(1)
     for needed in ("cum = node_cum, mx = node_max", "want_voltages = of.write_volt_maps", "want_currents = per_pair_cur",
                    "write_volt_maps(name, out, component_data, flags, cfg)", "write_grid(cmap, name, cfg, hbmeta)",
                    "process_grid!(cmap, cellmap, hbmeta", "write_currents(node_currents_array, branch_currents_array, name, cfg)",
