@@ -531,8 +531,7 @@ inline void spgemm(const Csr<T>& A, const Csr<T>& B, Csr<T>& C, hipStream_t st);
 template <class T>
 inline void spgemm_tentative(const Csr<T>& A, const Csr<T>& Tm, const int* agg, Csr<T>& C, hipStream_t st) {
   constexpr int MAXL = 32;  // (rows of a cell-space level hold up to 25 entries)
-  static const bool off = getenv("CSGPU_NO_DIRECT_AT") != nullptr;  // A/B knob
-  if (off || max_row_len(A, st) > MAXL) return spgemm(A, Tm, C, st);
+  if (!knobs().direct_at || max_row_len(A, st) > MAXL) return spgemm(A, Tm, C, st);
   const int n = A.nrows;
   C.nrows = n;
   C.ncols = Tm.ncols;
@@ -839,8 +838,8 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   for (int i = 0; i < n; ++i) smax = std::max(smax, std::fabs(M[(size_t)i * n + i]));
   // eigenvalues below n*eps(T)*lambda_max are treated as the null space (Julia pinv's default rtol)
   double cut = eps * (double)n * smax;
-  if (getenv("CSGPU_PINV_CUT")) cut = atof(getenv("CSGPU_PINV_CUT")) * smax;  // experiment knob
-  if (getenv("CSGPU_VERBOSE")) {
+  if (knobs().pinv_cut > 0.0) cut = knobs().pinv_cut * smax;  // experiment knob
+  if (knobs().verbose) {
     std::vector<double> ev(n);
     for (int i = 0; i < n; ++i) ev[i] = M[(size_t)i * n + i];
     std::sort(ev.begin(), ev.end());
@@ -879,7 +878,7 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
   // (Giving it the gain of the smoothest kept mode instead -- a non-singular preconditioner -- was measured too,
   // CSGPU_KERNEL_GAIN_REF=1: fine up to 5000^2, but at 10000^2 the fp32 restriction chain of eight levels has put so much
   // spurious weight on the candidate that any gain feeds it back: 13.3 iterations instead of 11.1.)
-  static const bool kernel_ref = getenv("CSGPU_KERNEL_GAIN_REF") != nullptr;  // A/B knob
+  const bool kernel_ref = knobs().kernel_gain_ref;  // A/B knob
   if (defl_out) defl_out->assign((size_t)n * n, 0.0);
   for (int e = 0; e < n; ++e) {
     if (kind[e] == 0) continue;
@@ -930,16 +929,14 @@ inline std::vector<double> dense_sym_pinv(std::vector<double> M, int n, double e
 // tiles are what keeps level 1 a nine-point lattice (lattice_level1_setup). CSGPU_TILE_THETA / CSGPU_TILE_SPLIT_MIN
 // override the defaults (theta 0 switches the filter off).
 inline double default_tile_theta() {
-  static const double t = getenv("CSGPU_TILE_THETA") ? atof(getenv("CSGPU_TILE_THETA")) : 0.03;
-  return t;
+  return knobs().tile_theta;
 }
 inline int tile_sample_stride(int64_t ntiles) {  // the heterogeneity test looks at ~65 k tiles
   const int64_t s = ntiles / 65536;
   return (int)std::max<int64_t>(1, s);
 }
 inline double default_tile_split_min() {
-  static const double t = getenv("CSGPU_TILE_SPLIT_MIN") ? atof(getenv("CSGPU_TILE_SPLIT_MIN")) : 0.005;
-  return t;
+  return knobs().tile_split_min;
 }
 
 template <class T>
@@ -1337,7 +1334,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
                      bool cell_level = false, TileStrength* ts = nullptr) {
   const int n = A.nrows;
   const double theta2 = theta * theta;
-  static const bool no_direct_tiles = getenv("CSGPU_NO_DIRECT_TILES") != nullptr;  // A/B knob
+  const bool no_direct_tiles = !knobs().direct_tiles;  // A/B knob
   if (!no_direct_tiles && theta == 0.0 && nrow && gridR >= 6 && gridC >= 6 && (int64_t)gridR * gridC == n) {
     const int Rc = (gridR + 1) / 3, Cc = (gridC + 1) / 3;
     agg.alloc((size_t)n * sizeof(int));
@@ -1345,7 +1342,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
     ccol.alloc((size_t)Rc * Cc * sizeof(int));
     hipLaunchKernelGGL(tile_aggregate_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, nrow, ncol, Rc, Cc, dptr<int>(agg),
                        dptr<int>(crow), dptr<int>(ccol));
-    static const bool no_pieces = getenv("CSGPU_NO_TILE_PIECES") != nullptr;  // A/B knob
+    const bool no_pieces = !knobs().tile_pieces;  // A/B knob
     if (size_f && !no_pieces) {
       DBuf piece((size_t)n), mainlab((size_t)Rc * Cc);
       const int gt = grid_for((int64_t)Rc * Cc);
@@ -1373,7 +1370,7 @@ inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nr
         }
         const bool hetero = th2 > 0.0 && (double)(out1 - out0) > ts->split_min * (double)std::max<int64_t>(valid, 1);
         if (th2 > 0.0) ts->hetero_frac = (double)(out1 - out0) / (double)std::max<int64_t>(valid, 1);
-        if (getenv("CSGPU_VERBOSE"))
+        if (knobs().verbose)
           fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
                   (long long)out1, (long long)valid, ts->theta, (long long)out0, hetero ? "filter ON" : "filter off");
         if (!hetero) {
@@ -1667,7 +1664,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       lattice_level1_setup(L, (const int*)dptr<int>(agg), lvlR, lvlC, nagg, st);
     if (H.levels.size() >= 2 && !L.lattice_v22() && lvlR >= 6 && (int64_t)lvlR * lvlC == n && n >= dia25_min_rows()) {
       // refined tiles: the level's operator reaches two lattice steps; index-free 25-point form when it fits (dia25.h)
-      if (dia25_from_csr(L.A, lvlR, L.A25, st) && getenv("CSGPU_VERBOSE"))
+      if (dia25_from_csr(L.A, lvlR, L.A25, st) && knobs().verbose)
         fprintf(stderr, "csgpu: level %d (%d x %d) in 25-point lattice form\n", (int)H.levels.size() - 1, lvlR, lvlC);
     }
     if (sp.two_product && H.levels.size() == 1 && L.A.nnz + L.Q.nnz < 0x7fffffffLL &&
@@ -1678,7 +1675,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
         build_qt_matrix(L, st);
         build_sq_matrix(L, st);
       }
-      if (getenv("CSGPU_VERBOSE"))
+      if (knobs().verbose)
         fprintf(stderr, "csgpu: two-product level: nnz(Q^T)=%lld nnz([S Q])=%lld periodA=%lld orderA=%s orderQT=%s\n",
                 (long long)L.QT.nnz, (long long)L.M.nnz, L.periodA, L.orderA.p ? "yes" : "no", L.orderQT.p ? "yes" : "no");
     }
@@ -1718,7 +1715,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       for (int i = 0; i < n; ++i)
         for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + ci[k]] += (double)va[k];
       std::vector<std::vector<double>> kc;
-      const bool deflate = sizeof(T) == 4 && !getenv("CSGPU_NO_DEFLATION");
+      const bool deflate = sizeof(T) == 4 && knobs().deflation;
       std::vector<double> cand((size_t)n, 1.0);
       if (size_prev.p) {
         std::vector<long long> sz((size_t)n);
@@ -1729,7 +1726,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       kc = component_candidates(M, n, cand);
       // Dirichlet-masked solves may use the correction along the per-component candidates (pcg.h, DirichletCoarse);
       // weightless rows of a cell-space hierarchy have a zero candidate entry and belong to no component
-      const bool dir_ok = !kc.empty() && (int)kc.size() <= kMaxDirComp && !getenv("CSGPU_NO_DIRICHLET_COARSE");
+      const bool dir_ok = !kc.empty() && (int)kc.size() <= kMaxDirComp && knobs().dirichlet_coarse;
       H.dir_ncomp = dir_ok ? (int)kc.size() : 0;
       int dropped = 0;
       std::vector<double> Pdefl;
@@ -1754,7 +1751,7 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       }
       H.near_singular = deflate && dropped > 0;
       H.cand_norm2 = sp.n_real > 0 ? (double)sp.n_real : (double)H.levels[0].A.nrows;
-      if (deflate && getenv("CSGPU_VERBOSE"))
+      if (deflate && knobs().verbose)
         fprintf(stderr, "csgpu: coarsest level: %d near-kernel eigenpair(s) of %zu candidate(s) dropped\n", dropped, kc.size());
       std::vector<T> Pt((size_t)n * n);
       for (size_t i = 0; i < Pt.size(); ++i) Pt[i] = (T)Pi[i];

@@ -45,6 +45,71 @@ inline void check_launch(const char* what) {
   if (e != hipSuccess) throw Error(CSGPU_HIP_ERROR, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// ---- knobs ----------------------------------------------------------------------------------------------------------
+// Every decision that used to be an environment switch inside the library lives here: the RESOLVED
+// choices of ONE handle -- library defaults, overridden by the caller's csgpu_opts fields of the same names (0 = default
+// there), overridden by the CSGPU_* environment variables as a DEBUG aid, read ONCE when the handle is set up
+// (knobs_from_opts, csgpu.hip) and never on a call path. The handle that is being set up or solved on puts its knobs in
+// scope for the calling thread (KnobScope at the top of every Solver method); code without a handle in reach -- launch
+// helpers, the set-up routines of the levels -- reads knobs(). Two handles of one process may differ.
+struct Knobs {
+  int last_level_sweeps = 0;      // damped-Jacobi sweeps standing in for the coarsest solve of a level too large for a dense
+                                  // inverse (vcycle, pcg.h): 0 = the library's rule (8 below a coarsened hierarchy,
+                                  // kSingleLevelSweeps for a hierarchy of one level), -1 = none (plain Jacobi scaling)
+  bool enrich = true;             // second coarse function on badly shaped aggregates (enrich.h)
+  int enrich_steps = 6;
+  double enrich_tau = 0.06;
+  int64_t dia25_min_rows = 16384;  // smallest level that takes the 25-point lattice form (dia25.h); < 0: none
+  bool dia25_prefetch = true;
+  int dia25_waves = 0;            // 0: the rule of dia25_waves()
+  bool dia25_fused_j0 = true;     // first two sweeps of a 25-point level as one marching pass
+  int stream = 0;                 // streaming pair solves: 0 = decided by the first batch's spread, 1 = from the first pair, -1 = never
+  int64_t stream_min = (int64_t)1 << 25;
+  double hetero_fp64_frac = 0.03;  // fp32 hierarchy replaced by fp64 above this fraction of cells leaving their tile (>= 1: never)
+  int tail_rows = 4096;           // levels with at most this many rows run in the single-launch coarse tail; <= 0: no tail
+  int poly_lattice = 0;           // polygon rasters on the lattice path: 0 = shape rule, 1 = any shape, -1 = never
+  double poly_strength = 0.0, poly_coef = 1.0, poly_smin = 8.0, poly_smax = 1000.0;
+  bool cellspace = true, cellspace_from_csr = true;
+  double cellspace_min_frac = 0.5;
+  bool lattice_l1 = true;
+  int lattice_l1_min_rows = 16384;
+  bool stencil = true, two_product = true;  // (csgpu_opts.stencil / .two_product = -1 or the NO_STENCIL / NO_TWO_PRODUCT variables)
+  bool direct_lattice = true, lattice_s = true, lattice_q = true, direct_tiles = true, tile_pieces = true, direct_at = true;
+  double tile_theta = 0.03, tile_split_min = 0.005;
+  bool dirichlet_coarse = true, deflation = true, tail_projection = true;
+  int coarse_smoother = 0;        // 0 = Chebyshev weights unless the hierarchy is fp32 above 3e7 rows, 1 = Chebyshev, 2 = damped Jacobi
+  int nu_l1 = 0, nu_deep = 0;     // sweeps on level 1 / below; 0 = nu_coarse / nu_coarse + 1
+  int64_t host_stream_block = 0;  // entries per block of a streamed host matrix; 0 = stream only matrices with >= 2^31 entries
+  bool wide_csr = false;          // fp64 CSR-path handles at K = 32 too
+  bool fixed_k = false;           // every batch of a call at the call's width (round-5 behaviour)
+  bool recompute_ap = true;       // residual update recomputes A p from the lattice form instead of storing it
+  int64_t collapse_min = -1;      // < 0: the default rule of pcg.h
+  bool longrow = true, narrow_tile = false;
+  int spmv_grid_cap = 65536, dia_seg = 0, restrict_seg = 32;
+  int verbose = 0;
+  // experiments / debugging only (no csgpu_opts field)
+  double pinv_cut = 0.0;
+  bool kernel_gain_ref = false, tail_debug = false;
+  int timed_launches = 512;
+};
+
+inline const Knobs*& knobs_slot() {
+  static thread_local const Knobs* p = nullptr;
+  return p;
+}
+inline const Knobs& knobs() {
+  static const Knobs dflt;
+  const Knobs* p = knobs_slot();
+  return p ? *p : dflt;
+}
+struct KnobScope {
+  const Knobs* prev;
+  explicit KnobScope(const Knobs* k) : prev(knobs_slot()) { knobs_slot() = k; }
+  ~KnobScope() { knobs_slot() = prev; }
+  KnobScope(const KnobScope&) = delete;
+  KnobScope& operator=(const KnobScope&) = delete;
+};
+
 static std::atomic<int64_t> g_live_bytes{0};  // bookkeeping only (handles of a multi-device set are built by concurrent threads)
 
 // ---- device memory pool ---------------------------------------------------------------------------------------------

@@ -27,8 +27,128 @@ struct GroundedJob {
   void *check_out = nullptr, *x_out = nullptr, *curr_out = nullptr, *cum_inout = nullptr, *max_inout = nullptr;
 };
 
+// The knobs of one handle: library defaults <- the caller's csgpu_opts (0 = default in every field) <- the CSGPU_* environment
+// variables as a debug aid. This is the ONLY place the library reads its environment for them, once per set-up.
+inline Knobs knobs_from_opts(const csgpu_opts& o) {
+  Knobs k;
+  auto flag = [](int32_t v, bool dflt) { return v == 0 ? dflt : v > 0; };
+  k.last_level_sweeps = o.last_level_sweeps;
+  k.enrich = flag(o.enrich, true);
+  if (o.enrich_steps > 0) k.enrich_steps = o.enrich_steps;
+  if (o.enrich_tau > 0.0) k.enrich_tau = o.enrich_tau;
+  if (o.dia25_min_rows != 0) k.dia25_min_rows = o.dia25_min_rows;
+  k.dia25_prefetch = flag(o.dia25_prefetch, true);
+  k.dia25_waves = std::max(o.dia25_waves, 0);
+  k.dia25_fused_j0 = flag(o.dia25_fused_j0, true);
+  k.stream = o.stream;
+  if (o.stream_min > 0) k.stream_min = o.stream_min;
+  if (o.hetero_fp64_frac > 0.0) k.hetero_fp64_frac = o.hetero_fp64_frac;
+  if (o.tail_rows != 0) k.tail_rows = o.tail_rows;
+  k.poly_lattice = o.poly_lattice;
+  if (o.poly_strength > 0.0) k.poly_strength = o.poly_strength;
+  if (o.poly_coef > 0.0) k.poly_coef = o.poly_coef;
+  if (o.poly_smin > 0.0) k.poly_smin = o.poly_smin;
+  if (o.poly_smax > 0.0) k.poly_smax = o.poly_smax;
+  k.cellspace = flag(o.cellspace, true);
+  k.cellspace_from_csr = flag(o.cellspace_from_csr, true);
+  if (o.cellspace_min_frac > 0.0) k.cellspace_min_frac = o.cellspace_min_frac;
+  k.lattice_l1 = flag(o.lattice_level1, true);
+  if (o.lattice_level1_min_rows > 0) k.lattice_l1_min_rows = o.lattice_level1_min_rows;
+  k.stencil = o.stencil >= 0;
+  k.two_product = o.two_product >= 0;
+  k.direct_lattice = flag(o.lattice_setup, true);
+  k.lattice_s = flag(o.lattice_s, true);
+  k.lattice_q = flag(o.lattice_q, true);
+  k.direct_tiles = flag(o.direct_tiles, true);
+  k.tile_pieces = flag(o.tile_pieces, true);
+  k.direct_at = flag(o.direct_at, true);
+  if (o.tile_theta != 0.0) k.tile_theta = std::max(o.tile_theta, 0.0);
+  if (o.tile_split_min > 0.0) k.tile_split_min = o.tile_split_min;
+  k.dirichlet_coarse = flag(o.dirichlet_coarse, true);
+  k.deflation = flag(o.deflation, true);
+  k.tail_projection = flag(o.tail_projection, true);
+  k.coarse_smoother = o.coarse_smoother;
+  k.nu_l1 = std::max(o.nu_l1, 0);
+  k.nu_deep = std::max(o.nu_deep, 0);
+  k.host_stream_block = std::max<int64_t>(o.host_stream_block, 0);
+  k.wide_csr = o.wide_csr > 0;
+  k.fixed_k = o.fixed_k > 0;
+  k.recompute_ap = flag(o.recompute_ap, true);
+  k.longrow = flag(o.longrow, true);
+  k.narrow_tile = o.narrow_tile > 0;
+  if (o.spmv_grid_cap != 0) k.spmv_grid_cap = std::max(o.spmv_grid_cap, 0);
+  k.dia_seg = std::max(o.dia_seg, 0);
+  if (o.restrict_seg > 0) k.restrict_seg = o.restrict_seg;
+  if (o.collapse_min > 0) k.collapse_min = o.collapse_min;
+  k.verbose = o.verbose > 0;
+  // ---- debug overrides (the variables that used to BE the switches) ----
+  auto env = [](const char* name) -> const char* { return getenv((std::string("CSGPU_") + name).c_str()); };
+  auto on = [&](const char* name) { return env(name) != nullptr; };
+  auto num = [&](const char* name, auto set) {
+    if (const char* e = env(name)) set(atof(e));
+  };
+  num("LAST_SWEEPS", [&](double v) { k.last_level_sweeps = v <= 0 ? -1 : (int)v; });
+  num("ENRICH", [&](double v) { if (v <= 0.0) k.enrich = false; });
+  num("ENRICH_TAU", [&](double v) { k.enrich_tau = v; });
+  num("ENRICH_STEPS", [&](double v) { k.enrich_steps = (int)v; });
+  num("DIA25", [&](double v) { if (v != 1.0) k.dia25_min_rows = v <= 0 ? -1 : (int64_t)v; });
+  num("DIA25_PF", [&](double v) { k.dia25_prefetch = v != 0.0; });
+  num("DIA25_WAVES", [&](double v) { k.dia25_waves = (int)v; });
+  if (on("DIA25_NO_J0")) k.dia25_fused_j0 = false;
+  num("STREAM", [&](double v) { if (v > 0) k.stream = 1; });
+  if (on("NO_STREAM")) k.stream = -1;
+  num("STREAM_MIN", [&](double v) { k.stream_min = (int64_t)v; });
+  num("HETERO_FP64_FRAC", [&](double v) { k.hetero_fp64_frac = v; });
+  num("TAIL_ROWS", [&](double v) { k.tail_rows = v <= 0 ? -1 : (int)v; });
+  if (on("NO_POLY_LATTICE")) k.poly_lattice = -1;
+  if (on("POLY_LATTICE_ANY_SHAPE")) k.poly_lattice = 1;
+  num("POLY_STRENGTH", [&](double v) { k.poly_strength = v; });
+  num("POLY_COEF", [&](double v) { k.poly_coef = v; });
+  num("POLY_SMIN", [&](double v) { k.poly_smin = v; });
+  num("POLY_SMAX", [&](double v) { k.poly_smax = v; });
+  if (on("NO_CELLSPACE")) k.cellspace = false;
+  if (on("NO_CELLSPACE_FROM_CSR")) k.cellspace_from_csr = false;
+  num("CELLSPACE_MIN_FRAC", [&](double v) { k.cellspace_min_frac = v; });
+  if (on("NO_LATTICE_L1")) k.lattice_l1 = false;
+  num("LATTICE_L1_MIN_ROWS", [&](double v) { k.lattice_l1_min_rows = (int)v; });
+  if (on("NO_STENCIL")) k.stencil = false;
+  if (on("NO_TWO_PRODUCT")) k.two_product = false;
+  if (on("NO_DIRECT_LATTICE")) k.direct_lattice = false;
+  if (on("NO_LATTICE_S")) k.lattice_s = false;
+  if (on("NO_LATTICE_Q")) k.lattice_q = false;
+  if (on("NO_DIRECT_TILES")) k.direct_tiles = false;
+  if (on("NO_TILE_PIECES")) k.tile_pieces = false;
+  if (on("NO_DIRECT_AT")) k.direct_at = false;
+  num("TILE_THETA", [&](double v) { k.tile_theta = v; });
+  num("TILE_SPLIT_MIN", [&](double v) { k.tile_split_min = v; });
+  if (on("NO_DIRICHLET_COARSE")) k.dirichlet_coarse = false;
+  if (on("NO_DEFLATION")) k.deflation = false;
+  if (on("NO_TAIL_PROJECTION")) k.tail_projection = false;
+  if (on("COARSE_JACOBI")) k.coarse_smoother = 2;
+  if (on("COARSE_CHEBYSHEV")) k.coarse_smoother = 1;
+  num("NU_L1", [&](double v) { k.nu_l1 = (int)v; });
+  num("NU_DEEP", [&](double v) { k.nu_deep = (int)v; });
+  num("STREAM_HOST_CSR", [&](double v) { k.host_stream_block = (int64_t)v; });
+  if (on("WIDE_CSR")) k.wide_csr = true;
+  if (on("FIXED_K")) k.fixed_k = true;
+  if (on("NO_RECOMPUTE")) k.recompute_ap = false;
+  num("COLLAPSE_MIN", [&](double v) { k.collapse_min = (int64_t)v; });
+  if (on("NO_LONGROW")) k.longrow = false;
+  if (on("NARROW_TILE")) k.narrow_tile = true;
+  num("SPMV_GRID_CAP", [&](double v) { k.spmv_grid_cap = (int)v; });
+  num("DIA_SEG", [&](double v) { k.dia_seg = (int)v; });
+  num("RESTRICT_SEG", [&](double v) { k.restrict_seg = (int)v; });
+  if (on("VERBOSE")) k.verbose = 1;
+  num("PINV_CUT", [&](double v) { k.pinv_cut = v; });
+  if (on("KERNEL_GAIN_REF")) k.kernel_gain_ref = true;
+  if (on("TAIL_DEBUG")) k.tail_debug = true;
+  num("TIMED_LAUNCHES", [&](double v) { k.timed_launches = (int)v; });
+  return k;
+}
+
 struct ISolver {
   virtual ~ISolver() {}
+  Knobs kn;  // resolved at construction (knobs_from_opts); in scope of the calling thread inside every method
   bool rebuilt_fp64 = false;  // the C API replaced the fp32 hierarchy the caller asked for by an fp64 one (csgpu_info)
   virtual void solve_pairs(const int64_t* src, const int64_t* dst, int64_t npairs, void* volt_out,
                            const int64_t* gather, int64_t ngather, void* gathered_out, void* resist_out,
@@ -206,6 +326,7 @@ struct Solver : ISolver {
   std::mutex mu;
 
   explicit Solver(const csgpu_opts& o) : opts(o) {
+    kn = knobs_from_opts(o);
     if (opts.device >= 0) {
       CS_HIP(hipSetDevice(opts.device));
       device = opts.device;
@@ -226,14 +347,13 @@ struct Solver : ISolver {
     sp.theta = opts.theta;
     sp.omega_p = opts.omega_p;
     sp.omega_s = opts.omega_s;
-    static const bool no_two_product = getenv("CSGPU_NO_TWO_PRODUCT") != nullptr;  // tuning / A-B knob
-    sp.two_product = opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0 && !no_two_product;
+    sp.two_product = opts.nu_pre == 1 && opts.nu_post == 1 && kn.two_product;
     // coarse levels: Chebyshev weights for the sweep counts the solve phase will run (CSGPU_COARSE_JACOBI=1: the damped
     // Jacobi of round 1, A/B knob)
     const int nuc = opts.nu_coarse > 0 ? opts.nu_coarse : 1;
-    sp.nu_l1 = getenv("CSGPU_NU_L1") ? atoi(getenv("CSGPU_NU_L1")) : nuc;
-    sp.nu_deep = getenv("CSGPU_NU_DEEP") ? atoi(getenv("CSGPU_NU_DEEP")) : nuc + 1;
-    sp.coarse_chebyshev = getenv("CSGPU_COARSE_JACOBI") == nullptr;
+    sp.nu_l1 = kn.nu_l1 > 0 ? kn.nu_l1 : nuc;
+    sp.nu_deep = kn.nu_deep > 0 ? kn.nu_deep : nuc + 1;
+    sp.coarse_chebyshev = kn.coarse_smoother != 2;
     return sp;
   }
   PcgParams pcg_params(int K = 1) const {
@@ -305,9 +425,8 @@ struct Solver : ISolver {
   // Lattice form of the CG matrix: period known (raster built here, every cell valid) or detected from the band
   // structure of a host-built matrix (candidates around the dominant band offset found by spmv_block_order).
   void detect_lattice(const Csr<T>& A, int known_period) {
-    static const bool off = getenv("CSGPU_NO_STENCIL") != nullptr;  // A/B knob
     dia = Dia<T>();
-    if (off || opts.stencil < 0 || known_period < 0) return;
+    if (!kn.stencil || known_period < 0) return;
     if (known_period > 0) {
       dia_from_csr(A, known_period, dia, st, /*trusted=*/true);
       return;
@@ -452,7 +571,7 @@ struct Solver : ISolver {
     dia.rows = std::move(rows);
     if (lattice_pipeline_hierarchy(size0, R, C)) {
       host_blocks = (int)cuts.size() - 1;
-      if (getenv("CSGPU_VERBOSE"))
+      if (kn.verbose)
         fprintf(stderr, "csgpu: host matrix streamed in %zu block(s) of rows (%lld stored entries, %lld x %lld cells)\n",
                 cuts.size() - 1, (long long)nnz_api, (long long)R, (long long)C);
       return true;
@@ -468,10 +587,10 @@ struct Solver : ISolver {
 
   void setup_from_host(const void* rowptr, const void* colidx, const void* vals, int64_t n_, int64_t nnz_,
                        int idx_bytes, int index_base) {
+    KnobScope ks(&kn);
     auto t0 = std::chrono::steady_clock::now();
     {
-      const char* ev = getenv("CSGPU_STREAM_HOST_CSR");  // (read per call: a test knob, not a tuning constant)
-      const int64_t forced = ev ? atoll(ev) : 0;
+      const int64_t forced = kn.host_stream_block;  // (csgpu_opts.host_stream_block: a test / tuning knob)
       if (nnz_ >= ((int64_t)1 << 31) || forced > 0) {
         const csgpu_opts keep = opts;
         if (setup_from_host_streamed(rowptr, colidx, vals, n_, nnz_, idx_bytes, index_base,
@@ -562,8 +681,7 @@ struct Solver : ISolver {
   // period is detected from the matrix, detect_lattice). False -- nothing changed -- when the matrix is no such raster
   // (polygons: couplings between cells that are not neighbours; two nodes on one cell; too few valid cells).
   bool setup_cellspace_from_csr(Csr<T>& A, const int* prow, const int* pcol) {
-    static const bool off = getenv("CSGPU_NO_CELLSPACE_FROM_CSR") != nullptr;  // A/B knob
-    if (off || n_api < 36 || A.nnz < 1) return false;
+    if (!kn.cellspace_from_csr || n_api < 36 || A.nnz < 1) return false;
     DBuf mm = dalloc<int>(4);
     const int init[4] = {-0x7fffffff, -0x7fffffff, 0x7fffffff, 0x7fffffff};
     CS_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -661,8 +779,7 @@ struct Solver : ISolver {
       sp.grid_rows = known_period;
       sp.grid_cols = (int)(n / known_period);
     }
-    static const bool no_lattice_s = getenv("CSGPU_NO_LATTICE_S") != nullptr;  // A/B knob
-    sp.lattice_s = sp.two_product && dia.n > 0 && !no_lattice_s;
+    sp.lattice_s = sp.two_product && dia.n > 0 && kn.lattice_s;
     // Chebyshev weights on the coarse levels need a clean restriction chain: measured on MI355X they save 4-17 % of the
     // iterations on rasters up to 5000^2 (7 levels) with an fp32 hierarchy and at 10000^2 (8 levels) with an fp64 one,
     // but the fp32 hierarchy of a 10000^2 raster lost with them (11.8 / 21 instead of 10.9 / 11 iterations, mean /
@@ -672,7 +789,7 @@ struct Solver : ISolver {
     // profiles/r2_coarse_chebyshev.json) -- measured on 48 pairs at the very end of the round, after the full evidence
     // set had been taken with the rule below in place; CSGPU_COARSE_CHEBYSHEV=1 lifts it, and the next full evidence run
     // should.
-    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;
+    if (sizeof(TP) == 4 && n > 30000000 && kn.coarse_smoother != 1) sp.coarse_chebyshev = false;
     if constexpr (MIXED) {
       Csr<TP> Ap;
       convert_csr(A, Ap, st);
@@ -694,11 +811,10 @@ struct Solver : ISolver {
       CS_HIP(hipEventCreate(&e0));
       CS_HIP(hipEventCreate(&e1));
       CS_HIP(hipEventRecord(e0, st));
-      static const bool no_lattice_q = getenv("CSGPU_NO_LATTICE_Q") != nullptr;  // A/B knob
-      const bool ok = !no_lattice_q && lattice_q_from_csr(L0.Q, (const int*)dptr<int>(L0.agg0), dia.R, (int)(n / dia.R),
+      const bool ok = kn.lattice_q && lattice_q_from_csr(L0.Q, (const int*)dptr<int>(L0.agg0), dia.R, (int)(n / dia.R),
                                                           L0.Ql, st);
       L0.agg0.release();
-      if (getenv("CSGPU_VERBOSE"))
+      if (kn.verbose)
         fprintf(stderr, "csgpu: two-product level on a %d x %lld lattice: index-free Q %s\n", dia.R, (long long)(n / dia.R),
                 ok ? "built" : "not applicable (CSR forms)");
       if (ok) {
@@ -722,20 +838,18 @@ struct Solver : ISolver {
   // ~half-full rasters the compact CSR path moves fewer bytes (CSGPU_CELLSPACE_MIN_FRAC, default 0.5; CSGPU_NO_CELLSPACE=1
   // keeps the compact numbering of round 2).
   bool want_cellspace(int64_t nvalid, int64_t ncells, int64_t R, int64_t C) const {
-    if (getenv("CSGPU_NO_CELLSPACE") || getenv("CSGPU_NO_STENCIL") || opts.stencil < 0) return false;
+    if (!kn.cellspace || !kn.stencil) return false;
     if (nvalid == ncells || R < 6 || C < 6) return false;
-    if (!(opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0) || getenv("CSGPU_NO_TWO_PRODUCT")) return false;
+    if (!(opts.nu_pre == 1 && opts.nu_post == 1 && kn.two_product)) return false;
     if (opts.aggregation == CSGPU_AGG_MIS2 || opts.theta != 0.0) return false;
-    const double minfrac = getenv("CSGPU_CELLSPACE_MIN_FRAC") ? atof(getenv("CSGPU_CELLSPACE_MIN_FRAC")) : 0.5;
+    const double minfrac = kn.cellspace_min_frac;
     return (double)nvalid >= minfrac * (double)ncells;
   }
 
   // The index-free pipeline needs what the lattice two-product level needs (and its A/B knobs off).
   bool want_lattice_pipeline(int64_t R, int64_t C) const {
-    if (getenv("CSGPU_NO_DIRECT_LATTICE") || getenv("CSGPU_NO_STENCIL") || getenv("CSGPU_NO_LATTICE_S") ||
-        getenv("CSGPU_NO_LATTICE_Q") || getenv("CSGPU_NO_TWO_PRODUCT") || getenv("CSGPU_NO_DIRECT_TILES"))
-      return false;
-    if (opts.stencil < 0 || !(opts.nu_pre == 1 && opts.nu_post == 1 && opts.two_product >= 0)) return false;
+    if (!(kn.direct_lattice && kn.stencil && kn.lattice_s && kn.lattice_q && kn.two_product && kn.direct_tiles)) return false;
+    if (!(opts.nu_pre == 1 && opts.nu_post == 1)) return false;
     if (opts.aggregation == CSGPU_AGG_MIS2 || opts.theta != 0.0) return false;
     return R >= 6 && C >= 6 && R * C > opts.max_coarse && opts.max_levels >= 2;
   }
@@ -754,7 +868,7 @@ struct Solver : ISolver {
     sp.lattice_s = true;
     sp.size0 = cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr;
     sp.n_real = cellspace ? n_api : 0;
-    if (sizeof(TP) == 4 && n > 30000000 && !getenv("CSGPU_COARSE_CHEBYSHEV")) sp.coarse_chebyshev = false;  // (see finish_setup)
+    if (sizeof(TP) == 4 && n > 30000000 && kn.coarse_smoother != 1) sp.coarse_chebyshev = false;  // (see finish_setup)
     // polygon handles: the strength-aware tiles are what keeps the strengthened polygon interiors (poly.h) out of the
     // aggregates of their surroundings -- always on, however few cells the polygons cover
     if (poly_proj) sp.tile_split_min = -1.0;
@@ -770,7 +884,7 @@ struct Solver : ISolver {
       H.setup_ms = ms;
       if constexpr (MIXED) Aouter.nrows = Aouter.ncols = (int)n;
       csr_ready = false;
-      if (getenv("CSGPU_VERBOSE"))
+      if (kn.verbose)
         fprintf(stderr, "csgpu: %lld x %lld raster through the index-free pipeline (%lld rows, %lld nodes, %d levels)\n",
                 (long long)R, (long long)C, (long long)n, (long long)n_api, (int)H.levels.size());
     }
@@ -832,6 +946,7 @@ struct Solver : ISolver {
 
   void setup_from_raster(const void* cond, int64_t R, int64_t C, int four, int avg_res, int reg,
                          const void* ground = nullptr) {
+    KnobScope ks(&kn);
     auto t0 = std::chrono::steady_clock::now();
     const int64_t ncells = R * C;
     DBuf dcond((size_t)ncells * sizeof(T));
@@ -912,7 +1027,7 @@ struct Solver : ISolver {
     // every cell a row: row i couples to i+-1, i+-(R-1), i+-R, i+-(R+1) -> lattice form (stencil.h)
     finish_setup(std::move(A), dptr<int>(drow), dptr<int>(dcol), n == ncells ? (int)R : -1,
                  cellspace ? (const long long*)dptr<long long>(size0) : (const long long*)nullptr);
-    if (cellspace && !(dia.n > 0 && H.levels[0].lattice_two_product()) && getenv("CSGPU_VERBOSE"))
+    if (cellspace && !(dia.n > 0 && H.levels[0].lattice_two_product()) && kn.verbose)
       fprintf(stderr, "csgpu: cell-space raster without the index-free fine level (CSR kernels on %lld rows)\n", (long long)n);
   }
 
@@ -924,8 +1039,8 @@ struct Solver : ISolver {
   // 10.9 on the merged CSR graph).
   bool setup_poly_lattice(const void* cond, const int32_t* polymap, int64_t R, int64_t C, int four, int avg_res, int reg,
                           bool is_fallback) {
-    if (is_fallback || getenv("CSGPU_NO_POLY_LATTICE") || !want_lattice_pipeline(R, C)) return false;
-    if (getenv("CSGPU_NO_CELLSPACE") || ground_node.p) return false;
+    if (is_fallback || kn.poly_lattice < 0 || !want_lattice_pipeline(R, C)) return false;
+    if (!kn.cellspace || ground_node.p) return false;
     auto t0 = std::chrono::steady_clock::now();
     const int64_t ncells = R * C;
     const T* hc = (const T*)cond;
@@ -953,7 +1068,7 @@ struct Solver : ISolver {
       if (member) ++count[(size_t)dense[(size_t)p]];
       if (member || hc[k] > T(0)) ++nrows;
     }
-    const double minfrac = getenv("CSGPU_CELLSPACE_MIN_FRAC") ? atof(getenv("CSGPU_CELLSPACE_MIN_FRAC")) : 0.5;
+    const double minfrac = kn.cellspace_min_frac;
     if ((double)nrows < minfrac * (double)ncells) return false;
     // (polygons of a single cell are ordinary nodes: nothing to project)
     std::vector<int> hptr((size_t)npoly + 1, 0);
@@ -1054,12 +1169,12 @@ struct Solver : ISolver {
         if (reached != hi - lo) split_polygon = true;
       }
     }
-    if (split_polygon && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
-      if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a polygon in several pieces: merged CSR graph instead of the lattice path\n");
+    if (split_polygon && kn.poly_lattice <= 0) {
+      if (kn.verbose) fprintf(stderr, "csgpu: a polygon in several pieces: merged CSR graph instead of the lattice path\n");
       return false;
     }
-    if (wire_like && !getenv("CSGPU_POLY_LATTICE_ANY_SHAPE")) {
-      if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: a long thin polygon: merged CSR graph instead of the lattice path\n");
+    if (wire_like && kn.poly_lattice <= 0) {
+      if (kn.verbose) fprintf(stderr, "csgpu: a long thin polygon: merged CSR graph instead of the lattice path\n");
       return false;
     }
     // ---- device: labels and node numbering exactly as the merged path computes them (raster.h)
@@ -1116,10 +1231,7 @@ struct Solver : ISolver {
     // few cells less still -- the hierarchy copes with a stiff inclusion once it spans several 3x3 tiles, while a stiff
     // speck inside a tile only unbalances the smoother. Hence strength = coef * (member cells), clamped.
     // CSGPU_POLY_STRENGTH fixes one value for all polygons (A/B knob).
-    const double s_fixed = getenv("CSGPU_POLY_STRENGTH") ? atof(getenv("CSGPU_POLY_STRENGTH")) : 0.0;
-    const double s_coef = getenv("CSGPU_POLY_COEF") ? atof(getenv("CSGPU_POLY_COEF")) : 1.0;
-    const double s_min = getenv("CSGPU_POLY_SMIN") ? atof(getenv("CSGPU_POLY_SMIN")) : 8.0;
-    const double s_max = getenv("CSGPU_POLY_SMAX") ? atof(getenv("CSGPU_POLY_SMAX")) : 1000.0;
+    const double s_fixed = kn.poly_strength, s_coef = kn.poly_coef, s_min = kn.poly_smin, s_max = kn.poly_smax;
     // ... of a BLOB: the member count is discounted by the polygon's share of core cells -- full weight from 40 % core
     // cells on (a square of 5 x 5 has 36 %), proportionally less below.
     std::vector<double> hstrength((size_t)npoly);
@@ -1187,7 +1299,7 @@ struct Solver : ISolver {
     poly_four = four;
     poly_avg = avg_res;
     poly_reg = reg;
-    if (getenv("CSGPU_VERBOSE"))
+    if (kn.verbose)
       fprintf(stderr, "csgpu: %d polygons (%d member cells, %d chunks) on the lattice path, interior strength %s %g\n", npoly,
               hptr[(size_t)npoly], proj.nchunks, strength > 0 ? "fixed at" : "per polygon, coefficient", strength > 0 ? strength : s_coef);
     return true;
@@ -1207,6 +1319,7 @@ struct Solver : ISolver {
   // csgpu_raster_setup_poly: raster with short-circuit polygons, graph built on the device (raster.h, second half)
   void setup_from_raster_poly(const void* cond, const int32_t* polymap, int64_t R, int64_t C, int four, int avg_res,
                               int reg, bool is_fallback = false) {
+    KnobScope ks(&kn);
     if (setup_poly_lattice(cond, polymap, R, C, four, avg_res, reg, is_fallback)) return;
     auto t0 = std::chrono::steady_clock::now();
     const int64_t ncells = R * C;
@@ -1317,6 +1430,7 @@ struct Solver : ISolver {
 
   void raster_nodemap(int32_t* out, int64_t* rows, int64_t* cols) override {
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(nodemap.p != nullptr, CSGPU_BAD_ARGS, "handle was not built by csgpu_raster_setup");
     if (rows) *rows = raster_rows;
@@ -1335,6 +1449,7 @@ struct Solver : ISolver {
   int64_t components(int32_t* out) override {
     if (poly_proj) return poly_fallback().components(out);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     ensure_components();
     if (!cellspace) {
@@ -1366,6 +1481,7 @@ struct Solver : ISolver {
   void solve_raster(const void* source, void* curr_out, void* volt_out, csgpu_stats* stats) override {
     if (poly_proj) return poly_fallback().solve_raster(source, curr_out, volt_out, stats);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1442,7 +1558,7 @@ struct Solver : ISolver {
     // the level-0 kernels of a CSR-path handle (networks, rasters with thin polygons: spmv_launch_cg / _wide, the long-row
     // kernel) have no such form and run 1.75x slower per column with 8 rows per lane, so fp64 hierarchies without a
     // lattice level 0 stay at 16 columns. fp32 hierarchies (8 lanes per row at K = 32) are fine. CSGPU_WIDE_CSR=1 lifts it.
-    if (kmax > 16 && sizeof(TP) == 8 && !getenv("CSGPU_WIDE_CSR")) {
+    if (kmax > 16 && sizeof(TP) == 8 && !kn.wide_csr) {
       if (!(H.levels.size() > 1 && H.levels[0].lattice_two_product())) kmax = 16;
     }
     int k = 1;
@@ -1521,6 +1637,7 @@ struct Solver : ISolver {
       return poly_fallback().solve_pairs(src, dst, npairs, volt_out, gather, ngather, gathered_out, resist_out, stats, weights,
                                          curr_out, cum_inout, max_inout, branch_out);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1591,11 +1708,9 @@ struct Solver : ISolver {
     // 2^25) moves that bound; CSGPU_STREAM=1 streams from the first pair on (tests, A/B), CSGPU_NO_STREAM=1 never.
     bool stream_eligible = false, stream_now = false;
     if (!(volt_out || curr_out || cum_inout || max_inout || branch_out || opts.explicit_check > 0) && dia_ptr() && npairs > Kmax &&
-        Kmax >= 8 && !poly_proj && !getenv("CSGPU_NO_STREAM")) {
-      const char* sm = getenv("CSGPU_STREAM_MIN");
-      stream_eligible = (int64_t)n * Kmax >= (sm ? atoll(sm) : ((int64_t)1 << 25));
-      const char* fs = getenv("CSGPU_STREAM");
-      stream_now = stream_eligible && fs && atoi(fs) > 0;
+        Kmax >= 8 && !poly_proj && kn.stream >= 0) {
+      stream_eligible = (int64_t)n * Kmax >= kn.stream_min;
+      stream_now = stream_eligible && kn.stream > 0;
     }
     // the rest of the list [p0, npairs) as a stream; false when the stream declined (the batches go on)
     auto stream_rest = [&](int64_t p0) -> bool {
@@ -1658,7 +1773,7 @@ struct Solver : ISolver {
       }
     }
     std::vector<int> s32(Kmax), d32(Kmax), w32(Kmax);
-    static const bool fixed_k = getenv("CSGPU_FIXED_K") != nullptr;  // A/B knob: every batch at the call's width (round 5)
+    const bool fixed_k = kn.fixed_k;  // A/B knob (csgpu_opts.fixed_k): every batch at the call's width (round 5)
     int K = Kmax;
     for (int64_t p0 = 0; p0 < npairs; p0 += K) {
       if (stream_now && npairs - p0 > Kmax) {
@@ -1794,6 +1909,7 @@ struct Solver : ISolver {
   void solve_rhs(const void* rhs, int64_t nrhs, void* x_out, csgpu_stats* stats) override {
     if (poly_proj) return poly_fallback().solve_rhs(rhs, nrhs, x_out, stats);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1824,6 +1940,7 @@ struct Solver : ISolver {
   void solve_grounded(const GroundedJob& J, int64_t nrhs, csgpu_stats* stats) override {
     if (poly_proj) return poly_fallback().solve_grounded(J, nrhs, stats);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1906,7 +2023,7 @@ struct Solver : ISolver {
       T val;
     };
     std::vector<Ent> ents;
-    static const bool fixed_k = getenv("CSGPU_FIXED_K") != nullptr;  // A/B knob, as in solve_pairs
+    const bool fixed_k = kn.fixed_k;  // A/B knob, as in solve_pairs
     int K = Kmax;
     for (int64_t p0 = 0; p0 < nrhs; p0 += K) {
       K = fixed_k ? Kmax : pick_k(nrhs - p0);
@@ -2042,6 +2159,7 @@ struct Solver : ISolver {
                           const int64_t* dst_set, int64_t npairs, double* resistances, csgpu_stats* stats) override {
     if (poly_proj) return poly_fallback().solve_region_pairs(set_ptr, set_nodes, nsets, src_set, dst_set, npairs, resistances, stats);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -2193,6 +2311,7 @@ struct Solver : ISolver {
   }
 
   void get_info(csgpu_info* info) const override {
+    KnobScope ks(&kn);
     memset(info, 0, sizeof(*info));
     info->n = n_api;      // (cell space: the caller's node count; level_n[0] / level_nnz[0] are the device matrix's)
     info->nnz = nnz_api;
@@ -2206,6 +2325,19 @@ struct Solver : ISolver {
     info->hierarchy_rebuilt_fp64 = rebuilt_fp64 ? 1 : 0;
     info->enrich_vectors = H.enr.nvec;
     info->host_blocks = host_blocks;
+    info->batch_width = pick_k(opts.batch);
+    info->stream_mode = kn.stream;
+    info->tail_first_level = tail_first;
+    {
+      const bool sweeps_level = !H.coarse_dense;  // the last level runs Jacobi sweeps instead of a dense pseudo-inverse
+      const int want = kn.last_level_sweeps;
+      info->last_level_sweeps = !sweeps_level ? -1 : (want == 0 ? (H.levels.size() == 1 ? kSingleLevelSweeps : 8) : std::max(want, 0));
+    }
+    info->coarse_chebyshev = (H.levels.size() > 1 && !H.levels[1].weights.empty()) ? 1 : 0;
+    info->cellspace = cellspace ? 1 : 0;
+    info->poly_lattice = poly_proj ? 1 : 0;
+    info->enrich_on = kn.enrich ? 1 : 0;
+    info->enrich_tau = kn.enrich ? kn.enrich_tau : 0.0;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];
       if (l < 32) {
@@ -2262,6 +2394,7 @@ struct Solver : ISolver {
   double spmv_bench(int k, int reps) override {
     if (poly_proj) return poly_fallback().spmv_bench(k, reps);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     ensure_csr();
     const Csr<T>& A = cg_matrix();
@@ -2291,6 +2424,7 @@ struct Solver : ISolver {
   void spmv_host(const void* xh, void* yh, int k) override {
     if (poly_proj) return poly_fallback().spmv_host(xh, yh, k);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     ensure_csr();
     const Csr<T>& A = cg_matrix();
@@ -2370,6 +2504,7 @@ struct Solver : ISolver {
   void level_spmv_host(int lvl, int which, const void* xh, void* yh, int k, double* dots) override {
     if (poly_proj) return poly_fallback().level_spmv_host(lvl, which, xh, yh, k, dots);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
     Level<TP>& L = H.levels[lvl];   // the forms the solve phase uses (lattice kernels)
@@ -2420,6 +2555,7 @@ struct Solver : ISolver {
 
   void get_level_matrix(int lvl, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz_out, int32_t* rowptr,
                         int32_t* colidx, void* vals) const override {
+    KnobScope ks(&kn);
     if (poly_proj)
       return const_cast<Solver<T, TP>*>(this)->poly_fallback().get_level_matrix(lvl, which, nrows, ncols, nnz_out, rowptr, colidx, vals);
     CS_REQUIRE(lvl >= 0 && lvl < (int)H.levels.size(), CSGPU_BAD_ARGS, "level out of range");
@@ -2487,6 +2623,7 @@ struct Solver : ISolver {
                         double* dots) override {
     if (poly_proj) return poly_fallback().dia_product_host(zh, ph, beta, pout_h, yh, k, dots);
     std::lock_guard<std::mutex> lk(mu);
+    KnobScope ks(&kn);
     CS_HIP(hipSetDevice(device));
     CS_REQUIRE(dia.n > 0, CSGPU_BAD_ARGS, "matrix has no lattice form");
     const size_t xb = (size_t)n * k * sizeof(TP), yb = (size_t)n * k * sizeof(T);
@@ -2627,9 +2764,9 @@ static void single_level_precision(csgpu_opts& o, int64_t n) {
 // asked for with precond_bytes = 4 is rebuilt with an fp64 hierarchy (csgpu_get_info then reports the precision in effect);
 // CSGPU_HETERO_FP64_FRAC=1 switches the fallback off.
 static bool hetero_wants_fp64(const csgpu::ISolver& s) {
-  static const double lim = getenv("CSGPU_HETERO_FP64_FRAC") ? atof(getenv("CSGPU_HETERO_FP64_FRAC")) : 0.03;
+  const double lim = s.kn.hetero_fp64_frac;
   const bool yes = s.hetero_frac() > lim;
-  if (yes && getenv("CSGPU_VERBOSE"))
+  if (yes && s.kn.verbose)
     fprintf(stderr, "csgpu: heterogeneous raster (%.1f %% of the cells leave their tile): fp64 hierarchy instead of fp32\n",
             100.0 * s.hetero_frac());
   return yes;

@@ -46,12 +46,11 @@ __global__ __launch_bounds__(256) void dia25_fill_kernel(int n, int R, const int
   }
 }
 
-// smallest level that takes the 25-point form. A/B knob CSGPU_DIA25: 0 = never, n > 1 = levels with at least n rows
+// smallest level that takes the 25-point form. Knobs::dia25_min_rows (csgpu_opts.dia25_min_rows): -1 = never, n = levels with at least n rows
 // (default 16384: below that the level sits in the coarse tail kernel, tail.h, or costs microseconds either way)
 inline int64_t dia25_min_rows() {
-  const char* e = getenv("CSGPU_DIA25");  // (read at every set-up: the tests switch it inside one process)
-  if (!e || atoll(e) == 1) return 16384;
-  return atoll(e) <= 0 ? (int64_t)0x7fffffffffffLL : (int64_t)atoll(e);
+  const int64_t v = knobs().dia25_min_rows;
+  return v < 0 ? (int64_t)0x7fffffffffffLL : v;
 }
 
 template <class T>
@@ -278,17 +277,14 @@ __global__ __launch_bounds__(256, WV) void dia25w_kernel(Dia25Args<T> a) {
   }
 }
 
-inline bool dia25_prefetch_b() {
-  const char* e = getenv("CSGPU_DIA25_PF");  // (read at every launch: the tests switch it inside one process)
-  return e ? atoi(e) != 0 : true;
-}
+inline bool dia25_prefetch_b() { return knobs().dia25_prefetch; }
 
 // Register bound of the launch: 3 waves per SIMD where that costs at most a few spilled dwords (8 or more lanes per node:
 // K = 32, K = 16 fp64; measured at K = 32: 325.3 against 327.7 ms per 16 pairs on the mixed path), no bound for the
 // narrower batches (K = 8 fp64 would spill 52 B per lane under the bound; without it 2 waves per SIMD and no scratch).
 inline int dia25_waves(int lanes_per_node) {
-  const char* e = getenv("CSGPU_DIA25_WAVES");
-  return e ? atoi(e) : (lanes_per_node >= 8 ? 3 : 1);
+  const int w = knobs().dia25_waves;
+  return w > 0 ? w : (lanes_per_node >= 8 ? 3 : 1);
 }
 
 template <class T, int K>

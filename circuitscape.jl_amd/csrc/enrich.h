@@ -386,13 +386,8 @@ __global__ __launch_bounds__(256) void enrich_vec_of_tile_kernel(int ntiles, con
 }
 
 // ---- set-up ---------------------------------------------------------------------------------------------------------
-// A/B knobs: CSGPU_ENRICH=0 switches the enrichment off, CSGPU_ENRICH_TAU (default below), CSGPU_ENRICH_STEPS (default 6).
-inline double enrich_tau() {
-  const char* e = getenv("CSGPU_ENRICH");
-  if (e && atof(e) <= 0.0) return 0.0;
-  const char* t = getenv("CSGPU_ENRICH_TAU");
-  return t ? atof(t) : 0.06;
-}
+// Knobs (csgpu_opts.enrich = -1 switches the enrichment off, .enrich_tau, .enrich_steps; defaults 0.06 and 6).
+inline double enrich_tau() { return knobs().enrich ? knobs().enrich_tau : 0.0; }
 
 template <class U, class T>
 inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc, const long long* size0, const int* agg,
@@ -400,7 +395,7 @@ inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc,
   E = Enrich();
   const double tau = enrich_tau();
   if (!(tau > 0.0)) return;
-  const int psteps = getenv("CSGPU_ENRICH_STEPS") ? atoi(getenv("CSGPU_ENRICH_STEPS")) : 6;
+  const int psteps = knobs().enrich_steps;
   const int64_t n = (int64_t)R * C;
   const int ntiles = Rc * Cc;
   DBuf phi((size_t)n * sizeof(T)), flag = dalloc<int>((size_t)ntiles + 1), mcount = dalloc<int>((size_t)ntiles + 1);
@@ -480,7 +475,7 @@ inline void enrich_setup(Enrich& E, const U* rows, int R, int C, int Rc, int Cc,
   E.R = R;
   E.n = n;
   E.ntiles = ntiles;
-  if (getenv("CSGPU_VERBOSE"))
+  if (knobs().verbose)
     fprintf(stderr, "csgpu: coarse-space enrichment: %d of %d aggregates get a second function (tau %.3g), %d members, %d halo cells, %d + %d entries of A E\n",
             nvec, ntiles, tau, nmem, nhalo, nae, nhe);
 }

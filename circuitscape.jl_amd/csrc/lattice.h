@@ -242,13 +242,9 @@ __global__ __launch_bounds__(NT) void lattice_restrict_kernel(RestrictArgs<T> a)
   }
 }
 
-inline int lattice_segc() {  // coarse columns per restriction tile (tuning knob CSGPU_RESTRICT_SEG)
-  static int seg = [] {
-    const char* e = getenv("CSGPU_RESTRICT_SEG");
-    const int v = e ? atoi(e) : 32;
-    return v < 2 ? 2 : v;
-  }();
-  return seg;
+inline int lattice_segc() {  // coarse columns per restriction tile (tuning knob Knobs::restrict_seg)
+  const int v = knobs().restrict_seg;
+  return v < 2 ? 2 : v;
 }
 
 // bc = Q^T b

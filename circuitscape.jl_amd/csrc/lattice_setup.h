@@ -800,7 +800,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   carry.ccol.alloc((size_t)nc * sizeof(int));
   hipLaunchKernelGGL(lattice_tile_kernel, dim3(g), dim3(256), 0, st, n, R, Rc, Cc, dptr<int>(agg), dptr<int>(carry.crow),
                      dptr<int>(carry.ccol));
-  static const bool no_pieces = getenv("CSGPU_NO_TILE_PIECES") != nullptr;  // A/B knob
+  const bool no_pieces = !knobs().tile_pieces;  // A/B knob
   // strength filter of the piece analysis (TileStrength in amg_setup.h): decided here for the whole hierarchy
   DBuf ones;  // unit weights of an all-valid raster that turns out heterogeneous
   double th2 = 0.0;
@@ -832,7 +832,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
     }
     const bool hetero = t2 > 0.0 && (double)(out1 - out0) > sp.tile_split_min * (double)std::max<int64_t>(valid, 1);
     if (t2 > 0.0) H.hetero_frac = (double)(out1 - out0) / (double)std::max<int64_t>(valid, 1);
-    if (getenv("CSGPU_VERBOSE"))
+    if (knobs().verbose)
       fprintf(stderr, "csgpu: tile strength test: %lld of %lld cells leave their tile at theta %.3g (%lld without): %s\n",
               (long long)out1, (long long)valid, sp.tile_theta, (long long)out0, hetero ? "filter ON" : "filter off");
     if (hetero) {
@@ -863,7 +863,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   CS_HIP(hipMemsetAsync(size_c.p, 0, size_c.bytes, st));
   hipLaunchKernelGGL(lattice_sizes_kernel, dim3(g), dim3(256), 0, st, n, (const int*)dptr<int>(agg), (const long long*)size0,
                      dptr<unsigned long long>(size_c));
-  if (size0 && getenv("CSGPU_VERBOSE")) {
+  if (size0 && knobs().verbose) {
     std::vector<unsigned long long> hs((size_t)nc);
     CS_HIP(hipMemcpy(hs.data(), size_c.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long tot = 0, empty = 0;
@@ -950,8 +950,8 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
 // hierarchies whose tiles were refined by the piece analysis.
 template <class T>
 inline void lattice_level1_setup(Level<T>& L, const int* agg, int R, int C, int nagg, hipStream_t st) {
-  static const bool off = getenv("CSGPU_NO_LATTICE_L1") != nullptr;  // A/B knob
-  static const int min_rows = getenv("CSGPU_LATTICE_L1_MIN_ROWS") ? atoi(getenv("CSGPU_LATTICE_L1_MIN_ROWS")) : 16384;
+  const bool off = !knobs().lattice_l1;  // A/B knob
+  const int min_rows = knobs().lattice_l1_min_rows;
   const int64_t n = (int64_t)R * C;
   const int Rc = (R + 1) / 3, Cc = (C + 1) / 3;
   if (off || n < min_rows || L.A.nrows != n || (int64_t)Rc * Cc != nagg || R < 6 || C < 6) return;
@@ -980,7 +980,7 @@ inline void lattice_level1_setup(Level<T>& L, const int* agg, int R, int C, int 
   L.Ql.Rc = Rc;
   L.Ql.Cc = Cc;
   L.Ql.q = std::move(ql);
-  if (getenv("CSGPU_VERBOSE")) fprintf(stderr, "csgpu: level 1 (%d x %d) in lattice form\n", R, C);
+  if (knobs().verbose) fprintf(stderr, "csgpu: level 1 (%d x %d) in lattice form\n", R, C);
 }
 
 }  // namespace csgpu

@@ -52,6 +52,9 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
   H.work_kcap = K;
 }
 
+// Jacobi sweeps per preconditioner application of a hierarchy of ONE level (see vcycle; csgpu_opts.last_level_sweeps)
+constexpr int kSingleLevelSweeps = 8;
+
 // Optional fusions at level 0 of the V-cycle.
 template <class T>
 struct VcycleFuse {
@@ -69,13 +72,13 @@ struct VcycleFuse {
 template <class T>
 inline int tail_first_level(Hierarchy<T>& H) {
   if (H.tail_first != -2) return H.tail_first;
-  const int rows = getenv("CSGPU_TAIL_ROWS") ? atoi(getenv("CSGPU_TAIL_ROWS")) : 4096;  // (read once per hierarchy)
+  const int rows = knobs().tail_rows;  // (read once per hierarchy)
   H.tail_first = -1;
   const int nl = (int)H.levels.size();
   for (int l = 1; l + 1 < nl; ++l) {
     if (H.levels[l].A.nrows <= rows && nl - l <= kTailMaxLevels) {
       H.tail_first = l;
-      if (getenv("CSGPU_TAIL_DEBUG")) fprintf(stderr, "csgpu: coarse tail from level %d (%d rows) of %d\n", l, H.levels[l].A.nrows, nl);
+      if (knobs().tail_debug) fprintf(stderr, "csgpu: coarse tail from level %d (%d rows) of %d\n", l, H.levels[l].A.nrows, nl);
       break;
     }
   }
@@ -86,7 +89,7 @@ inline int tail_first_level(Hierarchy<T>& H) {
 template <class T>
 inline int tail_first_level_peek(const Hierarchy<T>& H) {
   if (H.tail_first != -2) return H.tail_first;
-  const int rows = getenv("CSGPU_TAIL_ROWS") ? atoi(getenv("CSGPU_TAIL_ROWS")) : 4096;
+  const int rows = knobs().tail_rows;
   const int nl = (int)H.levels.size();
   for (int l = 1; l + 1 < nl; ++l)
     if (H.levels[l].A.nrows <= rows && nl - l <= kTailMaxLevels) return l;
@@ -141,7 +144,7 @@ inline void launch_tail(Hierarchy<T>& H, int first, const T* b, T* out, int nu_f
   // projection of the candidate out of the tail's right-hand sides: near-singular fp32 hierarchies only (A/B knob:
   // CSGPU_NO_TAIL_PROJECTION)
   // (not for Dirichlet-masked solves: their right-hand sides DO have a component along the candidate)
-  a.cand_inv_norm2 = (H.near_singular && H.cand_norm2 > 0 && !dirichlet && !getenv("CSGPU_NO_TAIL_PROJECTION")) ? (T)(1.0 / H.cand_norm2) : T(0);
+  a.cand_inv_norm2 = (H.near_singular && H.cand_norm2 > 0 && !dirichlet && knobs().tail_projection) ? (T)(1.0 / H.cand_norm2) : T(0);
   a.scratch = dptr<T>(H.tail_ws);
   a.stride = off;
   a.bin = b;
@@ -171,8 +174,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   // Level 1 gets nu_coarse sweeps, the levels below it one more: they hold 1/81 of the fine level's work and the extra
   // sweep saves an iteration of the slowest column (measured at 10000^2, profiles/r2_sweeps_per_level.json: level 1 with
   // one sweep costs 2 iterations whatever the deeper levels do). Experiment knobs: CSGPU_NU_L1, CSGPU_NU_DEEP.
-  static const int nu_l1 = getenv("CSGPU_NU_L1") ? atoi(getenv("CSGPU_NU_L1")) : 0;
-  static const int nu_deep = getenv("CSGPU_NU_DEEP") ? atoi(getenv("CSGPU_NU_DEEP")) : 0;
+  const int nu_l1 = knobs().nu_l1, nu_deep = knobs().nu_deep;
   const int nu_lvl = l == 1 ? (nu_l1 > 0 ? nu_l1 : nu_coarse) : (nu_deep > 0 ? nu_deep : nu_coarse + 1);
   // Chebyshev levels (amg_setup.h): one weight per sweep, fixed at setup; the sweep count is the polynomial's degree
   const bool cheb = l >= 1 && !L.weights.empty();
@@ -226,7 +228,17 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   if (last) {
     // coarsest level too large for a dense inverse: a fixed number of damped-Jacobi sweeps
     hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, cur, b, dptr<T>(L.dinv), omega, skip);
-    const int sweeps = 8;
+    // (a hierarchy of ONE level -- a graph the set-up declines to coarsen, BASELINE configs[4] -- is polynomial-preconditioned
+    // CG: every sweep is one more pass over the matrix per iteration; Knobs::last_level_sweeps, 0 = the Jacobi scaling alone)
+    const int want = knobs().last_level_sweeps;
+    const int sweeps = want == 0 ? (H.levels.size() == 1 ? kSingleLevelSweeps : 8) : std::max(want, 0);
+    if (sweeps <= 0) {
+      hipLaunchKernelGGL((scale_dinv_kernel<T, K>), dim3(gv), dim3(256), 0, st, (int64_t)n, out, b, dptr<T>(L.dinv), omega, skip);
+      if (want_dot)
+        hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(spmv_grid<T, K>(n)), dim3(256), 0, st, (int64_t)n, fuse->dotw,
+                           (const T*)out, fuse->partials, (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+      return;
+    }
     for (int s = 0; s < sweeps; ++s) {
       const bool fin = (s + 1 == sweeps);
       jacobi_sweep(cur, fin ? out : oth, fin && want_dot);
@@ -284,7 +296,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
   // pre-smoothing (first sweep from x = 0 is a scaling)
   if (nu_pre >= 1) {
     int s_first = 1;
-    static const bool no_j0 = getenv("CSGPU_DIA25_NO_J0") != nullptr;  // A/B knob
+    const bool no_j0 = !knobs().dia25_fused_j0;  // A/B knob
     if (use25 && nu_pre >= 2 && !no_j0 && !(fuse && fuse->xa_ready && l == 0)) {
       // 25-point lattice level: the sweep from zero and the first real sweep in one marching pass (dia25.h, JACOBI0)
       dia25_launch<T, (K >= 8 ? K : 8)>(L.A25, D25_JACOBI0, (const T*)nullptr, oth, b, (const T*)dptr<T>(L.dinv), weight(1), skip, st,
@@ -631,7 +643,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   const bool fuse_xa = pp.nu_pre >= 1 && H.levels.size() > 1 && !two_product && !grounded && !projected;
   // lattice path: the residual update recomputes A p from the lattice form (one read of p, 5 matrix values per row)
   // instead of the product kernel writing A p and the update reading it back (2 x sizeof(T) per vector element)
-  static const bool no_recompute = getenv("CSGPU_NO_RECOMPUTE") != nullptr;  // A/B knob
+  const bool no_recompute = !knobs().recompute_ap;  // A/B knob
   const bool recompute = use_dia && !fuse_xa && !no_recompute;
   // A p is stored unless the residual update recomputes it; the explicit post-check of a carried solution uses the
   // buffer too. b is read unless the caller wrote the right-hand side straight into r.
@@ -708,9 +720,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // partial rows of the big SpMM-shaped launches are collapsed before the single-workgroup scalar kernels read them
   double* pac = dptr<double>(W.part_ca);
   double* pcc = dptr<double>(W.part_cc);
-  // (CSGPU_COLLAPSE_MIN: test knob, read per call so that a test can exercise the path on a small problem)
-  const char* cm_env = getenv("CSGPU_COLLAPSE_MIN");
-  const int collapse_min = cm_env ? std::max(1, atoi(cm_env)) : 4 * kCollapsedParts;
+  // (Knobs::collapse_min: test knob, so that a test can exercise the path on a small problem)
+  const int collapse_min = knobs().collapse_min >= 0 ? (int)std::max<int64_t>(1, knobs().collapse_min) : 4 * kCollapsedParts;
   auto collapsed = [&](double* src, int nparts, double* dst) -> std::pair<const double*, int> {
     if (nparts <= collapse_min) return {src, nparts};
     hipLaunchKernelGGL((collapse_partials_kernel<K>), dim3(ceil_div(kCollapsedParts * K, 256)), dim3(256), 0, st,
@@ -731,7 +742,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
 
-  static const int max_timed = getenv("CSGPU_TIMED_LAUNCHES") ? atoi(getenv("CSGPU_TIMED_LAUNCHES")) : 512;  // per solve
+  const int max_timed = knobs().timed_launches;  // per solve
   int timed = 0;
   int it = 0;
   int graph_launches = 0;
@@ -1052,7 +1063,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   const int64_t n = dia.n;
   const bool two_product = H.levels.size() > 1 && L0.two_product() && L0.lattice_two_product() && pp.nu_pre == 1 &&
                            pp.nu_post == 1 && W.tail >= H.levels[1].A.nrows;
-  static const bool off = getenv("CSGPU_NO_STREAM") != nullptr || getenv("CSGPU_NO_RECOMPUTE") != nullptr;
+  const bool off = knobs().stream < 0 || !knobs().recompute_ap;
   if (off || !two_product || W.n != n || W.K != K) return res;
   // focal nodes: the gathered nodes first, then every distinct node of the pair list
   std::vector<int> focal;
@@ -1099,8 +1110,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   const double atol = pp.atol < 0 ? std::sqrt((double)std::numeric_limits<T>::epsilon()) : pp.atol;
   const int spmv_g = dia_grid<T, TP, K>(dia);
   const int spmv_gp = dia_grid<TP, TP, K>(L0.Sdia);
-  const char* cm_env = getenv("CSGPU_COLLAPSE_MIN");
-  const int collapse_min = cm_env ? std::max(1, atoi(cm_env)) : 4 * kCollapsedParts;
+  const int collapse_min = knobs().collapse_min >= 0 ? (int)std::max<int64_t>(1, knobs().collapse_min) : 4 * kCollapsedParts;
   auto collapsed = [&](double* from, int nparts, double* to) -> std::pair<const double*, int> {
     if (nparts <= collapse_min) return {from, nparts};
     hipLaunchKernelGGL((collapse_partials_kernel<K>), dim3(ceil_div(kCollapsedParts * K, 256)), dim3(256), 0, st,
@@ -1164,7 +1174,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
     enrich_ensure_work<TP, K>(EN);
   }
   const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
-  static const int max_timed = getenv("CSGPU_TIMED_LAUNCHES") ? atoi(getenv("CSGPU_TIMED_LAUNCHES")) : 512;
+  const int max_timed = knobs().timed_launches;
   int timed = 0;
   int parity = 0;
   std::vector<T> hxf;

@@ -480,8 +480,7 @@ __global__ __launch_bounds__(256) void spmm_longrow_kernel(SpmvArgs<T, T> a) {
 // rows per workgroup the long-row kernel uses for a matrix (0: the 256-row kernel handles it)
 inline int longrow_rows(long long nnz, int nrows) {
   if (nnz < 16 * (long long)nrows) return 0;
-  static const bool off = getenv("CSGPU_NO_LONGROW") != nullptr;
-  if (off) return 0;
+  if (!knobs().longrow) return 0;
   return nnz < 40 * (long long)nrows ? 64 : 32;
 }
 
@@ -508,12 +507,8 @@ inline bool spmm_longrow_launch(const SpmvArgs<T, T>& a, hipStream_t st) {
 // makes the band re-use hit in L2); capped so the dot-partial arrays stay small. Measured on MI355X, 10000^2 fp64:
 // 4096 -> 16384 workgroups: K=1 3.22 -> 2.84 ms, K=8 5.74 -> 5.52 ms; 16384 -> 65536 at K=16: 8.12 -> 7.51 ms (262144:
 // 7.79 ms). The partial rows are collapsed to 256 by collapse_partials_kernel before the scalar kernels read them.
-inline int spmv_grid_cap() {  // tuning knob (CSGPU_SPMV_GRID_CAP): 0 = one workgroup per row block
-  static int cap = [] {
-    const char* e = getenv("CSGPU_SPMV_GRID_CAP");
-    return e ? atoi(e) : 65536;
-  }();
-  return cap;
+inline int spmv_grid_cap() {  // tuning knob (Knobs::spmv_grid_cap): 0 = one workgroup per row block
+  return knobs().spmv_grid_cap;
 }
 
 // upper bound of spmv_grid() over all K for an nrows-row product (sizes the dot-partial arrays)
@@ -579,8 +574,7 @@ inline void spmv_launch(const SpmvArgs<T>& a, int epi, bool dot, hipStream_t st)
 template <class T, int K>
 inline void spmv_launch_wide(const SpmvArgs<T>& a, bool dot, hipStream_t st) {
   if (a.nrows <= 0) return;
-  static const bool narrow = getenv("CSGPU_NARROW_TILE") != nullptr;
-  const bool wide = !narrow && a.nnz > 11 * (long long)a.nrows;
+  const bool wide = !knobs().narrow_tile && a.nnz > 11 * (long long)a.nrows;
   const dim3 g(spmv_grid<T, K>(a.nrows));
   if (wide) {
     if (dot)

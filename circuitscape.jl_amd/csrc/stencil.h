@@ -499,16 +499,13 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DI
   if (tid < K) a.partials[(size_t)blockIdx.x * K + tid] = s_red[tid] + s_red[K + tid] + s_red[2 * K + tid] + s_red[3 * K + tid];
 }
 
-// raster columns per tile (tuning knob CSGPU_DIA_SEG). Default 32; 64 for batches of 32 columns, whose tiles hold half
+// raster columns per tile (tuning knob Knobs::dia_seg). Default 32; 64 for batches of 32 columns, whose tiles hold half
 // as many rows (fp64: 16): measured at 10000^2, K = 32 (profiles/r4_dia_seg_k32.txt): 346.3 / 341.3 / 339.5 / 340.2 ms per
 // 16 pairs at 32 / 48 / 64 / 96 (fp64), 211.7 / 205.6 / 205.3 / 204.5 (mixed). At K = 16 the knob is inside the noise
 // (profiles/r3_tile_shape_knobs.txt).
 inline int dia_seg(int K = 16) {
-  static int seg = [] {
-    const char* e = getenv("CSGPU_DIA_SEG");
-    const int v = e ? atoi(e) : 0;
-    return v <= 0 ? 0 : (v < 4 ? 4 : v);
-  }();
+  const int v = knobs().dia_seg;
+  const int seg = v <= 0 ? 0 : (v < 4 ? 4 : v);
   return seg > 0 ? seg : (K >= 32 ? 64 : 32);
 }
 

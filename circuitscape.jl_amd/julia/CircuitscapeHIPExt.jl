@@ -21,6 +21,17 @@ mutable struct CsgpuOpts
     node_row::Ptr{Int32}; node_col::Ptr{Int32}
     precond_bytes::Int32; use_graph::Int32; two_product::Int32; stencil::Int32
     explicit_check::Int32; reserved3::Int32
+    # round 6: the decisions that used to be environment switches (include/csgpu.h; 0 = the library's default in every field)
+    last_level_sweeps::Int32; enrich::Int32; enrich_steps::Int32; dia25_min_rows::Int32; dia25_prefetch::Int32
+    dia25_waves::Int32; dia25_fused_j0::Int32; stream::Int32; tail_rows::Int32; poly_lattice::Int32; cellspace::Int32
+    cellspace_from_csr::Int32; lattice_level1::Int32; lattice_level1_min_rows::Int32; lattice_setup::Int32; lattice_s::Int32
+    lattice_q::Int32; direct_tiles::Int32; tile_pieces::Int32; direct_at::Int32; dirichlet_coarse::Int32; deflation::Int32
+    tail_projection::Int32; coarse_smoother::Int32; nu_l1::Int32; nu_deep::Int32; wide_csr::Int32; fixed_k::Int32
+    recompute_ap::Int32; longrow::Int32; narrow_tile::Int32; spmv_grid_cap::Int32; dia_seg::Int32; restrict_seg::Int32
+    collapse_min::Int32; verbose::Int32; reserved4::Int32; reserved5::Int32
+    stream_min::Int64; host_stream_block::Int64
+    enrich_tau::Float64; hetero_fp64_frac::Float64; poly_strength::Float64; poly_coef::Float64; poly_smin::Float64
+    poly_smax::Float64; cellspace_min_frac::Float64; tile_theta::Float64; tile_split_min::Float64
     CsgpuOpts() = new()
 end
 

@@ -37,6 +37,17 @@ class CsgpuError(RuntimeError):
         self.code = code
 
 
+# csgpu_opts, round-6 block (include/csgpu.h): the decisions that used to be environment switches; 0 = library default
+OPTS_INT_FIELDS = ("last_level_sweeps", "enrich", "enrich_steps", "dia25_min_rows", "dia25_prefetch", "dia25_waves",
+                   "dia25_fused_j0", "stream", "tail_rows", "poly_lattice", "cellspace", "cellspace_from_csr", "lattice_level1",
+                   "lattice_level1_min_rows", "lattice_setup", "lattice_s", "lattice_q", "direct_tiles", "tile_pieces",
+                   "direct_at", "dirichlet_coarse", "deflation", "tail_projection", "coarse_smoother", "nu_l1", "nu_deep",
+                   "wide_csr", "fixed_k", "recompute_ap", "longrow", "narrow_tile", "spmv_grid_cap", "dia_seg", "restrict_seg",
+                   "collapse_min", "verbose", "reserved4", "reserved5")
+OPTS_DOUBLE_FIELDS = ("enrich_tau", "hetero_fp64_frac", "poly_strength", "poly_coef", "poly_smin", "poly_smax",
+                      "cellspace_min_frac", "tile_theta", "tile_split_min")
+
+
 class Opts(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("max_levels", ctypes.c_int32),
@@ -49,7 +60,9 @@ class Opts(ctypes.Structure):
         ("precond_bytes", ctypes.c_int32), ("use_graph", ctypes.c_int32),
         ("two_product", ctypes.c_int32), ("stencil", ctypes.c_int32),
         ("explicit_check", ctypes.c_int32), ("reserved3", ctypes.c_int32),
-    ]
+    ] + [(name, ctypes.c_int32) for name in OPTS_INT_FIELDS] + [
+        ("stream_min", ctypes.c_int64), ("host_stream_block", ctypes.c_int64),
+    ] + [(name, ctypes.c_double) for name in OPTS_DOUBLE_FIELDS]
 
 
 class Info(ctypes.Structure):
@@ -62,6 +75,9 @@ class Info(ctypes.Structure):
         ("spmv_bytes_fine", ctypes.c_int64), ("bytes_per_iteration", ctypes.c_int64),
         ("level_form", ctypes.c_int32 * 32), ("hierarchy_rebuilt_fp64", ctypes.c_int32),
         ("enrich_vectors", ctypes.c_int32), ("host_blocks", ctypes.c_int32), ("reserved_info", ctypes.c_int32),
+        ("batch_width", ctypes.c_int32), ("stream_mode", ctypes.c_int32), ("tail_first_level", ctypes.c_int32),
+        ("last_level_sweeps", ctypes.c_int32), ("coarse_chebyshev", ctypes.c_int32), ("cellspace", ctypes.c_int32),
+        ("poly_lattice", ctypes.c_int32), ("enrich_on", ctypes.c_int32), ("enrich_tau", ctypes.c_double),
     ]
 
 

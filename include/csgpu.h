@@ -167,6 +167,71 @@ typedef struct csgpu_opts {
    * Default 0. */
   int32_t explicit_check;
   int32_t reserved3;
+  /* ---- Round 6: every decision that used to be an environment switch inside the library. 0 = the
+   * library's default in every field; csgpu_default_opts writes zeros. The CSGPU_* environment variables that carried these
+   * choices remain as DEBUG overrides only: they are read ONCE, when a handle is set up (csrc/csgpu.hip: knobs_from_opts),
+   * never on a call path, and a handle keeps what it was set up with -- two handles of one process may differ.
+   * csgpu_get_info reports what a handle ended up with (level_form, enrich_vectors, hierarchy_rebuilt_fp64, host_blocks,
+   * batch_width, stream_mode, tail_first_level, last_level_sweeps, coarse_chebyshev, cellspace, poly_lattice). */
+  int32_t last_level_sweeps;  /* damped-Jacobi sweeps that stand in for the coarsest solve when the last level is too large
+                                 for a dense inverse. A hierarchy of ONE level -- a graph the set-up declines to coarsen,
+                                 BASELINE configs[4] -- is then CG with a polynomial preconditioner of that degree: every sweep
+                                 is one more pass over the matrix per iteration. 0 = default: 8 below a coarsened hierarchy,
+                                 1 for a single-level one (measured on the 5e6-node network, profiles/r6_network_sweeps.json);
+                                 -1 = none (plain Jacobi scaling) */
+  int32_t enrich;             /* second coarse function on badly shaped aggregates (csrc/enrich.h): 0 = on where the tiles
+                                 were refined, -1 = off */
+  int32_t enrich_steps;       /* power steps of the local Fiedler vectors, 0 = 6 */
+  int32_t dia25_min_rows;     /* smallest coarse level that takes the 25-point lattice form (csrc/dia25.h): 0 = 16384, -1 = none */
+  int32_t dia25_prefetch;     /* 0 = b and D^-1 loaded one column ahead (default), -1 = off */
+  int32_t dia25_waves;        /* waves per SIMD asked of the 25-point kernel, 0 = the library's rule */
+  int32_t dia25_fused_j0;     /* 0 = first two sweeps of a 25-point level as one marching pass (default), -1 = off */
+  int32_t stream;             /* streaming pair solves (a column takes the next pair when its own has converged): 0 = decided
+                                 by the spread of the first batch's iteration counts, 1 = from the first pair on, -1 = never */
+  int32_t tail_rows;          /* coarse levels with at most this many rows run in ONE launch (csrc/tail.h): 0 = 4096, -1 = off */
+  int32_t poly_lattice;       /* csgpu_raster_setup_poly on the lattice path: 0 = when every polygon is contiguous and none
+                                 is long and thin, 1 = whatever the shapes, -1 = never (merged CSR graph) */
+  int32_t cellspace;          /* rasters with NODATA cells on the full lattice: 0 = when at least cellspace_min_frac of the
+                                 cells are valid, -1 = never (compact CSR numbering) */
+  int32_t cellspace_from_csr; /* the same for a host CSR matrix that comes with node_row / node_col: 0 = auto, -1 = never */
+  int32_t lattice_level1;     /* level 1 of an all-valid raster in the collapsed four-product lattice form: 0 = auto, -1 = off */
+  int32_t lattice_level1_min_rows; /* 0 = 16384 */
+  int32_t lattice_setup;      /* level 0 built from the raster without a CSR matrix (csrc/lattice_setup.h): 0 = auto, -1 = off */
+  int32_t lattice_s;          /* S of the two-product level in lattice form: 0 = auto, -1 = CSR */
+  int32_t lattice_q;          /* Q of the two-product level in its index-free form: 0 = auto, -1 = CSR */
+  int32_t direct_tiles;       /* 3x3 tiles written down directly on rasters of known extent: 0 = yes, -1 = MIS(2) seeded */
+  int32_t tile_pieces;        /* per-tile piece analysis (NODATA lines, weak couplings): 0 = on, -1 = off */
+  int32_t direct_at;          /* A*T by the one-thread-per-row kernel: 0 = on, -1 = general SpGEMM */
+  int32_t dirichlet_coarse;   /* coarsest-level correction of Dirichlet-masked solves: 0 = on, -1 = off */
+  int32_t deflation;          /* near-kernel eigenpair of an fp32 hierarchy's coarsest operator dropped: 0 = on, -1 = off */
+  int32_t tail_projection;    /* candidate projected out of the coarse tail's right-hand sides (fp32): 0 = on, -1 = off */
+  int32_t coarse_smoother;    /* sweeps of levels >= 1: 0 = Chebyshev weights unless the hierarchy is fp32 above 3e7 rows,
+                                 1 = Chebyshev weights always, 2 = one damped-Jacobi weight */
+  int32_t nu_l1;              /* sweeps on level 1, 0 = nu_coarse */
+  int32_t nu_deep;            /* sweeps below level 1, 0 = nu_coarse + 1 */
+  int32_t wide_csr;           /* 1 = fp64 hierarchies without a lattice level 0 run batches of 32 too */
+  int32_t fixed_k;            /* 1 = every batch of a call runs at the call's width (the short last batch is padded with
+                                 idle columns: round-5 behaviour; default 0 = the width is picked per batch) */
+  int32_t recompute_ap;       /* lattice path: 0 = the residual update recomputes A p (default), -1 = A p stored and re-read */
+  int32_t longrow;            /* long-row CSR kernel for R / Q^T: 0 = on, -1 = off */
+  int32_t narrow_tile;        /* 1 = the narrow SpMM tile for [S Q] */
+  int32_t spmv_grid_cap;      /* workgroups per CSR product, 0 = 65536 */
+  int32_t dia_seg;            /* raster columns per tile of the marching kernels, 0 = 32 (64 at K = 32) */
+  int32_t restrict_seg;       /* coarse columns per tile of the marching restriction, 0 = 32 */
+  int32_t collapse_min;       /* partial rows above which the dot partials are collapsed first, 0 = the library's rule */
+  int32_t verbose;            /* 1 = one line per set-up decision on stderr */
+  int32_t reserved4, reserved5; /* (keeps the 64-bit fields below aligned without implicit padding) */
+  int64_t stream_min;         /* vector elements n * batch from which streaming is considered, 0 = 2^25 */
+  int64_t host_stream_block;  /* csgpu_setup: stream the host matrix in blocks of at most this many entries (test / tuning);
+                                 0 = only matrices with >= 2^31 stored entries, in blocks of 2^28 */
+  double enrich_tau;          /* local Fiedler value below which an aggregate gets its second function, 0 = 0.06 */
+  double hetero_fp64_frac;    /* an fp32 hierarchy is rebuilt in fp64 when more than this fraction of the cells leaves its
+                                 tile in the strength test, 0 = 0.03, >= 1 = never */
+  double poly_strength;       /* interior strength of every polygon (poly.h), 0 = per polygon from its size and shape */
+  double poly_coef, poly_smin, poly_smax; /* ... = clamp(coef * cells * blob share, smin, smax); 0 = 1, 8, 1000 */
+  double cellspace_min_frac;  /* 0 = 0.5 */
+  double tile_theta;          /* strength filter of the tiles, 0 = 0.03 (negative: off) */
+  double tile_split_min;      /* ... applied when more than this fraction of the cells would leave their tile, 0 = 0.005 */
 } csgpu_opts;
 
 /* csgpu_info.level_form: CSR = general CSR SpMM; LATTICE9 = index-free nine-point lattice form (level 0: the marching
@@ -203,6 +268,16 @@ typedef struct csgpu_info {
                                    scattered straight into the lattice form (matrices with 2^31 stored entries and more; the
                                    device holds no CSR form of it); 0 = any other set-up */
   int32_t reserved_info;
+  /* round 6: the choices a handle ended up with (options, defaults and debug overrides resolved at set-up) */
+  int32_t batch_width;          /* columns of a full batch (opts.batch after the K <= 16 rule of fp64 CSR-path handles) */
+  int32_t stream_mode;          /* csgpu_opts.stream as resolved: 0 auto, 1 always, -1 never */
+  int32_t tail_first_level;     /* first level inside the single-launch coarse tail, -1 = no tail */
+  int32_t last_level_sweeps;    /* Jacobi sweeps of a last level without a dense inverse (0 = scaling only); -1 = dense inverse */
+  int32_t coarse_chebyshev;     /* 1 = Chebyshev weights on the coarse levels, 0 = one damped-Jacobi weight */
+  int32_t cellspace;            /* 1 = one device row per raster CELL (NODATA rasters on the lattice kernels) */
+  int32_t poly_lattice;         /* 1 = polygon raster on the lattice path (projected PCG), 0 = merged CSR graph / no polygons */
+  int32_t enrich_on;            /* 1 = the enrichment was allowed (enrich_vectors tells how many aggregates took it) */
+  double enrich_tau;            /* threshold in effect */
 } csgpu_info;
 
 typedef struct csgpu_stats {

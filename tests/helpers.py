@@ -698,19 +698,15 @@ def check_coarse_tail(L, shapes=((150, 131),), batches=(1, 4, 16), pbs=(0, 4), m
                 ids = rng.choice(n, size=2 * batch, replace=False)
                 src, dst = [int(v) for v in ids[:batch]], [int(v) for v in ids[batch:]]
                 res = {}
-                for tag, rows in (("tail", None), ("classic", "0")):
-                    if rows is None:
-                        os.environ.pop("CSGPU_TAIL_ROWS", None)
-                    else:
-                        os.environ["CSGPU_TAIL_ROWS"] = rows
+                for tag, rows in (("tail", 0), ("classic", -1)):     # csgpu_opts.tail_rows: 0 = default, -1 = no tail
                     try:
-                        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+                        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, tail_rows=rows)) as h:
                             assert h.info["levels"] >= 3
                             R, _, _, st = h.solve_pairs(src, dst)
                             R2, _, _, st2 = h.solve_pairs(dst, src)      # second solve on the same scratch area
                             res[tag] = (R, st["total_iters"], R2, st["not_converged"])
                     finally:
-                        os.environ.pop("CSGPU_TAIL_ROWS", None)
+                        pass
                 a, b = res["tail"], res["classic"]
                 assert a[3] == 0 and b[3] == 0
                 # (fp32 hierarchies on rasters with islands are sensitive to the summation order: a few iterations either way)
@@ -757,19 +753,17 @@ def check_coarse_chebyshev(L, oracle, N=150, sigmas=(1.0, 2.5), batch=4, gain=0.
         Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
         its = {}
         for tag in ("chebyshev", "jacobi"):
-            if tag == "jacobi":
-                os.environ["CSGPU_COARSE_JACOBI"] = "1"
-            else:
-                os.environ.pop("CSGPU_COARSE_JACOBI", None)
+            smoother = 2 if tag == "jacobi" else 0      # csgpu_opts.coarse_smoother: 2 = one damped-Jacobi weight
             try:
                 for pb in (0, 4):
-                    with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:
+                    with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, coarse_smoother=smoother)) as h:
+                        assert h.info["coarse_chebyshev"] == (0 if tag == "jacobi" else 1)
                         R, _, _, st = h.solve_pairs(src, dst)
                         assert st["not_converged"] == 0
                         assert np.max(np.abs(R - Ro) / Ro) < 1e-6, (sigma, tag, pb)
                         its[(tag, pb)] = st["total_iters"] / batch
             finally:
-                os.environ.pop("CSGPU_COARSE_JACOBI", None)
+                pass
         for pb in (0, 4):
             assert its[("chebyshev", pb)] <= its[("jacobi", pb)] + 0.5, (sigma, its)
             if sigma >= 2.0:
@@ -790,12 +784,8 @@ def check_tail_projection(L, N=120, batch=4):
     dst = [p[1] for p in pairs[:batch]]
     out = {}
     for tag in ("on", "off"):
-        if tag == "off":
-            os.environ["CSGPU_NO_TAIL_PROJECTION"] = "1"
-        else:
-            os.environ.pop("CSGPU_NO_TAIL_PROJECTION", None)
         try:
-            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=4)) as h:
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=4, tail_projection=-1 if tag == "off" else 0)) as h:
                 R, _, _, st = h.solve_pairs(src, dst)
                 rhs = np.zeros((h.info["n"], batch))
                 grounds = []
@@ -805,7 +795,7 @@ def check_tail_projection(L, N=120, batch=4):
                 X, _, st2 = h.solve_grounded(rhs, grounds)
                 out[tag] = (R, st["total_iters"], X[src, np.arange(batch)], st2["total_iters"], st["not_converged"] + st2["not_converged"])
         finally:
-            os.environ.pop("CSGPU_NO_TAIL_PROJECTION", None)
+            pass
     a, b = out["on"], out["off"]
     assert a[4] == 0 and b[4] == 0
     assert np.max(np.abs(a[0] - b[0]) / b[0]) < 1e-9 and abs(a[1] - b[1]) <= batch
@@ -925,13 +915,11 @@ def check_cellspace(L, oracle, shape=(70, 61), batch=4, monkeypatch=None):
         n = int(nm_ref.max())
         out = {}
         for mode in ("cell", "compact"):
-            if mode == "compact":
-                monkeypatch.setenv("CSGPU_NO_CELLSPACE", "1")
-            else:
-                monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+            cs = -1 if mode == "compact" else 0          # csgpu_opts.cellspace: -1 = the compact numbering of round 2
             for pb in (0, 4):
-                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), four_neighbors=four) as h:
+                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, cellspace=cs), four_neighbors=four) as h:
                     info = h.info
+                    assert info["cellspace"] == (1 if mode == "cell" else 0)
                     # (a valid cell without a valid neighbour keeps its -- zero -- diagonal entry in the device-built matrix)
                     assert info["n"] == n and info["nnz"] == Aref.nnz + int(np.sum(np.diff(Aref.indptr) == 0))
                     assert (info["lattice_period"] == shape[0]) == (mode == "cell")
@@ -961,7 +949,6 @@ def check_cellspace(L, oracle, shape=(70, 61), batch=4, monkeypatch=None):
                     assert st["not_converged"] == st2["not_converged"] == st3["not_converged"] == st4["not_converged"] == 0
                     out[(mode, pb)] = dict(labels=labels, nc=nc, R=R, R2=R2, gath=gath, volt=volt, cur=cur, cum=cum, mx=mx,
                                            X=X, Xg=Xg, Cg=Cg, y=y, iters=st2["total_iters"], B=B, src=src, dst=dst)
-        monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
         Ro, _, _ = oracle.OracleAMG(Aref).solve_pairs(out[("cell", 0)]["src"], out[("cell", 0)]["dst"], rtol=1e-12, atol=0.0,
                                                      criterion=1)
         for pb in (0, 4):
@@ -1003,19 +990,15 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
     rng = np.random.default_rng(21)
     # (the comparison is between two PIPELINES for the same hierarchy: the coarse-space enrichment of enrich.h, which only
     # the lattice pipeline sets up, is switched off for it -- it has a test of its own, check_enrichment)
-    monkeypatch.setenv("CSGPU_ENRICH", "0")
     for (R, C) in shapes:
         for holes, four, avg in ((False, False, False), (True, False, False), (True, True, False), (False, True, True)):
             g = _nodata_raster((R, C), R + C, wall=True) if holes else np.exp(rng.standard_normal((R, C)))
             out = {}
             for mode in ("lattice", "csr"):
-                if mode == "csr":
-                    monkeypatch.setenv("CSGPU_NO_DIRECT_LATTICE", "1")
-                else:
-                    monkeypatch.delenv("CSGPU_NO_DIRECT_LATTICE", raising=False)
+                ls = -1 if mode == "csr" else 0         # csgpu_opts.lattice_setup: -1 = level 0 through the CSR pipeline
                 for pb in (0, 4):
-                    with L.raster_setup(g, L.default_opts(batch=4, precond_bytes=pb), four_neighbors=four,
-                                        avg_resistances=avg) as h:
+                    with L.raster_setup(g, L.default_opts(batch=4, precond_bytes=pb, lattice_setup=ls, enrich=-1),
+                                        four_neighbors=four, avg_resistances=avg) as h:
                         info = h.info
                         assert info["lattice_period"] == R and info["level_n"][0] == R * C
                         labels, nc = h.components()
@@ -1030,7 +1013,6 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
                         y = h.spmv(x.copy())
                         assert st["not_converged"] == 0 and st2["not_converged"] == 0
                         out[(mode, pb)] = dict(info=info, R=Rr, Rv=Rv, volt=volt, A0=A0, A1=A1, x=x, y=y, it=st["total_iters"])
-            monkeypatch.delenv("CSGPU_NO_DIRECT_LATTICE", raising=False)
             for pb in (0, 4):
                 a, b = out[("lattice", pb)], out[("csr", pb)]
                 for key in ("n", "nnz", "levels"):
@@ -1044,7 +1026,6 @@ def check_lattice_pipeline(L, monkeypatch, shapes=((61, 50), (64, 70), (35, 36))
                 assert np.max(np.abs(a["Rv"] - a["R"][:2]) / a["R"][:2]) < 1e-6
                 assert abs(a["it"] - b["it"]) <= (0 if pb == 0 else 2)
                 assert np.allclose(a["y"], a["A0"] @ a["x"], rtol=1e-12, atol=1e-12)
-    monkeypatch.delenv("CSGPU_ENRICH", raising=False)
 
 
 def check_lattice_level1(L, monkeypatch, shapes=((420, 427),), batch=4, extra_env=None):
@@ -1135,10 +1116,10 @@ def check_enrichment(L, oracle, monkeypatch, shape=(150, 141), batch=8, frac=0.1
     out = {}
     for pb in (0, 4):
         for on in (False, True):
-            monkeypatch.setenv("CSGPU_ENRICH", "1" if on else "0")
-            monkeypatch.setenv("CSGPU_ENRICH_TAU", "0.1")     # (the default threshold is chosen for cost at 10000^2; the
-            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb)) as h:   # mechanism is tested at 0.1)
+            # (csgpu_opts.enrich / .enrich_tau: the default threshold is chosen for cost at 10000^2; the mechanism is tested at 0.1)
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, enrich=0 if on else -1, enrich_tau=0.1)) as h:
                 info = h.info
+                assert info["enrich_on"] == int(on) and abs(info["enrich_tau"] - (0.1 if on else 0.0)) < 1e-15
                 assert info["n"] == A.shape[0] and info["lattice_period"] == shape[0]
                 assert (info["enrich_vectors"] > 0) == on, info["enrich_vectors"]
                 labels, _ = h.components()
@@ -1154,8 +1135,6 @@ def check_enrichment(L, oracle, monkeypatch, shape=(150, 141), batch=8, frac=0.1
                 b = np.zeros(info["n"]); b[dst[0]] = 1.0; b[src[0]] = -1.0
                 assert np.linalg.norm(A @ volt[:, 0] - b) < 1e-4 * np.linalg.norm(b)
                 out[(pb, on)] = (R, st["total_iters"], st["max_iters"], R1, Rv, src, dst, info["enrich_vectors"])
-    monkeypatch.delenv("CSGPU_ENRICH", raising=False)
-    monkeypatch.delenv("CSGPU_ENRICH_TAU", raising=False)
     src, dst = out[(0, True)][5], out[(0, True)][6]
     Ro, _, res = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=min(8, batch))
     for pb in (0, 4):
@@ -1429,17 +1408,13 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8, st
         for stencil in stencils:
             out = {}
             for off in (False, True):
-                if off:
-                    monkeypatch.setenv("CSGPU_NO_DIRICHLET_COARSE", "1")
-                else:
-                    monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
-                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, stencil=stencil)) as h:
+                with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, stencil=stencil,
+                                                      dirichlet_coarse=-1 if off else 0)) as h:
                     X1, _, s1 = h.solve_grounded(B1, g1)
                     X2, _, s2 = h.solve_grounded(B2, g2)
                 assert s1["not_converged"] == 0 and s2["not_converged"] == 0
                 assert s1["max_relres"] < 1e-5 and s2["max_relres"] < 1e-5
                 out[off] = (X1, X2, s1["total_iters"], s2["total_iters"])
-            monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
             assert np.max(np.abs(out[False][0][:, 0] - x_direct)) / np.max(np.abs(x_direct)) < 1e-4
             for k in (0, 1):
                 assert np.max(np.abs(out[False][k] - out[True][k])) / np.max(np.abs(out[True][k])) < 1e-4
@@ -1477,11 +1452,7 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8, st
         Xc_d[keep, c] = spla.spsolve(A2[keep][:, keep].tocsc(), Bc[keep, c])
     its = {}
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("CSGPU_NO_DIRICHLET_COARSE", "1")
-        else:
-            monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
-        with L.raster_setup(g2c, L.default_opts(batch=4, rtol=1e-8), reg=False) as h:
+        with L.raster_setup(g2c, L.default_opts(batch=4, rtol=1e-8, dirichlet_coarse=-1 if off else 0), reg=False) as h:
             Xc, _, sc = h.solve_grounded(Bc, gc)
         assert sc["not_converged"] == 0 and sc["max_relres"] < 1e-7
         for c in range(4):
@@ -1491,7 +1462,6 @@ def check_dirichlet_coarse_correction(L, monkeypatch, N=150, npts=6, batch=8, st
             # caller reads a component the column does not belong to; the other large component stays exactly zero)
             assert np.all(Xc[lab == order[(c + 1) % 2], c] == 0.0)
         its[off] = sc["total_iters"]
-    monkeypatch.delenv("CSGPU_NO_DIRICHLET_COARSE", raising=False)
     # (the constant mode costs more the larger the component: 36 -> 21 iterations per column at 240^2, 18.2 -> 17.5 at 96^2)
     assert its[False] <= (0.9 if N >= 200 else 1.0) * its[True], its
 
@@ -1543,14 +1513,10 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
     res = {}
     for pb in pbs:
         for mode in ("batch", "stream"):
-            monkeypatch.setenv("CSGPU_STREAM_MIN", "1")
-            if mode == "stream":
-                monkeypatch.setenv("CSGPU_STREAM", "1")          # from the first pair on
-                monkeypatch.delenv("CSGPU_NO_STREAM", raising=False)
-            else:
-                monkeypatch.delenv("CSGPU_STREAM", raising=False)
-                monkeypatch.setenv("CSGPU_NO_STREAM", "1")
-            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1)) as h:
+            # csgpu_opts.stream: 1 = from the first pair on, -1 = never; .stream_min = 1: whatever the problem size
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1,
+                                                  stream=1 if mode == "stream" else -1)) as h:
+                assert h.info["stream_mode"] == (1 if mode == "stream" else -1)
                 nm = h.raster_nodemap()
                 lab, _ = h.components()
                 big = np.flatnonzero(lab == np.bincount(lab).argmax())
@@ -1586,17 +1552,14 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
         assert ss["stream_slots"] >= -(-(ss["total_iters"] + nsolved) // batch)
         assert ss["stream_slots"] <= (ss["total_iters"] + nsolved) // batch + ss["max_iters"] + 2
     # the adaptive rule (default): the first batch runs as a batch, the spread of its iteration counts decides for the rest
-    monkeypatch.delenv("CSGPU_NO_STREAM", raising=False)
-    monkeypatch.delenv("CSGPU_STREAM", raising=False)
     for pb in pbs:
-        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1)) as h:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1)) as h:
             R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
             if pb == 0:
                 assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])
             else:
                 assert np.max(np.abs(R - res[(pb, "batch")][0])) < 1e-10 * float(np.max(np.abs(R)))
             assert st["total_iters"] == res[(pb, "batch")][2]["total_iters"]
-    monkeypatch.delenv("CSGPU_STREAM_MIN", raising=False)
     if oracle is not None:
         A = oracle.regularize(rg.laplacian(rg.construct_graph(g, rg.construct_node_map(g, None), False, False)))
         S = oracle.OracleAMG(A)
@@ -1630,13 +1593,12 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
     poly[20, 30] = 3                         # a single cell
     poly[50:60, 20:26] = 4
     g[20, 30] = 1.3
-    monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
-    with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-11, atol=0.0, criterion=1), polymap=poly) as h:
-        assert h.info["lattice_period"] == 0
+    # (csgpu_opts.poly_lattice = -1: the merged CSR graph)
+    with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-11, atol=0.0, criterion=1, poly_lattice=-1), polymap=poly) as h:
+        assert h.info["lattice_period"] == 0 and h.info["poly_lattice"] == 0
         nm_ref = h.raster_nodemap()
         A = h.level_matrix(0, "A").astype(np.float64)
         lab, _ = h.components()
-    monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
     n = A.shape[0]
     big = np.flatnonzero(lab == np.bincount(lab).argmax())
     pnodes = [int(nm_ref[6, 9]) - 1, int(nm_ref[41, 41]) - 1, int(nm_ref[20, 30]) - 1, int(nm_ref[55, 21]) - 1]
@@ -1699,14 +1661,11 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
     poly2[25, 5:45] = 9
     res = {}
     for mode in ("auto", "csr"):
-        if mode == "csr":
-            monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
-        with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-10), polymap=poly2) as h:
+        with L.raster_setup(g, L.default_opts(batch=batch, rtol=1e-10, poly_lattice=-1 if mode == "csr" else 0), polymap=poly2) as h:
             assert h.info["lattice_period"] == 0
             nm2 = h.raster_nodemap()
             ids = [int(nm2[25, 6]) - 1, int(nm2[6, 9]) - 1, int(nm2[60, 50]) - 1 if nm2[60, 50] > 0 else int(nm2[6, 9]) - 1]
             res[mode] = h.solve_pairs([ids[0], ids[0]], [ids[1], ids[2]])[0]
-    monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
     assert np.array_equal(res["auto"], res["csr"])
     # one polygon id in two places (it may be the only link between two parts of the raster): merged CSR graph as well
     poly3 = poly.copy()
@@ -1802,7 +1761,6 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
     the form, its marching product must equal the level's CSR operator, and pair solves through it (coarse tail off, so
     the V-cycle's generic branch really runs the levels) must take the same iterations and give the same resistances as
     the CSR SpMM path. AMG cycle products: AlgebraicMultigrid.jl smoother / residual, called from src/core.jl:164-178."""
-    monkeypatch.setenv("CSGPU_TAIL_ROWS", "0")
     if hetero:
         rng = np.random.default_rng(3)
         g = np.exp(3.0 * rng.standard_normal(shape))
@@ -1810,11 +1768,11 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
         g = _nodata_raster(shape, 11)
     out = {}
     for mode in ("csr", "dia25", "dia25nopf"):   # (nopf: the kernel variant without the one-column-ahead load of b / dinv)
-        monkeypatch.setenv("CSGPU_DIA25", "64" if mode != "csr" else "0")
-        monkeypatch.setenv("CSGPU_DIA25_PF", "0" if mode == "dia25nopf" else "1")
+        # csgpu_opts: tail_rows = -1 (no coarse tail), dia25_min_rows (-1 = CSR), dia25_prefetch (-1 = off)
+        knobs = dict(tail_rows=-1, dia25_min_rows=64 if mode != "csr" else -1, dia25_prefetch=-1 if mode == "dia25nopf" else 0)
         for pb in (0, 4):
             for K in batches:
-                with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb)) as h:
+                with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb, **knobs)) as h:
                     info = h.info
                     labels, _ = h.components()
                     big = np.flatnonzero(labels == np.bincount(labels).argmax())
@@ -1833,8 +1791,6 @@ def check_dia25_levels(L, monkeypatch, shape=(100, 90), batches=(8, 32), hetero=
                             y, _ = h.level_spmv(lvl, "A", x)
                             ref = A @ x.astype(y.dtype)
                             assert np.abs(y - ref).max() < (1e-13 if y.dtype == np.float64 else 2e-6) * np.abs(ref).max()
-    for key in ("CSGPU_DIA25", "CSGPU_DIA25_PF", "CSGPU_TAIL_ROWS"):
-        monkeypatch.delenv(key, raising=False)
     for pb in (0, 4):
         for K in batches:
             for mode in ("dia25", "dia25nopf"):
@@ -1862,19 +1818,17 @@ def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4, exact=True):
     from circuitscape_jl_amd import solver as ps
 
     def both(A, row, col, src, dst, pb, block, **kw):
-        os.environ.pop("CSGPU_STREAM_HOST_CSR", None)
         with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb), node_row=row, node_col=col, **kw) as h:
             assert h.info["host_blocks"] == 0
             base = (h.solve_pairs(src, dst), h.info)
-        os.environ["CSGPU_STREAM_HOST_CSR"] = str(block)
-        try:
-            with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb), node_row=row, node_col=col, **kw) as h:
+        try:   # csgpu_opts.host_stream_block: the streamed set-up at test sizes
+            with L.setup(A, L.default_opts(batch=batch, precond_bytes=pb, host_stream_block=block), node_row=row, node_col=col, **kw) as h:
                 info = h.info
                 out = h.solve_pairs(src, dst)
                 x = np.random.default_rng(1).standard_normal(A.shape[0])
                 assert np.allclose(h.spmv(x.copy()), A @ x, rtol=1e-12, atol=1e-12)   # (CSR form rebuilt from the lattice form)
         finally:
-            os.environ.pop("CSGPU_STREAM_HOST_CSR", None)
+            pass
         return base, (out, info)
 
     # (1) NODATA raster, a connected component with an offset bounding box
@@ -1928,22 +1882,21 @@ def check_streamed_host_csr(L, oracle, shape=(52, 47), batch=4, exact=True):
     B = sp.csr_matrix(B)
     perm = np.random.default_rng(9).permutation(ga.size)
     Ap = sp.csr_matrix(Aa)[perm][:, perm]
-    os.environ["CSGPU_STREAM_HOST_CSR"] = "500"
     try:
-        with L.setup(B, L.default_opts(batch=batch), node_row=row, node_col=col) as h:
+        with L.setup(B, L.default_opts(batch=batch, host_stream_block=500), node_row=row, node_col=col) as h:
             assert h.info["host_blocks"] == 0 and h.info["lattice_period"] == 0
             assert h.solve_pairs(src[:2], dst[:2])[3]["not_converged"] == 0
-        with L.setup(A, L.default_opts(batch=batch)) as h:
+        with L.setup(A, L.default_opts(batch=batch, host_stream_block=500)) as h:
             assert h.info["host_blocks"] == 0
             Rn, _, _, stn = h.solve_pairs(src, dst)
             assert stn["not_converged"] == 0 and np.max(np.abs(Rn - Ro) / Ro) < 1e-6
-        with L.setup(Ap, L.default_opts(batch=batch), node_row=rowa[perm], node_col=cola[perm]) as h:
+        with L.setup(Ap, L.default_opts(batch=batch, host_stream_block=500), node_row=rowa[perm], node_col=cola[perm]) as h:
             assert h.info["host_blocks"] == 0
             inv = np.argsort(perm)
             Rp, _, _, stp = h.solve_pairs([int(inv[s]) for s in srca], [int(inv[d]) for d in dsta])
             assert stp["not_converged"] == 0 and np.max(np.abs(Rp - Roa) / Roa) < 1e-6
     finally:
-        os.environ.pop("CSGPU_STREAM_HOST_CSR", None)
+        pass
 
 
 def check_golden_single_precision(L, name):

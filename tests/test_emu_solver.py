@@ -581,12 +581,8 @@ def test_collapsed_partials_path(emu_lib, oracle, monkeypatch):
     src, dst = list(cells[:-1]), list(cells[1:])      # 9 pairs -> one batch of width 16
     Ro, _, _ = oracle.OracleAMG(oracle.regularize(G)).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1)
     out = []
-    for env in ("8", None):
-        if env is None:
-            monkeypatch.delenv("CSGPU_COLLAPSE_MIN", raising=False)
-        else:
-            monkeypatch.setenv("CSGPU_COLLAPSE_MIN", env)
-        h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=16, precond_bytes=4))
+    for cmin in (8, 0):      # csgpu_opts.collapse_min: 0 = the library's rule
+        h = emu_lib.raster_setup(g, emu_lib.default_opts(batch=16, precond_bytes=4, collapse_min=cmin))
         R, _, _, st = h.solve_pairs(src, dst)
         assert st["not_converged"] == 0 and st["batch"] == 16
         assert np.max(np.abs(R - Ro) / Ro) < 1e-5

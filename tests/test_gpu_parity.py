@@ -434,12 +434,10 @@ def test_nodata_raster_2000_lattice_kernels_vs_tight_oracle(gpu_lib, oracle, mon
     A = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
     res = {}
     for mode in ("cell", "compact", "all-valid"):
-        if mode == "compact":
-            monkeypatch.setenv("CSGPU_NO_CELLSPACE", "1")
-        else:
-            monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
+        cs = -1 if mode == "compact" else 0          # csgpu_opts.cellspace
         for pb in (0, 4):
-            with gpu_lib.raster_setup(base if mode == "all-valid" else g, gpu_lib.default_opts(batch=16, precond_bytes=pb)) as h:
+            with gpu_lib.raster_setup(base if mode == "all-valid" else g,
+                                      gpu_lib.default_opts(batch=16, precond_bytes=pb, cellspace=cs)) as h:
                 info = h.info
                 assert (info["lattice_period"] == N) == (mode != "compact")
                 if mode == "all-valid":
@@ -453,7 +451,6 @@ def test_nodata_raster_2000_lattice_kernels_vs_tight_oracle(gpu_lib, oracle, mon
                 R, _, _, st = h.solve_pairs(src, dst)
                 assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
                 res[(mode, pb)] = (R, st["total_iters"] / 16.0, src, dst)
-    monkeypatch.delenv("CSGPU_NO_CELLSPACE", raising=False)
     src, dst = res[("cell", 0)][2], res[("cell", 0)][3]
     Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src[:8], dst[:8], rtol=1e-12, atol=0.0, criterion=1, nthreads=8)
     for pb in (0, 4):
@@ -635,11 +632,8 @@ def test_polygon_rasters_on_the_lattice_path_gpu(gpu_lib, monkeypatch):
     cells = np.concatenate([cells, pcell])
     out = {}
     for mode in ("lattice", "csr", "free"):
-        if mode == "csr":
-            monkeypatch.setenv("CSGPU_NO_POLY_LATTICE", "1")
-        else:
-            monkeypatch.delenv("CSGPU_NO_POLY_LATTICE", raising=False)
-        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16), polymap=None if mode == "free" else poly) as h:
+        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, poly_lattice=-1 if mode == "csr" else 0),
+                                  polymap=None if mode == "free" else poly) as h:
             nm = h.raster_nodemap()
             nodes = nm.ravel()[cells].astype(np.int64) - 1
             R, _, _, st = h.solve_pairs([int(v) for v in nodes[:16]], [int(v) for v in nodes[16:]])
