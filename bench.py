@@ -169,6 +169,42 @@ def cpu_baseline(sample_size, nsolve=2, max_threads=32, ntight=16, single=False)
     return out
 
 
+def cpu_full_size_measure(size, threads, single=False):
+    """CPU child: the oracle (C++ restatement of the reference CG+AMG path) AT THE FULL SIZE of the workload -- the
+    reference's graph construction restated (oracle/refgraph.py), regularised like core.jl:161, set-up once, then `threads`
+    pairs at the reference's tolerances, one pair per host thread as the reference parallelises (src/core.jl:262-272).
+    10000^2: ~20 s graph + ~47 s set-up + ~115 s for 16 pairs on 16 threads, ~150 GB of host memory."""
+    from oracle import refgraph as rg, refsolve as rs
+    t0 = time.time()
+    G = rg.raster_laplacian_from_conductance(make_raster(size))
+    A = rs.regularize(G, dtype=np.float32).astype(np.float64) if single else rs.regularize(G)
+    del G
+    t_graph = time.time() - t0
+    t0 = time.time()
+    S = rs.OracleAMG(A)
+    t_setup = time.time() - t0
+    _, pairs = focal_pairs(size)
+    T = max(1, min(threads, len(pairs), os.cpu_count() or 1))
+    t0 = time.time()
+    R, _, res = S.solve_pairs([p[0] for p in pairs[:T]], [p[1] for p in pairs[:T]], nthreads=T)
+    t_mt = time.time() - t0
+    return {"size": size, "n": int(A.shape[0]), "nnz": int(A.nnz), "host_cores": os.cpu_count(), "threads": T,
+            "graph_build_s": t_graph, "setup_s": t_setup, "pairs": T, "pairs_wall_s": t_mt, "iters": [r["iters"] for r in res],
+            "value_pair_solves_per_s": 1.0 / (t_mt / T + t_setup / 100.0)}
+
+
+def host_can_measure_full_size(size):
+    """enough cores and memory for cpu_full_size_measure without getting in the GPU legs' way"""
+    try:
+        avail = 0.0
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 1e6
+        return size >= 8000 and (os.cpu_count() or 1) >= 32 and avail >= 200.0
+    except Exception:
+        return False
+
+
 NODATA_SEED, NODATA_PTS_SEED = 2468, 97531
 
 
@@ -517,15 +553,17 @@ def one_to_all_columns(focal):
     return [[p] for p in focal], [[q for q in focal if q != p] for p in focal], focal
 
 
-def config4_network_leg(lib, dev_index, n=5000000, nsrc=16, ncheck=2, torch=None, dev=None, batch=16):
+def config4_network_leg(lib, dev_index, n=5000000, nsrc=32, ncheck=2, torch=None, dev=None, batch=32):
     """BASELINE configs[4] at its stated size on one GPU (5e6 nodes, 5e7 undirected edges -> 1.05e8 stored entries):
     network mode, advanced one-to-all (src/raster/advanced.jl:274-312, src/network/advanced.jl:1-51) -- unit current at one
     focal node, the other focal nodes tied to ground, every source a column of ONE csgpu_solve_sources call on ONE handle:
     sparse right-hand sides in (a column is a single +1), the sources' voltages and the cumulative node-current vector out
     (what the one-to-all driver keeps, onetoall.jl:141,153-158) -- no n x nrhs array crosses PCIe in the timed call. Reported
     wall AND device (HIP-event time of the PCG loops) with a roofline of the CSR SpMM.
-    This random graph is an expander: the setup declines to coarsen it, so the preconditioner is JACOBI (levels = 1), not
-    AMG. The first `ncheck` columns are solved again with their voltages handed back (untimed) and compared with an
+    This random graph is an expander: the setup declines to coarsen it, so the preconditioner is JACOBI (levels = 1: one
+    damped-Jacobi sweep after the scaling -- a degree-1 polynomial, csgpu_opts.last_level_sweeps), not AMG; batches of 32
+    columns (an fp32 hierarchy gathers one full 128-byte line of x per stored entry at that width).
+    The first `ncheck` columns are solved again with their voltages handed back (untimed) and compared with an
     independent scipy Jacobi-CG solve of the reduced system at true-residual 1e-12 (parity: resistance to the grounded set +
     whole voltage vector), and their true residual is evaluated on the host."""
     t0 = time.perf_counter()
@@ -575,7 +613,8 @@ def config4_network_leg(lib, dev_index, n=5000000, nsrc=16, ncheck=2, torch=None
             "value_device_note": "sources / (device time of the set-up + HIP-event time of the PCG loops)",
             "n": int(n), "nnz": int(G.nnz),
             "undirected_edges": int((G.nnz - n) // 2), "sources": nsrc, "batch": K, "levels": info["levels"],
-            "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi (expander: the setup declines to coarsen, amg_setup.h)",
+            "preconditioner": "AMG" if info["levels"] > 1 else "Jacobi polynomial, %d sweep(s) (expander: the setup declines to "
+                              "coarsen, amg_setup.h)" % info["last_level_sweeps"],
             "setup_s": t_setup, "setup_device_s": info["setup_ms"] / 1e3, "upload_s": info["upload_ms"] / 1e3,
             "solve_s_all_sources": t_solve, "solve_device_s_all_sources": dev_s,
             "pcg_device_ms_per_iteration": st["device_ms"] / max(st["max_iters"] * nbatches, 1),
@@ -752,10 +791,18 @@ def main():
     ap.add_argument("--workload", default="raster", choices=["raster", "network"],
                     help="raster = BASELINE configs[2] (the headline); network = BASELINE configs[4]: random network, "
                          "advanced one-to-all, sources dealt over the GPUs (a step = one batch of --net-batch sources)")
-    ap.add_argument("--net-batch", type=int, default=16, help="--workload network: one-to-all sources per step")
+    ap.add_argument("--net-batch", type=int, default=32, help="--workload network: one-to-all sources per step")
     ap.add_argument("--network-n", type=int, default=5000000, help="nodes of the config4_network leg (BASELINE: 5e6)")
     ap.add_argument("--geometric-n", type=int, default=1000000, help="nodes of the network_geometric leg")
+    ap.add_argument("--cpu-full-size", default="auto", choices=["auto", "0", "1"],
+                    help="cpu_baseline.value MEASURED at the full size in this run (a second CPU child, in the background "
+                         "while the GPU legs run): auto = when the host has the memory (>= 200 GB available) and >= 32 cores")
+    ap.add_argument("--cpu-full-only", type=int, default=0, help="internal (CPU child): measure the oracle at --size")
+    ap.add_argument("--cpu-full-threads", type=int, default=16)
     args = ap.parse_args()
+    if args.cpu_full_only > 0:
+        print(json.dumps(cpu_full_size_measure(args.size, args.cpu_full_threads, args.precision == "single")), flush=True)
+        return
     if args.cpu_baseline_only > 0:
         # CPU child: the cpu_baseline object (+ the tight resistances of the headline's parity figure) and, when asked for,
         # the CHECKER side of the other legs' parity figures -- everything that touches oracle/ lives in this process
@@ -1017,6 +1064,25 @@ def main():
                 "max_rel_diff_R_vs_%s_path" % path_name: float(max(np.max(np.abs(res2[k] - results[k]) / np.abs(res2[k]))
                                                                    for k in range(ncmp)))}
             h2.close()
+        # The CPU children start HERE -- after the two timed paths, so that the headline figures see an idle host -- and work in
+        # the background while the GPU legs below run: (1) the bounded-sample child (cpu_baseline of the task's contract + the
+        # checker side of every parity figure), (2) the oracle measured AT THE FULL SIZE when the host
+        # has the cores and the memory. Both are collected at the end of the run.
+        cpu_children = {}
+        if args.cpu_sample > 0 and world == 1:
+            import subprocess
+            want_legs = "nodata,fp32,geometric" if (args.extra_legs and vb == 8) else ""
+            t_children = time.perf_counter()
+            cpu_children["sample"] = subprocess.Popen(
+                [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(info["n"]), "--cpu-sample",
+                 str(args.cpu_sample), "--size", str(size), "--precision", args.precision, "--cpu-legs", want_legs,
+                 "--leg-sample", str(args.leg_sample), "--geometric-n", str(args.geometric_n)],
+                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if args.cpu_full_size == "1" or (args.cpu_full_size == "auto" and host_can_measure_full_size(size)):
+                cpu_children["full"] = subprocess.Popen(
+                    [sys.executable, os.path.abspath(__file__), "--cpu-full-only", "1", "--size", str(size), "--precision",
+                     args.precision, "--cpu-full-threads", str(args.cpu_full_threads)],
+                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if world == 1 and args.extra_legs:
             # what a maps-on run pays on the solve side: the whole solution vector carried (x += alpha p fused into the
             # residual update) and the reference's 1e-4 check evaluated as ||A x - b|| / ||b|| with an explicit product
@@ -1090,21 +1156,45 @@ def main():
             except Exception as e:
                 out["roofline"]["traffic_live_failed"] = repr(e)
             leg_seconds["pmc_live"] = time.perf_counter() - t_leg
-        if args.cpu_sample > 0 and world == 1:
+        if "sample" in cpu_children:
             try:
-                import subprocess
-                want_legs = "nodata,fp32,geometric" if (args.extra_legs and vb == 8) else ""
                 t_leg = time.perf_counter()
-                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(info["n"]),
-                                        "--cpu-sample", str(args.cpu_sample), "--size", str(size), "--precision",
-                                        args.precision, "--cpu-legs", want_legs, "--leg-sample", str(args.leg_sample),
-                                        "--geometric-n", str(args.geometric_n)],
-                                       capture_output=True, text=True, timeout=1200)
-                leg_seconds["cpu_child"] = time.perf_counter() - t_leg
-                cb = json.loads(child.stdout.strip().splitlines()[-1])
+                child_out, _ = cpu_children["sample"].communicate(timeout=1200)
+                leg_seconds["cpu_child_wait"] = time.perf_counter() - t_leg
+                leg_seconds["cpu_child"] = time.perf_counter() - t_children
+                cb = json.loads(child_out.strip().splitlines()[-1])
                 tight = cb.pop("_tight", None)
                 legs = cb.pop("_legs", {})
                 out["cpu_baseline"] = cb
+                if "full" in cpu_children:
+                    # the figure measured at the full size leads; the bounded sample's extrapolation stays beside it
+                    try:
+                        t_leg = time.perf_counter()
+                        full_out, _ = cpu_children["full"].communicate(timeout=900)
+                        leg_seconds["cpu_full_size_wait"] = time.perf_counter() - t_leg
+                        leg_seconds["cpu_full_size"] = time.perf_counter() - t_children
+                        m = json.loads(full_out.strip().splitlines()[-1])
+                        cb["bounded_sample"] = {"value": cb["value"], "cores": cb["cores"], "sample": cb["sample"],
+                                                "kind": "port, extrapolated linearly in n from the bounded sample"}
+                        cb.update({"value": m["value_pair_solves_per_s"], "cores": m["threads"],
+                                   "kind": "port", "measured": "at the full size, in this run",
+                                   "sample": "oracle (C++ restatement of the reference CG+AMG path) AT THE FULL SIZE of the workload "
+                                             "(%dx%d, n = %d, nnz = %d) on this box's host cores, in the background of this run: "
+                                             "graph %.0f s, set-up %.0f s, then %d pairs at the reference's tolerances on %d "
+                                             "threads (one pair per thread, src/core.jl:262-272) in %.0f s, %s iterations; "
+                                             "set-up amortised over 100 pairs" % (size, size, m["n"], m["nnz"], m["graph_build_s"],
+                                                                                  m["setup_s"], m["pairs"], m["threads"],
+                                                                                  m["pairs_wall_s"], m["iters"]),
+                                   "host_cores": m["host_cores"], "full_size": m})
+                    except Exception as e:
+                        try:
+                            cpu_children["full"].kill()
+                        except Exception:
+                            pass
+                        cb["kind"] = "port (extrapolated from the bounded sample: the full-size measurement failed: %r)" % (e,)
+                else:
+                    cb["kind"] = "port (extrapolated linearly in n from the bounded sample; host too small for the full size)" \
+                        if size >= 8000 else "port"
                 if tight:
                     out["parity"] = gpu_parity(lib, args.cpu_sample, tight, make_opts, dtype, vb == 8)
                 # an oracle figure on every leg: the leg's own options on a bounded sample of the leg's

@@ -890,9 +890,19 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   labs.release();
   // refined tiles (NODATA cells, strength-aware tiles): a second coarse function on the badly shaped aggregates (enrich.h)
   H.enr = Enrich();
-  if (size0 && n < 0x7fffffffLL)
-    enrich_setup<U, T>(H.enr, A0.data(), R, C, Rc, Cc, (const long long*)size0, (const int*)dptr<int>(agg),
-                       (const unsigned long long*)dptr<unsigned long long>(size_c), st);
+  if (size0 && n < 0x7fffffffLL) {
+    // (optional: its n-sized temporaries come on top of pl / apl / ql -- a raster that fitted without it must not fail with
+    // it)
+    try {
+      enrich_setup<U, T>(H.enr, A0.data(), R, C, Rc, Cc, (const long long*)size0, (const int*)dptr<int>(agg),
+                         (const unsigned long long*)dptr<unsigned long long>(size_c), st);
+    } catch (const Error& e) {
+      if (e.code != CSGPU_OOM) throw;
+      (void)hipGetLastError();
+      H.enr = Enrich();
+      if (knobs().verbose) fprintf(stderr, "csgpu: enrichment skipped (out of device memory during its set-up)\n");
+    }
+  }
   agg.release();
   // Galerkin operator of level 1
   Csr<T> Ac;

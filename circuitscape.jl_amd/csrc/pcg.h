@@ -52,8 +52,12 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
   H.work_kcap = K;
 }
 
-// Jacobi sweeps per preconditioner application of a hierarchy of ONE level (see vcycle; csgpu_opts.last_level_sweeps)
-constexpr int kSingleLevelSweeps = 8;
+// Jacobi sweeps per preconditioner application of a hierarchy of ONE level (see vcycle; csgpu_opts.last_level_sweeps).
+// Measured on BASELINE configs[4]'s network (n = 5e6, 1.05e8 stored entries, one MI355X, profiles/r6_network_sweeps.jsonl):
+// every sweep is one more pass over the matrix per iteration, and on an expander -- D^-1 A is well conditioned -- the
+// iterations it saves do not pay for it: 8 sweeps 6 iterations / 113 sources/s (K = 16) and 157 (K = 32), 4: 7 / 168 / 222,
+// 2: 10 / 189 / 239, 1: 12 / 216 / 256, none (plain Jacobi scaling): 20 / 202 / 219.
+constexpr int kSingleLevelSweeps = 1;
 
 // Optional fusions at level 0 of the V-cycle.
 template <class T>
@@ -552,7 +556,25 @@ struct PcgBatchResult {
   int64_t graph_launches = 0;
   int polished = 0;
   int64_t spmv_bytes = 0;  // algorithmic bytes of one of the timed CG-product launches
+  bool explicit_relres = false;  // s.relres is ||A x - b|| / ||b|| of an explicit product (x carried), not the recurrence residual
 };
+
+// The coarse-space enrichment (enrich.h) wraps the V-cycle of the lattice two-product level only; polygon handles
+// (`projected`) do not use it. ONE predicate for the batch and the streaming loops.
+template <class TP>
+inline bool enrich_applicable(const Enrich& EN, int64_t n, bool lattice_two_product_path, bool projected) {
+  return lattice_two_product_path && !projected && EN.nvec > 0 && EN.n == n && EN.phi_bytes == (int)sizeof(TP);
+}
+
+// Acceptance of one column (the reference's only test is the residual, src/core.jl:639-641). When the figure is the fp64
+// RECURRENCE residual (resistance-only solves carry no x) and the column did not stop on the rule -- breakdown of the
+// recurrence, itmax: exactly the stagnation cases in which the recurrence may have drifted from b - A x -- it is
+// accepted only with two decades of margin.
+inline bool column_accepted(double relres, int done, bool explicit_relres) {
+  if (!(relres < 1e-4)) return false;
+  if (!explicit_relres && done != 1 && !(relres < 1e-6)) return false;
+  return true;
+}
 
 // Solve A X = B for the K interleaved columns held in W.b. With pp.need_x the solution is left in W.x; otherwise only
 // the entries at W.fnode are accumulated (W.xf) and W.x is not touched (not even allocated).
@@ -659,8 +681,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // (Dirichlet-masked solves keep it: with Pm the mask, the preconditioner in effect is Pm M Pm -- r is zero at the grounded
   // entries and z is masked after the correction, so symmetry and the r'z terms hold; polygon handles -- `projected` -- do
   // not use it: their hierarchy's matrix carries the strengthened interiors)
-  const bool enrich = use_dia && EN.nvec > 0 && EN.n == n && two_product && L0.lattice_two_product() && !projected &&
-                      EN.phi_bytes == (int)sizeof(TP);
+  const bool enrich = enrich_applicable<TP>(EN, n, use_dia && two_product && L0.lattice_two_product(), projected);
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();  // (captured chunks hold the old work pointers)
     enrich_ensure_work<TP, K>(EN);
@@ -931,6 +952,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // the reference's post-check (core.jl:640): ||A x - b|| / ||b||, explicitly when x is carried, otherwise from the
   // fp64 recurrence residual
   PcgBatchResult res;
+  res.explicit_relres = need_x;
   auto post_check = [&]() {
     if (need_x) {
       SpmvArgs<T> a = spmv_args(A, (const T*)x, Ap);
@@ -1168,7 +1190,8 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   fuse.dotw = rp;
   fuse.partials = pa;
   Enrich& EN = H.enr;  // (enrich.h; as in pcg_solve)
-  const bool enrich = EN.nvec > 0 && EN.n == n && EN.phi_bytes == (int)sizeof(TP);
+  // (the stream only runs on the lattice two-product path of a handle without polygons -- checked above and by the caller)
+  const bool enrich = enrich_applicable<TP>(EN, n, two_product, pp.proj != nullptr);
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();
     enrich_ensure_work<TP, K>(EN);

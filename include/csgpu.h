@@ -177,7 +177,7 @@ typedef struct csgpu_opts {
                                  for a dense inverse. A hierarchy of ONE level -- a graph the set-up declines to coarsen,
                                  BASELINE configs[4] -- is then CG with a polynomial preconditioner of that degree: every sweep
                                  is one more pass over the matrix per iteration. 0 = default: 8 below a coarsened hierarchy,
-                                 1 for a single-level one (measured on the 5e6-node network, profiles/r6_network_sweeps.json);
+                                 1 for a single-level one (measured on the 5e6-node network, profiles/r6_network_sweeps.jsonl);
                                  -1 = none (plain Jacobi scaling) */
   int32_t enrich;             /* second coarse function on badly shaped aggregates (csrc/enrich.h): 0 = on where the tiles
                                  were refined, -1 = off */
