@@ -1669,23 +1669,6 @@ struct Solver : ISolver {
     src = src_r.p;
     dst = dst_r.p;
     gather = gather_r.p;
-    std::vector<int> src_psize, dst_psize;  // polygon handles: cells of the polygon a pair's node stands for (1: ordinary)
-    if (poly_proj && npairs > 0) {
-      DBuf ids = dalloc<int64_t>((size_t)2 * npairs), pidx = dalloc<int>((size_t)2 * npairs);
-      CS_HIP(hipMemcpyAsync(ids.p, src, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
-      CS_HIP(hipMemcpyAsync(dptr<int64_t>(ids) + npairs, dst, (size_t)npairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(gather_int_kernel, dim3(grid_for(2 * npairs)), dim3(256), 0, st, 2 * npairs,
-                         (const int64_t*)dptr<int64_t>(ids), (const int*)dptr<int>(cell_poly), dptr<int>(pidx));
-      std::vector<int> hp((size_t)2 * npairs);
-      CS_HIP(hipMemcpyAsync(hp.data(), pidx.p, hp.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-      CS_HIP(hipStreamSynchronize(st));
-      src_psize.resize((size_t)npairs);
-      dst_psize.resize((size_t)npairs);
-      for (int64_t p = 0; p < npairs; ++p) {
-        src_psize[(size_t)p] = hp[(size_t)p] >= 0 ? poly_size[(size_t)hp[(size_t)p]] : 1;
-        dst_psize[(size_t)p] = hp[(size_t)npairs + p] >= 0 ? poly_size[(size_t)hp[(size_t)npairs + p]] : 1;
-      }
-    }
     if (ncomp > 1) {
       // a pair across two components is an inconsistent singular system (the reference only pairs points of one
       // component, core.jl:146-153): refuse it instead of iterating to itmax
@@ -1812,14 +1795,8 @@ struct Solver : ISolver {
                                            dptr<int>(ddst), ncols));
       double bb[kMaxK];
       for (int c = 0; c < kMaxK; ++c) bb[c] = (c < K && s32[c] != d32[c]) ? 2.0 : 0.0;
-      if (poly_proj) {
-        // ||Pi b||^2: a unit current into a polygon's node is spread evenly over the polygon's cells
-        for (int c = 0; c < K; ++c)
-          if (s32[c] != d32[c]) {
-            const int64_t q = p0 + std::min(c, ncols - 1);
-            bb[c] = 1.0 / (double)std::max(src_psize[(size_t)q], 1) + 1.0 / (double)std::max(dst_psize[(size_t)q], 1);
-          }
-      }
+      // (polygon handles: norms are taken in NODE space -- the merged system's ||b_m||^2 = 2 whatever the polygons' sizes; a
+      // unit current into a polygon's node is spread evenly over its cells by the first projection; pcg.h, poly.h)
       if (!need_x && MIXED) {  // the fp32 copy of r0 the V-cycle reads, written directly
         CS_HIP(hipMemsetAsync(W.rp.p, 0, (size_t)n * K * sizeof(TP), st));
         CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<TP, KK>), dim3(1), dim3(64), 0, st, dptr<TP>(W.rp),
@@ -2518,6 +2495,36 @@ struct Solver : ISolver {
   bool csr_ready_at_setup() const { return H.levels[0].Q.nnz > 0 || !H.levels[0].lattice_two_product() || H.levels.size() < 2; }
 
   void level_spmv_host(int lvl, int which, const void* xh, void* yh, int k, double* dots) override {
+    if (which == 6) {
+      // test hook of the polygon lattice path (poly.h): y = Pi x for a cell-space vector x ([R*C][k], column-major cell ids)
+      // and dots[c] = ||Pi x||^2 in NODE space -- the merged system's norm -- from the very kernels the PCG loop uses
+      CS_REQUIRE(poly_proj && proj.nchunks > 0, CSGPU_BAD_ARGS, "not a polygon handle on the lattice path");
+      std::lock_guard<std::mutex> lk(mu);
+      KnobScope ks(&kn);
+      CS_HIP(hipSetDevice(device));
+      DBuf x((size_t)n * k * sizeof(TP));
+      const int gv = grid_for(n * k);
+      DBuf part = dalloc<double>((size_t)(gv + 1) * kMaxK);
+      CS_HIP(hipMemcpyAsync(x.p, xh, x.bytes, hipMemcpyHostToDevice, st));
+      CS_DISPATCH_K(k, (poly_project<TP, TP, KK>(proj, dptr<TP>(x), (TP*)nullptr, (const int*)nullptr, st)));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((dot_kernel<TP, KK, false>), dim3(gv), dim3(256), 0, st, n, (const TP*)dptr<TP>(x),
+                                          (const TP*)dptr<TP>(x), dptr<double>(part), (const TP*)nullptr, (const TP*)nullptr,
+                                          (double*)nullptr));
+      CS_DISPATCH_K(k, hipLaunchKernelGGL((poly_norm_corr_kernel<KK>), dim3(1), dim3(256), 0, st, proj,
+                                          dptr<double>(part) + (size_t)gv * KK, (const int*)nullptr));
+      check_launch("polygon projection hook");
+      std::vector<double> hp((size_t)(gv + 1) * k);
+      CS_HIP(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      CS_HIP(hipMemcpyAsync(yh, x.p, x.bytes, hipMemcpyDeviceToHost, st));
+      CS_HIP(hipStreamSynchronize(st));
+      if (dots)
+        for (int c = 0; c < k; ++c) {
+          double t = 0.0;
+          for (int r = 0; r <= gv; ++r) t += hp[(size_t)r * k + c];
+          dots[c] = t;
+        }
+      return;
+    }
     if (poly_proj) return poly_fallback().level_spmv_host(lvl, which, xh, yh, k, dots);
     std::lock_guard<std::mutex> lk(mu);
     KnobScope ks(&kn);
@@ -3181,7 +3188,7 @@ int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k) {
 
 int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, void* y, int k, double* dots) {
   CS_API_BEGIN
-  if (!h || !x || !y || which < 0 || which > 5 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
+  if (!h || !x || !y || which < 0 || which > 6 || !(k == 1 || k == 2 || k == 4 || k == 8 || k == 16 || k == 32)) {
     g_last_error = "bad arguments";
     return CSGPU_BAD_ARGS;
   }

@@ -838,9 +838,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     const bool rr_after_mask = (grounded || projected) && criterion != CSGPU_CRIT_KRYLOV;
     if (projected) {  // r <- Pi r: the residual of the projected system (both precisions)
       poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done, st);
-      if (rr_after_mask)
+      if (rr_after_mask) {
+        // ||r||^2 in NODE space = the merged system's (the reference's figure): cell-space partials + one correction row
         hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pb,
                            (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((poly_norm_corr_kernel<K>), dim3(1), dim3(256), 0, st, *pp.proj, pb + (size_t)gv * K,
+                           (const int*)&S->all_done);
+      }
     }
     if (grounded) {  // the update put (A p) at the grounded rows into r: back to zero, in both precisions
       hipLaunchKernelGGL((mask_grounds_kernel<T, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, r,
@@ -863,7 +867,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       auto rz = collapsed(pa, rz_rows, pac);
       // r'r partials (true-residual criterion): one row per workgroup of whichever kernel updated r
       const double* prr = pb;
-      int nrr = gv;
+      int nrr = (projected && rr_after_mask) ? gv + 1 : gv;   // (+ the node-space correction row of a polygon handle)
       if (recompute && criterion != CSGPU_CRIT_KRYLOV && !rr_after_mask) {
         auto rr = collapsed(pb, spmv_g, pcc);
         prr = rr.first;
@@ -988,7 +992,17 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       } else {
         hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa,
                            (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
-        hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, gv, (const double*)nullptr,
+        int rows = gv;
+        if (projected) {
+          // polygon handle: the figure of the MERGED system, ||b_m - A_m y|| / ||b_m|| (src/core.jl:640-641) -- r is
+          // polygon-wise constant, its chunk sums are taken again (the last projection was z's), the correction row follows
+          hipLaunchKernelGGL((poly_chunk_sum_kernel<T, K>), dim3(pp.proj->nchunks), dim3(256), 0, st, *pp.proj, (const T*)r,
+                             (const int*)nullptr);
+          hipLaunchKernelGGL((poly_norm_corr_kernel<K>), dim3(1), dim3(256), 0, st, *pp.proj, pa + (size_t)gv * K,
+                             (const int*)nullptr);
+          rows = gv + 1;
+        }
+        hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, (const double*)pa, rows, (const double*)nullptr,
                            0);
       }
       CS_HIP(hipMemcpyAsync(&res.s, S, sizeof(CgScalars), hipMemcpyDeviceToHost, st));

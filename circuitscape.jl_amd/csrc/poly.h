@@ -99,6 +99,38 @@ inline void poly_project(const PolyProj& pp, V* v, V2* v2, const int* skip, hipS
   hipLaunchKernelGGL((poly_apply_kernel<V, V2, K>), dim3(pp.nchunks), dim3(256), 0, st, pp, v, v2, skip);
 }
 
+// Residual norms in NODE space (the reference's check is ||A x - b|| / ||b|| of the MERGED system,
+// src/core.jl:640-641). A polygon of s cells whose projected residual is the constant rho per cell carries the node residual
+// s rho in the merged system: ||r_m||^2 = sum_ordinary r^2 + sum_polygons (s rho)^2, while the cell-space norm of Pi r holds
+// s rho^2 for it. The difference, sum_p (s^2 - s) rho_p^2, is one extra row of r'r partials:
+//   row[c] = sum_p s_p (s_p - 1) mean_p[c]^2,   mean_p = (chunk sums of p, in order) / s_p
+// from the chunk sums the LAST projection left behind (poly_project, or poly_chunk_sum_kernel alone). One workgroup, fixed
+// summation order (polygons strided over 256 / K thread groups, groups combined in order): bit-reproducible.
+template <int K>
+__global__ __launch_bounds__(256) void poly_norm_corr_kernel(PolyProj pp, double* __restrict__ row, const int* skip) {
+  if (skip && *skip) return;
+  __shared__ double s_part[256];
+  constexpr int G = 256 / K;
+  const int c = threadIdx.x % K, g = threadIdx.x / K;
+  double acc = 0.0;
+  if (g < G)
+    for (int p = g; p < pp.npoly; p += G) {
+      const double s = (double)(pp.ptr[p + 1] - pp.ptr[p]);
+      if (!(s > 1.0)) continue;
+      double t = 0.0;
+      for (int q = pp.poly_chunk0[p]; q < pp.poly_chunk0[p + 1]; ++q) t += pp.chunk_sum[(size_t)q * kMaxK + c];
+      const double mean = t / s;
+      acc += s * (s - 1.0) * mean * mean;
+    }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = 0.0;
+    for (int gg = 0; gg < G; ++gg) t += s_part[gg * K + threadIdx.x];
+    row[threadIdx.x] = t;
+  }
+}
+
 // ---- raster + polygon labels -> lattice form -------------------------------------------------------------------------
 // label[k] (column-major cell id k): the polygon's representative cell for every cell of a merged polygon (NODATA cells
 // included), k itself for an ordinary valid cell, -1 for a cell without a node (poly_label_kernel, raster.h).

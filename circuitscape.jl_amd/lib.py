@@ -442,6 +442,18 @@ class Handle:
         _check(lib().csgpu_level_spmv_host(self._p, lvl, w, xi.ctypes.data, y.ctypes.data, k, dots.ctypes.data))
         return (y[:, 0] if x.ndim == 1 else y), (dots if which == "M" else None)
 
+    def poly_project_norm(self, x):
+        """Test hook (csgpu_level_spmv_host, which = 6) of a polygon handle on the lattice path: returns (Pi x, node-space
+        squared norms per column) for a cell-space array x of shape (R * C, k), rows = column-major cell ids."""
+        info = self.info
+        dt = np.float32 if (info["precond_bytes"] or info["val_bytes"]) == 4 else np.float64
+        x = np.ascontiguousarray(x, dtype=dt)
+        k = x.shape[1]
+        y = np.zeros_like(x)
+        dots = np.zeros(k, dtype=np.float64)
+        _check(lib().csgpu_level_spmv_host(self._p, 0, 6, x.ctypes.data, y.ctypes.data, k, dots.ctypes.data))
+        return y, dots
+
     def dia_product(self, z, p_in, beta):
         """Fused lattice-form CG product (test hook): returns (p_out, y, dots) with p_out = z + beta * p_in,
         y = A p_out, dots = column-wise p_out . y. z, p_in: (n, k) arrays, beta: k values."""

@@ -471,7 +471,11 @@ int csgpu_spmv_host(csgpu_handle* h, const void* x, void* y, int k);
 /* y = (level `lvl` operator `which`, numbering as in csgpu_get_level_matrix) x, launched the way the V-cycle launches
  * that operator (tests: parity of the restriction / [S Q] kernels). Host arrays in the hierarchy's precision
  * (precond_bytes, else val_bytes), interleaved [ncols][k] -> [nrows][k]. For which == 5 `dots` (k doubles, may be
- * NULL) receives the fused dot products sum_i x[i][c] * y[i][c] over the first nrows entries of x. */
+ * NULL) receives the fused dot products sum_i x[i][c] * y[i][c] over the first nrows entries of x.
+ * which == 6 (polygon handles on the lattice path only, lvl ignored): y = Pi x, the average over every polygon's cells, for a
+ * cell-space vector x [nrows * ncols of the raster][k] (column-major cell ids), and dots[c] = ||Pi x||^2 in NODE space -- the
+ * norm of the MERGED system the reference checks (src/core.jl:640-641): a polygon of s cells at the value rho counts
+ * (s rho)^2 -- evaluated by the kernels the PCG loop uses for its residual norms (csrc/poly.h). */
 int csgpu_level_spmv_host(csgpu_handle* h, int lvl, int which, const void* x, void* y, int k, double* dots);
 
 /* Copy level `lvl`'s operator (which: 0 = A, 1 = P, 2 = R, 3 = Q, 4 = Q^T, 5 = [S Q]; the

@@ -1676,6 +1676,88 @@ def check_polygons_on_lattice_path(L, monkeypatch, shape=(64, 57), batch=4, pbs=
         assert nm3[31, 4] == nm3[41, 41]
 
 
+def check_polygon_residuals_in_node_space(L, shape=(150, 140), batch=4, big=100):
+    """Residual norms of the polygon lattice path are the MERGED system's (the reference's check is
+    ||A x - b|| / ||b|| on the merged graph, src/core.jl:640-641): a raster with ONE polygon of big x big cells (10^4 at the
+    default) plus two small ones.
+    (1) The hook (csgpu_level_spmv_host, which = 6) runs the very kernels the PCG loop takes its norms from: Pi x must be the
+        polygon-wise average and the squared norm must equal the norm of E'x on the merged numbering -- a polygon of s cells at
+        the value rho counts (s rho)^2, not s rho^2 -- for random vectors, all batch widths, both precisions.
+    (2) Pairs whose source IS the big polygon: the lattice path and the merged-graph path of the same library agree on the
+        resistances (direct solve of the merged matrix as the referee), on converged / not converged (default options: both
+        converged with max_relres < 1e-4; itmax = 2: both report every column as not converged), and the TRUE-residual rule
+        (criterion 1, rtol 1e-5) stops the lattice path at a figure that is below the rule in NODE space, which the
+        cell-space figure of round 5 under-stated by up to sqrt(s) = 100."""
+    import scipy.sparse.linalg as spla
+    R_, C_ = shape
+    rng = np.random.default_rng(23)
+    g = np.exp(0.5 * rng.standard_normal(shape))
+    poly = np.zeros(shape, dtype=np.int32)
+    poly[20:20 + big, 15:15 + big] = 1
+    poly[5:9, 5:12] = 2
+    poly[R_ - 20:R_ - 10, C_ - 15:C_ - 9] = 3
+    pm = poly.T.ravel()                      # column-major cell order
+    for pb in (0, 4):
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), polymap=poly) as h:
+            info = h.info
+            assert info["poly_lattice"] == 1 and info["lattice_period"] == R_
+            for k in (1, 4, 32):
+                x = rng.standard_normal((R_ * C_, k))
+                x[pm == 1] += 0.3                       # (a residual that SITS on the big polygon's node)
+                y, dots = h.poly_project_norm(x)
+                xe = x.astype(y.dtype).astype(np.float64)
+                ref = xe.copy()
+                node2 = np.zeros(k)
+                ordinary = pm == 0
+                node2 += (xe[ordinary] ** 2).sum(axis=0)
+                for pid in (1, 2, 3):
+                    m = pm == pid
+                    mean = xe[m].mean(axis=0)
+                    ref[m] = mean
+                    node2 += (m.sum() * mean) ** 2
+                tol = 1e-12 if y.dtype == np.float64 else 2e-6
+                assert np.max(np.abs(y - ref)) < tol * np.max(np.abs(ref)), (pb, k)
+                assert np.max(np.abs(dots - node2) / node2) < (1e-12 if y.dtype == np.float64 else 1e-5), (pb, k, dots, node2)
+                cell2 = (ref ** 2).sum(axis=0)
+                assert np.all(node2 > 1.5 * cell2)        # (the two norms really differ on this raster)
+            nm = h.raster_nodemap()
+        # merged-graph path of the same library: the referee matrix and the second opinion on converged / not converged
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, poly_lattice=-1), polymap=poly) as hm:
+            assert hm.info["poly_lattice"] == 0 and np.array_equal(hm.raster_nodemap(), nm)
+            A = hm.level_matrix(0, "A").astype(np.float64).tocsc()
+            big_node = int(nm[25, 20]) - 1
+            others = [int(nm[2, 2]) - 1, int(nm[R_ - 5, 3]) - 1, int(nm[R_ // 2, C_ - 5]) - 1, int(nm[6, 6]) - 1]
+            src, dst = [big_node] * 4, others
+            n = A.shape[0]
+            Rd = []
+            lu = spla.splu((A + 1e-12 * __import__("scipy.sparse").sparse.identity(n)).tocsc())
+            for s_, d_ in zip(src, dst):
+                b = np.zeros(n)
+                b[d_] = 1.0
+                b[s_] = -1.0
+                xs = lu.solve(b)
+                Rd.append(xs[d_] - xs[s_])
+            Rd = np.array(Rd)
+            Rm, _, _, stm = hm.solve_pairs(src, dst)
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb), polymap=poly) as h:
+            Rl, _, _, stl = h.solve_pairs(src, dst)
+        assert stl["not_converged"] == 0 and stm["not_converged"] == 0 and stl["max_relres"] < 1e-4 and stm["max_relres"] < 1e-4
+        assert np.max(np.abs(Rl - Rd) / Rd) < 1e-5 and np.max(np.abs(Rm - Rd) / Rd) < 1e-5, (pb, Rl, Rm, Rd)
+        for path, pl in (("lattice", 0), ("merged", -1)):
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, poly_lattice=pl, itmax=2), polymap=poly) as h2:
+                try:
+                    h2.solve_pairs(src, dst)
+                    raise AssertionError("%s path: two iterations reported as converged" % path)
+                except L.CsgpuError as e:
+                    assert e.code == L.CSGPU_NOT_CONVERGED, (path, e)
+        # the true-residual rule in node space: tight enough that the resistances are good whatever the polygon's size
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, criterion=L.CRIT_TRUE_RESIDUAL, rtol=1e-7, atol=0.0),
+                            polymap=poly) as h3:
+            R3, _, _, st3 = h3.solve_pairs(src, dst)
+            assert st3["not_converged"] == 0 and st3["max_relres"] <= 1.5e-7, st3
+            assert np.max(np.abs(R3 - Rd) / Rd) < 1e-6
+
+
 def check_contrast_triggered_fp64_hierarchy(L):
     """A graph handed over in CSR form whose conductances span more than five decades gets an fp64 hierarchy whatever
     precond_bytes says (csgpu.hip, setup_from_host): tools/fuzz_networks.py, run on the DEVICE at the end of round 4, found a

@@ -1031,6 +1031,12 @@ def test_ragged_tail_batch_runs_at_its_own_width(emu_lib, holes):
     check_ragged_tail_batches(emu_lib, holes=holes)
 
 
+def test_polygon_lattice_path_residuals_in_node_space(emu_lib):
+    """see helpers.check_polygon_residuals_in_node_space"""
+    from helpers import check_polygon_residuals_in_node_space
+    check_polygon_residuals_in_node_space(emu_lib, shape=(90, 84), big=50)
+
+
 def test_multi_device_sources_and_grounded(emu_lib):
     """csgpu_multi_solve_sources / csgpu_multi_solve_grounded (configs[4] across the GPUs of a node): the
     columns of a one-to-all job on a NETWORK dealt over three (emulated) devices in contiguous ranges, one call per device

@@ -691,3 +691,10 @@ def test_ragged_tail_batch_runs_at_its_own_width_gpu(gpu_lib, holes, batch, npai
     """K picked per batch on the device (see helpers.check_ragged_tail_batches): 37 pairs at batch 32 = 32 + 5 at K = 8."""
     from helpers import check_ragged_tail_batches
     check_ragged_tail_batches(gpu_lib, shape=(130, 121), batch=batch, npairs=npairs, holes=holes)
+
+
+def test_polygon_lattice_path_residuals_in_node_space_gpu(gpu_lib):
+    """Residual norms of the polygon lattice path are the merged system's, with one polygon of 10^4 cells (see
+    helpers.check_polygon_residuals_in_node_space)."""
+    from helpers import check_polygon_residuals_in_node_space
+    check_polygon_residuals_in_node_space(gpu_lib)
