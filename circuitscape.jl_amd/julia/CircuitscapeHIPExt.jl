@@ -21,7 +21,7 @@ mutable struct CsgpuOpts
     node_row::Ptr{Int32}; node_col::Ptr{Int32}
     precond_bytes::Int32; use_graph::Int32; two_product::Int32; stencil::Int32
     explicit_check::Int32; reserved3::Int32
-    # round 6: the decisions that used to be environment switches (include/csgpu.h; 0 = the library's default in every field)
+    # round 6: the decisions that used to be environment switches (include/csgpu.h, 0 = the default in every field)
     last_level_sweeps::Int32; enrich::Int32; enrich_steps::Int32; dia25_min_rows::Int32; dia25_prefetch::Int32
     dia25_waves::Int32; dia25_fused_j0::Int32; stream::Int32; tail_rows::Int32; poly_lattice::Int32; cellspace::Int32
     cellspace_from_csr::Int32; lattice_level1::Int32; lattice_level1_min_rows::Int32; lattice_setup::Int32; lattice_s::Int32
@@ -228,6 +228,72 @@ function solve_grounded(factor::HIPFactor, rhs::Matrix{T}, grounds::Vector{Vecto
 end
 
 """
+csgpu_solve_sources / csgpu_multi_solve_sources: Dirichlet-masked solves whose right-hand sides have a few entries each -- the
+columns the one-to-all / all-to-one drivers build (raster/onetoall.jl:106-117: one +1 per one-to-all column) -- handed over
+as lists, with what those drivers keep of a solve: the voltage of one node per column (`res[i] = v[1]`, onetoall.jl:141) and
+the cumulative / maximum node-current vectors (onetoall.jl:153-158), accumulated on the device. No n x nrhs array crosses
+PCIe unless `want_voltages` / `want_currents` ask for it. `sources[c]` / `grounds[c]`: 0-based node ids; `values[c]`: the
+entries (empty = ones); `check[c]`: node whose voltage is returned (-1: none). With a `HIPMultiFactor` the columns are dealt
+over the GPUs of the node (the fan-out of onetoall.jl:146-151 as one host thread per GPU).
+"""
+function solve_sources(factor::Union{HIPFactor,HIPMultiFactor}, ::Type{T}, n::Int, sources::Vector{Vector{Int64}},
+                       grounds::Vector{Vector{Int64}}; values::Vector{Vector{T}} = Vector{T}[], check::Vector{Int64} = Int64[],
+                       want_voltages = false, want_currents = false, cum::Vector{T} = T[], mx::Vector{T} = T[]) where {T}
+    nrhs = length(sources)
+    sptr = Int64[0; cumsum(length.(sources))]
+    sidx = isempty(sources) ? Int64[] : reduce(vcat, sources)
+    isempty(sidx) && (sidx = Int64[0])
+    sval = isempty(values) ? T[] : reduce(vcat, values)
+    gptr = Int64[0; cumsum(length.(grounds))]
+    gidx = isempty(grounds) ? Int64[] : reduce(vcat, grounds)
+    isempty(gidx) && (gidx = Int64[0])
+    cout = Vector{T}(undef, length(check))
+    volt = want_voltages ? Matrix{T}(undef, n, nrhs) : Matrix{T}(undef, 0, 0)
+    cur = want_currents ? Matrix{T}(undef, n, nrhs) : Matrix{T}(undef, 0, 0)
+    st = CsgpuStats()
+    rc = GC.@preserve sptr sidx sval gptr gidx check cout volt cur cum mx begin
+        pval = isempty(sval) ? C_NULL : pointer(sval)
+        pchk = isempty(check) ? C_NULL : pointer(check)
+        pout = isempty(check) ? C_NULL : pointer(cout)
+        pv = want_voltages ? pointer(volt) : C_NULL
+        pc = want_currents ? pointer(cur) : C_NULL
+        pcum = isempty(cum) ? C_NULL : pointer(cum)
+        pmx = isempty(mx) ? C_NULL : pointer(mx)
+        if factor isa HIPMultiFactor
+            ccall((:csgpu_multi_solve_sources, LIBCSGPU), Cint,
+                  (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid},
+                   Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+                  factor.ptr, nrhs, sptr, sidx, pval, gptr, gidx, pchk, pout, pv, pc, pcum, pmx, st)
+        else
+            ccall((:csgpu_solve_sources, LIBCSGPU), Cint,
+                  (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid},
+                   Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+                  factor.ptr, nrhs, sptr, sidx, pval, gptr, gidx, pchk, pout, pv, pc, pcum, pmx, st)
+        end
+    end
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_solve_sources failed: $(csgpu_error())")
+    cout, volt, cur, st
+end
+
+"csgpu_multi_solve_grounded: `solve_grounded` with the columns dealt over the GPUs of the node (dense right-hand sides)."
+function solve_grounded(factor::HIPMultiFactor, rhs::Matrix{T}, grounds::Vector{Vector{Int64}}; want_currents = false) where {T}
+    n, nrhs = size(rhs)
+    gptr = Int64[0; cumsum(length.(grounds))]
+    gidx = isempty(grounds) ? Int64[] : reduce(vcat, grounds)
+    isempty(gidx) && (gidx = Int64[0])
+    x = similar(rhs)
+    cur = want_currents ? similar(rhs) : Matrix{T}(undef, 0, 0)
+    st = CsgpuStats()
+    rc = GC.@preserve rhs gptr gidx x cur ccall((:csgpu_multi_solve_grounded, LIBCSGPU), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{CsgpuStats}),
+              factor.ptr, rhs, nrhs, gptr, gidx, x, want_currents ? pointer(cur) : C_NULL, st)
+    rc == 1 && error("CG solver did not converge: relative residual $(st.max_relres) exceeds tolerance 1e-4")
+    rc == 0 || error("csgpu_multi_solve_grounded failed: $(csgpu_error())")
+    x, cur, st
+end
+
+"""
 One-to-all / all-to-one with ONE graph build and ONE AMG setup for all focal points (scope rows N2 + N4; the Julia twin of
 `solver.py::onetoall_on_device`). `onetoall_kernel` (raster/onetoall.jl:13-162) builds the graph once but calls
 `advanced_kernel` -> `multiple_solver` per focal point, which deletes the grounded rows / columns and factorises again
@@ -260,7 +326,7 @@ function onetoall_on_device(data, flags, cfg, s::HIPAMGSolver)
     n = Int(maximum(nodemap))
     node = Int64[nodemap[rows[i], cols[i]] - 1 for i in 1:np]          # 0-based; -1: the focal cell is NODATA
     comp, _ = components(factor, n)
-    rhs = zeros(T, n, np)
+    sources = Vector{Vector{Int64}}(undef, np)        # the columns as the driver builds them: a few unit entries each
     grounds = Vector{Vector{Int64}}(undef, np)
     solvable = falses(np)
     gcomps = Vector{Set{Int32}}(undef, np)
@@ -269,12 +335,36 @@ function onetoall_on_device(data, flags, cfg, s::HIPAMGSolver)
         own = node[i] >= 0 ? Int64[node[i]] : Int64[]
         src, gnd = one_to_all ? (own, others) : (others, own)
         gcomps[i] = Set{Int32}(comp[g + 1] for g in gnd)
-        for q in src
-            comp[q + 1] in gcomps[i] || continue      # a component without a ground is not solved (advanced.jl:186-191)
-            rhs[q + 1, i] = one(T)
-            solvable[i] = true
-        end
+        # a component without a ground is not solved (advanced.jl:186-191)
+        sources[i] = Int64[q for q in src if comp[q + 1] in gcomps[i]]
+        solvable[i] = !isempty(sources[i])
         grounds[i] = gnd
+    end
+    if !of.write_volt_maps && !(of.write_cur_maps && !of.write_cum_cur_map_only)
+        # Nothing per focal point is written: the driver keeps the voltage of the source (`res[i] = v[1]`, onetoall.jl:141)
+        # and the accumulated current maps (onetoall.jl:153-158) -- csgpu_solve_sources hands back exactly those (sparse
+        # right-hand sides in, np voltages + at most two n-vectors out; the maps are accumulated on the device).
+        node_cum = want_cur ? zeros(T, n) : T[]
+        node_max = (want_cur && of.write_max_cur_maps) ? zeros(T, n) : T[]
+        vchk, _, _, _ = solve_sources(factor, T, n, sources, grounds; check = Int64[one_to_all ? node[i] : -1 for i in 1:np],
+                                      cum = node_cum, mx = node_max)
+        finalize(factor)
+        for i in 1:np
+            res[i] = one_to_all ? ((solvable[i] && vchk[i] != 0) ? vchk[i] : T(-1)) : (solvable[i] ? T(0) : T(-1))
+        end
+        if want_cur
+            for k in eachindex(nodemap)
+                nodemap[k] == 0 && continue
+                cum.cum_curr[k] += node_cum[nodemap[k]]
+                of.write_max_cur_maps && (cum.max_curr[k] = max(cum.max_curr[k], node_max[nodemap[k]]))
+            end
+            write_cum_maps(cum, gmap, cfg, hbmeta, of.write_max_cur_maps, of.write_cum_cur_map_only)
+        end
+        return hcat(ids, res)
+    end
+    rhs = zeros(T, n, np)
+    for i in 1:np, q in sources[i]
+        rhs[q + 1, i] = one(T)
     end
     volt, curr, _ = solve_grounded(factor, rhs, grounds; want_currents = want_cur)
     finalize(factor)                                  # (releases the device-resident hierarchy now; HIPFactor finalizer)
