@@ -727,3 +727,41 @@ def test_polygon_lattice_path_residuals_in_node_space_gpu(gpu_lib):
     helpers.check_polygon_residuals_in_node_space)."""
     from helpers import check_polygon_residuals_in_node_space
     check_polygon_residuals_in_node_space(gpu_lib)
+
+
+def test_multi_sources_two_replicas_on_one_device(gpu_lib):
+    """csgpu_multi_solve_sources / csgpu_multi_solve_grounded on real HIP: two replicas of a network's handle on the ONE device
+    of this box (devices = [0, 0]: two host threads, two streams, two hierarchies), columns dealt as contiguous ranges --
+    check voltages, voltages, node currents and the combined cumulative / maximum current vectors against the single-handle
+    call (BASELINE configs[4]'s multi-GPU code path; the 3-device twin runs on the emulator)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import geometric_network
+    G, rng = geometric_network(60000, seed=11)
+    n = G.shape[0]
+    pts = [int(q) for q in rng.choice(n, size=21, replace=False)]
+    src = [[p] for p in pts]
+    gnd = [[q for q in pts if q != p] for p in pts]
+    o = lambda: gpu_lib.default_opts(batch=8, itmax=3000)
+    with gpu_lib.setup(G, o(), index_dtype=np.int32, index_base=0) as h:
+        cum1 = np.zeros(n)
+        mx1 = np.zeros(n)
+        v1, X1, C1, st1 = h.solve_sources(src, gnd, check=pts, want_voltages=True, want_currents=True, cum=cum1, mx=mx1)
+        assert h.info["levels"] > 1 and st1["not_converged"] == 0
+    with gpu_lib.multi_setup(G, o(), devices=[0, 0], index_dtype=np.int32, index_base=0) as m:
+        assert m.ndevices == 2
+        cumm = np.zeros(n)
+        mxm = np.zeros(n)
+        vm, Xm, Cm, stm = m.solve_sources(src, gnd, check=pts, want_voltages=True, want_currents=True, cum=cumm, mx=mxm)
+        assert stm["device_pairs"] == [11, 10] and stm["not_converged"] == 0 and stm["device_ms"] > 0
+        B = np.zeros((n, 21))
+        for c, p in enumerate(pts):
+            B[p, c] = 1.0
+        Xg, _, stg = m.solve_grounded(B, gnd)
+        assert stg["not_converged"] == 0
+    # (a replica's range runs at the batch widths ITS column count asks for: 8 + 3 and 8 + 2 against 8 + 8 + 5 -- the same
+    # systems to the slack of the solve tolerance)
+    assert np.max(np.abs(vm - v1) / v1) < 1e-6
+    assert np.max(np.abs(Xm - X1)) < 1e-6 * np.max(np.abs(X1)) and np.max(np.abs(Xg - X1)) < 1e-6 * np.max(np.abs(X1))
+    assert np.max(np.abs(Cm - C1)) < 1e-6 * np.max(C1)
+    assert np.max(np.abs(cumm - cum1)) < 1e-6 * np.max(cum1) and np.max(np.abs(mxm - mx1)) < 1e-6 * np.max(mx1)
