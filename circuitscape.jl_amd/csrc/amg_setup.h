@@ -999,6 +999,7 @@ struct Hierarchy {
   int coarse_n = 0;
   bool coarse_dense = false;
   double setup_ms = 0;
+  bool expander_probe_hit = false;  // the set-up skipped the aggregation of level 0: the expansion probe predicted the bail-out
   int work_k = 0;       // batch width the work vectors are laid out for
   int work_kcap = 0;    // batch width they were allocated for (>= work_k)
   // coarse tail (tail.h): first level run inside the single-launch tail kernel (-1: none, -2: not decided yet), the
@@ -1328,6 +1329,72 @@ struct TileStrength {
 // (Measured on MI355X, 15 % random NODATA: MIS(2) on the levels below the raster's own made the iteration count grow
 // with the raster, 17 at 3000^2 and 32 at 10000^2; profiles/r3_nodata_*.) In the MIS(2) path weightless rows seed and
 // join nothing.
+// ---- expander probe ----------------------------------------------------------------------------------------------------
+// The coarsening loop stops when the smoothed prolongator is as dense as the matrix (nnz(P) > 0.75 nnz(A): a graph without
+// locality, whose Galerkin operator would be dense while the graph is well conditioned to begin with) -- but finds out only
+// AFTER the MIS(2) aggregation, which on exactly those graphs is all random gathers: 44 propagation launches of 3.9 ms =
+// 172 of the 200 ms of device set-up on BASELINE configs[4]'s network (profiles/r6_network_kernel_stats_a.csv). The outcome is
+// predictable from the growth of the 2-hop balls: an MIS(2) aggregate holds about deg + 1 nodes, so the neighbours of a node
+// fall into about |B2| / (deg + 1) aggregates (B2 = the node, its neighbours and theirs) and nnz(P) / nnz(A) is about
+// mean|B2| / mean((deg + 1)^2): 0.31 on an 8-neighbour raster (measured nnz(P) / nnz(A): 0.3), 0.34 on a geometric network of
+// mean degree 10, 0.52 / 0.63 on a 4-neighbour lattice / a binary tree, 0.92 on an Erdos-Renyi graph of mean degree 21. One
+// wavefront per sampled row counts |B2| with an LDS hash set (rows and neighbour lists capped at 64 entries).
+static const int kProbeSamples = 2048, kProbeTable = 2048, kProbeCap = 1400;
+__global__ __launch_bounds__(64) void expansion_probe_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                             unsigned long long* __restrict__ out) {
+  __shared__ int tab[kProbeTable];
+  __shared__ int cnt;
+  const int lane = threadIdx.x;
+  const int i = (int)(((unsigned long long)blockIdx.x * 2654435761ull + 12345ull) % (unsigned long long)n);
+  for (int e = lane; e < kProbeTable; e += 64) tab[e] = -1;
+  if (lane == 0) cnt = 0;
+  __syncthreads();
+  auto insert = [&](int v) {
+    unsigned h = ((unsigned)v * 2654435761u) & (kProbeTable - 1);
+    for (int probe = 0; probe < kProbeTable; ++probe) {
+      const int old = atomicCAS(&tab[h], -1, v);
+      if (old == -1) {
+        atomicAdd(&cnt, 1);
+        return;
+      }
+      if (old == v) return;
+      h = (h + 1) & (kProbeTable - 1);
+    }
+  };
+  const int b0 = rp[i], deg = min(rp[i + 1] - b0, 64);
+  if (lane == 0) insert(i);
+  if (lane < deg) insert(ci[b0 + lane]);
+  __syncthreads();
+  for (int q = 0; q < deg; ++q) {
+    if (cnt >= kProbeCap) break;   // (block-uniform: read after the barrier below)
+    const int j = ci[b0 + q];
+    const int c0 = rp[j], dj = min(rp[j + 1] - c0, 64);
+    if (lane < dj) insert(ci[c0 + lane]);
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const int own = rp[i + 1] - b0;   // stored entries of the row (the diagonal included: deg + 1)
+    atomicAdd(&out[0], (unsigned long long)min(cnt, kProbeCap));
+    atomicAdd(&out[1], (unsigned long long)own * (unsigned long long)own);
+    atomicAdd(&out[2], (unsigned long long)own);
+  }
+}
+
+// estimate of nnz(P) / nnz(A) after an MIS(2) aggregation of A (see above); `mean_row` receives the mean row length
+template <class T>
+inline double expansion_estimate(const Csr<T>& A, hipStream_t st, double* mean_row) {
+  DBuf out = dalloc<unsigned long long>(3);
+  CS_HIP(hipMemsetAsync(out.p, 0, out.bytes, st));
+  hipLaunchKernelGGL(expansion_probe_kernel, dim3(kProbeSamples), dim3(64), 0, st, A.nrows, A.rp(), A.ci(),
+                     dptr<unsigned long long>(out));
+  unsigned long long h[3];
+  CS_HIP(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  CS_HIP(hipStreamSynchronize(st));
+  check_launch("expansion probe");
+  if (mean_row) *mean_row = (double)h[2] / kProbeSamples;
+  return h[1] > 0 ? (double)h[0] / (double)h[1] : 0.0;
+}
+
 template <class T>
 inline int aggregate(const Csr<T>& A, const T* diag, double theta, const int* nrow, const int* ncol, DBuf& agg,
                      DBuf& crow, DBuf& ccol, hipStream_t st, int gridR = 0, int gridC = 0, long long* size_f = nullptr,
@@ -1582,6 +1649,19 @@ inline void amg_setup_levels(Hierarchy<T>& H, const SetupParams& sp, const int* 
       ts.unit_weights = true;
     }
     const bool cell_level = (sp.size0 || ts.unit_weights) && H.levels.size() == 1;
+    if (knobs().expander_probe && H.levels.size() == 1 && !cur_row && !wts && sp.theta == 0.0 && n >= 100000) {
+      // a large graph without coordinates: would the aggregation be thrown away? (expansion_probe_kernel)
+      double mean_row = 0.0;
+      const double est = expansion_estimate(L.A, st, &mean_row);
+      if (knobs().verbose)
+        fprintf(stderr, "csgpu: expansion probe: mean row %.1f entries, estimated nnz(P) / nnz(A) after MIS(2) = %.2f\n", mean_row, est);
+      if (est > 0.8 && mean_row >= 7.0) {
+        H.expander_probe_hit = true;
+        L.weights.clear();
+        L.omega = sp.omega_s / L.rho;
+        break;
+      }
+    }
     int nagg = aggregate(L.A, dptr<T>(diag), sp.theta, cur_row, cur_col, agg, crow, ccol, st, gridR, gridC, wts, cell_level, &ts);
     if (ts.decide) {
       H.hetero_frac = ts.hetero_frac;

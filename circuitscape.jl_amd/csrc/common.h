@@ -77,6 +77,7 @@ struct Knobs {
   bool direct_lattice = true, lattice_s = true, lattice_q = true, direct_tiles = true, tile_pieces = true, direct_at = true;
   double tile_theta = 0.03, tile_split_min = 0.005;
   bool dirichlet_coarse = true, deflation = true, tail_projection = true;
+  bool expander_probe = true;     // large graphs without coordinates: predict the expander bail-out before the MIS(2) aggregation
   int coarse_smoother = 0;        // 0 = Chebyshev weights unless the hierarchy is fp32 above 3e7 rows, 1 = Chebyshev, 2 = damped Jacobi
   int nu_l1 = 0, nu_deep = 0;     // sweeps on level 1 / below; 0 = nu_coarse / nu_coarse + 1
   int64_t host_stream_block = 0;  // entries per block of a streamed host matrix; 0 = stream only matrices with >= 2^31 entries

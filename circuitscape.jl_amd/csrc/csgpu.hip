@@ -68,6 +68,7 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   k.deflation = flag(o.deflation, true);
   k.tail_projection = flag(o.tail_projection, true);
   k.coarse_smoother = o.coarse_smoother;
+  k.expander_probe = flag(o.expander_probe, true);
   k.nu_l1 = std::max(o.nu_l1, 0);
   k.nu_deep = std::max(o.nu_deep, 0);
   k.host_stream_block = std::max<int64_t>(o.host_stream_block, 0);
@@ -124,6 +125,7 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   if (on("NO_DIRICHLET_COARSE")) k.dirichlet_coarse = false;
   if (on("NO_DEFLATION")) k.deflation = false;
   if (on("NO_TAIL_PROJECTION")) k.tail_projection = false;
+  if (on("NO_EXPANDER_PROBE")) k.expander_probe = false;
   if (on("COARSE_JACOBI")) k.coarse_smoother = 2;
   if (on("COARSE_CHEBYSHEV")) k.coarse_smoother = 1;
   num("NU_L1", [&](double v) { k.nu_l1 = (int)v; });
@@ -1457,7 +1459,7 @@ struct Solver : ISolver {
     ensure_csr();
     const Csr<T>& A = cg_matrix();
     comp_label.alloc((size_t)n * sizeof(int));
-    ncomp = connected_components((int)n, A.rp(), A.ci(), dptr<int>(comp_label), st);
+    ncomp = connected_components<T>((int)n, A.rp(), A.ci(), A.va(), dptr<int>(comp_label), st);
   }
 
   int64_t components(int32_t* out) override {
@@ -2330,6 +2332,7 @@ struct Solver : ISolver {
     info->cellspace = cellspace ? 1 : 0;
     info->poly_lattice = poly_proj ? 1 : 0;
     info->enrich_on = kn.enrich ? 1 : 0;
+    info->expander_probe_hit = H.expander_probe_hit ? 1 : 0;
     info->enrich_tau = kn.enrich ? kn.enrich_tau : 0.0;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];

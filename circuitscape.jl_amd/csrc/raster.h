@@ -232,12 +232,23 @@ __global__ __launch_bounds__(256) void raster_scatter_kernel(int64_t ncells, con
 // ---- connected components of a symmetric CSR graph (connected_components(SimpleGraph(G)), pairwise.jl:233,
 // advanced.jl:59): min-label hooking + pointer jumping. Invariant: f[x] <= x and f[x] lies in x's component; at the
 // fixed point every node of a component carries the component's smallest node id.
+// An off-diagonal entry that is not NEGATIVE carries no conductance and is no edge: construct_graph stores the zero weights
+// res_avg yields next to a zero-conductance cell that still has a node (a NODATA cell inside a short-circuit polygon,
+// src/raster/pairwise.jl:316-362), the regularisation then lifts them to +eps ||nzval|| (src/core.jl:161), and the reference's
+// connected_components(SimpleGraph(A)) never sees them as edges (A[i, j] != 0 decides there). Found by tools/fuzz_polygons.py
+// (round 6, seed 61: two parts of a raster hanging together through such entries only were one "component" here, and
+// pairs across them were solved on a numerically disconnected system instead of being refused).
+template <class T>
 __global__ __launch_bounds__(256) void cc_hook_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
-                                                      int* __restrict__ f, int* __restrict__ changed) {
+                                                      const T* __restrict__ va, int* __restrict__ f,
+                                                      int* __restrict__ changed) {
   for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
     const int fu = f[u];
     int m = fu;
-    for (int k = rp[u]; k < rp[u + 1]; ++k) m = min(m, f[ci[k]]);
+    for (int k = rp[u]; k < rp[u + 1]; ++k) {
+      if (va && ci[k] != u && !(va[k] < T(0))) continue;
+      m = min(m, f[ci[k]]);
+    }
     if (m < fu) {
       atomicMin(&f[fu], m);  // hook u's current representative under the smaller label seen next door
       atomicMin(&f[u], m);
@@ -267,14 +278,15 @@ __global__ __launch_bounds__(256) void cc_relabel_kernel(int n, const int* __res
 }
 
 // label[u] = dense component index (components ordered by their smallest node id); returns the number of components.
-inline int connected_components(int n, const int* rp, const int* ci, int* label, hipStream_t st) {
+template <class T>
+inline int connected_components(int n, const int* rp, const int* ci, const T* va, int* label, hipStream_t st) {
   if (n <= 0) return 0;
   DBuf f = dalloc<int>(n), flag = dalloc<int>((size_t)n + 1), changed = dalloc<int>(1);
   const int g = grid_for(n);
   hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(256), 0, st, dptr<int>(f), (int64_t)n);
   for (int round = 0; round < 256; ++round) {
     CS_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(cc_hook_kernel, dim3(g), dim3(256), 0, st, n, rp, ci, dptr<int>(f), dptr<int>(changed));
+    hipLaunchKernelGGL((cc_hook_kernel<T>), dim3(g), dim3(256), 0, st, n, rp, ci, va, dptr<int>(f), dptr<int>(changed));
     if (read_int(dptr<int>(changed), st) == 0) break;
     for (int pass = 0; pass < 64; ++pass) {
       CS_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));

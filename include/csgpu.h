@@ -172,7 +172,7 @@ typedef struct csgpu_opts {
    * choices remain as DEBUG overrides only: they are read ONCE, when a handle is set up (csrc/csgpu.hip: knobs_from_opts),
    * never on a call path, and a handle keeps what it was set up with -- two handles of one process may differ.
    * csgpu_get_info reports what a handle ended up with (level_form, enrich_vectors, hierarchy_rebuilt_fp64, host_blocks,
-   * batch_width, stream_mode, tail_first_level, last_level_sweeps, coarse_chebyshev, cellspace, poly_lattice). */
+   * batch_width, stream_mode, tail_first_level, last_level_sweeps, coarse_chebyshev, cellspace, poly_lattice, expander_probe_hit). */
   int32_t last_level_sweeps;  /* damped-Jacobi sweeps that stand in for the coarsest solve when the last level is too large
                                  for a dense inverse. A hierarchy of ONE level -- a graph the set-up declines to coarsen,
                                  BASELINE configs[4] -- is then CG with a polynomial preconditioner of that degree: every sweep
@@ -220,7 +220,11 @@ typedef struct csgpu_opts {
   int32_t restrict_seg;       /* coarse columns per tile of the marching restriction, 0 = 32 */
   int32_t collapse_min;       /* partial rows above which the dot partials are collapsed first, 0 = the library's rule */
   int32_t verbose;            /* 1 = one line per set-up decision on stderr */
-  int32_t reserved4, reserved5; /* (keeps the 64-bit fields below aligned without implicit padding) */
+  int32_t expander_probe;     /* large graphs without coordinates: 0 = before the MIS(2) aggregation of level 0 a sample of
+                                 2-hop balls predicts nnz(P) / nnz(A); above 0.8 the graph is an expander whose aggregation the
+                                 set-up would throw away (nnz(P) > 0.75 nnz(A)) and the handle gets its one level at once
+                                 (BASELINE configs[4]: 0.20 -> 0.03 s of device set-up); -1 = always aggregate first */
+  int32_t reserved5;          /* (keeps the 64-bit fields below aligned without implicit padding) */
   int64_t stream_min;         /* vector elements n * batch from which streaming is considered, 0 = 2^25 */
   int64_t host_stream_block;  /* csgpu_setup: stream the host matrix in blocks of at most this many entries (test / tuning);
                                  0 = only matrices with >= 2^31 stored entries, in blocks of 2^28 */
@@ -278,6 +282,8 @@ typedef struct csgpu_info {
   int32_t poly_lattice;         /* 1 = polygon raster on the lattice path (projected PCG), 0 = merged CSR graph / no polygons */
   int32_t enrich_on;            /* 1 = the enrichment was allowed (enrich_vectors tells how many aggregates took it) */
   double enrich_tau;            /* threshold in effect */
+  int32_t expander_probe_hit;   /* 1 = the expansion probe predicted the expander bail-out and the aggregation was skipped */
+  int32_t reserved_info2;
 } csgpu_info;
 
 typedef struct csgpu_stats {

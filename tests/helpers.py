@@ -1514,7 +1514,9 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
     for pb in pbs:
         for mode in ("batch", "stream"):
             # csgpu_opts.stream: 1 = from the first pair on, -1 = never; .stream_min = 1: whatever the problem size
-            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1,
+            # (fixed_k = 1: the identity between the stream and the batches is one between columns of the SAME width -- the
+            # batch path otherwise runs a short last batch at its own, narrower width, whose results differ in the last bits)
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1,
                                                   stream=1 if mode == "stream" else -1)) as h:
                 assert h.info["stream_mode"] == (1 if mode == "stream" else -1)
                 nm = h.raster_nodemap()
@@ -1553,7 +1555,7 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
         assert ss["stream_slots"] <= (ss["total_iters"] + nsolved) // batch + ss["max_iters"] + 2
     # the adaptive rule (default): the first batch runs as a batch, the spread of its iteration counts decides for the rest
     for pb in pbs:
-        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1)) as h:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1)) as h:
             R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
             if pb == 0:
                 assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])
@@ -1756,6 +1758,73 @@ def check_polygon_residuals_in_node_space(L, shape=(150, 140), batch=4, big=100)
             R3, _, _, st3 = h3.solve_pairs(src, dst)
             assert st3["not_converged"] == 0 and st3["max_relres"] <= 1.5e-7, st3
             assert np.max(np.abs(R3 - Rd) / Rd) < 1e-6
+
+
+def check_zero_weight_edges_are_no_edges(L):
+    """Connected components ignore stored entries without conductance (fuzz finding of round 6, tools/fuzz_polygons.py seed
+    61). With averaged RESISTANCES (res_avg, src/raster/pairwise.jl:316-362) the edge between a cell and a zero-conductance
+    cell that still has a node -- a NODATA cell inside a short-circuit polygon -- has weight 1 / inf = 0; the reference's
+    `sparse(I, J, V)` stores it, the regularisation (src/core.jl:161) lifts it to +eps ||nzval||, and
+    `connected_components(SimpleGraph(A))` does not see it (A[i, j] != 0 decides there). Raster: two valid halves separated
+    by a NODATA wall whose cells all belong to polygon 1, which also holds one valid cell of the left half: with averaged
+    resistances the halves hang together through zero-weight entries only -> two components, a pair across them is refused;
+    with averaged conductances the wall's edges weigh g / 2 -> one component, and the pair is solved."""
+    rng = np.random.default_rng(4)
+    g = np.exp(0.3 * rng.standard_normal((6, 9)))
+    g[:, 4] = 0.0
+    poly = np.zeros((6, 9), dtype=np.int32)
+    poly[:, 4] = 1
+    poly[0, 0] = 1
+    for avg, want in ((True, 2), (False, 1)):
+        with L.raster_setup(g, L.default_opts(batch=2), four_neighbors=True, avg_resistances=avg, polymap=poly) as h:
+            nm = h.raster_nodemap()
+            lab, nc = h.components()
+            assert nc == want, (avg, nc)
+            a, b = int(nm[3, 1]) - 1, int(nm[3, 7]) - 1
+            assert (lab[a] != lab[b]) == (want == 2)
+            if want == 2:
+                try:
+                    h.solve_pairs([a], [b])
+                    raise AssertionError("a pair across zero-weight entries was solved")
+                except L.CsgpuError as e:
+                    assert e.code == L.CSGPU_BAD_ARGS and "components" in str(e)
+                R, _, _, st = h.solve_pairs([a], [int(nm[1, 2]) - 1])
+            else:
+                R, _, _, st = h.solve_pairs([a], [b])
+            assert st["not_converged"] == 0 and R[0] > 0
+
+
+def check_expander_probe(L, n=120000, compare=True):
+    """The expansion probe (amg_setup.h): before the MIS(2) aggregation of a large graph without coordinates a sample of
+    2-hop balls predicts nnz(P) / nnz(A); on an Erdos-Renyi graph (BASELINE configs[4]'s kind) the prediction is ~0.9 and the
+    handle gets its one level at once -- the same hierarchy (one level), the same answers and iteration counts as with the
+    aggregation run first and thrown away (csgpu_opts.expander_probe = -1; `compare`: the emulator build skips that twin,
+    whose MIS rounds take minutes there, and checks one column against scipy instead); a geometric network is left alone
+    and coarsens."""
+    import bench
+    G, rng = bench.random_network(n)
+    focal = rng.choice(G.shape[0], size=8, replace=False)
+    src, gnd, chk = bench.one_to_all_columns(focal)
+    out = {}
+    for probe in ((0, -1) if compare else (0,)):
+        with L.setup(G, L.default_opts(batch=8, precond_bytes=4, itmax=3000, expander_probe=probe), index_dtype=np.int32,
+                     index_base=0) as h:
+            info = h.info
+            v, _, _, st = h.solve_sources(src, gnd, check=chk)
+            out[probe] = (info["levels"], info["expander_probe_hit"], v, st["total_iters"], st["not_converged"], info["setup_ms"])
+    assert out[0][:2] == (1, 1) and out[0][4] == 0
+    if compare:
+        assert out[-1][:2] == (1, 0)
+        assert np.array_equal(out[0][2], out[-1][2]) and out[0][3] == out[-1][3]
+        assert out[0][5] < 0.5 * out[-1][5]          # (the aggregation it skipped was most of the set-up)
+    else:
+        b = np.zeros(G.shape[0])
+        b[chk[0]] = 1.0
+        xs, flag, res = bench._masked_jacobi_cg(G, b, gnd[0])
+        assert flag == 0 and abs(out[0][2][0] - xs[chk[0]]) < 1e-6 * abs(xs[chk[0]])
+    G2, _ = bench.geometric_network(n)
+    with L.setup(G2, L.default_opts(batch=8), index_dtype=np.int32, index_base=0) as h:
+        assert h.info["levels"] >= 3 and h.info["expander_probe_hit"] == 0
 
 
 def check_contrast_triggered_fp64_hierarchy(L):

@@ -1037,6 +1037,18 @@ def test_polygon_lattice_path_residuals_in_node_space(emu_lib):
     check_polygon_residuals_in_node_space(emu_lib, shape=(90, 84), big=50)
 
 
+def test_zero_weight_edges_are_no_edges(emu_lib):
+    """see helpers.check_zero_weight_edges_are_no_edges"""
+    from helpers import check_zero_weight_edges_are_no_edges
+    check_zero_weight_edges_are_no_edges(emu_lib)
+
+
+def test_expander_probe_skips_the_aggregation(emu_lib):
+    """see helpers.check_expander_probe"""
+    from helpers import check_expander_probe
+    check_expander_probe(emu_lib, n=100000, compare=False)
+
+
 def test_multi_device_sources_and_grounded(emu_lib):
     """csgpu_multi_solve_sources / csgpu_multi_solve_grounded (configs[4] across the GPUs of a node): the
     columns of a one-to-all job on a NETWORK dealt over three (emulated) devices in contiguous ranges, one call per device

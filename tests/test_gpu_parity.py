@@ -765,3 +765,15 @@ def test_multi_sources_two_replicas_on_one_device(gpu_lib):
     assert np.max(np.abs(Xm - X1)) < 1e-6 * np.max(np.abs(X1)) and np.max(np.abs(Xg - X1)) < 1e-6 * np.max(np.abs(X1))
     assert np.max(np.abs(Cm - C1)) < 1e-6 * np.max(C1)
     assert np.max(np.abs(cumm - cum1)) < 1e-6 * np.max(cum1) and np.max(np.abs(mxm - mx1)) < 1e-6 * np.max(mx1)
+
+
+def test_zero_weight_edges_are_no_edges_gpu(gpu_lib):
+    """see helpers.check_zero_weight_edges_are_no_edges"""
+    from helpers import check_zero_weight_edges_are_no_edges
+    check_zero_weight_edges_are_no_edges(gpu_lib)
+
+
+def test_expander_probe_skips_the_aggregation_gpu(gpu_lib):
+    """see helpers.check_expander_probe (1e6 nodes on the device)"""
+    from helpers import check_expander_probe
+    check_expander_probe(gpu_lib, n=1000000)

@@ -23,7 +23,10 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
 stats = {"lattice": 0, "csr": 0}
+only = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]     # (re-run single cases of a seed)
 for case in range(ncases):
+    if only and case not in only:
+        continue
     rng = np.random.default_rng(seed0 * 100003 + case)
     lo_, hi_ = int(os.environ.get("FUZZ_MIN", "12")), int(os.environ.get("FUZZ_MAX", "46"))
     R, C = int(rng.integers(lo_, hi_)), int(rng.integers(lo_, hi_))

@@ -36,7 +36,7 @@ for case in range(ncases):
     try:
         # (round 6: the three modes are options of a handle -- csgpu_opts.stream = -1 / 1 / 0 -- not environment variables
         # looked at per call; the three handles are the same hierarchy, built by deterministic kernels)
-        with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb, check_every=1, stream_min=1, stream=-1), four_neighbors=four) as h:
+        with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1, stream=-1), four_neighbors=four) as h:
             lab, _ = h.components()
             big = np.flatnonzero(lab == np.bincount(lab).argmax())
             if len(big) < 8 or h.info["lattice_period"] == 0:
@@ -52,7 +52,7 @@ for case in range(ncases):
             out["batch"] = (Rr, Gv, st)
             hpb = h.info["precond_bytes"]
         for mode, sm in (("stream", 1), ("adaptive", 0)):
-            with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb, check_every=1, stream_min=1, stream=sm), four_neighbors=four) as h:
+            with L.raster_setup(g, L.default_opts(batch=K, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1, stream=sm), four_neighbors=four) as h:
                 Rr, Gv, _, st = h.solve_pairs(src, dst, gather=gather if gather else None)
                 out[mode] = (Rr, Gv, st)
         if True:
