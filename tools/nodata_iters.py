@@ -33,10 +33,13 @@ for seed in seeds:
     else:
         g = base
     for tau in taus:
-        os.environ["CSGPU_ENRICH_TAU"] = str(tau)
-        os.environ["CSGPU_ENRICH"] = "1" if tau > 0 else "0"
+        # (round 6: options of the handle -- csgpu_opts.enrich / .enrich_tau / .stream -- instead of environment variables)
+        knobs = dict(enrich=0 if tau > 0 else -1, stream=-1)
+        if tau > 0:
+            knobs["enrich_tau"] = tau
+        knobs.update(EXTRA)
         t0 = time.perf_counter()
-        with L.raster_setup(g, L.default_opts(batch=B, precond_bytes=PB, **EXTRA)) as h:
+        with L.raster_setup(g, L.default_opts(batch=B, precond_bytes=PB, **knobs)) as h:
             t_setup = time.perf_counter() - t0
             info = h.info
             if FRAC > 0:
@@ -49,7 +52,6 @@ for seed in seeds:
             pairs = bench.lexicographic_pairs(pts)[:P]
             src, dst = [p[0] for p in pairs], [p[1] for p in pairs]
             h.solve_pairs(src[:B], dst[:B])
-            os.environ["CSGPU_NO_STREAM"] = "1"
             t0 = time.perf_counter()
             R, _, _, st = h.solve_pairs(src, dst)
             ms = (time.perf_counter() - t0) * 1e3
