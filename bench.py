@@ -539,8 +539,10 @@ def csr_spmm_roofline(st, info, K):
     avg_ms = st["cg_spmv_ms"] / calls
     nbytes = st["cg_spmv_bytes"]
     ach = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    tp = "float" if (info["precond_bytes"] or info["val_bytes"]) == 4 else "double"
-    return {"bound": "hbm", "kernel": "csgpu::spmv_kernel<%s, %d, ...> (CSR SpMM, the CG product A p of a network)" % (tp, K),
+    tv = "float" if info["val_bytes"] == 4 else "double"
+    tx = "float" if (info["precond_bytes"] or info["val_bytes"]) == 4 else "double"
+    return {"bound": "hbm", "kernel": "csgpu::spmv_kernel<%s, %d, PLAIN, DOT, x = %s> (CSR SpMM: the CG product A p of a network; "
+                                      "matrix values %s, gathered search direction %s)" % (tv, K, tx, tv, tx),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
             "traffic_source": "not collected in this run (profiles/r6_network_* hold the rocprofv3 --pmc passes)",
             "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms, "launches_timed": st["cg_spmv_calls"]}
