@@ -232,8 +232,7 @@ def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, 
             n = h.info["n"]
             node = nodemap[rows, cols].astype(np.int64) - 1          # -1: the focal cell is NODATA
             comp, _ = h.components()
-            B = np.zeros((n, len(ids)))
-            grounds, solvable, ground_comps = [], [], []
+            sources, grounds, solvable, ground_comps = [], [], [], []
             for i in range(len(ids)):
                 others = [int(node[k]) for k in range(len(ids)) if k != i and node[k] >= 0]
                 if flags.is_onetoall:
@@ -242,10 +241,36 @@ def onetoall_on_device(cellmap, points_rc, flags, solver, four_neighbors=False, 
                     src, gnd = others, ([int(node[i])] if node[i] >= 0 else [])
                 gcomps = set(int(comp[g]) for g in gnd)
                 src = [q for q in src if int(comp[q]) in gcomps]      # a component without a ground is not solved
-                B[src, i] = 1.0
+                sources.append(src)
                 grounds.append(gnd)
                 solvable.append(len(src) > 0)
                 ground_comps.append(gcomps)
+            if not of.write_volt_maps and not (of.write_cur_maps and not of.write_cum_cur_map_only) \
+                    and not of.log_transform_maps and len(ids) > 1:
+                # Nothing per focal point is written: the driver keeps `res[i] = v[1]` (onetoall.jl:141) and the accumulated
+                # current maps (onetoall.jl:153-158) -- csgpu_solve_sources returns exactly those: sparse right-hand sides in,
+                # one voltage per point + at most two n-vectors out, the maps accumulated on the device (round 6)
+                node_cum = np.zeros(n) if want_cur else None
+                node_max = np.zeros(n) if (want_cur and of.write_max_cur_maps) else None
+                chk = [int(node[i]) if flags.is_onetoall else -1 for i in range(len(ids))]
+                v, _, _, st = h.solve_sources(sources, grounds, check=chk, cum=node_cum, mx=node_max)
+                if stats is not None:
+                    stats.update(st)
+                for i in range(len(ids)):
+                    if flags.is_onetoall:
+                        res[i] = v[i] if (solvable[i] and v[i] != 0) else -1
+                    else:
+                        res[i] = 0 if solvable[i] else -1
+                if want_cur:
+                    cum.cum_curr = _process_grid(cum.cum_curr + _scatter(node_cum, nodemap), gmap, False,
+                                                 of.set_null_currents_to_nodata)
+                    if of.write_max_cur_maps:
+                        cum.max_curr = _process_grid(np.maximum(cum.max_curr, _scatter(node_max, nodemap)), gmap, False,
+                                                     of.set_null_currents_to_nodata)
+                return np.column_stack([np.asarray(ids, dtype=np.float64), res]), cum, {nid: {} for nid in ids}
+            B = np.zeros((n, len(ids)))
+            for i, src in enumerate(sources):
+                B[src, i] = 1.0
             X, C, st = h.solve_grounded(B, grounds, want_currents=want_cur)
             # a component without a ground is not part of the column's system (advanced.jl:186-191). An island whose cells
             # share a 3x3 aggregate with a solved component can pick up a constant from the preconditioner (residual-free:

@@ -185,6 +185,36 @@ def check_onetoall_against_golden(case, res, cum, points):
     return checked
 
 
+def check_onetoall_sparse_sources_against_golden(name):
+    """csgpu_solve_sources pinned on the reference's one-to-all / all-to-one goldens: the same fixtures with the output flags
+    of the configuration the docs recommend for big landscapes -- cumulative current map only, no voltage maps -- so that the
+    driver takes the sparse path (sparse right-hand sides in; `res[i] = v[1]` and the cumulative / maximum node-current
+    vectors out, accumulated on the device). Golden resistances (`*_resistances.out`) and the golden cumulative current map
+    (`*_cum_curmap.asc`), the reference's criteria."""
+    from circuitscape_jl_amd import solver as ps
+    from helpers import flags_from_case
+    from conftest import compare_aagrid
+    from conftest import load_case
+    case = load_case(name)
+    o = case["options"]
+    flags = flags_from_case(case, True)
+    flags.is_onetoall = case["kind"] == "one_to_all"
+    flags.is_alltoone = not flags.is_onetoall
+    flags.outputflags.write_volt_maps = False
+    flags.outputflags.write_cur_maps = True
+    flags.outputflags.write_cum_cur_map_only = True
+    st = {}
+    res, cum, pts = ps.onetoall_on_device(np.array(case["cellmap"], dtype=np.float64), case["points_rc"], flags,
+                                          ps.HIPAMGSolver(bs=4, opts={"rtol": 1e-10, "atol": 0.0, "criterion": 1}),
+                                          four_neighbors=o["connect_four_neighbors_only"],
+                                          avg_res=o["connect_using_avg_resistances"], stats=st)
+    assert all(m == {} for m in pts.values()) and st["nrhs"] == len(case["points_rc"][2])   # the sparse path ran
+    exp = np.array(case["expected"])
+    assert np.array_equal(exp[:, 0], res[:, 0]) and np.max(np.abs(exp[:, 1] - res[:, 1])) < 1e-6 * max(1.0, np.abs(exp[:, 1]).max())
+    if "cum_curmap" in case["maps"] and not o["log_transform_maps"]:
+        assert compare_aagrid(case["maps"]["cum_curmap"], cum.cum_curr), "cum_curmap"
+
+
 def check_level_products(L, n_side, precond_bytes, ks=(1, 2, 4, 8, 16), seed=0, n_cols=None):
     """Every operator of level 0 (A, P, R, Q, Q^T, [S Q]) times a random block of vectors, through the launcher the
     V-cycle uses for it, against scipy on the matrices read back from the handle; plus the dot fused into [S Q]."""

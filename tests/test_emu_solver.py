@@ -839,6 +839,13 @@ def test_onetoall_on_device_built_graph(emu_lib, name):
     assert check_onetoall_against_golden(case, res, cum, pts) > 0
 
 
+@pytest.mark.parametrize("name", ["oneToAllVerify4", "allToOneVerify4"])
+def test_onetoall_cumulative_maps_through_sparse_sources(emu_lib, name):
+    """see helpers.check_onetoall_sparse_sources_against_golden"""
+    from helpers import check_onetoall_sparse_sources_against_golden
+    check_onetoall_sparse_sources_against_golden(name)
+
+
 def test_closed_form_circuits(emu_lib):
     """Known-answer circuits (series, cycle, complete graph, star, parallel chains) and the metric properties of the
     effective resistance -- checks that do not go through the oracle at all."""

@@ -287,3 +287,10 @@ def test_omniscape_moving_window_driver_on_gpu(gpu_lib):
     # the reference's default tolerances (rtol 1e-6 on the M-norm, 1e-4 post-check per component)
     got2, _ = ps.omniscape_moving_window(cond, strength, radius=12, block_size=5, solver=ps.HIPAMGSolver(bs=1))
     assert np.max(np.abs(got2 - ref)) < 1e-3 * ref.max()
+
+
+@pytest.mark.parametrize("name", ["oneToAllVerify4", "allToOneVerify4"])
+def test_onetoall_cumulative_maps_through_sparse_sources_on_gpu(gpu_lib, name):
+    """csgpu_solve_sources pinned on the reference's goldens (see helpers.check_onetoall_sparse_sources_against_golden)."""
+    from helpers import check_onetoall_sparse_sources_against_golden
+    check_onetoall_sparse_sources_against_golden(name)
