@@ -84,6 +84,9 @@ struct Knobs {
   bool wide_csr = false;          // fp64 CSR-path handles at K = 32 too
   bool fixed_k = false;           // every batch of a call at the call's width (round-5 behaviour)
   bool recompute_ap = true;       // residual update recomputes A p from the lattice form instead of storing it
+  bool fused_restrict = true;     // residual update and the V-cycle's restriction in one marching pass (lattice.h; measured
+                                  // in round 6, DESIGN.md section 9 R6-f: +5 % pair-solves/s at 10000^2)
+  int fused_seg = 64;             // coarse columns per tile of that pass (restrict_seg, when given, sets both)
   int64_t collapse_min = -1;      // < 0: the default rule of pcg.h
   bool longrow = true, narrow_tile = false;
   int spmv_grid_cap = 65536, dia_seg = 0, restrict_seg = 32;

@@ -75,11 +75,12 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   k.wide_csr = o.wide_csr > 0;
   k.fixed_k = o.fixed_k > 0;
   k.recompute_ap = flag(o.recompute_ap, true);
+  if (o.fused_restrict != 0) k.fused_restrict = o.fused_restrict > 0;
   k.longrow = flag(o.longrow, true);
   k.narrow_tile = o.narrow_tile > 0;
   if (o.spmv_grid_cap != 0) k.spmv_grid_cap = std::max(o.spmv_grid_cap, 0);
   k.dia_seg = std::max(o.dia_seg, 0);
-  if (o.restrict_seg > 0) k.restrict_seg = o.restrict_seg;
+  if (o.restrict_seg > 0) k.restrict_seg = k.fused_seg = o.restrict_seg;
   if (o.collapse_min > 0) k.collapse_min = o.collapse_min;
   k.verbose = o.verbose > 0;
   // ---- debug overrides (the variables that used to BE the switches) ----
@@ -134,12 +135,13 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   if (on("WIDE_CSR")) k.wide_csr = true;
   if (on("FIXED_K")) k.fixed_k = true;
   if (on("NO_RECOMPUTE")) k.recompute_ap = false;
+  num("FUSED_RESTRICT", [&](double v) { k.fused_restrict = v > 0; });
   num("COLLAPSE_MIN", [&](double v) { k.collapse_min = (int64_t)v; });
   if (on("NO_LONGROW")) k.longrow = false;
   if (on("NARROW_TILE")) k.narrow_tile = true;
   num("SPMV_GRID_CAP", [&](double v) { k.spmv_grid_cap = (int)v; });
   num("DIA_SEG", [&](double v) { k.dia_seg = (int)v; });
-  num("RESTRICT_SEG", [&](double v) { k.restrict_seg = (int)v; });
+  num("RESTRICT_SEG", [&](double v) { k.restrict_seg = k.fused_seg = (int)v; });
   if (on("VERBOSE")) k.verbose = 1;
   num("PINV_CUT", [&](double v) { k.pinv_cut = v; });
   if (on("KERNEL_GAIN_REF")) k.kernel_gain_ref = true;
@@ -2333,6 +2335,7 @@ struct Solver : ISolver {
     info->poly_lattice = poly_proj ? 1 : 0;
     info->enrich_on = kn.enrich ? 1 : 0;
     info->expander_probe_hit = H.expander_probe_hit ? 1 : 0;
+    info->fused_restrict_solves = H.fused_restrict_solves;
     info->enrich_tau = kn.enrich ? kn.enrich_tau : 0.0;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];

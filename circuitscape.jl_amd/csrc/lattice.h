@@ -247,6 +247,365 @@ inline int lattice_segc() {  // coarse columns per restriction tile (tuning knob
   return v < 2 ? 2 : v;
 }
 
+// ---- residual update + restriction in ONE marching pass (round 6; VERDICT r5 item 4: measured) --
+// r_out = r_in - alpha (A p)  AND  b_c = Q^T r_out, so that the restriction does not read r again (8 of ~80 bytes per node and
+// column of a PCG iteration). A workgroup owns TIC coarse rows x segc coarse columns as in lattice_restrict_kernel and
+// marches through the fine columns that feed them; per fine column it stages p (FR + 2 rows, four-slot ring: the nine-point
+// product needs three columns) and the matrix rows, computes the updated residual of ALL FR staged rows -- its own and the
+// one-tile halo above and below, whose values the neighbouring workgroups compute as well, bit for bit the same -- into an
+// LDS slot, writes the OWNED entries to r_out, and accumulates the coarse sums from the slot. Because halo rows are
+// recomputed from r_in, the update cannot be in place: r_in and r_out are different buffers (pcg.h ping-pongs them).
+// Two barriers per fine column (ring ready -> compute; slot ready -> accumulate), which is also what lets the ring hold three
+// columns and the residual slot one. 512 threads: TIC = 32 coarse rows at K = 32 (halo 8 of 104 staged rows), 130 KB of LDS.
+// The arithmetic of an entry is that of dia_cg_kernel<..., DIA_RUPD> (same products, same order): r_out is bit-identical to
+// the unfused update's; the coarse sums are lattice_restrict_kernel's, bit for bit. Only the order in which the partials of
+// r'r are summed differs.
+template <class T>
+struct RupdRestrictArgs {
+  int64_t n;
+  int R, C, Rc, Cc;
+  int nstrips, nseg, segc;
+  const T* rows;        // lattice form of A, [n][5]
+  const T* q;           // index-free Q, [n][9]
+  const T* p;           // search direction, [n][K]
+  const T* r_in;        // [n][K]
+  T* r_out;             // [n][K], must not alias r_in
+  T* bc;                // [Rc*Cc][K]
+  const CgScalars* S;   // alpha[c], all_done
+  double* partials;     // [gridDim.x][K] partials of r_out'r_out (may be null)
+  // streaming pair solves (pcg_stream_pairs): a column with restart[c] != 0 takes a new pair -- its new residual is the
+  // pair's right-hand side, -1 at node src[c] and +1 at dst[c] (nothing when they coincide), which stream_restart_kernel
+  // writes AFTER the two-pass update; here the coarse sums need it at once
+  const int* restart = nullptr;
+  const int* src = nullptr;
+  const int* dst = nullptr;
+};
+
+template <class T, int K, int NT>
+struct RupdRestrictShape {
+  typedef RestrictShape<T, K, NT> RS;
+  static constexpr int CPL = RS::CPL, LPR = RS::LPR, TIC = RS::TIC, FR = RS::FR;
+  static constexpr int PR = FR + 2;                         // rows of p / of the matrix staged per fine column
+  static constexpr int BU = (FR * LPR + NT - 1) / NT;       // residual entries (16-byte vectors) per thread and fine column
+  static constexpr int PU = (PR * LPR + NT - 1) / NT;       // loads of p per thread and fine column
+  static constexpr int MU = (PR * 5 + NT - 1) / NT;
+  static constexpr int QU = (FR * 9 + NT - 1) / NT;
+  static constexpr size_t lds_bytes = (size_t)3 * PR * LPR * 16 + (size_t)3 * PR * 5 * sizeof(T) + (size_t)FR * LPR * 16 +
+                                      (size_t)FR * 9 * sizeof(T) + (size_t)(NT / 64) * K * sizeof(double);
+};
+
+template <class T, int K, int NT>
+__global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictArgs<T> a) {
+  typedef RupdRestrictShape<T, K, NT> SH;
+  constexpr int CPL = SH::CPL, LPR = SH::LPR, TIC = SH::TIC, FR = SH::FR, PR = SH::PR, BU = SH::BU, PU = SH::PU, MU = SH::MU,
+                QU = SH::QU;
+  typedef SpmvVec<T, CPL> XV;
+  __shared__ XV s_p[3][PR * LPR];
+  __shared__ T s_m[3][PR * 5];
+  __shared__ XV s_b[FR * LPR];
+  __shared__ T s_q[FR * 9];
+  __shared__ double s_red[(NT / 64) * K];
+  if (a.S && a.S->all_done) return;
+  const int tid = threadIdx.x;
+  const int t = tid / LPR, lq = tid % LPR, c0 = lq * CPL;
+  T alpha[CPL];
+#pragma unroll
+  for (int qq = 0; qq < CPL; ++qq) alpha[qq] = (T)a.S->alpha[c0 + qq];
+  double dot_acc[CPL];
+  bool fresh[CPL];
+  int64_t nsrc[CPL], ndst[CPL];
+#pragma unroll
+  for (int qq = 0; qq < CPL; ++qq) {
+    dot_acc[qq] = 0.0;
+    fresh[qq] = a.restart && a.restart[c0 + qq] != 0;
+    nsrc[qq] = fresh[qq] ? a.src[c0 + qq] : -1;
+    ndst[qq] = fresh[qq] ? a.dst[c0 + qq] : -1;
+    if (nsrc[qq] == ndst[qq]) nsrc[qq] = ndst[qq] = -1;
+  }
+  const int ntiles = a.nstrips * a.nseg;
+  int t_first = blockIdx.x, t_last = ntiles, t_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {  // XCD-aware tile walk (see dia_cg_kernel)
+    const int xcd = blockIdx.x & 7, chunk = (ntiles + 7) >> 3;
+    t_first = xcd * chunk + (blockIdx.x >> 3);
+    t_last = min(ntiles, (xcd + 1) * chunk);
+    t_step = gridDim.x >> 3;
+  }
+  for (int tile = t_first; tile < t_last; tile += t_step) {
+    const int si = tile % a.nstrips, sj = tile / a.nstrips;
+    const int Ic0 = si * TIC;
+    const int Jc0 = sj * a.segc, Jc1 = min(a.Cc, Jc0 + a.segc);
+    const int Ic = Ic0 + t;
+    const bool row_on = Ic < a.Rc;
+    const int f0 = max(3 * (Ic0 - 1), 0);
+    const int last_tile = min(Ic0 + TIC, a.Rc - 1);
+    const int f1 = last_tile >= a.Rc - 1 ? a.R : 3 * last_tile + 3;
+    const int nfr = f1 - f0;  // <= FR
+    const int fc0 = max(3 * (Jc0 - 1), 0);
+    const int fc1 = Jc1 >= a.Cc - 1 ? a.C : 3 * Jc1 + 3;
+    // the fine cells this workgroup OWNS (writes r_out for): the tiles of its own coarse rows / columns
+    const int o0 = 3 * Ic0, o1 = (Ic0 + TIC >= a.Rc) ? a.R : 3 * (Ic0 + TIC);
+    const int oc0 = 3 * Jc0, oc1 = (Jc1 >= a.Cc) ? a.C : 3 * Jc1;
+    int rlo[3], rhi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int tI = Ic - 1 + d;
+      const bool on = row_on && tI >= 0 && tI < a.Rc;
+      rlo[d] = on ? 3 * tI - f0 : 0;
+      rhi[d] = on ? (tI >= a.Rc - 1 ? a.R : 3 * tI + 3) - f0 : 0;
+    }
+    XV preg[PU];
+    T mreg[MU];
+    XV rreg[BU];
+    T qreg[QU];
+    auto load_pm = [&](int f) {  // column f of p and of the matrix: staged rows f0 - 1 .. f0 + nfr (ids outside [0, n): zero)
+      const int64_t base = (int64_t)f * a.R + f0 - 1;
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int e = tid + u * NT;
+        XV v;
+#pragma unroll
+        for (int qq = 0; qq < CPL; ++qq) v.e[qq] = T(0);
+        const int64_t id = base + e / LPR;
+        if (e < (nfr + 2) * LPR && id >= 0 && id < a.n) v = *reinterpret_cast<const XV*>(a.p + (size_t)id * K + (e % LPR) * CPL);
+        preg[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * NT;
+        const int64_t g = base * 5 + e;
+        mreg[u] = (e < (nfr + 2) * 5 && g >= 0 && g < a.n * 5) ? a.rows[g] : T(0);
+      }
+    };
+    auto store_pm = [&](int slot) {
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int e = tid + u * NT;
+        if (e < PR * LPR) s_p[slot][e] = preg[u];
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int e = tid + u * NT;
+        if (e < PR * 5) s_m[slot][e] = mreg[u];
+      }
+    };
+    auto load_rq = [&](int f) {  // column f of r_in and of Q: staged rows f0 .. f0 + nfr - 1
+      const int64_t base = (int64_t)f * a.R + f0;
+#pragma unroll
+      for (int u = 0; u < BU; ++u) {
+        const int e = tid + u * NT;
+        XV v;
+#pragma unroll
+        for (int qq = 0; qq < CPL; ++qq) v.e[qq] = T(0);
+        if (f < fc1 && e < nfr * LPR) v = *reinterpret_cast<const XV*>(a.r_in + (size_t)(base + e / LPR) * K + (e % LPR) * CPL);
+        rreg[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+        const int e = tid + u * NT;
+        qreg[u] = (f < fc1 && e < nfr * 9) ? a.q[base * 9 + e] : T(0);
+      }
+    };
+    T acc[3][CPL];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int qq = 0; qq < CPL; ++qq) acc[d][qq] = T(0);
+    auto emit = [&](int Jc, const T* v) {
+      if (row_on && Jc >= Jc0 && Jc < Jc1) {
+        XV o;
+#pragma unroll
+        for (int qq = 0; qq < CPL; ++qq) o.e[qq] = v[qq];
+        *reinterpret_cast<XV*>(a.bc + ((size_t)Jc * a.Rc + Ic) * K + c0) = o;
+      }
+    };
+    __syncthreads();  // previous tile finished with the rings
+    // prologue: columns fc0 - 1 and fc0 of p / the matrix in the ring, column fc0 + 1 in flight; column fc0 of r / Q in flight
+    load_pm(fc0 - 1);
+    store_pm(0);
+    load_pm(fc0);
+    store_pm(1);
+    load_pm(fc0 + 1);
+    load_rq(fc0);
+    int Jf = lat_tile(fc0, a.Cc);
+    int sm = 0, sc = 1, sp = 2;  // ring slots of fine columns f - 1, f, f + 1
+    for (int f = fc0; f < fc1; ++f) {
+      store_pm(sp);  // (the slot column f - 2 had: its last readers passed the second barrier of the previous step)
+      load_pm(f + 2);
+      XV rv[BU];
+      T qv[QU];
+#pragma unroll
+      for (int u = 0; u < BU; ++u) rv[u] = rreg[u];
+#pragma unroll
+      for (int u = 0; u < QU; ++u) qv[u] = qreg[u];
+      load_rq(f + 1);
+      __syncthreads();  // column f + 1 of the ring is in place; s_b / s_q are free (the previous step's accumulation is over)
+      const T* mp = s_m[sm];
+      const T* mc = s_m[sc];
+      const XV* xm = s_p[sm];
+      const XV* x0 = s_p[sc];
+      const XV* xp = s_p[sp];
+      const bool col_owned = f >= oc0 && f < oc1;
+#pragma unroll
+      for (int u = 0; u < BU; ++u) {
+        const int e = tid + u * NT;
+        if (e < nfr * LPR) {
+          const int row = e / LPR;          // staged residual row; its p / matrix row is row + 1
+          const int me = 5 * (row + 1);
+          const T w_mm = mp[me - 5 + 4], w_m0 = mp[me + 3], w_mp = mp[me + 5 + 2];
+          const T w_0m = mc[me - 5 + 1], w_00 = mc[me + 0], w_0p = mc[me + 1];
+          const T w_pm = mc[me + 2], w_p0 = mc[me + 3], w_pp = mc[me + 4];
+          const XV a00 = xm[(row + 0) * LPR + lq], a01 = xm[(row + 1) * LPR + lq], a02 = xm[(row + 2) * LPR + lq];
+          const XV a10 = x0[(row + 0) * LPR + lq], a11 = x0[(row + 1) * LPR + lq], a12 = x0[(row + 2) * LPR + lq];
+          const XV a20 = xp[(row + 0) * LPR + lq], a21 = xp[(row + 1) * LPR + lq], a22 = xp[(row + 2) * LPR + lq];
+          XV rn;
+#pragma unroll
+          for (int qq = 0; qq < CPL; ++qq) {
+            T s = w_mm * a00.e[qq];
+            s = fma(w_m0, a01.e[qq], s);
+            s = fma(w_mp, a02.e[qq], s);
+            s = fma(w_0m, a10.e[qq], s);
+            s = fma(w_00, a11.e[qq], s);
+            s = fma(w_0p, a12.e[qq], s);
+            s = fma(w_pm, a20.e[qq], s);
+            s = fma(w_p0, a21.e[qq], s);
+            s = fma(w_pp, a22.e[qq], s);
+            rn.e[qq] = fresh[qq] ? T(0) : rv[u].e[qq] - alpha[qq] * s;
+          }
+          const int fr = f0 + row;
+          const bool owned = col_owned && fr >= o0 && fr < o1;
+          if (owned) {  // (partials as the two-pass update writes them: a restarting column contributes nothing)
+#pragma unroll
+            for (int qq = 0; qq < CPL; ++qq) dot_acc[qq] += (double)rn.e[qq] * (double)rn.e[qq];
+          }
+          const int64_t id = (int64_t)f * a.R + fr;
+#pragma unroll
+          for (int qq = 0; qq < CPL; ++qq)
+            if (fresh[qq]) rn.e[qq] = id == nsrc[qq] ? T(-1) : (id == ndst[qq] ? T(1) : T(0));
+          s_b[e] = rn;
+          if (owned) dia_store(reinterpret_cast<XV*>(a.r_out + (size_t)id * K + c0), rn);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+        const int e = tid + u * NT;
+        if (e < FR * 9) s_q[e] = qv[u];
+      }
+      __syncthreads();
+      const int Jn = lat_tile(f, a.Cc);
+      if (Jn != Jf) {  // entered the next tile column: coarse column Jf - 1 is complete
+        emit(Jf - 1, acc[0]);
+#pragma unroll
+        for (int qq = 0; qq < CPL; ++qq) {
+          acc[0][qq] = acc[1][qq];
+          acc[1][qq] = acc[2][qq];
+          acc[2][qq] = T(0);
+        }
+        Jf = Jn;
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int sI = (1 - d) + 1;
+        for (int r = rlo[d]; r < rhi[d]; ++r) {
+          const XV bv = s_b[r * LPR + lq];
+          const T* qr = s_q + r * 9;
+          const T wm = qr[0 * 3 + sI];
+          const T w0 = qr[1 * 3 + sI];
+          const T wp = qr[2 * 3 + sI];
+#pragma unroll
+          for (int qq = 0; qq < CPL; ++qq) {
+            acc[0][qq] = fma(wm, bv.e[qq], acc[0][qq]);
+            acc[1][qq] = fma(w0, bv.e[qq], acc[1][qq]);
+            acc[2][qq] = fma(wp, bv.e[qq], acc[2][qq]);
+          }
+        }
+      }
+      const int s0 = sm;
+      sm = sc;
+      sc = sp;
+      sp = s0;
+    }
+    emit(Jf - 1, acc[0]);
+    emit(Jf, acc[1]);
+    emit(Jf + 1, acc[2]);
+  }
+  if (!a.partials) return;  // (block-uniform)
+  const int lane = tid & 63, w = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int qq = 0; qq < CPL; ++qq) {
+    double v = dot_acc[qq];
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < LPR) s_red[w * K + lane * CPL + qq] = v;
+  }
+  __syncthreads();
+  if (tid < K) {
+    double ssum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < NT / 64; ++ww) ssum += s_red[ww * K + tid];
+    a.partials[(size_t)blockIdx.x * K + tid] = ssum;
+  }
+}
+
+// Threads per workgroup of the fused pass (build-time A/B knob). Measured at 10000^2, K = 32, fp64, one box
+// (profiles/r6_fused_restrict_shape_ab.json; two-pass path: 46.2 - 46.9 pair-solves/s): 128 threads (8 coarse rows per
+// workgroup, 8 halo rows of 32 staged, 3 workgroups per CU) 45.7 - 46.0; 256 (16 rows, 8 of 56, 2 per CU) 48.4 - 48.7;
+// 512 (32 rows, 8 of 104, ONE workgroup of 130 KB per CU) 49.0, and 49.3 - 49.4 with 64 coarse columns per tile instead of 32.
+#ifndef CSGPU_FUSED_NT
+#define CSGPU_FUSED_NT 512
+#endif
+constexpr int kFusedNT = CSGPU_FUSED_NT;
+// does the fused pass exist for this batch width?
+template <class T, int K>
+constexpr bool lattice_rupd_restrict_fits() {
+  return K >= 16 && RupdRestrictShape<T, K, kFusedNT>::lds_bytes <= (kFusedNT >= 512 ? 160 : 80) * 1024;  // (256 threads: two workgroups per CU)
+}
+
+template <class T, int K>
+inline int lattice_rupd_restrict_grid(const LatticeQ<T>& Q, int& nstrips, int& nseg, int& segc) {
+  constexpr int NT = kFusedNT;
+  segc = std::min(std::max(knobs().fused_seg, 2), Q.Cc);
+  nstrips = ceil_div(Q.Rc, RestrictShape<T, K, NT>::TIC);
+  nseg = ceil_div(Q.Cc, segc);
+  int64_t g = (int64_t)nstrips * nseg;
+  if (g > 16384) g = 16384;  // (rows of dot partials: PcgWork::ensure)
+  if (g >= 64) g &= ~(int64_t)7;
+  return (int)std::max<int64_t>(g, 1);
+}
+
+// r_out = r_in - alpha (A p) and bc = Q^T r_out in one pass; returns the number of partial rows written (0: none asked for)
+template <class T, int K>
+inline int lattice_rupd_restrict(const Dia<T>& D, const LatticeQ<T>& Q, const CgScalars* S, const T* p, const T* r_in, T* r_out,
+                                 T* bc, double* partials, hipStream_t st, const int* restart = nullptr,
+                                 const int* src = nullptr, const int* dst = nullptr) {
+  if constexpr (lattice_rupd_restrict_fits<T, K>()) {
+    constexpr int NT = kFusedNT;
+    RupdRestrictArgs<T> a;
+    a.n = D.n;
+    a.R = Q.R;
+    a.C = Q.C;
+    a.Rc = Q.Rc;
+    a.Cc = Q.Cc;
+    const int g = lattice_rupd_restrict_grid<T, K>(Q, a.nstrips, a.nseg, a.segc);
+    a.rows = D.data();
+    a.q = Q.data();
+    a.p = p;
+    a.r_in = r_in;
+    a.r_out = r_out;
+    a.bc = bc;
+    a.S = S;
+    a.partials = partials;
+    a.restart = restart;
+    a.src = src;
+    a.dst = dst;
+    hipLaunchKernelGGL((lattice_rupd_restrict_kernel<T, K, NT>), dim3(g), dim3(NT), 0, st, a);
+    return partials ? g : 0;
+  } else {
+    (void)D; (void)Q; (void)S; (void)p; (void)r_in; (void)r_out; (void)bc; (void)partials; (void)st; (void)restart; (void)src; (void)dst;
+    return 0;
+  }
+}
+
 // bc = Q^T b
 template <class T, int K>
 inline void lattice_restrict(const LatticeQ<T>& Q, const T* b, T* bc, const int* skip, hipStream_t st) {

@@ -68,6 +68,8 @@ struct VcycleFuse {
   double* partials = nullptr;  // [spmv_grid][K]
   bool b_has_tail = false;     // level 0: the input vector b is followed by room for the level-1 solution, so the
                                // two-product form out = [S Q][b; x_c] can be used (needs L.M and V(1,1))
+  bool bc_ready = false;       // lattice two-product level 0: the caller already wrote b_c = Q^T b into the level-1 right-hand
+                               // side (lattice_rupd_restrict, lattice.h), the cycle skips its restriction
 };
 
 // Levels from `first` down run in one launch (tail.h) when they are small: the first level l >= 1 with at most
@@ -256,7 +258,7 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     T* bc = dptr<T>(Lc.b);
     T* xc = const_cast<T*>(b) + (size_t)n * K;
     if (L.lattice_two_product()) {
-      lattice_restrict<T, K>(L.Ql, b, bc, skip, st);  // index-free Q^T b (lattice.h)
+      if (!fuse->bc_ready) lattice_restrict<T, K>(L.Ql, b, bc, skip, st);  // index-free Q^T b (lattice.h)
     } else {
       SpmvArgs<T> a = spmv_args(L.QT, b, bc);
       a.skip = skip;
@@ -467,6 +469,8 @@ struct PcgWork {
   DBuf z, rp;                 // TP: preconditioned residual; TP copy of r (aliases r when TP == T)
   DBuf p2;                    // TP: second search-direction buffer (stencil path: p = z + beta p is fused into the
                               // product and must not overwrite values neighbouring workgroups still read)
+  DBuf r2;                    // T: second residual buffer (with the tail) of the fused residual update + restriction, which
+                              // recomputes halo rows from the old residual and so cannot update in place (lattice.h)
   DBuf fnode, xf;             // focal mode (PcgParams::need_x == false): nf node ids, solution values [nf][K] (T)
   int nf = 0;
   bool have_x = false;        // x holds the solution of the last solve (need_x was set)
@@ -501,6 +505,7 @@ struct PcgWork {
     constexpr bool SAME = std::is_same<T, TP>::value;
     x.release();  // allocated by the first solve that needs the whole solution vector
     p2.release();
+    r2.release();
     r.alloc(bytes + (SAME ? (size_t)tail * K * sizeof(T) : 0));
     p.alloc((size_t)n * K * sizeof(TP));
     Ap.release();  // A p is stored only when the residual update does not recompute it, b only when the caller hands the
@@ -682,6 +687,31 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // entries and z is masked after the correction, so symmetry and the r'z terms hold; polygon handles -- `projected` -- do
   // not use it: their hierarchy's matrix carries the strengthened interiors)
   const bool enrich = enrich_applicable<TP>(EN, n, use_dia && two_product && L0.lattice_two_product(), projected);
+  // Fused residual update + restriction (lattice.h, Knobs::fused_restrict): r_new = r - alpha A p and b_c = Q^T r_new in one
+  // pass. The residual then ping-pongs between W.r and W.r2 -- `r` / `rp` below are re-pointed after every fused launch and
+  // `rsel` (which buffer holds the current residual) is part of the graph key. One precision only (the V-cycle reads r
+  // itself), resistance-only pair solves without masks, projections or the enrichment (which all touch r between the update
+  // and the cycle; enrich_pre reads r before the cycle).
+  bool fused_rr = false;
+  T* rbuf[2] = {r, nullptr};
+  int rsel = 0;
+  if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
+    fused_rr = knobs().fused_restrict && recompute && two_product && L0.lattice_two_product() && !need_x && !grounded &&
+               !projected && !enrich && pp.nu_pre == 1 && pp.nu_post == 1;
+    if (fused_rr) {
+      const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
+      if (W.r2.bytes < want) {
+        W.drop_graphs();
+        W.r2.alloc(want);
+      }
+      rbuf[1] = dptr<T>(W.r2);
+      ++H.fused_restrict_solves;
+    }
+  }
+  if (!fused_rr && W.r2.p) {  // (a solve that carries x, b and A p: give the second residual buffer back first)
+    W.drop_graphs();
+    W.r2.release();
+  }
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();  // (captured chunks hold the old work pointers)
     enrich_ensure_work<TP, K>(EN);
@@ -768,6 +798,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int it = 0;
   int graph_launches = 0;
   int parity = 0;  // pbuf[parity] holds the current search direction (stencil path: ping-pong; CSR path: one buffer)
+  int rr_fused_rows = 0;  // rows of r'r partials the fused update wrote (one per workgroup)
+  if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
+    int a_, b_, c_;
+    if (fused_rr) rr_fused_rows = lattice_rupd_restrict_grid<T, K>(L0.Ql, a_, b_, c_);
+  }
   fuse.xa_ready = fuse_xa;
   fuse.skip = &S->all_done;
   int criterion = crit0;  // switches to the true residual for the polishing phase (below)
@@ -820,7 +855,19 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     if (recompute) {
       // (the partials of r'r come for free here; the focal path's post-check reads the last ones instead of making
       // another pass over r)
-      dia_residual_update<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, x, pb, st);
+      if (fused_rr) {
+        if constexpr (!MIXED) {
+          T* rnew = rbuf[rsel ^ 1];
+          rr_fused_rows = lattice_rupd_restrict<T, K>(*dia, L0.Ql, (const CgScalars*)S, (const T*)pcur, (const T*)r, rnew,
+                                                      dptr<T>(H.levels[1].b), pb, st);
+          rsel ^= 1;
+          r = rnew;
+          rp = (TP*)rnew;
+          fuse.dotw = rp;
+        }
+      } else {
+        dia_residual_update<T, TP, K>(*dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, x, pb, st);
+      }
     } else {
       TP* rpo = MIXED ? rp : (TP*)nullptr;
       TP* xao = fuse_xa ? xa0 : (TP*)nullptr;
@@ -858,7 +905,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     if (nf > 0)
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
+    fuse.bc_ready = fused_rr;
     precondition((const int*)&S->all_done);
+    fuse.bc_ready = false;
     if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)&S->all_done, st);
     if (grounded)
       hipLaunchKernelGGL((mask_grounds_kernel<TP, TP, K>), dim3(gm), dim3(256), 0, st, pp.gptr, pp.gidx, z, (TP*)nullptr,
@@ -869,7 +918,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       const double* prr = pb;
       int nrr = (projected && rr_after_mask) ? gv + 1 : gv;   // (+ the node-space correction row of a polygon handle)
       if (recompute && criterion != CSGPU_CRIT_KRYLOV && !rr_after_mask) {
-        auto rr = collapsed(pb, spmv_g, pcc);
+        auto rr = collapsed(pb, fused_rr ? rr_fused_rows : spmv_g, pcc);
         prr = rr.first;
         nrr = rr.second;
       }
@@ -914,13 +963,19 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     bool ok = true;
-    const int parity0 = parity;
+    const int parity0 = parity, rsel0 = rsel;
     try {
       for (int c = 0; c < chunk; ++c) iteration(false);
     } catch (...) {
       ok = false;
     }
     parity = parity0;  // capturing executed nothing: the launch below advances the parity
+    if (fused_rr && rsel != rsel0) {
+      rsel = rsel0;
+      r = rbuf[rsel];
+      rp = (TP*)r;
+      fuse.dotw = rp;
+    }
     if (hipStreamEndCapture(st, &g) != hipSuccess || !g) ok = false;
     if (ok && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ok = false;
     if (g) hipGraphDestroy(g);
@@ -938,12 +993,12 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     while (!host_done && it < pp.itmax) {
       const int todo = (int)std::min<int64_t>(chunk, (int64_t)pp.itmax - it);
       gkey.criterion = criterion;
-      gkey.parity = parity;
+      gkey.parity = parity | (rsel << 1);
       hipGraphExec_t ge = (want_graph && it > 0 && todo == chunk) ? chunk_graph() : nullptr;
       if (ge) {
         CS_HIP(hipGraphLaunch(ge, st));
-        if (use_dia && (chunk & 1)) parity ^= 1;
-        ++graph_launches;
+        if (use_dia && (chunk & 1)) parity ^= 1;  // (unreachable: want_graph asks for an even chunk -- which also brings
+        ++graph_launches;                         // the fused update's residual back to the buffer it started in)
       } else {
         for (int c = 0; c < todo; ++c) iteration(true);
       }
@@ -987,7 +1042,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       // fp64 recurrence residual against ||b|| recorded at start-up
       if (recompute && it > 0 && !grounded && !projected) {
         // ||r||^2 partials of the last residual update that ran (surplus launches exit before writing)
-        auto rr = collapsed(pb, spmv_g, pcc);
+        auto rr = collapsed(pb, fused_rr ? rr_fused_rows : spmv_g, pcc);
         hipLaunchKernelGGL((relres_kernel<K>), dim3(1), dim3(256), 0, st, S, rr.first, rr.second, (const double*)nullptr, 0);
       } else {
         hipLaunchKernelGGL((dot_kernel<T, K, false>), dim3(gv), dim3(256), 0, st, n, (const T*)r, (const T*)r, pa,
@@ -1026,6 +1081,18 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     for (int c = 0; c < ncols_active && c < kMaxK; ++c)
       if (res.s.done[c] == 1 && !(res.s.relres[c] < 1e-4)) reopen = true;
     if (reopen && it < pp.itmax) {
+      if (fused_rr) {
+        // Launches enqueued after the last column stopped returned without writing (device flag), yet each re-pointed r on
+        // the host: the residual is in the buffer the last REAL update wrote -- update number max_c iters[c] of this solve
+        // (buffer 0 holds r_0). The polishing phase then runs the two-pass update in place.
+        int real = 0;
+        for (int c = 0; c < ncols_active && c < kMaxK; ++c) real = std::max(real, res.s.iters[c]);
+        rsel = real & 1;
+        r = rbuf[rsel];
+        rp = (TP*)r;
+        fuse.dotw = rp;
+        fused_rr = false;
+      }
       criterion = CSGPU_CRIT_TRUE_RESIDUAL;
       hipLaunchKernelGGL((cg_reopen_kernel<K>), dim3(1), dim3(64), 0, st, S, 1e-4, 2.5e-5, ncols_active);
       host_done = 0;
@@ -1211,6 +1278,24 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
     enrich_ensure_work<TP, K>(EN);
   }
   const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
+  // fused residual update + restriction (see pcg_solve): the residual ping-pongs between W.r and W.r2
+  bool fused_rr = false;
+  T* rbuf[2] = {r, nullptr};
+  int rsel = 0, rr_rows = spmv_g;
+  if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
+    fused_rr = knobs().fused_restrict && !enrich;
+    if (fused_rr) {
+      const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
+      if (W.r2.bytes < want) {
+        W.drop_graphs();
+        W.r2.alloc(want);
+      }
+      rbuf[1] = dptr<T>(W.r2);
+      int a_, b_, c_;
+      rr_rows = lattice_rupd_restrict_grid<T, K>(L0.Ql, a_, b_, c_);
+      ++H.fused_restrict_solves;
+    }
+  }
   const int max_timed = knobs().timed_launches;
   int timed = 0;
   int parity = 0;
@@ -1239,8 +1324,21 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
       auto pap = collapsed(pc, spmv_g, pcc);
       hipLaunchKernelGGL((cg_alpha_kernel<K>), dim3(1), dim3(256), 0, st, S, pap.first, pap.second);
     }
-    dia_residual_update<T, TP, K>(dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, (T*)nullptr, pb, st,
-                                  (const int*)S->ctl.restart);
+    if (fused_rr) {
+      if constexpr (!MIXED) {
+        T* rnew = rbuf[rsel ^ 1];
+        lattice_rupd_restrict<T, K>(dia, L0.Ql, (const CgScalars*)S, (const T*)pcur, (const T*)r, rnew, dptr<T>(H.levels[1].b),
+                                    pb, st, (const int*)S->ctl.restart, (const int*)S->ctl.src, (const int*)S->ctl.dst);
+        rsel ^= 1;
+        r = rnew;
+        rp = (TP*)rnew;
+        fuse.dotw = rp;
+        fuse.bc_ready = true;
+      }
+    } else {
+      dia_residual_update<T, TP, K>(dia, (const CgScalars*)S, (const TP*)pcur, r, MIXED ? rp : (TP*)nullptr, (T*)nullptr, pb,
+                                    st, (const int*)S->ctl.restart);
+    }
     if (nf > 0)
       hipLaunchKernelGGL((cg_focal_x_kernel<T, TP, K>), dim3(ceil_div(nf * K, 256)), dim3(256), 0, st, (const CgScalars*)S,
                          fnode, nf, (const TP*)pcur, xf);
@@ -1251,7 +1349,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
     if (enrich) enrich_post<TP, K, !MIXED>(EN, rp, z, pa + (size_t)spmv_gp * K, (const int*)nullptr, st);
     {
       auto rz = collapsed(pa, rz_rows, pac);
-      auto rr = collapsed(pb, spmv_g, pbc);
+      auto rr = collapsed(pb, rr_rows, pbc);
       hipLaunchKernelGGL((cg_stream_beta_kernel<K>), dim3(1), dim3(256), 0, st, S, rz.first, rz.second, rr.first, rr.second,
                          pp.criterion, pp.rtol, atol, pp.itmax);
     }

@@ -217,14 +217,18 @@ typedef struct csgpu_opts {
   int32_t narrow_tile;        /* 1 = the narrow SpMM tile for [S Q] */
   int32_t spmv_grid_cap;      /* workgroups per CSR product, 0 = 65536 */
   int32_t dia_seg;            /* raster columns per tile of the marching kernels, 0 = 32 (64 at K = 32) */
-  int32_t restrict_seg;       /* coarse columns per tile of the marching restriction, 0 = 32 */
+  int32_t restrict_seg;       /* coarse columns per tile of the marching restriction, 0 = 32 (64 in the fused pass) */
   int32_t collapse_min;       /* partial rows above which the dot partials are collapsed first, 0 = the library's rule */
   int32_t verbose;            /* 1 = one line per set-up decision on stderr */
   int32_t expander_probe;     /* large graphs without coordinates: 0 = before the MIS(2) aggregation of level 0 a sample of
                                  2-hop balls predicts nnz(P) / nnz(A); above 0.8 the graph is an expander whose aggregation the
                                  set-up would throw away (nnz(P) > 0.75 nnz(A)) and the handle gets its one level at once
                                  (BASELINE configs[4]: 0.20 -> 0.03 s of device set-up); -1 = always aggregate first */
-  int32_t reserved5;          /* (keeps the 64-bit fields below aligned without implicit padding) */
+  int32_t fused_restrict;     /* lattice path, batches of 16 / 32 columns in one precision, resistance-only pair solves: 0 / 1 =
+                                 the residual update and the restriction of the V-cycle run as ONE marching pass over r (the
+                                 residual ping-pongs between two buffers: + n x batch values of device memory; results are
+                                 those of the two-pass path bit for bit; +5 % pair-solves/s at 10000^2, DESIGN.md section 9
+                                 R6-f); -1 = two passes */
   int64_t stream_min;         /* vector elements n * batch from which streaming is considered, 0 = 2^25 */
   int64_t host_stream_block;  /* csgpu_setup: stream the host matrix in blocks of at most this many entries (test / tuning);
                                  0 = only matrices with >= 2^31 stored entries, in blocks of 2^28 */
@@ -283,7 +287,7 @@ typedef struct csgpu_info {
   int32_t enrich_on;            /* 1 = the enrichment was allowed (enrich_vectors tells how many aggregates took it) */
   double enrich_tau;            /* threshold in effect */
   int32_t expander_probe_hit;   /* 1 = the expansion probe predicted the expander bail-out and the aggregation was skipped */
-  int32_t reserved_info2;
+  int32_t fused_restrict_solves; /* batches so far whose PCG ran the fused residual update + restriction (csgpu_opts.fused_restrict) */
 } csgpu_info;
 
 typedef struct csgpu_stats {

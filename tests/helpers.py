@@ -576,6 +576,68 @@ def check_ragged_tail_batches(L, shape=(64, 57), batch=8, npairs=11, pbs=(0, 4),
             assert np.array_equal(v[nfull:], vt) and np.array_equal(X[:, nfull:], Xt) and sot["batch"] < batch
 
 
+def check_fused_residual_restriction(L, shapes=((64, 57), (101, 130), (31, 200)), batches=(16, 32), check_every=(1, 4)):
+    """csgpu_opts.fused_restrict = 1 (round 6): the residual update and the restriction of the V-cycle as
+    ONE marching pass with the residual ping-ponging between two buffers (lattice_rupd_restrict_kernel, lattice.h). An entry
+    of the new residual and of the coarse right-hand side is computed with the two-pass path's arithmetic, so resistances,
+    gathered voltages and iteration counts must equal the two-pass path's BIT FOR BIT: whole batches and a short last one,
+    direct launches (check_every = 1, odd iteration counts leave r in the second buffer) and captured chunks (4), the
+    true-residual criterion (the partials of r'r come from the fused kernel, summed in another order: 1e-12), a second call on
+    the same handle, and single precision throughout (precond_bytes = 0 with dtype fp32 when the library handle is fp32)."""
+    for shape in shapes:
+        g, G, pts, cases = sources_problem(shape, 12, seed=7, holes=0.0)
+        rng = np.random.default_rng(11)
+        for batch in batches:
+            npairs = batch + 5
+            src = [int(pts[i]) for i in rng.integers(0, 12, npairs)]
+            dst = [int(pts[(pts.index(s_) + 1 + int(k)) % 12]) for s_, k in zip(src, rng.integers(0, 10, npairs))]
+            for ce in check_every:
+                out = {}
+                for fused in (-1, 1):
+                    with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=0, check_every=ce, fixed_k=1, stream=-1,
+                                                          fused_restrict=fused)) as h:
+                        R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
+                        R2, _, _, st2 = h.solve_pairs(src, dst)
+                        assert st["not_converged"] == 0
+                        assert np.array_equal(R, R2)
+                        assert (h.info["fused_restrict_solves"] > 0) == (fused == 1)
+                        out[fused] = (R, ga, st["total_iters"], st["max_relres"])
+                assert np.array_equal(out[1][0], out[-1][0]), (shape, batch, ce, np.max(np.abs(out[1][0] - out[-1][0])))
+                assert np.array_equal(out[1][1], out[-1][1])
+                assert out[1][2] == out[-1][2]
+                assert abs(out[1][3] - out[-1][3]) <= 1e-9 * max(out[-1][3], 1e-300), (out[1][3], out[-1][3])
+    # streaming pair solves (more pairs than columns): a restarting column's new right-hand side enters the coarse sums in
+    # the fused pass itself
+    g, G, pts, cases = sources_problem((90, 64), 12, seed=9, holes=0.0)
+    rng = np.random.default_rng(5)
+    for batch in batches:
+        npairs = 3 * batch + 7
+        src = [int(pts[i]) for i in rng.integers(0, 12, npairs)]
+        dst = [int(pts[(pts.index(s_) + int(k)) % 12]) for s_, k in zip(src, rng.integers(0, 11, npairs))]  # (some src == dst)
+        out = {}
+        for fused in (-1, 1):
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=0, check_every=1, fixed_k=1, stream=1, stream_min=1,
+                                                  fused_restrict=fused)) as h:
+                R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
+                assert st["not_converged"] == 0 and h.info["stream_mode"] == 1
+                assert (h.info["fused_restrict_solves"] > 0) == (fused == 1)
+                out[fused] = (R, ga, st["total_iters"])
+        assert np.array_equal(out[1][0], out[-1][0]), (batch, np.max(np.abs(out[1][0] - out[-1][0])))
+        assert np.array_equal(out[1][1], out[-1][1]) and out[1][2] == out[-1][2]
+    # the true-residual criterion reads the fused kernel's partials of r'r
+    g, G, pts, cases = sources_problem((80, 75), 12, seed=3, holes=0.0)
+    src, dst = [int(p_) for p_ in pts[:6]] * 3, [int(p_) for p_ in pts[6:]] * 3
+    res = {}
+    for fused in (-1, 1):
+        with L.raster_setup(g, L.default_opts(batch=16, precond_bytes=0, check_every=1, fixed_k=1, stream=-1, criterion=1,
+                                              rtol=1e-9, fused_restrict=fused)) as h:
+            R, _, _, st = h.solve_pairs(src, dst)
+            assert st["not_converged"] == 0
+            res[fused] = (R, st["total_iters"])
+    assert res[1][1] == res[-1][1]
+    assert np.max(np.abs(res[1][0] - res[-1][0]) / res[-1][0]) < 1e-12
+
+
 def check_polygon_graph_on_device(L, seeds=(1, 2, 3, 4, 5)):
     """csgpu_raster_setup_poly: node map and Laplacian of rasters with random rectangular polygons (overlapping,
     touching, covering NODATA cells), NODATA holes, 4/8 neighbours, both averaging rules, against the oracle's

@@ -1463,3 +1463,9 @@ def test_golden_fixtures_in_single_precision(emu_lib, name):
     """see helpers.check_golden_single_precision: runtests(precision = "single") of test/test_utils.jl through the product path"""
     from helpers import check_golden_single_precision
     check_golden_single_precision(emu_lib, name)
+
+
+def test_fused_residual_update_and_restriction(emu_lib):
+    """see helpers.check_fused_residual_restriction"""
+    from helpers import check_fused_residual_restriction
+    check_fused_residual_restriction(emu_lib, shapes=((64, 57), (31, 100)))

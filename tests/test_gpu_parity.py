@@ -777,3 +777,10 @@ def test_expander_probe_skips_the_aggregation_gpu(gpu_lib):
     """see helpers.check_expander_probe (1e6 nodes on the device)"""
     from helpers import check_expander_probe
     check_expander_probe(gpu_lib, n=1000000)
+
+
+@pytest.mark.gpu
+def test_fused_residual_update_and_restriction_gpu(gpu_lib):
+    """see helpers.check_fused_residual_restriction (more and larger shapes on the device)"""
+    from helpers import check_fused_residual_restriction
+    check_fused_residual_restriction(gpu_lib, shapes=((64, 57), (101, 130), (31, 200), (700, 333)))
