@@ -999,6 +999,7 @@ struct Hierarchy {
   int coarse_n = 0;
   bool coarse_dense = false;
   double setup_ms = 0;
+  int virtual_rhs_solves = 0;       // ... of which the batch's right-hand side was never stored (Knobs::sparse_init)
   int fused_restrict_solves = 0;    // pcg_solve calls that ran the fused residual update + restriction (csgpu_info)
   bool expander_probe_hit = false;  // the set-up skipped the aggregation of level 0: the expansion probe predicted the bail-out
   int work_k = 0;       // batch width the work vectors are laid out for

@@ -84,9 +84,14 @@ struct Knobs {
   bool wide_csr = false;          // fp64 CSR-path handles at K = 32 too
   bool fixed_k = false;           // every batch of a call at the call's width (round-5 behaviour)
   bool recompute_ap = true;       // residual update recomputes A p from the lattice form instead of storing it
-  bool fused_restrict = true;     // residual update and the V-cycle's restriction in one marching pass (lattice.h; measured
-                                  // in round 6, DESIGN.md section 9 R6-f: +5 % pair-solves/s at 10000^2)
+  int fused_restrict = 0;         // residual update and the V-cycle's restriction in one marching pass (lattice.h): 1 on, -1 off,
+                                  // 0 = on in double precision only. Measured at 10000^2, K = 32:
+                                  // fp64 45.2 - 46.8 -> 49.1 - 49.4 pair-solves/s; single precision 117.5 - 119.4 with two
+                                  // passes against 111.7 - 113.7 fused (512 / 256 threads): half the bytes per entry, the same
+                                  // LDS traffic and barriers
   int fused_seg = 64;             // coarse columns per tile of that pass (restrict_seg, when given, sets both)
+  int fused_level1 = 0;           // lattice V(2,2) levels: x = S b and b_c = Q2' b in one pass over b (1 on, -1 off, 0 = fp64 only)
+  bool sparse_init = true;        // fused path, pair solves: r0 = e_dst - e_src is never stored (PcgParams::pair_src, pcg.h)
   int64_t collapse_min = -1;      // < 0: the default rule of pcg.h
   bool longrow = true, narrow_tile = false;
   int spmv_grid_cap = 65536, dia_seg = 0, restrict_seg = 32;

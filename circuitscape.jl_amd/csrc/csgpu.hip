@@ -75,7 +75,9 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   k.wide_csr = o.wide_csr > 0;
   k.fixed_k = o.fixed_k > 0;
   k.recompute_ap = flag(o.recompute_ap, true);
-  if (o.fused_restrict != 0) k.fused_restrict = o.fused_restrict > 0;
+  k.fused_restrict = o.fused_restrict > 0 ? 1 : (o.fused_restrict < 0 ? -1 : 0);
+  if (o.sparse_init != 0) k.sparse_init = o.sparse_init > 0;
+  k.fused_level1 = o.fused_level1 > 0 ? 1 : (o.fused_level1 < 0 ? -1 : 0);
   k.longrow = flag(o.longrow, true);
   k.narrow_tile = o.narrow_tile > 0;
   if (o.spmv_grid_cap != 0) k.spmv_grid_cap = std::max(o.spmv_grid_cap, 0);
@@ -135,7 +137,9 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   if (on("WIDE_CSR")) k.wide_csr = true;
   if (on("FIXED_K")) k.fixed_k = true;
   if (on("NO_RECOMPUTE")) k.recompute_ap = false;
-  num("FUSED_RESTRICT", [&](double v) { k.fused_restrict = v > 0; });
+  num("FUSED_RESTRICT", [&](double v) { k.fused_restrict = v > 0 ? 1 : -1; });
+  num("SPARSE_INIT", [&](double v) { k.sparse_init = v > 0; });
+  num("FUSED_LEVEL1", [&](double v) { k.fused_level1 = v > 0 ? 1 : -1; });
   num("COLLAPSE_MIN", [&](double v) { k.collapse_min = (int64_t)v; });
   if (on("NO_LONGROW")) k.longrow = false;
   if (on("NARROW_TILE")) k.narrow_tile = true;
@@ -1585,22 +1589,29 @@ struct Solver : ISolver {
   }
 
   template <int K>
-  PcgBatchResult run_batch(int ncols, bool need_x, const double* bb_host = nullptr) {
+  PcgBatchResult run_batch(int ncols, bool need_x, const double* bb_host = nullptr, const int* pair_src = nullptr,
+                           const int* pair_dst = nullptr) {
     PcgParams pp = pcg_params(K);
     pp.need_x = need_x;
-    pp.rhs_in_r = !need_x;  // (only solve_pairs runs without the whole solution; it writes the +-1 entries into r ...
-    pp.rp_ready = !need_x;  //  ... and into its preconditioner-precision copy, and knows ||b||^2 = 2)
+    pp.rhs_in_r = !need_x;  // (only solve_pairs runs without the whole solution; it hands the pairs over instead of b:
+    pp.rp_ready = false;    //  pcg_solve writes -- or synthesises -- the +-1 entries of r0, and ||b||^2 = 2 is known)
     pp.bb_host = need_x ? nullptr : bb_host;
+    if (!need_x) {
+      pp.pair_src = pair_src;
+      pp.pair_dst = pair_dst;
+      pp.pair_cols = ncols;
+    }
     return pcg_solve<T, TP, K>(cg_matrix(), H, W, pp, ncols, st, dia_ptr());
   }
-  PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true, const double* bb_host = nullptr) {
+  PcgBatchResult run_batch_k(int K, int ncols, bool need_x = true, const double* bb_host = nullptr,
+                             const int* pair_src = nullptr, const int* pair_dst = nullptr) {
     switch (K) {
-      case 1: return run_batch<1>(ncols, need_x, bb_host);
-      case 2: return run_batch<2>(ncols, need_x, bb_host);
-      case 4: return run_batch<4>(ncols, need_x, bb_host);
-      case 8: return run_batch<8>(ncols, need_x, bb_host);
-      case 32: return run_batch<32>(ncols, need_x, bb_host);
-      default: return run_batch<16>(ncols, need_x, bb_host);
+      case 1: return run_batch<1>(ncols, need_x, bb_host, pair_src, pair_dst);
+      case 2: return run_batch<2>(ncols, need_x, bb_host, pair_src, pair_dst);
+      case 4: return run_batch<4>(ncols, need_x, bb_host, pair_src, pair_dst);
+      case 8: return run_batch<8>(ncols, need_x, bb_host, pair_src, pair_dst);
+      case 32: return run_batch<32>(ncols, need_x, bb_host, pair_src, pair_dst);
+      default: return run_batch<16>(ncols, need_x, bb_host, pair_src, pair_dst);
     }
   }
 
@@ -1792,20 +1803,18 @@ struct Solver : ISolver {
       }
       CS_HIP(hipMemcpyAsync(dsrc.p, s32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
       CS_HIP(hipMemcpyAsync(ddst.p, d32.data(), K * sizeof(int), hipMemcpyHostToDevice, st));
-      // right-hand side: into b, or -- focal path -- straight into the residual vector (r0 = b; nothing reads b later)
-      T* rhs = need_x ? W.rhs() : dptr<T>(W.r);
-      CS_HIP(hipMemsetAsync(rhs, 0, (size_t)n * K * sizeof(T), st));
-      CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, rhs, dptr<int>(dsrc),
-                                           dptr<int>(ddst), ncols));
+      // right-hand side: into b, or -- focal path -- the pairs themselves go down (r0 = b; nothing reads b later: pcg_solve
+      // writes r0, or on the fused lattice path never stores it)
+      if (need_x) {
+        T* rhs = W.rhs();
+        CS_HIP(hipMemsetAsync(rhs, 0, (size_t)n * K * sizeof(T), st));
+        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<T, KK>), dim3(1), dim3(64), 0, st, rhs, dptr<int>(dsrc),
+                                             dptr<int>(ddst), ncols));
+      }
       double bb[kMaxK];
       for (int c = 0; c < kMaxK; ++c) bb[c] = (c < K && s32[c] != d32[c]) ? 2.0 : 0.0;
       // (polygon handles: norms are taken in NODE space -- the merged system's ||b_m||^2 = 2 whatever the polygons' sizes; a
       // unit current into a polygon's node is spread evenly over its cells by the first projection; pcg.h, poly.h)
-      if (!need_x && MIXED) {  // the fp32 copy of r0 the V-cycle reads, written directly
-        CS_HIP(hipMemsetAsync(W.rp.p, 0, (size_t)n * K * sizeof(TP), st));
-        CS_DISPATCH_K(K, hipLaunchKernelGGL((pairs_rhs_kernel<TP, KK>), dim3(1), dim3(64), 0, st, dptr<TP>(W.rp),
-                                             dptr<int>(dsrc), dptr<int>(ddst), ncols));
-      }
       if (!need_x) {  // focal list: [gathered nodes..., src of every column..., dst of every column...]
         focal.resize((size_t)ngather + 2 * K);
         for (int64_t g = 0; g < ngather; ++g) focal[g] = (int)gather[g];
@@ -1815,7 +1824,7 @@ struct Solver : ISolver {
         }
         W.set_focal(focal, st);
       }
-      PcgBatchResult r = run_batch_k(K, ncols, need_x, bb);
+      PcgBatchResult r = run_batch_k(K, ncols, need_x, bb, dptr<int>(dsrc), dptr<int>(ddst));
       accumulate(stats, r, ncols);
       if (stream_eligible && ncols == K) {
         // spread of this batch's iteration counts: stream the rest when (mean + 1) slots per pair beat (max + 1/2)
@@ -2336,6 +2345,8 @@ struct Solver : ISolver {
     info->enrich_on = kn.enrich ? 1 : 0;
     info->expander_probe_hit = H.expander_probe_hit ? 1 : 0;
     info->fused_restrict_solves = H.fused_restrict_solves;
+    info->virtual_rhs_solves = H.virtual_rhs_solves;
+    info->reserved_info3 = 0;
     info->enrich_tau = kn.enrich ? kn.enrich_tau : 0.0;
     for (size_t l = 0; l < H.levels.size(); ++l) {
       const Level<TP>& L = H.levels[l];

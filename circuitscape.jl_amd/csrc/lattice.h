@@ -279,6 +279,14 @@ struct RupdRestrictArgs {
   const int* restart = nullptr;
   const int* src = nullptr;
   const int* dst = nullptr;
+  // first update of a batch whose r0 was never materialised (pcg.h): r_in is not read, column c of it is -1 at node
+  // isrc[c] and +1 at idst[c] (columns >= icols and pairs with isrc == idst: zero)
+  const int* isrc = nullptr;
+  const int* idst = nullptr;
+  int icols = 0;
+  // APPLY form of the kernel (a lattice V(2,2) level, pcg.h): r_out = D p and bc = Q^T p in one pass over p -- `rows` is the
+  // lattice form of D (the level's two-sweep operator S), r_in / S / partials are unused, `skip` is the cycle's skip flag
+  const int* skip = nullptr;
 };
 
 template <class T, int K, int NT>
@@ -294,7 +302,7 @@ struct RupdRestrictShape {
                                       (size_t)FR * 9 * sizeof(T) + (size_t)(NT / 64) * K * sizeof(double);
 };
 
-template <class T, int K, int NT>
+template <class T, int K, int NT, bool APPLY = false>
 __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictArgs<T> a) {
   typedef RupdRestrictShape<T, K, NT> SH;
   constexpr int CPL = SH::CPL, LPR = SH::LPR, TIC = SH::TIC, FR = SH::FR, PR = SH::PR, BU = SH::BU, PU = SH::PU, MU = SH::MU,
@@ -304,23 +312,32 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
   __shared__ T s_m[3][PR * 5];
   __shared__ XV s_b[FR * LPR];
   __shared__ T s_q[FR * 9];
-  __shared__ double s_red[(NT / 64) * K];
+  __shared__ double s_red[APPLY ? 1 : (NT / 64) * K];
   if (a.S && a.S->all_done) return;
+  if (a.skip && *a.skip) return;
   const int tid = threadIdx.x;
   const int t = tid / LPR, lq = tid % LPR, c0 = lq * CPL;
   T alpha[CPL];
 #pragma unroll
-  for (int qq = 0; qq < CPL; ++qq) alpha[qq] = (T)a.S->alpha[c0 + qq];
+  for (int qq = 0; qq < CPL; ++qq) alpha[qq] = APPLY ? T(0) : (T)a.S->alpha[c0 + qq];
   double dot_acc[CPL];
   bool fresh[CPL];
   int64_t nsrc[CPL], ndst[CPL];
 #pragma unroll
   for (int qq = 0; qq < CPL; ++qq) {
     dot_acc[qq] = 0.0;
-    fresh[qq] = a.restart && a.restart[c0 + qq] != 0;
+    fresh[qq] = !APPLY && a.restart && a.restart[c0 + qq] != 0;
     nsrc[qq] = fresh[qq] ? a.src[c0 + qq] : -1;
     ndst[qq] = fresh[qq] ? a.dst[c0 + qq] : -1;
     if (nsrc[qq] == ndst[qq]) nsrc[qq] = ndst[qq] = -1;
+  }
+  const bool synth_in = !APPLY && a.isrc != nullptr;
+  int64_t is_[CPL], id_[CPL];
+#pragma unroll
+  for (int qq = 0; qq < CPL; ++qq) {
+    const bool on = synth_in && c0 + qq < a.icols && a.isrc[c0 + qq] != a.idst[c0 + qq];
+    is_[qq] = on ? a.isrc[c0 + qq] : -1;
+    id_[qq] = on ? a.idst[c0 + qq] : -1;
   }
   const int ntiles = a.nstrips * a.nseg;
   int t_first = blockIdx.x, t_last = ntiles, t_step = gridDim.x;
@@ -396,7 +413,15 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
         XV v;
 #pragma unroll
         for (int qq = 0; qq < CPL; ++qq) v.e[qq] = T(0);
-        if (f < fc1 && e < nfr * LPR) v = *reinterpret_cast<const XV*>(a.r_in + (size_t)(base + e / LPR) * K + (e % LPR) * CPL);
+        if (!APPLY && f < fc1 && e < nfr * LPR) {
+          if (synth_in) {  // (e % LPR == lq: NT is a multiple of LPR)
+            const int64_t id = base + e / LPR;
+#pragma unroll
+            for (int qq = 0; qq < CPL; ++qq) v.e[qq] = id == is_[qq] ? T(-1) : (id == id_[qq] ? T(1) : T(0));
+          } else {
+            v = *reinterpret_cast<const XV*>(a.r_in + (size_t)(base + e / LPR) * K + (e % LPR) * CPL);
+          }
+        }
         rreg[u] = v;
       }
 #pragma unroll
@@ -469,7 +494,7 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
             s = fma(w_pm, a20.e[qq], s);
             s = fma(w_p0, a21.e[qq], s);
             s = fma(w_pp, a22.e[qq], s);
-            rn.e[qq] = fresh[qq] ? T(0) : rv[u].e[qq] - alpha[qq] * s;
+            rn.e[qq] = APPLY ? s : (fresh[qq] ? T(0) : rv[u].e[qq] - alpha[qq] * s);
           }
           const int fr = f0 + row;
           const bool owned = col_owned && fr >= o0 && fr < o1;
@@ -481,7 +506,7 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
 #pragma unroll
           for (int qq = 0; qq < CPL; ++qq)
             if (fresh[qq]) rn.e[qq] = id == nsrc[qq] ? T(-1) : (id == ndst[qq] ? T(1) : T(0));
-          s_b[e] = rn;
+          s_b[e] = APPLY ? a11 : rn;  // (APPLY: the restriction is of the INPUT vector)
           if (owned) dia_store(reinterpret_cast<XV*>(a.r_out + (size_t)id * K + c0), rn);
         }
       }
@@ -528,22 +553,24 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
     emit(Jf, acc[1]);
     emit(Jf + 1, acc[2]);
   }
-  if (!a.partials) return;  // (block-uniform)
-  const int lane = tid & 63, w = tid >> 6;
-  __syncthreads();
+  if (APPLY || !a.partials) return;  // (block-uniform)
+  if constexpr (!APPLY) {
+    const int lane = tid & 63, w = tid >> 6;
+    __syncthreads();
 #pragma unroll
-  for (int qq = 0; qq < CPL; ++qq) {
-    double v = dot_acc[qq];
+    for (int qq = 0; qq < CPL; ++qq) {
+      double v = dot_acc[qq];
 #pragma unroll
-    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane < LPR) s_red[w * K + lane * CPL + qq] = v;
-  }
-  __syncthreads();
-  if (tid < K) {
-    double ssum = 0.0;
+      for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LPR) s_red[w * K + lane * CPL + qq] = v;
+    }
+    __syncthreads();
+    if (tid < K) {
+      double ssum = 0.0;
 #pragma unroll
-    for (int ww = 0; ww < NT / 64; ++ww) ssum += s_red[ww * K + tid];
-    a.partials[(size_t)blockIdx.x * K + tid] = ssum;
+      for (int ww = 0; ww < NT / 64; ++ww) ssum += s_red[ww * K + tid];
+      a.partials[(size_t)blockIdx.x * K + tid] = ssum;
+    }
   }
 }
 
@@ -566,6 +593,8 @@ inline int lattice_rupd_restrict_grid(const LatticeQ<T>& Q, int& nstrips, int& n
   constexpr int NT = kFusedNT;
   segc = std::min(std::max(knobs().fused_seg, 2), Q.Cc);
   nstrips = ceil_div(Q.Rc, RestrictShape<T, K, NT>::TIC);
+  // (a coarser lattice: narrower tiles rather than fewer than four per CU)
+  while (segc > 16 && (int64_t)nstrips * ceil_div(Q.Cc, segc) < 1024) segc /= 2;
   nseg = ceil_div(Q.Cc, segc);
   int64_t g = (int64_t)nstrips * nseg;
   if (g > 16384) g = 16384;  // (rows of dot partials: PcgWork::ensure)
@@ -577,7 +606,8 @@ inline int lattice_rupd_restrict_grid(const LatticeQ<T>& Q, int& nstrips, int& n
 template <class T, int K>
 inline int lattice_rupd_restrict(const Dia<T>& D, const LatticeQ<T>& Q, const CgScalars* S, const T* p, const T* r_in, T* r_out,
                                  T* bc, double* partials, hipStream_t st, const int* restart = nullptr,
-                                 const int* src = nullptr, const int* dst = nullptr) {
+                                 const int* src = nullptr, const int* dst = nullptr, const int* isrc = nullptr,
+                                 const int* idst = nullptr, int icols = 0) {
   if constexpr (lattice_rupd_restrict_fits<T, K>()) {
     constexpr int NT = kFusedNT;
     RupdRestrictArgs<T> a;
@@ -598,12 +628,80 @@ inline int lattice_rupd_restrict(const Dia<T>& D, const LatticeQ<T>& Q, const Cg
     a.restart = restart;
     a.src = src;
     a.dst = dst;
+    a.isrc = isrc;
+    a.idst = idst;
+    a.icols = icols;
     hipLaunchKernelGGL((lattice_rupd_restrict_kernel<T, K, NT>), dim3(g), dim3(NT), 0, st, a);
     return partials ? g : 0;
   } else {
-    (void)D; (void)Q; (void)S; (void)p; (void)r_in; (void)r_out; (void)bc; (void)partials; (void)st; (void)restart; (void)src; (void)dst;
+    (void)D; (void)Q; (void)S; (void)p; (void)r_in; (void)r_out; (void)bc; (void)partials; (void)st; (void)restart; (void)src; (void)dst; (void)isrc; (void)idst; (void)icols;
     return 0;
   }
+}
+
+// y = D x and bc = Q^T x in one pass over x (the first two products of a lattice V(2,2) level: x = S b, b_c = Q2' b);
+// false = this batch width has no fused form (the caller runs dia_apply + lattice_restrict)
+template <class T, int K>
+inline bool lattice_apply_restrict(const Dia<T>& D, const LatticeQ<T>& Q, const T* x, T* y, T* bc, const int* skip,
+                                   hipStream_t st) {
+  if constexpr (lattice_rupd_restrict_fits<T, K>()) {
+    constexpr int NT = kFusedNT;
+    RupdRestrictArgs<T> a;
+    a.n = D.n;
+    a.R = Q.R;
+    a.C = Q.C;
+    a.Rc = Q.Rc;
+    a.Cc = Q.Cc;
+    const int g = lattice_rupd_restrict_grid<T, K>(Q, a.nstrips, a.nseg, a.segc);
+    a.rows = D.data();
+    a.q = Q.data();
+    a.p = x;
+    a.r_in = nullptr;
+    a.r_out = y;
+    a.bc = bc;
+    a.S = nullptr;
+    a.partials = nullptr;
+    a.skip = skip;
+    hipLaunchKernelGGL((lattice_rupd_restrict_kernel<T, K, NT, true>), dim3(g), dim3(NT), 0, st, a);
+    return true;
+  } else {
+    (void)D; (void)Q; (void)x; (void)y; (void)bc; (void)skip; (void)st;
+    return false;
+  }
+}
+
+// bc = Q^T b for the right-hand sides of a batch of pair solves (column c: -1 at node src[c], +1 at dst[c]; nothing when they
+// coincide or c >= ncols): at most 18 entries per column instead of a pass over n x K. bc is zeroed by the caller. One thread
+// per column; a coarse entry that takes both nodes' contributions gets w_dst - w_src rounded once, which is what the marching
+// restriction's fma chain over the (otherwise zero) fine cells leaves there: same bits.
+template <class T, int K>
+__global__ __launch_bounds__(64) void lattice_restrict_pairs_kernel(int R, int Rc, int Cc, const T* __restrict__ q,
+                                                                    const int* __restrict__ src, const int* __restrict__ dst,
+                                                                    int ncols, T* __restrict__ bc) {
+  const int c = threadIdx.x;
+  if (c >= ncols || c >= K || src[c] == dst[c]) return;
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+    const int64_t node = which == 0 ? src[c] : dst[c];
+    const T sign = which == 0 ? T(-1) : T(1);
+    const int i = (int)(node % R), j = (int)(node / R);
+    const int I = lat_tile(i, Rc), J = lat_tile(j, Cc);
+    for (int dj = 0; dj < 3; ++dj)
+      for (int di = 0; di < 3; ++di) {
+        const int Ic = I + di - 1, Jc = J + dj - 1;
+        if (Ic < 0 || Ic >= Rc || Jc < 0 || Jc >= Cc) continue;
+        const T w = q[(size_t)node * 9 + dj * 3 + di];
+        T* at = bc + ((size_t)Jc * Rc + Ic) * K + c;
+        *at = fma(w, sign, *at);
+      }
+  }
+}
+
+template <class T, int K>
+inline void lattice_restrict_pairs(const LatticeQ<T>& Q, const int* src, const int* dst, int ncols, T* bc, hipStream_t st) {
+  CS_HIP(hipMemsetAsync(bc, 0, (size_t)Q.Rc * Q.Cc * K * sizeof(T), st));
+  hipLaunchKernelGGL((lattice_restrict_pairs_kernel<T, K>), dim3(1), dim3(64), 0, st, Q.R, Q.Rc, Q.Cc, Q.data(), src, dst, ncols,
+                     bc);
 }
 
 // bc = Q^T b

@@ -59,6 +59,13 @@ inline void ensure_level_work(Hierarchy<T>& H, int K) {
 // 2: 10 / 189 / 239, 1: 12 / 216 / 256, none (plain Jacobi scaling): 20 / 202 / 219.
 constexpr int kSingleLevelSweeps = 1;
 
+// Knobs::fused_restrict resolved for a CG iteration in precision T
+template <class T>
+inline bool fused_restrict_wanted() {
+  const int f = knobs().fused_restrict;
+  return f > 0 || (f == 0 && sizeof(T) == 8);
+}
+
 // Optional fusions at level 0 of the V-cycle.
 template <class T>
 struct VcycleFuse {
@@ -70,6 +77,9 @@ struct VcycleFuse {
                                // two-product form out = [S Q][b; x_c] can be used (needs L.M and V(1,1))
   bool bc_ready = false;       // lattice two-product level 0: the caller already wrote b_c = Q^T b into the level-1 right-hand
                                // side (lattice_rupd_restrict, lattice.h), the cycle skips its restriction
+  const int* pair_src = nullptr;  // lattice two-product level 0, with bc_ready: b is the right-hand sides of a batch of pair
+  const int* pair_dst = nullptr;  // solves and was never stored -- the second product synthesises it (DIA_SQP, stencil.h)
+  int pair_cols = 0;
 };
 
 // Levels from `first` down run in one launch (tail.h) when they are small: the first level l >= 1 with at most
@@ -271,7 +281,8 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     if (want_dot) CS_REQUIRE(fuse->dotw == b, CSGPU_INTERNAL, "two-product level: fused dot must be with the input vector");
     if (L.lattice_two_product()) {
       // S in lattice form + index-free Q, one marching kernel (stencil.h); partials of b'out always written
-      dia_sq_product<T, K>(L.Sdia, L.Ql, b, (const T*)xc, out, fuse->partials, skip, st);
+      dia_sq_product<T, K>(L.Sdia, L.Ql, b, (const T*)xc, out, fuse->partials, skip, st, (const T*)nullptr,
+                           fuse->bc_ready ? fuse->pair_src : nullptr, fuse->pair_dst, fuse->pair_cols);
       return;
     }
     SpmvArgs<T> a = spmv_args(L.M, b, out);
@@ -290,8 +301,12 @@ inline void vcycle(Hierarchy<T>& H, int l, const T* b, T* out, int nu_pre0, int 
     const size_t celems = (size_t)std::max(Lc.A.nrows, 1) * K;
     T* bc = dptr<T>(Lc.b);
     T* xc = dptr<T>(Lc.b) + celems;
-    dia_apply<T, K>(L.Sdia, b, cur, (const T*)nullptr, skip, st);   // x = S b            (the two pre-sweeps)
-    lattice_restrict<T, K>(L.Ql, b, bc, skip, st);                  // b_c = Q2' b        (residual + restriction)
+    // x = S b (the two pre-sweeps) and b_c = Q2' b (residual + restriction): one pass over b, or two
+    const int f1 = knobs().fused_level1;
+    if (!((f1 > 0 || (f1 == 0 && sizeof(T) == 8)) && lattice_apply_restrict<T, K>(L.Sdia, L.Ql, b, cur, bc, skip, st))) {
+      dia_apply<T, K>(L.Sdia, b, cur, (const T*)nullptr, skip, st);
+      lattice_restrict<T, K>(L.Ql, b, bc, skip, st);
+    }
     VcycleFuse<T> cf;
     cf.skip = skip;
     vcycle<T, K>(H, l + 1, bc, xc, nu_pre0, nu_post0, nu_coarse, st, &cf);
@@ -417,6 +432,14 @@ struct PcgParams {
   // column (pair right-hand sides: 2, or 0 when src == dst) -- saves a conversion pass and a reduction pass over n x K
   bool rp_ready = false;
   const double* bb_host = nullptr;  // kMaxK values, valid until pcg_solve returns
+  // with rhs_in_r: INSTEAD of writing r the caller may hand over the batch's pairs (device arrays, one node id per column;
+  // columns >= pair_cols have a zero right-hand side, and so have pairs whose nodes coincide). pcg_solve then writes
+  // r0 = e_dst - e_src itself (and the copy in the preconditioner's precision) -- or, on the fused lattice path, never
+  // materialises it: the first restriction is a scatter of <= 18 entries per column, the first second-product and the first
+  // residual update synthesise it (Knobs::sparse_init; 3 passes over n x K values saved per batch)
+  const int* pair_src = nullptr;
+  const int* pair_dst = nullptr;
+  int pair_cols = 0;
   // Block-diagonal systems (K = 1, one PCG over many components): component label per node and the number of
   // components. When set, the post-check is the WORST component's ||A x - b|| / ||b|| (the reference checks every
   // component's solve separately, advanced.jl:186-312 -> core.jl:640).
@@ -696,7 +719,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   T* rbuf[2] = {r, nullptr};
   int rsel = 0;
   if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
-    fused_rr = knobs().fused_restrict && recompute && two_product && L0.lattice_two_product() && !need_x && !grounded &&
+    fused_rr = fused_restrict_wanted<T>() && recompute && two_product && L0.lattice_two_product() && !need_x && !grounded &&
                !projected && !enrich && pp.nu_pre == 1 && pp.nu_post == 1;
     if (fused_rr) {
       const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
@@ -712,6 +735,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     W.drop_graphs();
     W.r2.release();
   }
+  // pair solves on the lattice two-product path (see PcgParams::pair_src): the first restriction is a scatter of the pairs'
+  // <= 18 entries per column -- any precision, any batch width -- and on the fused path r0 is never stored at all
+  const bool sparse_bc = pp.pair_src && pp.rhs_in_r && knobs().sparse_init && use_dia && two_product &&
+                         L0.lattice_two_product() && !grounded && !projected && !enrich;
+  const bool virtual_r0 = sparse_bc && fused_rr && pp.bb_host;
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();  // (captured chunks hold the old work pointers)
     enrich_ensure_work<TP, K>(EN);
@@ -748,12 +776,34 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   CS_REQUIRE(!(pp.rhs_in_r && need_x), CSGPU_INTERNAL, "rhs_in_r needs the focal-node path");
   if (!pp.rhs_in_r) CS_HIP(hipMemcpyAsync(r, b, vbytes, hipMemcpyDeviceToDevice, st));
   CS_HIP(hipMemsetAsync(S, 0, sizeof(CgScalars), st));
-  if (MIXED && !(pp.rhs_in_r && pp.rp_ready))
+  bool rp_written = pp.rhs_in_r && pp.rp_ready;
+  if (pp.rhs_in_r && pp.pair_src && !virtual_r0) {  // r0 = e_dst - e_src, in both precisions
+    CS_HIP(hipMemsetAsync(r, 0, vbytes, st));
+    hipLaunchKernelGGL((pairs_rhs_kernel<T, K>), dim3(1), dim3(64), 0, st, r, pp.pair_src, pp.pair_dst, pp.pair_cols);
+    if (MIXED) {
+      CS_HIP(hipMemsetAsync(rp, 0, (size_t)n * K * sizeof(TP), st));
+      hipLaunchKernelGGL((pairs_rhs_kernel<TP, K>), dim3(1), dim3(64), 0, st, rp, pp.pair_src, pp.pair_dst, pp.pair_cols);
+    }
+    rp_written = true;
+  }
+  if (MIXED && !rp_written)
     hipLaunchKernelGGL((convert_kernel<T, TP>), dim3(gv), dim3(256), 0, st, n * K, (const T*)r, rp);
   // polygons: r0 = Pi b (a unit current into a polygon node is spread evenly over the polygon's cells)
   if (projected) poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)nullptr, st);
   // z = M^-1 r with the partials of r'z fused into the last smoothing product; r'r separately (criterion 1 / init)
+  if (sparse_bc) {
+    lattice_restrict_pairs<TP, K>(L0.Ql, pp.pair_src, pp.pair_dst, pp.pair_cols, dptr<TP>(H.levels[1].b), st);
+    fuse.bc_ready = true;
+    if (virtual_r0) {
+      ++H.virtual_rhs_solves;
+      fuse.pair_src = pp.pair_src;
+      fuse.pair_dst = pp.pair_dst;
+      fuse.pair_cols = pp.pair_cols;
+    }
+  }
   precondition(nullptr);
+  fuse.bc_ready = false;
+  fuse.pair_src = fuse.pair_dst = nullptr;
   // (the fused r'z partials are those of the projected z too: r is in the subspace, r'z = r'(Pi z))
   if (projected) poly_project<TP, TP, K>(*pp.proj, z, (TP*)nullptr, (const int*)nullptr, st);
   // (the fused r'z partials are unaffected by masking z afterwards: r is zero at the grounded entries)
@@ -792,6 +842,13 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int host_done = 0;
   CS_HIP(hipMemcpyAsync(&host_done, &S->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
   CS_HIP(hipStreamSynchronize(st));
+  bool r0_consumed = false;
+  if (virtual_r0 && host_done) {
+    // nothing will iterate (every column's right-hand side is zero): the post-check reads r, so store r0 after all
+    CS_HIP(hipMemsetAsync(r, 0, vbytes, st));
+    hipLaunchKernelGGL((pairs_rhs_kernel<T, K>), dim3(1), dim3(64), 0, st, r, pp.pair_src, pp.pair_dst, pp.pair_cols);
+    r0_consumed = true;
+  }
 
   const int max_timed = knobs().timed_launches;  // per solve
   int timed = 0;
@@ -858,8 +915,11 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       if (fused_rr) {
         if constexpr (!MIXED) {
           T* rnew = rbuf[rsel ^ 1];
+          const bool first = virtual_r0 && !r0_consumed;  // (r holds nothing yet: the kernel synthesises r0)
           rr_fused_rows = lattice_rupd_restrict<T, K>(*dia, L0.Ql, (const CgScalars*)S, (const T*)pcur, (const T*)r, rnew,
-                                                      dptr<T>(H.levels[1].b), pb, st);
+                                                      dptr<T>(H.levels[1].b), pb, st, nullptr, nullptr, nullptr,
+                                                      first ? pp.pair_src : nullptr, pp.pair_dst, pp.pair_cols);
+          r0_consumed = true;
           rsel ^= 1;
           r = rnew;
           rp = (TP*)rnew;
@@ -1283,7 +1343,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   T* rbuf[2] = {r, nullptr};
   int rsel = 0, rr_rows = spmv_g;
   if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
-    fused_rr = knobs().fused_restrict && !enrich;
+    fused_rr = fused_restrict_wanted<T>() && !enrich;
     if (fused_rr) {
       const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
       if (W.r2.bytes < want) {

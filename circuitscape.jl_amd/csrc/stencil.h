@@ -134,6 +134,8 @@ inline bool dia_from_csr(const Csr<T>& A, int R, Dia<T>& out, hipStream_t st, bo
 enum DiaMode {
   DIA_PLAIN = 0,  // y = A x, partials of x'y                                  (x = pin)
   DIA_CG = 1,     // x = z + beta pin -> pout ; y = A x ; partials of x'y      (Krylov.cg's p-update fused in)
+  DIA_SQP = 4,    // DIA_SQ with x = the right-hand sides of a batch of pair solves, never stored: column c of x is -1 at
+                  // node psrc[c] and +1 at pdst[c] (pcg.h: the first V-cycle of a batch whose r0 is not materialised)
   DIA_SQ = 2,     // y = S x + Q xc, partials of x'y                            (second product of the two-product V(1,1)
                   //                                                             level, amg_setup.h: A = S in lattice form,
                   //                                                             Q in its index-free 3x3-tile form
@@ -170,6 +172,9 @@ struct DiaArgs {
                                  // new pair -- their residual is ZEROED here (stream_restart_kernel then writes the +-1)
   const T* bsub = nullptr; // DIA_PLAIN: y = bsub - A x instead of A x (residual of a lattice level, pcg.h)
   const T* xadd = nullptr; // DIA_SQ: y = xadd + S x + Q xc (second half of a lattice V(2,2) level, pcg.h)
+  const int* psrc = nullptr;  // DIA_SQP: node ids of the pairs of the batch (device, one per column), columns >= pcols and
+  const int* pdst = nullptr;  // pairs with psrc == pdst have a zero right-hand side
+  int pcols = 0;
 };
 
 template <class T, class XT, int K>
@@ -203,7 +208,8 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DI
   typedef SpmvVec<XT, CPL> XV;
   typedef SpmvVec<T, CPL> YV;
   constexpr int QELEMS = SH::QELEMS, QU = SH::QU, CR = SH::CR;
-  constexpr bool SQ = MODE == DIA_SQ;
+  constexpr bool SQ = MODE == DIA_SQ || MODE == DIA_SQP;
+  constexpr bool SYNTH = MODE == DIA_SQP;
   static_assert(CR * LPR <= 256, "one lane per staged coarse entry");
   __shared__ XV s_x[4][(TI + 2) * LPR];
   __shared__ T s_m[4][MELEMS];
@@ -229,6 +235,21 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DI
   double dot_acc[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) dot_acc[q] = 0.0;
+  int64_t ps[SYNTH ? CPL : 1], pd[SYNTH ? CPL : 1];  // DIA_SQP: the pair of each of this lane's columns (-1: none)
+  if (SYNTH) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const bool on = c0 + q < a.pcols && a.psrc[c0 + q] != a.pdst[c0 + q];
+      ps[q] = on ? a.psrc[c0 + q] : -1;
+      pd[q] = on ? a.pdst[c0 + q] : -1;
+    }
+  }
+  auto synth = [&](int64_t id) {
+    XV v;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) v.e[q] = id == ps[SYNTH ? q : 0] ? XT(-1) : (id == pd[SYNTH ? q : 0] ? XT(1) : XT(0));
+    return v;
+  };
 
   const int ntiles = a.nstrips * a.nseg;
   // XCD-aware tile walk: workgroup b runs on XCD b % 8; give every XCD a contiguous range of tiles (strip index
@@ -289,7 +310,8 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DI
         }
         if (id >= 0 && id < a.n) {
           const size_t e = (size_t)id * K + c0;
-          xr = *reinterpret_cast<const XV*>(a.pin + e);
+          if (SYNTH) xr = synth(id);
+          else xr = *reinterpret_cast<const XV*>(a.pin + e);
           if (FUSE) zr = dia_load(reinterpret_cast<const XV*>(a.z + e));
         }
       }
@@ -302,7 +324,8 @@ __global__ __launch_bounds__(256, ((MODE == DIA_CG && K >= 8) ? 4 : ((MODE == DI
         }
         if (id >= 0 && id < a.n) {
           const size_t e = (size_t)id * K + c0;  // (tid < 2 LPR: tid % LPR is the lane's own column slice)
-          xh = *reinterpret_cast<const XV*>(a.pin + e);
+          if (SYNTH) xh = synth(id);
+          else xh = *reinterpret_cast<const XV*>(a.pin + e);
           if (FUSE) zh = *reinterpret_cast<const XV*>(a.z + e);
         }
       }
@@ -594,7 +617,8 @@ inline void dia_residual_update(const Dia<T>& D, const CgScalars* S, const XT* p
 // its index-free tile form)
 template <class T, int K>
 inline void dia_sq_product(const Dia<T>& Sd, const LatticeQ<T>& Q, const T* b, const T* xc, T* out, double* partials,
-                           const int* skip, hipStream_t st, const T* xadd = nullptr) {
+                           const int* skip, hipStream_t st, const T* xadd = nullptr, const int* psrc = nullptr,
+                           const int* pdst = nullptr, int pcols = 0) {
   DiaArgs<T, T> a;
   a.n = Sd.n;
   a.R = Sd.R;
@@ -618,6 +642,17 @@ inline void dia_sq_product(const Dia<T>& Sd, const LatticeQ<T>& Q, const T* b, c
   a.rp = nullptr;
   a.xsol = nullptr;
   a.xadd = xadd;
+  if (psrc) {  // b is the batch's pair right-hand sides, synthesised in the kernel (b itself is not read)
+    if constexpr (K >= 16) {
+      a.psrc = psrc;
+      a.pdst = pdst;
+      a.pcols = pcols;
+      hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_SQP>), dim3(grid), dim3(256), 0, st, a);
+      return;
+    } else {
+      CS_REQUIRE(false, CSGPU_INTERNAL, "synthesised pair right-hand sides: batches of 16 / 32 columns only");
+    }
+  }
   hipLaunchKernelGGL((dia_cg_kernel<T, T, K, DIA_SQ>), dim3(grid), dim3(256), 0, st, a);
 }
 

@@ -28,7 +28,7 @@ mutable struct CsgpuOpts
     lattice_q::Int32; direct_tiles::Int32; tile_pieces::Int32; direct_at::Int32; dirichlet_coarse::Int32; deflation::Int32
     tail_projection::Int32; coarse_smoother::Int32; nu_l1::Int32; nu_deep::Int32; wide_csr::Int32; fixed_k::Int32
     recompute_ap::Int32; longrow::Int32; narrow_tile::Int32; spmv_grid_cap::Int32; dia_seg::Int32; restrict_seg::Int32
-    collapse_min::Int32; verbose::Int32; expander_probe::Int32; fused_restrict::Int32
+    collapse_min::Int32; verbose::Int32; expander_probe::Int32; fused_restrict::Int32; sparse_init::Int32; fused_level1::Int32
     stream_min::Int64; host_stream_block::Int64
     enrich_tau::Float64; hetero_fp64_frac::Float64; poly_strength::Float64; poly_coef::Float64; poly_smin::Float64
     poly_smax::Float64; cellspace_min_frac::Float64; tile_theta::Float64; tile_split_min::Float64

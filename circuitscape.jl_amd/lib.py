@@ -43,7 +43,7 @@ OPTS_INT_FIELDS = ("last_level_sweeps", "enrich", "enrich_steps", "dia25_min_row
                    "lattice_level1_min_rows", "lattice_setup", "lattice_s", "lattice_q", "direct_tiles", "tile_pieces",
                    "direct_at", "dirichlet_coarse", "deflation", "tail_projection", "coarse_smoother", "nu_l1", "nu_deep",
                    "wide_csr", "fixed_k", "recompute_ap", "longrow", "narrow_tile", "spmv_grid_cap", "dia_seg", "restrict_seg",
-                   "collapse_min", "verbose", "expander_probe", "fused_restrict")
+                   "collapse_min", "verbose", "expander_probe", "fused_restrict", "sparse_init", "fused_level1")
 OPTS_DOUBLE_FIELDS = ("enrich_tau", "hetero_fp64_frac", "poly_strength", "poly_coef", "poly_smin", "poly_smax",
                       "cellspace_min_frac", "tile_theta", "tile_split_min")
 
@@ -78,7 +78,7 @@ class Info(ctypes.Structure):
         ("batch_width", ctypes.c_int32), ("stream_mode", ctypes.c_int32), ("tail_first_level", ctypes.c_int32),
         ("last_level_sweeps", ctypes.c_int32), ("coarse_chebyshev", ctypes.c_int32), ("cellspace", ctypes.c_int32),
         ("poly_lattice", ctypes.c_int32), ("enrich_on", ctypes.c_int32), ("enrich_tau", ctypes.c_double),
-        ("expander_probe_hit", ctypes.c_int32), ("fused_restrict_solves", ctypes.c_int32),
+        ("expander_probe_hit", ctypes.c_int32), ("fused_restrict_solves", ctypes.c_int32), ("virtual_rhs_solves", ctypes.c_int32), ("reserved_info3", ctypes.c_int32),
     ]
 
 

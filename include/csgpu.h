@@ -224,11 +224,18 @@ typedef struct csgpu_opts {
                                  2-hop balls predicts nnz(P) / nnz(A); above 0.8 the graph is an expander whose aggregation the
                                  set-up would throw away (nnz(P) > 0.75 nnz(A)) and the handle gets its one level at once
                                  (BASELINE configs[4]: 0.20 -> 0.03 s of device set-up); -1 = always aggregate first */
-  int32_t fused_restrict;     /* lattice path, batches of 16 / 32 columns in one precision, resistance-only pair solves: 0 / 1 =
-                                 the residual update and the restriction of the V-cycle run as ONE marching pass over r (the
+  int32_t fused_restrict;     /* lattice path, batches of 16 / 32 columns in one precision, resistance-only pair solves: 1 = the
+                                 residual update and the restriction of the V-cycle run as ONE marching pass over r (the
                                  residual ping-pongs between two buffers: + n x batch values of device memory; results are
-                                 those of the two-pass path bit for bit; +5 % pair-solves/s at 10000^2, DESIGN.md section 9
-                                 R6-f); -1 = two passes */
+                                 those of the two-pass path bit for bit); -1 = two passes; 0 = fused in double precision
+                                 (+7 % pair-solves/s at 10000^2), two passes in single precision (where the fused pass is
+                                 3 - 5 % slower) */
+  int32_t sparse_init;        /* fused lattice path, pair solves: 0 / 1 = the right-hand side of a batch, r0 = e_dst - e_src, is
+                                 never stored -- the first restriction scatters <= 18 entries per column, the first second
+                                 product and the first residual update synthesise it (three passes over n x batch values and
+                                 the clearing of r saved per batch, same bits); -1 = r0 written and read like any residual */
+  int32_t fused_level1;       /* lattice V(2,2) levels (level 1 of a full raster): 1 = x = S b and b_c = Q2' b in one marching pass
+                                 over b, -1 = two passes, 0 = fused in double precision; same bits either way */
   int64_t stream_min;         /* vector elements n * batch from which streaming is considered, 0 = 2^25 */
   int64_t host_stream_block;  /* csgpu_setup: stream the host matrix in blocks of at most this many entries (test / tuning);
                                  0 = only matrices with >= 2^31 stored entries, in blocks of 2^28 */
@@ -288,6 +295,8 @@ typedef struct csgpu_info {
   double enrich_tau;            /* threshold in effect */
   int32_t expander_probe_hit;   /* 1 = the expansion probe predicted the expander bail-out and the aggregation was skipped */
   int32_t fused_restrict_solves; /* batches so far whose PCG ran the fused residual update + restriction (csgpu_opts.fused_restrict) */
+  int32_t virtual_rhs_solves;    /* ... of which the right-hand side was never stored (csgpu_opts.sparse_init) */
+  int32_t reserved_info3;
 } csgpu_info;
 
 typedef struct csgpu_stats {

@@ -577,13 +577,16 @@ def check_ragged_tail_batches(L, shape=(64, 57), batch=8, npairs=11, pbs=(0, 4),
 
 
 def check_fused_residual_restriction(L, shapes=((64, 57), (101, 130), (31, 200)), batches=(16, 32), check_every=(1, 4)):
-    """csgpu_opts.fused_restrict = 1 (round 6): the residual update and the restriction of the V-cycle as
-    ONE marching pass with the residual ping-ponging between two buffers (lattice_rupd_restrict_kernel, lattice.h). An entry
-    of the new residual and of the coarse right-hand side is computed with the two-pass path's arithmetic, so resistances,
-    gathered voltages and iteration counts must equal the two-pass path's BIT FOR BIT: whole batches and a short last one,
-    direct launches (check_every = 1, odd iteration counts leave r in the second buffer) and captured chunks (4), the
-    true-residual criterion (the partials of r'r come from the fused kernel, summed in another order: 1e-12), a second call on
-    the same handle, and single precision throughout (precond_bytes = 0 with dtype fp32 when the library handle is fp32)."""
+    """csgpu_opts.fused_restrict (round 6): the residual update and the restriction of the V-cycle as
+    ONE marching pass with the residual ping-ponging between two buffers (lattice_rupd_restrict_kernel, lattice.h), and
+    csgpu_opts.sparse_init: the right-hand side of a batch of pair solves is never stored (first restriction = a scatter, first
+    second product and first update synthesise it). An entry of the new residual and of the coarse right-hand side is computed
+    with the two-pass path's arithmetic, so resistances, gathered voltages and iteration counts must equal the two-pass
+    path's BIT FOR BIT: whole batches and a short last one, pairs whose nodes coincide (zero right-hand side) inside a
+    batch and as a whole batch (nothing iterates), direct launches (check_every = 1, odd iteration counts leave r in the
+    second buffer) and captured chunks (4), the true-residual criterion (the partials of r'r come from the fused kernel,
+    summed in another order: 1e-12), a second call on the same handle."""
+    modes = ((-1, -1), (-1, 1), (1, -1), (1, 1))   # (fused_restrict, sparse_init)
     for shape in shapes:
         g, G, pts, cases = sources_problem(shape, 12, seed=7, holes=0.0)
         rng = np.random.default_rng(11)
@@ -591,21 +594,28 @@ def check_fused_residual_restriction(L, shapes=((64, 57), (101, 130), (31, 200))
             npairs = batch + 5
             src = [int(pts[i]) for i in rng.integers(0, 12, npairs)]
             dst = [int(pts[(pts.index(s_) + 1 + int(k)) % 12]) for s_, k in zip(src, rng.integers(0, 10, npairs))]
+            dst[3] = src[3]            # a zero right-hand side inside the first batch
             for ce in check_every:
                 out = {}
-                for fused in (-1, 1):
+                for fused, sparse in modes:
                     with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=0, check_every=ce, fixed_k=1, stream=-1,
-                                                          fused_restrict=fused)) as h:
+                                                          fused_restrict=fused, sparse_init=sparse)) as h:
                         R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
                         R2, _, _, st2 = h.solve_pairs(src, dst)
-                        assert st["not_converged"] == 0
+                        assert st["not_converged"] == 0 and R[3] == 0
                         assert np.array_equal(R, R2)
                         assert (h.info["fused_restrict_solves"] > 0) == (fused == 1)
-                        out[fused] = (R, ga, st["total_iters"], st["max_relres"])
-                assert np.array_equal(out[1][0], out[-1][0]), (shape, batch, ce, np.max(np.abs(out[1][0] - out[-1][0])))
-                assert np.array_equal(out[1][1], out[-1][1])
-                assert out[1][2] == out[-1][2]
-                assert abs(out[1][3] - out[-1][3]) <= 1e-9 * max(out[-1][3], 1e-300), (out[1][3], out[-1][3])
+                        assert (h.info["virtual_rhs_solves"] > 0) == (fused == 1 and sparse == 1)
+                        # a batch in which nothing iterates
+                        R0, g0, _, st0 = h.solve_pairs(src[:4], src[:4], gather=pts[:3])
+                        assert np.all(R0 == 0) and np.all(g0 == 0) and st0["not_converged"] == 0
+                        out[(fused, sparse)] = (R, ga, st["total_iters"], st["max_relres"])
+                ref = out[modes[0]]
+                for m in modes[1:]:
+                    assert np.array_equal(out[m][0], ref[0]), (shape, batch, ce, m, np.max(np.abs(out[m][0] - ref[0])))
+                    assert np.array_equal(out[m][1], ref[1])
+                    assert out[m][2] == ref[2]
+                    assert abs(out[m][3] - ref[3]) <= 1e-9 * max(ref[3], 1e-300), (out[m][3], ref[3])
     # streaming pair solves (more pairs than columns): a restarting column's new right-hand side enters the coarse sums in
     # the fused pass itself
     g, G, pts, cases = sources_problem((90, 64), 12, seed=9, holes=0.0)
@@ -624,6 +634,31 @@ def check_fused_residual_restriction(L, shapes=((64, 57), (101, 130), (31, 200))
                 out[fused] = (R, ga, st["total_iters"])
         assert np.array_equal(out[1][0], out[-1][0]), (batch, np.max(np.abs(out[1][0] - out[-1][0])))
         assert np.array_equal(out[1][1], out[-1][1]) and out[1][2] == out[-1][2]
+    # fp32 hierarchy under the fp64 iteration, and a narrow batch: the first restriction as a scatter (sparse_init) alone
+    g, G, pts, cases = sources_problem((70, 90), 12, seed=4, holes=0.0)
+    src, dst = [int(p_) for p_ in pts[:6]], [int(p_) for p_ in pts[6:]]
+    for pb, batch in ((4, 16), (4, 8), (0, 4)):
+        out = {}
+        for sparse in (-1, 1):
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, fixed_k=1, stream=-1,
+                                                  sparse_init=sparse)) as h:
+                R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
+                assert st["not_converged"] == 0 and h.info["virtual_rhs_solves"] == 0
+                out[sparse] = (R, ga, st["total_iters"])
+        assert np.array_equal(out[1][0], out[-1][0]) and np.array_equal(out[1][1], out[-1][1]) and out[1][2] == out[-1][2]
+    # level 1 in lattice form: x = S b and b_c = Q2' b in one pass (csgpu_opts.fused_level1), fp64 and fp32 hierarchies
+    g, G, pts, cases = sources_problem((150, 141), 12, seed=6, holes=0.0)
+    src, dst = [int(p_) for p_ in pts[:6]] * 3, [int(p_) for p_ in pts[6:]] * 3
+    for pb, batch in ((0, 16), (0, 32), (4, 32)):
+        out = {}
+        for f1 in (-1, 1):
+            with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, fixed_k=1, stream=-1,
+                                                  lattice_level1_min_rows=500, tail_rows=400, fused_level1=f1)) as h:
+                R, ga, _, st = h.solve_pairs(src, dst, gather=pts[:3])
+                info = h.info
+                assert st["not_converged"] == 0 and info["level_form"][1] == 1, info["level_form"][:info["levels"]]
+                out[f1] = (R, ga, st["total_iters"])
+        assert np.array_equal(out[1][0], out[-1][0]) and np.array_equal(out[1][1], out[-1][1]) and out[1][2] == out[-1][2]
     # the true-residual criterion reads the fused kernel's partials of r'r
     g, G, pts, cases = sources_problem((80, 75), 12, seed=3, holes=0.0)
     src, dst = [int(p_) for p_ in pts[:6]] * 3, [int(p_) for p_ in pts[6:]] * 3
