@@ -72,12 +72,18 @@ def pmc_traffic(size, batch, vb, lattice=False, pb=4):
 
 
 def live_pmc_traffic(args, precond, kernel_prefix, timeout_s=170):
+    """one kernel: see live_pmc_traffic_many"""
+    return live_pmc_traffic_many(args, precond, [kernel_prefix], timeout_s)[kernel_prefix]
+
+
+def live_pmc_traffic_many(args, precond, kernel_prefixes, timeout_s=170):
     """`roofline.traffic` measured in THIS run: two rocprofv3 passes -- `--pmc FETCH_SIZE` and `--pmc
     WRITE_SIZE`, separately, with `--kernel-trace` only, as MI355X_MICROARCH.md's HBM section prescribes -- over a child
     process that runs one warm-up and one timed batch of the same workload on the same path, nothing else. HBM bytes per
     launch of the roofline kernel = FETCH_SIZE x 2 (the counter's unit is 64 B on gfx950 while rocprofv3 scales it as 32 B;
     verified on streaming kernels of known size, profiles/pmc_traffic.json) + WRITE_SIZE, both KiB, averaged over the
-    full-size launches (the warm-up problem launches the same kernel on a 768^2 raster). Returns (bytes or None, note)."""
+    full-size launches (the warm-up problem launches the same kernel on a 768^2 raster). Returns {prefix: (bytes or None,
+    note)} for every kernel name prefix asked for, out of the SAME two passes."""
     import csv
     import glob
     import shutil
@@ -85,8 +91,9 @@ def live_pmc_traffic(args, precond, kernel_prefix, timeout_s=170):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    vals = {}
+        return {k: (None, "rocprofv3 not found") for k in kernel_prefixes}
+    vals = {k: {} for k in kernel_prefixes}
+    fail = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="csgpu_pmc_", dir="/tmp")
@@ -96,25 +103,36 @@ def live_pmc_traffic(args, precond, kernel_prefix, timeout_s=170):
                "--precond", precond, "--precision", args.precision, "--calls", args.calls]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
-            got = []
+            got = {k: [] for k in kernel_prefixes}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") == counter and row.get("Kernel_Name", "").startswith(kernel_prefix):
-                            got.append(float(row["Counter_Value"]))
-            if not got:
-                return None, "live PMC pass %s: no launches of %s in the counter file" % (counter, kernel_prefix)
-            full = [v for v in got if v >= 0.5 * max(got)]
-            vals[counter] = (sum(full) / len(full), len(full))
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        for k in kernel_prefixes:
+                            if row.get("Kernel_Name", "").startswith(k):
+                                got[k].append(float(row["Counter_Value"]))
+            for k in kernel_prefixes:
+                if not got[k]:
+                    fail.setdefault(k, "live PMC pass %s: no launches of %s in the counter file" % (counter, k))
+                    continue
+                full = [v for v in got[k] if v >= 0.5 * max(got[k])]
+                vals[k][counter] = (sum(full) / len(full), len(full))
         except Exception as e:
-            return None, "live PMC pass %s failed: %r" % (counter, e)
+            for k in kernel_prefixes:
+                fail.setdefault(k, "live PMC pass %s failed: %r" % (counter, e))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
-    note = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a "
-            "one-batch child run; FETCH x2 (gfx950 unit) + WRITE, KiB; mean over %d / %d full-size launches of %s; %.0f s"
-            % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1], kernel_prefix, time.perf_counter() - t0))
-    return traffic, note
+    res = {}
+    for k in kernel_prefixes:
+        if k in fail or len(vals[k]) < 2:
+            res[k] = (None, fail.get(k, "live PMC pass incomplete"))
+            continue
+        traffic = (2.0 * vals[k]["FETCH_SIZE"][0] + vals[k]["WRITE_SIZE"][0]) * 1024.0
+        res[k] = (traffic, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace "
+                  "only) over a one-batch child run; FETCH x2 (gfx950 unit) + WRITE, KiB; mean over %d / %d full-size launches "
+                  "of %s; %.0f s" % (vals[k]["FETCH_SIZE"][1], vals[k]["WRITE_SIZE"][1], k, time.perf_counter() - t0))
+    return res
 
 
 def make_raster(size, seed=12345, sigma=1.0, dtype=np.float64):
@@ -323,7 +341,7 @@ def run_pairs(h, batch_pairs, K, Wm, sync=None, first_batch=0, one_call=True):
     t0 = time.perf_counter()
     results = []
     agg = dict(total_iters=0, max_iters=0, cg_spmv_ms=0.0, cg_spmv_calls=0, device_ms=0.0, max_relres=0.0,
-               not_converged=0, stream_slots=0, calls=0)
+               not_converged=0, stream_slots=0, calls=0, resid_ms=0.0, resid_calls=0, resid_bytes=0, resid_fused=0)
     calls = [range(first_batch + Wm, first_batch + Wm + K)] if one_call else [[first_batch + Wm + k] for k in range(K)]
     for steps in calls:
         s, d = pairs_of(steps)
@@ -338,6 +356,10 @@ def run_pairs(h, batch_pairs, K, Wm, sync=None, first_batch=0, one_call=True):
         agg["max_relres"] = max(agg["max_relres"], st["max_relres"])
         agg["not_converged"] += st["not_converged"]
         agg["cg_spmv_bytes"] = st["cg_spmv_bytes"]
+        agg["resid_ms"] += st.get("resid_ms", 0.0)
+        agg["resid_calls"] += st.get("resid_calls", 0)
+        agg["resid_bytes"] = st.get("resid_bytes", 0)
+        agg["resid_fused"] = st.get("resid_fused", 0)
         agg["stream_slots"] += st.get("stream_slots", 0)
         agg["calls"] += 1
     return time.perf_counter() - t0, results, agg
@@ -954,6 +976,29 @@ def main():
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tnote,
                 "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms, "launches_timed": agg_p["cg_spmv_calls"]}
 
+    def resid_roofline_of(info_p, agg_p):
+        """roofline object of the OTHER big launch of an iteration on the lattice path: the residual update r -= alpha (A p)
+        with A p recomputed from the lattice form -- since round 6 fused with the restriction b_c = Q^T r of the V-cycle in
+        one marching pass (csrc/lattice.h) when the whole solve runs in double precision. Same events, same iterations as
+        the CG product's; algorithmic bytes from the library (csgpu_stats.resid_bytes, formula in include/csgpu.h)."""
+        if not agg_p.get("resid_calls") or not agg_p.get("resid_bytes"):
+            return None
+        tn = {8: "double", 4: "float"}
+        avg_ms = agg_p["resid_ms"] / max(agg_p["resid_calls"], 1)
+        nbytes = agg_p["resid_bytes"]
+        ach = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        xb = info_p["precond_bytes"] or vb
+        if agg_p.get("resid_fused"):
+            name = ("lattice_rupd_restrict_kernel<%s,%d,512> (residual update with A p recomputed + restriction of the V-cycle, "
+                    "one marching pass)" % (tn[vb], B))
+            prefix = "void csgpu::lattice_rupd_restrict_kernel<%s, %d, 512, false>" % (tn[vb], B)
+        else:
+            name = "dia_cg_kernel<%s,%s,%d,RUPD> (residual update with A p recomputed)" % (tn[vb], tn[xb], B)
+            prefix = "void csgpu::dia_cg_kernel<%s, %s, %d, 3>" % (tn[vb], tn[xb], B)
+        return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "traffic_source": "not collected", "algorithmic_bytes_per_launch": nbytes, "avg_ms": avg_ms,
+                "launches_timed": agg_p["resid_calls"], "_prefix": prefix}
+
     if rank == 0:
         pairs_done = K * B * world
         setup_s = (info["setup_ms"] + info["upload_ms"]) / 1e3
@@ -965,6 +1010,17 @@ def main():
         roof = roofline_of(info, agg)
         roof.update({"spmv_k1_avg_ms": spmv1_ms,
                      "spmv_k1_GBs": info["spmv_bytes_fine"] / (spmv1_ms * 1e-3) / 1e9 if spmv1_ms > 0 else 0.0})
+        tn_ = {8: "double", 4: "float"}
+        roof["_prefix"] = "void csgpu::dia_cg_kernel<%s, %s, %d, 1>" % (tn_[vb], tn_[info["precond_bytes"] or vb], B)
+        # the DOMINANT kernel is the one with the longest launch: since the residual update carries the restriction that is
+        # the fused pass, not the CG product (which stays beside it as roofline_cg_product)
+        roof_resid = resid_roofline_of(info, agg)
+        roof_cg = roof
+        if roof_resid is not None and roof_resid["avg_ms"] > roof["avg_ms"]:
+            roof_resid["dominant_by"] = "%.2f ms per launch against %.2f ms of the CG product, one launch each per iteration" % (
+                roof_resid["avg_ms"], roof["avg_ms"])
+            roof_resid.update({"spmv_k1_avg_ms": roof["spmv_k1_avg_ms"], "spmv_k1_GBs": roof["spmv_k1_GBs"]})
+            roof = roof_resid
         out = {
             "metric": "pair-solves/sec (AMG-PCG, setup amortised over 100 pairs) on %dx%d raster pairwise" % (size, size),
             "value": value,
@@ -1003,6 +1059,10 @@ def main():
             "calls": agg["calls"], "stream": stream_block(agg, K * B, B),
             "roofline": roof,
         }
+        if roof is not roof_cg:
+            out["roofline_cg_product"] = roof_cg
+        elif roof_resid is not None:
+            out["roofline_residual_update"] = roof_resid
         out["value_" + path_name] = value
         if multi is not None:
             out["multi_gpu"] = multi
@@ -1144,17 +1204,17 @@ def main():
             t_leg = time.perf_counter()
             try:
                 lib.trim_memory()
-                tn = {8: "double", 4: "float"}
-                xb = info["precond_bytes"] or vb
-                prefix = "void csgpu::dia_cg_kernel<%s, %s, %d, 1>" % (tn[vb], tn[xb], B)
-                traffic, note = live_pmc_traffic(args, args.precond, prefix)
-                if traffic is not None:
-                    out["roofline"]["traffic_committed_pass"] = out["roofline"]["traffic"]
-                    out["roofline"]["traffic"] = traffic
-                    out["roofline"]["traffic_source"] = note
-                    out["roofline"]["traffic_over_algorithmic"] = traffic / max(out["roofline"]["algorithmic_bytes_per_launch"], 1)
-                else:
-                    out["roofline"]["traffic_live_failed"] = note
+                objs = [out[k] for k in ("roofline", "roofline_cg_product", "roofline_residual_update") if k in out and out[k].get("_prefix")]
+                got = live_pmc_traffic_many(args, args.precond, [o["_prefix"] for o in objs])
+                for o in objs:
+                    traffic, note = got[o["_prefix"]]
+                    if traffic is not None:
+                        o["traffic_committed_pass"] = o["traffic"]
+                        o["traffic"] = traffic
+                        o["traffic_source"] = note
+                        o["traffic_over_algorithmic"] = traffic / max(o["algorithmic_bytes_per_launch"], 1)
+                    else:
+                        o["traffic_live_failed"] = note
             except Exception as e:
                 out["roofline"]["traffic_live_failed"] = repr(e)
             leg_seconds["pmc_live"] = time.perf_counter() - t_leg
@@ -1236,6 +1296,9 @@ def main():
                 out.setdefault("cpu_baseline", {"value": None, "unit": "pair-solves/s", "cores": 0, "kind": "port",
                                                 "sample": "failed: %r" % (e,)})
         out["leg_seconds"] = leg_seconds
+        for k_ in ("roofline", "roofline_cg_product", "roofline_residual_update"):
+            if isinstance(out.get(k_), dict):
+                out[k_].pop("_prefix", None)
         print(json.dumps(out), flush=True)
     try:
         if h is not None:

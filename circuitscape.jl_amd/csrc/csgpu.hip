@@ -1647,6 +1647,10 @@ struct Solver : ISolver {
     s->graph_launches += r.graph_launches;
     s->polished_batches += r.polished;
     s->cg_spmv_bytes = r.spmv_bytes;
+    s->resid_ms += r.resid_ms;
+    s->resid_calls += r.resid_calls;
+    s->resid_bytes = r.resid_bytes;
+    s->resid_fused = r.resid_fused;
   }
 
 #define CS_DISPATCH_K(K, ...)                               \
@@ -3436,6 +3440,10 @@ int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* d
       st[slot].graph_launches += cs.graph_launches;
       st[slot].polished_batches += cs.polished_batches;
       st[slot].cg_spmv_bytes = cs.cg_spmv_bytes;
+      st[slot].resid_ms += cs.resid_ms;
+      st[slot].resid_calls += cs.resid_calls;
+      st[slot].resid_bytes = cs.resid_bytes;
+      st[slot].resid_fused = cs.resid_fused;
       st[slot].batch = std::max(st[slot].batch, cs.batch);
       m->pairs_done[slot] += cnt;
       if (rc != CSGPU_OK && codes[slot] == CSGPU_OK) {
@@ -3463,6 +3471,10 @@ int csgpu_multi_solve_pairs(csgpu_multi* m, const int64_t* src, const int64_t* d
     s->graph_launches += st[i].graph_launches;
     s->polished_batches += st[i].polished_batches;
     s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->resid_ms += st[i].resid_ms;
+    s->resid_calls += st[i].resid_calls;
+    s->resid_bytes = std::max(s->resid_bytes, st[i].resid_bytes);
+    s->resid_fused = std::max(s->resid_fused, st[i].resid_fused);
     s->batch = std::max(s->batch, st[i].batch);
     if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
       rc_out = codes[i];
@@ -3552,6 +3564,10 @@ int csgpu_multi_solve_pairs_currents(csgpu_multi* m, const int64_t* src, const i
     s->graph_launches += st[i].graph_launches;
     s->polished_batches += st[i].polished_batches;
     s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->resid_ms += st[i].resid_ms;
+    s->resid_calls += st[i].resid_calls;
+    s->resid_bytes = std::max(s->resid_bytes, st[i].resid_bytes);
+    s->resid_fused = std::max(s->resid_fused, st[i].resid_fused);
     s->batch = std::max(s->batch, st[i].batch);
     if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
       rc_out = codes[i];
@@ -3632,6 +3648,10 @@ int multi_grounded(csgpu_multi* m, int64_t nrhs, void* cum_curr_inout, void* max
     s->graph_launches += st[i].graph_launches;
     s->polished_batches += st[i].polished_batches;
     s->cg_spmv_bytes = std::max(s->cg_spmv_bytes, st[i].cg_spmv_bytes);
+    s->resid_ms += st[i].resid_ms;
+    s->resid_calls += st[i].resid_calls;
+    s->resid_bytes = std::max(s->resid_bytes, st[i].resid_bytes);
+    s->resid_fused = std::max(s->resid_fused, st[i].resid_fused);
     s->batch = std::max(s->batch, st[i].batch);
     if (codes[i] != CSGPU_OK && (rc_out == CSGPU_OK || rc_out == CSGPU_NOT_CONVERGED)) {
       rc_out = codes[i];

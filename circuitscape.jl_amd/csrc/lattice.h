@@ -294,7 +294,11 @@ struct RupdRestrictShape {
   typedef RestrictShape<T, K, NT> RS;
   static constexpr int CPL = RS::CPL, LPR = RS::LPR, TIC = RS::TIC, FR = RS::FR;
   static constexpr int PR = FR + 2;                         // rows of p / of the matrix staged per fine column
-  static constexpr int BU = (FR * LPR + NT - 1) / NT;       // residual entries (16-byte vectors) per thread and fine column
+  // A thread updates BU ADJACENT rows of a fine column (rows tq * BU ... of its row group tq = tid / LPR): their 3 x 3
+  // windows of p overlap, 3 (BU + 2) reads of the ring instead of 9 BU. The kernel is as close to the LDS's bandwidth as to
+  // HBM's -- measured: section 8 of DESIGN.md, strided rows (one entry every NT / LPR rows) against adjacent ones.
+  static constexpr int RG = NT / LPR;                       // row groups
+  static constexpr int BU = (FR + RG - 1) / RG;             // residual entries (16-byte vectors) per thread and fine column
   static constexpr int PU = (PR * LPR + NT - 1) / NT;       // loads of p per thread and fine column
   static constexpr int MU = (PR * 5 + NT - 1) / NT;
   static constexpr int QU = (FR * 9 + NT - 1) / NT;
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
   if (a.skip && *a.skip) return;
   const int tid = threadIdx.x;
   const int t = tid / LPR, lq = tid % LPR, c0 = lq * CPL;
+  const int row0 = t * BU;  // first of this thread's adjacent rows in the update
   T alpha[CPL];
 #pragma unroll
   for (int qq = 0; qq < CPL; ++qq) alpha[qq] = APPLY ? T(0) : (T)a.S->alpha[c0 + qq];
@@ -409,17 +414,17 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
       const int64_t base = (int64_t)f * a.R + f0;
 #pragma unroll
       for (int u = 0; u < BU; ++u) {
-        const int e = tid + u * NT;
+        const int row = row0 + u;
         XV v;
 #pragma unroll
         for (int qq = 0; qq < CPL; ++qq) v.e[qq] = T(0);
-        if (!APPLY && f < fc1 && e < nfr * LPR) {
-          if (synth_in) {  // (e % LPR == lq: NT is a multiple of LPR)
-            const int64_t id = base + e / LPR;
+        if (!APPLY && f < fc1 && row < nfr) {
+          const int64_t id = base + row;
+          if (synth_in) {
 #pragma unroll
             for (int qq = 0; qq < CPL; ++qq) v.e[qq] = id == is_[qq] ? T(-1) : (id == id_[qq] ? T(1) : T(0));
           } else {
-            v = *reinterpret_cast<const XV*>(a.r_in + (size_t)(base + e / LPR) * K + (e % LPR) * CPL);
+            v = *reinterpret_cast<const XV*>(a.r_in + (size_t)id * K + c0);
           }
         }
         rreg[u] = v;
@@ -470,32 +475,57 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
       const XV* x0 = s_p[sc];
       const XV* xp = s_p[sp];
       const bool col_owned = f >= oc0 && f < oc1;
+      // nine-point products of this thread's BU adjacent rows, one ring column at a time (the order of an entry's fma chain is
+      // dia_cg_kernel's: column f - 1 rows -1, 0, +1, then f, then f + 1)
+      T sacc[BU][CPL];
+      XV ctr[BU];  // p at the entries themselves (APPLY restricts the input vector)
+#pragma unroll
+      for (int dj = 0; dj < 3; ++dj) {
+        const XV* xcol = dj == 0 ? xm : (dj == 1 ? x0 : xp);
+        XV win[BU + 2];
+#pragma unroll
+        for (int k = 0; k < BU + 2; ++k) {
+#pragma unroll
+          for (int qq = 0; qq < CPL; ++qq) win[k].e[qq] = T(0);
+          if (row0 + k < nfr + 2) win[k] = xcol[(row0 + k) * LPR + lq];
+        }
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+          const int row = row0 + u;          // staged residual row; its p / matrix row is row + 1
+          if (row < nfr) {
+            const int me = 5 * (row + 1);
+            T w0, w1, w2;
+            if (dj == 0) {
+              w0 = mp[me - 5 + 4];
+              w1 = mp[me + 3];
+              w2 = mp[me + 5 + 2];
+            } else if (dj == 1) {
+              w0 = mc[me - 5 + 1];
+              w1 = mc[me + 0];
+              w2 = mc[me + 1];
+            } else {
+              w0 = mc[me + 2];
+              w1 = mc[me + 3];
+              w2 = mc[me + 4];
+            }
+#pragma unroll
+            for (int qq = 0; qq < CPL; ++qq) {
+              T sv = dj == 0 ? w0 * win[u].e[qq] : fma(w0, win[u].e[qq], sacc[u][qq]);
+              sv = fma(w1, win[u + 1].e[qq], sv);
+              sacc[u][qq] = fma(w2, win[u + 2].e[qq], sv);
+            }
+            if (dj == 1) ctr[u] = win[u + 1];
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < BU; ++u) {
-        const int e = tid + u * NT;
-        if (e < nfr * LPR) {
-          const int row = e / LPR;          // staged residual row; its p / matrix row is row + 1
-          const int me = 5 * (row + 1);
-          const T w_mm = mp[me - 5 + 4], w_m0 = mp[me + 3], w_mp = mp[me + 5 + 2];
-          const T w_0m = mc[me - 5 + 1], w_00 = mc[me + 0], w_0p = mc[me + 1];
-          const T w_pm = mc[me + 2], w_p0 = mc[me + 3], w_pp = mc[me + 4];
-          const XV a00 = xm[(row + 0) * LPR + lq], a01 = xm[(row + 1) * LPR + lq], a02 = xm[(row + 2) * LPR + lq];
-          const XV a10 = x0[(row + 0) * LPR + lq], a11 = x0[(row + 1) * LPR + lq], a12 = x0[(row + 2) * LPR + lq];
-          const XV a20 = xp[(row + 0) * LPR + lq], a21 = xp[(row + 1) * LPR + lq], a22 = xp[(row + 2) * LPR + lq];
+        const int row = row0 + u;
+        if (row < nfr) {
           XV rn;
 #pragma unroll
-          for (int qq = 0; qq < CPL; ++qq) {
-            T s = w_mm * a00.e[qq];
-            s = fma(w_m0, a01.e[qq], s);
-            s = fma(w_mp, a02.e[qq], s);
-            s = fma(w_0m, a10.e[qq], s);
-            s = fma(w_00, a11.e[qq], s);
-            s = fma(w_0p, a12.e[qq], s);
-            s = fma(w_pm, a20.e[qq], s);
-            s = fma(w_p0, a21.e[qq], s);
-            s = fma(w_pp, a22.e[qq], s);
-            rn.e[qq] = APPLY ? s : (fresh[qq] ? T(0) : rv[u].e[qq] - alpha[qq] * s);
-          }
+          for (int qq = 0; qq < CPL; ++qq)
+            rn.e[qq] = APPLY ? sacc[u][qq] : (fresh[qq] ? T(0) : rv[u].e[qq] - alpha[qq] * sacc[u][qq]);
           const int fr = f0 + row;
           const bool owned = col_owned && fr >= o0 && fr < o1;
           if (owned) {  // (partials as the two-pass update writes them: a restarting column contributes nothing)
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(NT) void lattice_rupd_restrict_kernel(RupdRestrictA
 #pragma unroll
           for (int qq = 0; qq < CPL; ++qq)
             if (fresh[qq]) rn.e[qq] = id == nsrc[qq] ? T(-1) : (id == ndst[qq] ? T(1) : T(0));
-          s_b[e] = APPLY ? a11 : rn;  // (APPLY: the restriction is of the INPUT vector)
+          s_b[row * LPR + lq] = APPLY ? ctr[u] : rn;  // (APPLY: the restriction is of the INPUT vector)
           if (owned) dia_store(reinterpret_cast<XV*>(a.r_out + (size_t)id * K + c0), rn);
         }
       }

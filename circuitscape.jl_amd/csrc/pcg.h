@@ -503,6 +503,7 @@ struct PcgWork {
   DBuf part_ca, part_cc;      // collapsed copies of part_a / part_c (collapse_partials_kernel)
   DBuf part_cb;               // collapsed copy of part_b (streaming solves: ||r||^2 of every iteration)
   std::vector<hipEvent_t> ev;  // event pairs around the CG SpMV launches
+  std::vector<hipEvent_t> ev2; // ... and around the residual-update launches of the same iterations
   std::vector<std::pair<PcgGraphKey, hipGraphExec_t>> graphs;  // captured iteration chunks
   bool graph_broken = false;                                   // capture failed once: stay on direct launches
   void drop_graphs() {
@@ -573,6 +574,7 @@ struct PcgWork {
   ~PcgWork() {
     drop_graphs();
     for (auto e : ev) hipEventDestroy(e);
+    for (auto e : ev2) hipEventDestroy(e);
   }
 };
 
@@ -584,6 +586,9 @@ struct PcgBatchResult {
   int64_t graph_launches = 0;
   int polished = 0;
   int64_t spmv_bytes = 0;  // algorithmic bytes of one of the timed CG-product launches
+  double resid_ms = 0;     // the residual-update launches (with the restriction, on the fused path) of the same iterations
+  int64_t resid_calls = 0, resid_bytes = 0;
+  int resid_fused = 0;
   bool explicit_relres = false;  // s.relres is ||A x - b|| / ||b|| of an explicit product (x carried), not the recurrence residual
 };
 
@@ -869,14 +874,16 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     const TP* pin = pbuf[parity];
     TP* pcur = use_dia ? pbuf[parity ^ 1] : pbuf[parity];
     time_it = time_it && timed < max_timed;
+    const int tslot = timed;
     auto ev_begin = [&]() {
       if (!time_it) return;
-      if ((int)W.ev.size() < 2 * (timed + 1)) {
+      while ((int)W.ev.size() < 2 * (timed + 1) || (int)W.ev2.size() < 2 * (timed + 1)) {
         hipEvent_t ea, eb;
         CS_HIP(hipEventCreate(&ea));
         CS_HIP(hipEventCreate(&eb));
-        W.ev.push_back(ea);
-        W.ev.push_back(eb);
+        auto& v = (int)W.ev.size() < 2 * (timed + 1) ? W.ev : W.ev2;
+        v.push_back(ea);
+        v.push_back(eb);
       }
       CS_HIP(hipEventRecord(W.ev[2 * timed], st));
     };
@@ -909,6 +916,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     }
     // r -= alpha Ap (+ x += alpha p when the whole solution is wanted), fused with the TP copy of r, the level-0 first
     // pre-smoothing sweep xa = omega D^-1 r and (when the true residual is monitored) the partials of r'r
+    if (time_it && use_dia) CS_HIP(hipEventRecord(W.ev2[2 * tslot], st));
     if (recompute) {
       // (the partials of r'r come for free here; the focal path's post-check reads the last ones instead of making
       // another pass over r)
@@ -942,6 +950,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
       else CS_UPD_R(false, false);
 #undef CS_UPD_R
     }
+    if (time_it && use_dia) CS_HIP(hipEventRecord(W.ev2[2 * tslot + 1], st));
     const bool rr_after_mask = (grounded || projected) && criterion != CSGPU_CRIT_KRYLOV;
     if (projected) {  // r <- Pi r: the residual of the projected system (both precisions)
       poly_project<T, TP, K>(*pp.proj, r, MIXED ? rp : (TP*)nullptr, (const int*)&S->all_done, st);
@@ -1175,8 +1184,22 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
     float m2 = 0;
     CS_HIP(hipEventElapsedTime(&m2, W.ev[2 * t], W.ev[2 * t + 1]));
     res.spmv_ms += m2;
+    if (use_dia) {
+      CS_HIP(hipEventElapsedTime(&m2, W.ev2[2 * t], W.ev2[2 * t + 1]));
+      res.resid_ms += m2;
+    }
   }
   res.spmv_calls = counted;
+  if (use_dia) {
+    // algorithmic bytes of one residual-update launch: the lattice rows, p, r read and written (+ its copy in the
+    // preconditioner's precision); fused with the restriction: + the nine values of Q per row and the coarse right-hand side
+    res.resid_calls = counted;
+    res.resid_fused = rbuf[1] ? 1 : 0;  // (the second residual buffer exists only on the fused path)
+    res.resid_bytes = n * 5 * (int64_t)sizeof(T) + n * K * ((int64_t)sizeof(TP) + 2 * (int64_t)sizeof(T) + (MIXED ? (int64_t)sizeof(TP) : 0));
+    if (res.resid_fused && H.levels.size() > 1)
+      res.resid_bytes += n * 9 * (int64_t)sizeof(T) + (int64_t)H.levels[1].A.nrows * K * (int64_t)sizeof(T);
+    if (!recompute) res.resid_bytes = 0;  // (the generic update kernel: not this formula)
+  }
   res.graph_launches = graph_launches;
   if (use_dia)
     res.spmv_bytes = n * 5 * (int64_t)sizeof(T) + n * K * (3 * (int64_t)sizeof(TP) + (recompute ? 0 : (int64_t)sizeof(T)));

@@ -39,7 +39,8 @@ mutable struct CsgpuStats
     nrhs::Int32; max_iters::Int32; total_iters::Int64; max_relres::Float64; solve_ms::Float64; device_ms::Float64
     cg_spmv_ms::Float64; cg_spmv_calls::Int64; batch::Int32; not_converged::Int32; graph_launches::Int64; polished_batches::Int64
     cg_spmv_bytes::Int64; stream_slots::Int64
-    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0)
+    resid_ms::Float64; resid_calls::Int64; resid_bytes::Int64; resid_fused::Int32; reserved_stats::Int32
+    CsgpuStats() = new(0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0)
 end
 
 mutable struct HIPFactor          # cf. PardisoFactorize (Pardiso ext :8-13): owns the device-resident hierarchy

@@ -29,7 +29,7 @@ const CS_TEST = joinpath(CS_ROOT, "test")
     @test o.struct_size == sizeof(Circuitscape.CsgpuOpts)                # C struct and Julia mirror agree on the size
     @test Circuitscape.device_count() >= 1
     st = Circuitscape.CsgpuStats()
-    @test sizeof(st) == 96                                               # csgpu_stats (include/csgpu.h): 96 bytes
+    @test sizeof(st) == 128                                              # csgpu_stats (include/csgpu.h): 128 bytes
 end
 
 cd(CS_TEST) do

@@ -93,6 +93,8 @@ class Stats(ctypes.Structure):
         ("cg_spmv_ms", ctypes.c_double), ("cg_spmv_calls", ctypes.c_int64), ("batch", ctypes.c_int32),
         ("not_converged", ctypes.c_int32), ("graph_launches", ctypes.c_int64),
         ("polished_batches", ctypes.c_int64), ("cg_spmv_bytes", ctypes.c_int64), ("stream_slots", ctypes.c_int64),
+        ("resid_ms", ctypes.c_double), ("resid_calls", ctypes.c_int64), ("resid_bytes", ctypes.c_int64),
+        ("resid_fused", ctypes.c_int32), ("reserved_stats", ctypes.c_int32),
     ]
 
     def as_dict(self):

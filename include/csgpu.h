@@ -320,6 +320,14 @@ typedef struct csgpu_stats {
                                    pcg_stream_pairs: a column takes the next pair of the list as soon as its own has
                                    converged; a pair costs its own iterations + 1 slots). 0: the batch path. The columns'
                                    utilisation of a call is (total_iters + nrhs) / (stream_slots * batch) */
+  /* round 6: the OTHER big launch of an iteration on the lattice path, timed over the same iterations as cg_spmv_ms */
+  double resid_ms;              /* sum of HIP-event durations of the residual-update launches (batch path) */
+  int64_t resid_calls;          /* number of those launches */
+  int64_t resid_bytes;          /* algorithmic bytes of ONE of them: n*5*val + n*K*(p + 2 r [+ the copy of r in the
+                                   preconditioner's precision]); fused with the restriction (resid_fused): + n*9*val +
+                                   n_coarse*K*val. 0 when the update is not the lattice kernel */
+  int32_t resid_fused;          /* 1 = those launches are the fused residual update + restriction (csgpu_opts.fused_restrict) */
+  int32_t reserved_stats;
 } csgpu_stats;
 
 int csgpu_device_count(void);

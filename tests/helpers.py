@@ -595,7 +595,7 @@ def check_fused_residual_restriction(L, shapes=((64, 57), (101, 130), (31, 200))
             src = [int(pts[i]) for i in rng.integers(0, 12, npairs)]
             dst = [int(pts[(pts.index(s_) + 1 + int(k)) % 12]) for s_, k in zip(src, rng.integers(0, 10, npairs))]
             dst[3] = src[3]            # a zero right-hand side inside the first batch
-            for ce in check_every:
+            for ce in (check_every if shape == shapes[0] else check_every[:1]):
                 out = {}
                 for fused, sparse in modes:
                     with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=0, check_every=ce, fixed_k=1, stream=-1,
