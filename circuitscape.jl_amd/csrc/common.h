@@ -99,6 +99,9 @@ struct Knobs {
   // experiments / debugging only (no csgpu_opts field)
   double pinv_cut = 0.0;
   bool kernel_gain_ref = false, tail_debug = false;
+  bool galerkin_staged = true;    // level-1 Galerkin product of the lattice set-up from LDS-staged fine columns (lattice_setup.h)
+  bool enrich_fused = true;       // enriched levels take the fused residual update + restriction (enrich_coarse_fix, enrich.h)
+  int apq_nt = 128;               // cells per workgroup of lattice_ap_q_kernel (256 / 128 / 64)
   int timed_launches = 512;
 };
 

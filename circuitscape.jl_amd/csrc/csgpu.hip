@@ -150,6 +150,9 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   num("PINV_CUT", [&](double v) { k.pinv_cut = v; });
   if (on("KERNEL_GAIN_REF")) k.kernel_gain_ref = true;
   if (on("TAIL_DEBUG")) k.tail_debug = true;
+  if (on("GALERKIN_STAGED")) k.galerkin_staged = true;
+  if (on("NO_ENRICH_FUSED")) k.enrich_fused = false;
+  num("APQ_NT", [&](double v) { k.apq_nt = (int)v; });
   num("TIMED_LAUNCHES", [&](double v) { k.timed_launches = (int)v; });
   return k;
 }

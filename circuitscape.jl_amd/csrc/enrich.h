@@ -636,4 +636,123 @@ inline void enrich_post(Enrich& E, T* r, T* z, double* part, const int* skip, hi
                      skip);
 }
 
+// ---- the restriction's share of the pre-pass (fused residual update + restriction) ------------------------------------------
+// The fused pass of lattice.h leaves b_c = Q^T r; the V-cycle of an enriched level wants Q^T (r - s) with s = A E c on the halo
+// cells (enrich_pre_kernel keeps it in sbuf). Q^T s is a sum over <= 9 coarse nodes per halo cell: gathered per COARSE node
+// from a transposed list built once per set-up (counts and slots by atomics, every row then sorted by halo position: the
+// summation order is fixed), one thread per (coarse node, column).
+__device__ __forceinline__ int enr_tile(int i, int nc) {  // (lat_tile of lattice.h)
+  const int t = i / 3;
+  return t < nc ? t : nc - 1;
+}
+
+// PASS 0: entries per coarse node; PASS 1: (halo position, weight) at cptr[a] + a running slot
+template <class T, int PASS>
+__global__ __launch_bounds__(256) void enrich_coarse_lists_kernel(int nhalo, const int* __restrict__ hcell, int R, int Rc, int Cc,
+                                                                  const T* __restrict__ q, int* __restrict__ cnt,
+                                                                  const int* __restrict__ cptr, int* __restrict__ th,
+                                                                  double* __restrict__ tw) {
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nhalo * 9; id += (int64_t)gridDim.x * 256) {
+    const int h = (int)(id / 9), s = (int)(id % 9);
+    const int64_t cell = hcell[h];
+    const T w = q[cell * 9 + s];
+    if (w == T(0)) continue;
+    const int Ic = enr_tile((int)(cell % R), Rc) + s % 3 - 1, Jc = enr_tile((int)(cell / R), Cc) + s / 3 - 1;
+    if (Ic < 0 || Ic >= Rc || Jc < 0 || Jc >= Cc) continue;
+    const int a = Jc * Rc + Ic;
+    const int k = atomicAdd(&cnt[a], 1);
+    if (PASS == 1) {
+      th[cptr[a] + k] = h;
+      tw[cptr[a] + k] = (double)w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void enrich_coarse_flag_kernel(int nc, const int* __restrict__ cnt, int* __restrict__ flag) {
+  for (int a = blockIdx.x * 256 + threadIdx.x; a <= nc; a += gridDim.x * 256) flag[a] = (a < nc && cnt[a] > 0) ? 1 : 0;
+}
+
+// compact list of the touched coarse nodes; each sorts its entries by halo position (insertion sort: rows of <= 81 entries)
+__global__ __launch_bounds__(256) void enrich_coarse_rows_kernel(int nc, const int* __restrict__ cptr, const int* __restrict__ tpos,
+                                                                 int* __restrict__ tcell, int* __restrict__ tptr,
+                                                                 int* __restrict__ th, double* __restrict__ tw) {
+  for (int a = blockIdx.x * 256 + threadIdx.x; a < nc; a += gridDim.x * 256) {
+    const int b = cptr[a], e = cptr[a + 1];
+    if (e <= b) continue;
+    const int u = tpos[a];
+    tcell[u] = a;
+    tptr[u] = b;
+    for (int i = b + 1; i < e; ++i) {
+      const int hk = th[i];
+      const double wk = tw[i];
+      int j = i - 1;
+      while (j >= b && th[j] > hk) {
+        th[j + 1] = th[j];
+        tw[j + 1] = tw[j];
+        --j;
+      }
+      th[j + 1] = hk;
+      tw[j + 1] = wk;
+    }
+  }
+}
+
+template <class T>
+inline void enrich_coarse_setup(Enrich& E, const T* q, int R, int Rc, int Cc, hipStream_t st) {
+  E.ntouch = 0;
+  if (E.nvec <= 0 || E.nhalo <= 0) return;
+  const int nc = Rc * Cc;
+  DBuf cnt = dalloc<int>((size_t)nc + 1), flag = dalloc<int>((size_t)nc + 1), tot = dalloc<int>(2);
+  CS_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes, st));
+  const int g = grid_for((int64_t)E.nhalo * 9);
+  hipLaunchKernelGGL((enrich_coarse_lists_kernel<T, 0>), dim3(g), dim3(256), 0, st, E.nhalo, (const int*)dptr<int>(E.hcell), R, Rc, Cc,
+                     q, dptr<int>(cnt), (const int*)nullptr, (int*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(enrich_coarse_flag_kernel, dim3(grid_for((int64_t)nc + 1)), dim3(256), 0, st, nc, (const int*)dptr<int>(cnt),
+                     dptr<int>(flag));
+  exclusive_scan_i32(dptr<int>(flag), (int64_t)nc + 1, st, dptr<int>(tot));      // flag -> position in the compact list
+  exclusive_scan_i32(dptr<int>(cnt), (int64_t)nc + 1, st, dptr<int>(tot) + 1);   // cnt -> first entry
+  const int ntouch = read_int(dptr<int>(tot), st), nent = read_int(dptr<int>(tot) + 1, st);
+  if (ntouch <= 0 || nent <= 0) return;
+  DBuf cursor = dalloc<int>((size_t)nc + 1);
+  CS_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
+  E.tcell = dalloc<int>((size_t)ntouch);
+  E.tptr = dalloc<int>((size_t)ntouch + 1);
+  E.th = dalloc<int>((size_t)nent);
+  E.tw = dalloc<double>((size_t)nent);
+  hipLaunchKernelGGL((enrich_coarse_lists_kernel<T, 1>), dim3(g), dim3(256), 0, st, E.nhalo, (const int*)dptr<int>(E.hcell), R, Rc, Cc,
+                     q, dptr<int>(cursor), (const int*)dptr<int>(cnt), dptr<int>(E.th), dptr<double>(E.tw));
+  hipLaunchKernelGGL(enrich_coarse_rows_kernel, dim3(grid_for(nc)), dim3(256), 0, st, nc, (const int*)dptr<int>(cnt),
+                     (const int*)dptr<int>(flag), dptr<int>(E.tcell), dptr<int>(E.tptr), dptr<int>(E.th), dptr<double>(E.tw));
+  CS_HIP(hipMemcpyAsync(dptr<int>(E.tptr) + ntouch, &nent, sizeof(int), hipMemcpyHostToDevice, st));
+  check_launch("enrichment coarse lists");
+  CS_HIP(hipStreamSynchronize(st));  // (nent is a stack variable; the temporaries go back to the pool)
+  E.ntouch = ntouch;
+  if (knobs().verbose)
+    fprintf(stderr, "csgpu: coarse-space enrichment: %d coarse nodes take the restriction's share of the pre-pass (%d entries)\n",
+            ntouch, nent);
+}
+
+// bc -= Q^T s on the touched coarse nodes (s = sbuf of the pre-pass that has just run)
+template <class T, int K>
+__global__ __launch_bounds__(256) void enrich_coarse_fix_kernel(int ntouch, const int* __restrict__ tcell, const int* __restrict__ tptr,
+                                                                const int* __restrict__ th, const double* __restrict__ tw,
+                                                                const double* __restrict__ sbuf, T* __restrict__ bc,
+                                                                const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)ntouch * K; id += (int64_t)gridDim.x * 256) {
+    const int u = (int)(id / K), c = (int)(id % K);
+    double s = 0.0;
+    for (int e = tptr[u]; e < tptr[u + 1]; ++e) s += tw[e] * sbuf[(int64_t)th[e] * K + c];
+    const int64_t at = (int64_t)tcell[u] * K + c;
+    bc[at] = (T)((double)bc[at] - s);
+  }
+}
+
+template <class T, int K>
+inline void enrich_coarse_fix(Enrich& E, T* bc, const int* skip, hipStream_t st) {
+  hipLaunchKernelGGL((enrich_coarse_fix_kernel<T, K>), dim3(grid_for((int64_t)E.ntouch * K)), dim3(256), 0, st, E.ntouch,
+                     (const int*)dptr<int>(E.tcell), (const int*)dptr<int>(E.tptr), (const int*)dptr<int>(E.th),
+                     (const double*)dptr<double>(E.tw), (const double*)dptr<double>(E.sbuf), bc, skip);
+}
+
 }  // namespace csgpu

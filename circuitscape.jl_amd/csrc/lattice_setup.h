@@ -577,20 +577,23 @@ __global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc
 // neighbours -- are three contiguous runs of 258 rows (raster columns j-1, j, j+1), staged in LDS with coalesced loads:
 // read directly, every lane would fetch nine 72-byte rows at a 72-byte lane stride, 81 load instructions that each touch
 // 36 cache lines (measured at 1e8 cells, fp64: 52 ms -- the largest kernel of the setup; staged: see profiles/r3_setup_*).
-template <class U, class T>
-__global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
-                                                           const T* __restrict__ pl, const T* __restrict__ dinv, T omega,
-                                                           T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad,
-                                                           const T* __restrict__ base) {
-  constexpr int RUN = 258 * 9;
+// NT (cells per workgroup): the kernel is three phases between barriers (stage, multiply, store through LDS), so what hides
+// one workgroup's loads is the NEXT workgroup on the CU -- at 256 cells the 56 KB of fp64 runs leave room for two. Measured
+// at 10000^2 fp64 (round 6): 128 or 64 cells per workgroup change nothing (22.2 / 23.8 / 24 ms) -- occupancy is not the bound.
+template <class U, class T, int NT = 256>
+__global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int Rc, int Cc, const U* __restrict__ rows,
+                                                          const T* __restrict__ pl, const T* __restrict__ dinv, T omega,
+                                                          T* __restrict__ ap, T* __restrict__ q, int* __restrict__ bad,
+                                                          const T* __restrict__ base) {
+  constexpr int RUN = (NT + 2) * 9;
   __shared__ T s_x[3][RUN];
   const int tid = threadIdx.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+  for (int64_t i0 = (int64_t)blockIdx.x * NT; i0 < n; i0 += (int64_t)gridDim.x * NT) {
     __syncthreads();  // (the previous round's reads)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int64_t c0 = i0 + (int64_t)(r - 1) * R - 1;  // first cell of the run
-      for (int e = tid; e < RUN; e += 256) {
+      for (int e = tid; e < RUN; e += NT) {
         const int64_t cell = c0 + e / 9;
         s_x[r][e] = (cell >= 0 && cell < n) ? pl[c0 * 9 + e] : T(0);
       }
@@ -642,12 +645,25 @@ __global__ __launch_bounds__(256) void lattice_ap_q_kernel(int64_t n, int R, int
       }
     }
     __syncthreads();
-    const int cnt = (int)(n - i0 < 256 ? n - i0 : 256) * 9;
-    for (int e = tid; e < cnt; e += 256) {
+    const int cnt = (int)(n - i0 < NT ? n - i0 : NT) * 9;
+    for (int e = tid; e < cnt; e += NT) {
       if (ap) ap[i0 * 9 + e] = s_x[0][e];
       if (q) q[i0 * 9 + e] = s_x[2][e];
     }
   }
+}
+
+template <class U, class T>
+inline void lattice_ap_q(int64_t n, int R, int Rc, int Cc, const U* rows, const T* pl, const T* dinv, T omega, T* ap, T* q,
+                         int* bad, const T* base, hipStream_t st) {
+  const int nt = knobs().apq_nt;
+#define CS_APQ(NT_)                                                                                                      \
+  hipLaunchKernelGGL((lattice_ap_q_kernel<U, T, NT_>), dim3((int)std::min<int64_t>(ceil_div(n, (int64_t)NT_), kMaxGrid)), \
+                     dim3(NT_), 0, st, n, R, Rc, Cc, rows, pl, dinv, omega, ap, q, bad, base)
+  if (nt == 256) CS_APQ(256);
+  else if (nt == 64) CS_APQ(64);
+  else CS_APQ(128);
+#undef CS_APQ
 }
 
 // ---- Galerkin operator A_c = P^T (A P) ---------------------------------------------------------------------------------
@@ -690,6 +706,89 @@ __global__ __launch_bounds__(128) void lattice_galerkin_kernel(int R, int C, int
           }
         }
     }
+    int m = 0;
+#pragma unroll
+    for (int s = 0; s < 25; ++s) {
+      const int bI = Ia + s % 5 - 2, bJ = Ja + s / 5 - 2;
+      if (bI < 0 || bI >= Rc || bJ < 0 || bJ >= Cc) continue;
+      if (acc[s] == T(0) && s != 12) continue;
+      pcol[(size_t)a * 25 + m] = bJ * Rc + bI;
+      pval[(size_t)a * 25 + m] = acc[s];
+      ++m;
+    }
+    count[a] = m;
+  }
+}
+
+// The same sums with the fine rows staged in LDS. A workgroup owns TI consecutive coarse rows of ONE coarse column Ja and
+// walks the fine raster columns of the tile columns Ja-1 .. Ja+1 in ascending order; per fine column the rows of `pl` and
+// `ap` its coarse rows reach (tiles Ia0-1 .. Ia0+TI) are two contiguous runs, loaded with coalesced accesses. Read straight
+// from memory (kernel above) every lane fetches one value of a 72-byte row per load at a lane stride of 216 bytes: 81 such
+// loads per coarse node, each touching 64 cache lines (19.4 ms at 10000^2 fp64, 0.1 of the HBM roofline for its 14.4 GB).
+// Summation order per coarse node unchanged (fine columns ascending, tiles and rows ascending, slots ascending): same bits.
+// MEASURED SLOWER (round 6, 10000^2 fp64: 36.7 ms against 19.4; one wave per workgroup and two barriers per fine column leave
+// five waves per CU to hide the staging loads) -- kept behind the debug switch CSGPU_GALERKIN_STAGED for the next attempt.
+// Work items are dealt so that the workgroups of one XCD (blockIdx % 8) walk neighbouring coarse columns of one strip --
+// a fine column is staged by three of them and the second and third find it in that XCD's L2.
+template <class T, int TI>
+__global__ __launch_bounds__(TI) void lattice_galerkin_staged_kernel(int R, int C, int Rc, int Cc, const T* __restrict__ pl,
+                                                                      const T* __restrict__ ap, int* __restrict__ count,
+                                                                      int* __restrict__ pcol, T* __restrict__ pval) {
+  constexpr int ROWS = 3 * (TI + 2) + 2;  // (the raster's last tile holds up to 4 rows)
+  __shared__ T s_p[ROWS * 9];
+  __shared__ T s_a[ROWS * 9];
+  const int tid = threadIdx.x;
+  const int nstrips = (Rc + TI - 1) / TI;
+  const int64_t items = (int64_t)nstrips * Cc;
+  const int64_t chunk = (items + 7) / 8;
+  for (int64_t w = blockIdx.x; w < chunk * 8; w += gridDim.x) {
+    const int64_t item = (w % 8) * chunk + w / 8;
+    if (item >= items) continue;  // (uniform over the workgroup)
+    const int strip = (int)(item / Cc), Ja = (int)(item % Cc);
+    const int Ia0 = strip * TI;
+    const int Ia = Ia0 + tid;
+    const bool on = Ia < Rc;
+    int lo, hi, dummy;
+    tile_extent(max(Ia0 - 1, 0), Rc, R, lo, dummy);
+    tile_extent(min(Ia0 + TI, Rc - 1), Rc, R, dummy, hi);
+    const int len = (hi - lo) * 9;
+    T acc[25];
+#pragma unroll
+    for (int s = 0; s < 25; ++s) acc[s] = T(0);
+    for (int tJ = max(Ja - 1, 0); tJ <= min(Ja + 1, Cc - 1); ++tJ) {
+      int c0, c1;
+      tile_extent(tJ, Cc, C, c0, c1);
+      for (int jc = c0; jc < c1; ++jc) {
+        __syncthreads();  // (the previous column's reads)
+        const size_t base = ((size_t)jc * R + lo) * 9;
+        for (int e = tid; e < len; e += TI) {
+          s_p[e] = pl[base + e];
+          s_a[e] = ap[base + e];
+        }
+        __syncthreads();
+        if (!on) continue;
+        for (int tI = max(Ia - 1, 0); tI <= min(Ia + 1, Rc - 1); ++tI) {
+          int r0, r1;
+          tile_extent(tI, Rc, R, r0, r1);
+          const int sa = (Ja - tJ + 1) * 3 + (Ia - tI + 1);  // slot of a in the block around tile (tI, tJ)
+          for (int ir = r0; ir < r1; ++ir) {
+            const T pv = s_p[(ir - lo) * 9 + sa];
+            if (pv == T(0)) continue;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+              const T v = s_a[(ir - lo) * 9 + s];
+              const int wI = tI + s % 3 - 1 - Ia + 2, wJ = tJ + s / 3 - 1 - Ja + 2;  // 0..4
+              const int wi = wJ * 5 + wI;
+#pragma unroll
+              for (int s2 = 0; s2 < 25; ++s2)
+                if (s2 == wi) acc[s2] += pv * v;
+            }
+          }
+        }
+      }
+    }
+    if (!on) continue;
+    const int a = Ja * Rc + Ia;
     int m = 0;
 #pragma unroll
     for (int s = 0; s < 25; ++s) {
@@ -882,8 +981,8 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
   CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
   hipLaunchKernelGGL((lattice_p_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const int*)dptr<int>(agg),
                      (const T*)dptr<T>(tv), (const T*)dptr<T>(labs), sp.omega_p, dptr<T>(pl), dptr<int>(bad));
-  hipLaunchKernelGGL((lattice_ap_q_kernel<U, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, A0.data(), (const T*)dptr<T>(pl),
-                     (const T*)dptr<T>(L.dinv), (T)L.omega, dptr<T>(apl), dptr<T>(ql), dptr<int>(bad), (const T*)nullptr);
+  lattice_ap_q<U, T>(n, R, Rc, Cc, A0.data(), (const T*)dptr<T>(pl), (const T*)dptr<T>(L.dinv), (T)L.omega, dptr<T>(apl),
+                     dptr<T>(ql), dptr<int>(bad), (const T*)nullptr, st);
   check_launch("lattice P / A P / Q");
   if (read_int(dptr<int>(bad), st) != 0) return false;  // (cannot happen for tile aggregates; the CSR pipeline takes over)
   tv.release();
@@ -896,6 +995,7 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
     try {
       enrich_setup<U, T>(H.enr, A0.data(), R, C, Rc, Cc, (const long long*)size0, (const int*)dptr<int>(agg),
                          (const unsigned long long*)dptr<unsigned long long>(size_c), st);
+      if (knobs().enrich_fused) enrich_coarse_setup<T>(H.enr, (const T*)dptr<T>(ql), R, Rc, Cc, st);
     } catch (const Error& e) {
       if (e.code != CSGPU_OOM) throw;
       (void)hipGetLastError();
@@ -913,8 +1013,16 @@ inline bool lattice_level0_setup(Hierarchy<T>& H, const Dia<U>& A0, int R, int C
     DBuf pcol = dalloc<int>((size_t)nc * 25), pval((size_t)nc * 25 * sizeof(T)), total = dalloc<int>(1);
     int gg = ceil_div(nc, 128);
     if (gg > 65536) gg = 65536;
-    hipLaunchKernelGGL((lattice_galerkin_kernel<T>), dim3(gg), dim3(128), 0, st, R, C, Rc, Cc, (const T*)dptr<T>(pl),
-                       (const T*)dptr<T>(apl), Ac.rp(), dptr<int>(pcol), dptr<T>(pval));
+    if (knobs().galerkin_staged) {
+      constexpr int TI = 64;
+      const int64_t items = (int64_t)ceil_div(Rc, TI) * Cc;
+      hipLaunchKernelGGL((lattice_galerkin_staged_kernel<T, TI>), dim3((int)std::min<int64_t>(((items + 7) / 8) * 8, 16384)),
+                         dim3(TI), 0, st, R, C, Rc, Cc, (const T*)dptr<T>(pl), (const T*)dptr<T>(apl), Ac.rp(), dptr<int>(pcol),
+                         dptr<T>(pval));
+    } else {
+      hipLaunchKernelGGL((lattice_galerkin_kernel<T>), dim3(gg), dim3(128), 0, st, R, C, Rc, Cc, (const T*)dptr<T>(pl),
+                         (const T*)dptr<T>(apl), Ac.rp(), dptr<int>(pcol), dptr<T>(pval));
+    }
     exclusive_scan_i32(Ac.rp(), nc + 1, st, dptr<int>(total));
     Ac.nnz = read_int(dptr<int>(total), st);
     Ac.col.alloc((size_t)std::max<int64_t>(Ac.nnz, 1) * sizeof(int));
@@ -976,10 +1084,10 @@ inline void lattice_level1_setup(Level<T>& L, const int* agg, int R, int C, int 
   DBuf apl((size_t)n * 9 * sizeof(T)), ql((size_t)n * 9 * sizeof(T)), bad = dalloc<int>(1);
   CS_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
   const int g = grid_for(n);
-  hipLaunchKernelGGL((lattice_ap_q_kernel<T, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, Ad.data(), Pl.data(),
-                     (const T*)nullptr, T(0), dptr<T>(apl), (T*)nullptr, dptr<int>(bad), (const T*)nullptr);      // A P
-  hipLaunchKernelGGL((lattice_ap_q_kernel<T, T>), dim3(g), dim3(256), 0, st, n, R, Rc, Cc, Sd.data(), (const T*)dptr<T>(apl),
-                     (const T*)nullptr, T(1), (T*)nullptr, dptr<T>(ql), dptr<int>(bad), Pl.data());                 // P - S (A P)
+  lattice_ap_q<T, T>(n, R, Rc, Cc, Ad.data(), Pl.data(), (const T*)nullptr, T(0), dptr<T>(apl), (T*)nullptr, dptr<int>(bad),
+                     (const T*)nullptr, st);                                                                          // A P
+  lattice_ap_q<T, T>(n, R, Rc, Cc, Sd.data(), (const T*)dptr<T>(apl), (const T*)nullptr, T(1), (T*)nullptr, dptr<T>(ql),
+                     dptr<int>(bad), Pl.data(), st);                                                                  // P - S (A P)
   check_launch("lattice level 1");
   if (read_int(dptr<int>(bad), st) != 0) return;
   L.Adia = std::move(Ad);

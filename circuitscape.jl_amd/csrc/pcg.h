@@ -725,7 +725,7 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   int rsel = 0;
   if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
     fused_rr = fused_restrict_wanted<T>() && recompute && two_product && L0.lattice_two_product() && !need_x && !grounded &&
-               !projected && !enrich && pp.nu_pre == 1 && pp.nu_post == 1;
+               !projected && (!enrich || EN.ntouch > 0) && pp.nu_pre == 1 && pp.nu_post == 1;
     if (fused_rr) {
       const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
       if (W.r2.bytes < want) {
@@ -752,6 +752,8 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   const int rz_rows = spmv_gp + (enrich ? kEnrichParts : 0);
   auto precondition = [&](const int* skip_flag) {   // z = M^-1 r (r in its V-cycle precision: rp), partials of r'z in pa
     if (enrich) enrich_pre<TP, K, !MIXED>(EN, rp, skip_flag, st);
+    // (the fused pass restricted r as the update left it: the pre-pass's change of r follows on the coarse side)
+    if (enrich && fuse.bc_ready) enrich_coarse_fix<TP, K>(EN, dptr<TP>(H.levels[1].b), skip_flag, st);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
     if (enrich) enrich_post<TP, K, !MIXED>(EN, rp, z, pa + (size_t)spmv_gp * K, skip_flag, st);
   };
@@ -1366,7 +1368,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
   T* rbuf[2] = {r, nullptr};
   int rsel = 0, rr_rows = spmv_g;
   if constexpr (!MIXED && lattice_rupd_restrict_fits<T, K>()) {
-    fused_rr = fused_restrict_wanted<T>() && !enrich;
+    fused_rr = fused_restrict_wanted<T>() && (!enrich || EN.ntouch > 0);
     if (fused_rr) {
       const size_t want = ((size_t)n + (size_t)W.tail) * K * sizeof(T);
       if (W.r2.bytes < want) {
@@ -1428,6 +1430,7 @@ inline PcgStreamResult pcg_stream_pairs(Hierarchy<TP>& H, PcgWork<T, TP>& W, con
     hipLaunchKernelGGL((stream_restart_kernel<T, TP, K>), dim3(1), dim3(256), 0, st, (const CgScalars*)S, r,
                        MIXED ? rp : (TP*)nullptr, nf, xf);
     if (enrich) enrich_pre<TP, K, !MIXED>(EN, rp, (const int*)nullptr, st);
+    if (enrich && fuse.bc_ready) enrich_coarse_fix<TP, K>(EN, dptr<TP>(H.levels[1].b), (const int*)nullptr, st);
     vcycle<TP, K>(H, 0, rp, z, pp.nu_pre, pp.nu_post, pp.nu_coarse, st, &fuse);
     if (enrich) enrich_post<TP, K, !MIXED>(EN, rp, z, pa + (size_t)spmv_gp * K, (const int*)nullptr, st);
     {

@@ -1290,6 +1290,51 @@ def check_enrichment(L, oracle, monkeypatch, shape=(150, 141), batch=8, frac=0.1
     return {pb: (out[(pb, False)][1] / float(batch), out[(pb, True)][1] / float(batch), out[(pb, True)][7]) for pb in (0, 4)}
 
 
+def check_enrichment_fused(L, oracle, shape=(96, 85), batches=(16,), frac=0.15, streams=(-1, 1), check_every=(1, 3)):
+    """Enriched levels on the fused residual update + restriction (round 6, enrich_coarse_fix, csrc/enrich.h): the fused pass
+    restricts the residual as the update left it, the pre-pass of the enrichment then changes r on the halo cells, and the
+    restriction's share of that change is applied on the coarse side from a transposed list of Q (built with atomics, sorted
+    per coarse node: fixed summation order). Against the two-pass form of the same handle options (fused_restrict = -1):
+    same iteration counts, resistances equal to rounding (the two forms sum b_c in different orders -- not the same bits);
+    against the tight oracle 1e-6; bit-reproducible from call to call AND from set-up to set-up (the sort); batch and
+    streaming loops, graph-captured chunks of 1 and 3 iterations."""
+    from oracle import refgraph as rg
+    rng = np.random.default_rng(23)
+    base = np.exp(0.5 * rng.standard_normal(shape))
+    g = np.where(rng.random(shape) < frac, 0.0, base)
+    nm = rg.construct_node_map(g, None)
+    A = oracle.regularize(rg.laplacian(rg.construct_graph(g, nm, False, False)))
+    res = {}
+    for batch in batches:
+        src = dst = None
+        for stream in streams:
+            for ce in check_every:
+                out = {}
+                for fused in (-1, 1, 1):
+                    with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=0, enrich=0, enrich_tau=0.1, fused_restrict=fused,
+                                                          stream=stream, stream_min=1, check_every=ce, fixed_k=1)) as h:
+                        info = h.info
+                        assert info["enrich_vectors"] > 0 and info["n"] == A.shape[0]
+                        if src is None:
+                            labels, _ = h.components()
+                            big = np.flatnonzero(labels == np.bincount(labels).argmax())
+                            ids = np.random.default_rng(6).choice(big, size=2 * (batch + 5), replace=False)
+                            src, dst = [int(v) for v in ids[:batch + 5]], [int(v) for v in ids[batch + 5:]]
+                        R, _, _, st = h.solve_pairs(src, dst)
+                        R2, _, _, st2 = h.solve_pairs(src, dst)
+                        assert st["not_converged"] == 0 and np.array_equal(R, R2) and st["total_iters"] == st2["total_iters"]
+                        assert (h.info["fused_restrict_solves"] > 0) == (fused == 1), (fused, h.info["fused_restrict_solves"])
+                        out.setdefault(fused, []).append((R, st["total_iters"], st["max_relres"]))
+                two, fa, fb = out[-1][0], out[1][0], out[1][1]
+                assert np.array_equal(fa[0], fb[0]) and fa[1] == fb[1], "fused + enriched: not reproducible across set-ups"
+                assert np.max(np.abs(fa[0] - two[0]) / np.abs(two[0])) < 1e-7, np.max(np.abs(fa[0] - two[0]) / np.abs(two[0]))
+                assert abs(fa[1] - two[1]) <= max(1, two[1] // 50), (fa[1], two[1])
+                res[(batch, stream, ce)] = (two[1], fa[1], float(np.max(np.abs(fa[0] - two[0]) / np.abs(two[0]))))
+        Ro, _, _ = oracle.OracleAMG(A).solve_pairs(src, dst, rtol=1e-12, atol=0.0, criterion=1, nthreads=8)
+        assert np.max(np.abs(fa[0] - Ro) / Ro) < 1e-6
+    return res
+
+
 def check_heterogeneous_rasters(L, oracle, N=150, batch=4):
     """strongly heterogeneous conductances (log-normal sigma = 2, 3: cell-to-cell ratios up to e^+-9).
     The reference copes through symmetric Gauss-Seidel (src/core.jl:166-167); here the regular tiles are refined by the

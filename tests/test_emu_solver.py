@@ -1469,3 +1469,11 @@ def test_fused_residual_update_and_restriction(emu_lib):
     """see helpers.check_fused_residual_restriction"""
     from helpers import check_fused_residual_restriction
     check_fused_residual_restriction(emu_lib, shapes=((64, 57), (31, 100)))
+
+
+def test_enriched_levels_take_the_fused_residual_pass(emu_lib, oracle):
+    """see helpers.check_enrichment_fused"""
+    from helpers import check_enrichment_fused
+    r = check_enrichment_fused(emu_lib, oracle)
+    print("enrichment on the fused pass (iterations two-pass / fused, max rel diff):", r)
+

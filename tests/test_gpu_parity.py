@@ -784,3 +784,12 @@ def test_fused_residual_update_and_restriction_gpu(gpu_lib):
     """see helpers.check_fused_residual_restriction (more and larger shapes on the device)"""
     from helpers import check_fused_residual_restriction
     check_fused_residual_restriction(gpu_lib, shapes=((64, 57), (101, 130), (31, 200), (700, 333)))
+
+
+@pytest.mark.gpu
+def test_enriched_levels_take_the_fused_residual_pass_gpu(gpu_lib, oracle):
+    """csrc/enrich.h::enrich_coarse_fix on the device (helpers.check_enrichment_fused): 700 x 633 with 15 % NODATA, K = 16 and 32"""
+    from helpers import check_enrichment_fused
+    r = check_enrichment_fused(gpu_lib, oracle, shape=(700, 633), batches=(16, 32))
+    print("enrichment on the fused pass (iterations two-pass / fused, max rel diff):", r)
+

@@ -59,4 +59,6 @@ for seed in seeds:
                               "pairs": len(src), "iters_mean": st["total_iters"] / float(len(src)), "iters_max": st["max_iters"],
                               "ms_per_16_pairs": ms * 16.0 / len(src), "setup_device_ms": info["setup_ms"], "setup_wall_s": t_setup,
                               "not_converged": st["not_converged"], "max_relres": st["max_relres"],
-                              "device_bytes": info["device_bytes"], "R0": float(R[0])}), flush=True)
+                              "device_bytes": info["device_bytes"], "R0": float(R[0]),
+                              "fused_restrict_solves": h.info["fused_restrict_solves"],
+                              "enrich_fused": 0 if os.environ.get("CSGPU_NO_ENRICH_FUSED") else 1}), flush=True)
