@@ -426,10 +426,12 @@ def nodata_leg(lib, g, B, make_opts, precond, sync, frac=0.15, steps=2):
             idx = [(k * B + i) % len(pairs) for i in range(B)]
             return [pairs[i][0] for i in idx], [pairs[i][1] for i in idx]
         el, res, agg = run_pairs(h, batch_pairs, steps, 1, sync, one_call=True)
+        fused = h.info.get("fused_restrict_solves", 0)
     finally:
         h.close()
     sv = (info["setup_ms"] + info["upload_ms"]) / 1e3
     return {"value": steps * B / (el + sv * steps * B / 100.0), "unit": "pair-solves/s", "nodata_fraction": frac,
+            "fused_restrict_batches": int(fused),   # > 0: the enriched level took the fused residual update + restriction (enrich.h)
             "nodes": int(info["n"]), "giant_component_nodes": int(giant.size), "components": int(ncomp),
             "lattice_period": info["lattice_period"], "levels": info["levels"], "level_form": info["level_form"],
             "enrich_vectors": info.get("enrich_vectors", 0), "steps": steps,

@@ -984,11 +984,11 @@ struct Enrich {
   DBuf hptr, hvec, hcoef;   // A E by rows: (vector, coefficient) per halo cell
   DBuf t, c, c2, sbuf, save, ppart;  // work: [nvec][K] doubles x 3, [nhalo][K] (A E c) and saved residual entries, block partials
   int work_k = 0, work_bytes = 0;
-  // Q^T restricted to the halo cells, by coarse rows (enrich_coarse_setup): the correction of a restriction that ran on the
-  // residual BEFORE the pre-pass changed it (fused residual update + restriction, lattice.h)
+  // W = Q^T A E by coarse rows (enrich_coarse_setup): the correction of a restriction that ran on the residual BEFORE the
+  // pre-pass changed it (fused residual update + restriction, lattice.h): b_c -= W c
   int ntouch = 0;           // coarse nodes with a halo cell in their 3 x 3 block of tiles
   DBuf tcell, tptr;         // [ntouch] coarse node, [ntouch + 1] first entry
-  DBuf th, tw;              // per entry: position of the fine cell in hcell (ascending per row), Q[cell, coarse node] (double)
+  DBuf th, tw;              // per entry: vector, W[coarse node, vector] (double)
   size_t device_bytes() const {
     return vptr.bytes + vcell.bytes + vphi.bytes + vhalo.bytes + binv.bytes + aptr.bytes + acell.bytes + acoef.bytes +
            hcell.bytes + hptr.bytes + hvec.bytes + hcoef.bytes + t.bytes + c.bytes + c2.bytes + sbuf.bytes + save.bytes + ppart.bytes +

@@ -638,9 +638,12 @@ inline void enrich_post(Enrich& E, T* r, T* z, double* part, const int* skip, hi
 
 // ---- the restriction's share of the pre-pass (fused residual update + restriction) ------------------------------------------
 // The fused pass of lattice.h leaves b_c = Q^T r; the V-cycle of an enriched level wants Q^T (r - s) with s = A E c on the halo
-// cells (enrich_pre_kernel keeps it in sbuf). Q^T s is a sum over <= 9 coarse nodes per halo cell: gathered per COARSE node
-// from a transposed list built once per set-up (counts and slots by atomics, every row then sorted by halo position: the
-// summation order is fixed), one thread per (coarse node, column).
+// cells. Q^T s = (Q^T A E) c =: W c, and W is tiny: a coarse node meets the vectors of the 5 x 5 block of tiles around it at
+// most (2.2 M entries at 10000^2 / 15 % NODATA against 25 M entries of Q^T on the halo cells -- the first version gathered
+// sbuf through those and cost 1.3 ms per K = 32 iteration, more than any pass of the enrichment itself; c is 46 MB and stays
+// in the last-level cache). Built once per set-up: Q^T on the halo cells by coarse rows (counts and slots by atomics, every
+// row then sorted by halo position), multiplied with the rows of A E in that order -- fixed summation order, deterministic.
+// One thread per (coarse node, column) applies it.
 __device__ __forceinline__ int enr_tile(int i, int nc) {  // (lat_tile of lattice.h)
   const int t = i / 3;
   return t < nc ? t : nc - 1;
@@ -697,6 +700,52 @@ __global__ __launch_bounds__(256) void enrich_coarse_rows_kernel(int nc, const i
   }
 }
 
+// row u of W = Q^T A E from row u of Q^T (entries sorted by halo position) and the rows of A E; vectors in the order they
+// first appear. PASS 0: number of distinct vectors (ovf when more than kEnrichWMax); PASS 1: (vector, value) from wptr[u]
+static const int kEnrichWMax = 40;
+template <int PASS>
+__global__ __launch_bounds__(64) void enrich_coarse_w_kernel(int ntouch, const int* __restrict__ tptr, const int* __restrict__ th,
+                                                            const double* __restrict__ tw, const int* __restrict__ hptr,
+                                                            const int* __restrict__ hvec, const double* __restrict__ hcoef,
+                                                            int* __restrict__ wcnt, const int* __restrict__ wptr,
+                                                            int* __restrict__ wv, double* __restrict__ ww, int* __restrict__ ovf) {
+  for (int u = blockIdx.x * 64 + threadIdx.x; u < ntouch; u += gridDim.x * 64) {
+    int vid[kEnrichWMax];
+    double val[kEnrichWMax];
+    int m = 0;
+    bool over = false;
+    for (int e = tptr[u]; e < tptr[u + 1]; ++e) {
+      const int h = th[e];
+      const double w = tw[e];
+      for (int f = hptr[h]; f < hptr[h + 1]; ++f) {
+        const int v = hvec[f];
+        int k = 0;
+        while (k < m && vid[k] != v) ++k;
+        if (k == m) {
+          if (m == kEnrichWMax) {
+            over = true;
+            continue;
+          }
+          vid[m] = v;
+          val[m] = 0.0;
+          ++m;
+        }
+        val[k] += w * hcoef[f];
+      }
+    }
+    if (over) atomicOr(ovf, 1);
+    if (PASS == 0) {
+      wcnt[u] = m;
+    } else {
+      const int b = wptr[u];
+      for (int k = 0; k < m; ++k) {
+        wv[b + k] = vid[k];
+        ww[b + k] = val[k];
+      }
+    }
+  }
+}
+
 template <class T>
 inline void enrich_coarse_setup(Enrich& E, const T* q, int R, int Rc, int Cc, hipStream_t st) {
   E.ntouch = 0;
@@ -716,30 +765,62 @@ inline void enrich_coarse_setup(Enrich& E, const T* q, int R, int Rc, int Cc, hi
   DBuf cursor = dalloc<int>((size_t)nc + 1);
   CS_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
   E.tcell = dalloc<int>((size_t)ntouch);
-  E.tptr = dalloc<int>((size_t)ntouch + 1);
-  E.th = dalloc<int>((size_t)nent);
-  E.tw = dalloc<double>((size_t)nent);
+  DBuf qptr = dalloc<int>((size_t)ntouch + 1), qh = dalloc<int>((size_t)nent), qw = dalloc<double>((size_t)nent);   // Q^T on the halo cells
   hipLaunchKernelGGL((enrich_coarse_lists_kernel<T, 1>), dim3(g), dim3(256), 0, st, E.nhalo, (const int*)dptr<int>(E.hcell), R, Rc, Cc,
-                     q, dptr<int>(cursor), (const int*)dptr<int>(cnt), dptr<int>(E.th), dptr<double>(E.tw));
+                     q, dptr<int>(cursor), (const int*)dptr<int>(cnt), dptr<int>(qh), dptr<double>(qw));
   hipLaunchKernelGGL(enrich_coarse_rows_kernel, dim3(grid_for(nc)), dim3(256), 0, st, nc, (const int*)dptr<int>(cnt),
-                     (const int*)dptr<int>(flag), dptr<int>(E.tcell), dptr<int>(E.tptr), dptr<int>(E.th), dptr<double>(E.tw));
-  CS_HIP(hipMemcpyAsync(dptr<int>(E.tptr) + ntouch, &nent, sizeof(int), hipMemcpyHostToDevice, st));
+                     (const int*)dptr<int>(flag), dptr<int>(E.tcell), dptr<int>(qptr), dptr<int>(qh), dptr<double>(qw));
+  CS_HIP(hipMemcpyAsync(dptr<int>(qptr) + ntouch, &nent, sizeof(int), hipMemcpyHostToDevice, st));
+  // W = Q^T (A E), row by row
+  E.tptr = dalloc<int>((size_t)ntouch + 1);
+  CS_HIP(hipMemsetAsync(E.tptr.p, 0, E.tptr.bytes, st));
+  CS_HIP(hipMemsetAsync(tot.p, 0, tot.bytes, st));
+  const int gw = std::min(ceil_div(ntouch, 64), 65536);
+  hipLaunchKernelGGL((enrich_coarse_w_kernel<0>), dim3(gw), dim3(64), 0, st, ntouch, (const int*)dptr<int>(qptr), (const int*)dptr<int>(qh),
+                     (const double*)dptr<double>(qw), (const int*)dptr<int>(E.hptr), (const int*)dptr<int>(E.hvec),
+                     (const double*)dptr<double>(E.hcoef), dptr<int>(E.tptr), (const int*)nullptr, (int*)nullptr, (double*)nullptr,
+                     dptr<int>(tot) + 1);
+  exclusive_scan_i32(dptr<int>(E.tptr), (int64_t)ntouch + 1, st, dptr<int>(tot));
+  const int nw = read_int(dptr<int>(tot), st);
+  if (nw <= 0 || read_int(dptr<int>(tot) + 1, st) != 0) {  // (a coarse node that meets more than kEnrichWMax vectors: two passes)
+    E.tcell.release();
+    E.tptr.release();
+    return;
+  }
+  E.th = dalloc<int>((size_t)nw);
+  E.tw = dalloc<double>((size_t)nw);
+  hipLaunchKernelGGL((enrich_coarse_w_kernel<1>), dim3(gw), dim3(64), 0, st, ntouch, (const int*)dptr<int>(qptr), (const int*)dptr<int>(qh),
+                     (const double*)dptr<double>(qw), (const int*)dptr<int>(E.hptr), (const int*)dptr<int>(E.hvec),
+                     (const double*)dptr<double>(E.hcoef), (int*)nullptr, (const int*)dptr<int>(E.tptr), dptr<int>(E.th),
+                     dptr<double>(E.tw), dptr<int>(tot) + 1);
   check_launch("enrichment coarse lists");
   CS_HIP(hipStreamSynchronize(st));  // (nent is a stack variable; the temporaries go back to the pool)
   E.ntouch = ntouch;
   if (knobs().verbose)
-    fprintf(stderr, "csgpu: coarse-space enrichment: %d coarse nodes take the restriction's share of the pre-pass (%d entries)\n",
-            ntouch, nent);
+    fprintf(stderr, "csgpu: coarse-space enrichment: %d coarse nodes take the restriction's share of the pre-pass (%d entries of W = Q'AE from %d of Q')\n",
+            ntouch, nw, nent);
 }
 
-// bc -= Q^T s on the touched coarse nodes (s = sbuf of the pre-pass that has just run)
+// bc -= W c on the touched coarse nodes (c = cc of the gather pass that has just run)
 template <class T, int K>
 __global__ __launch_bounds__(256) void enrich_coarse_fix_kernel(int ntouch, const int* __restrict__ tcell, const int* __restrict__ tptr,
                                                                 const int* __restrict__ th, const double* __restrict__ tw,
                                                                 const double* __restrict__ sbuf, T* __restrict__ bc,
                                                                 const int* __restrict__ skip) {
   if (skip && *skip) return;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)ntouch * K; id += (int64_t)gridDim.x * 256) {
+  // (a vector's row of c is read by the coarse nodes of up to five coarse columns: every XCD -- blockIdx % 8 -- walks ONE
+  // contiguous eighth of the ascending list, so that the re-reads find the row in that XCD's L2)
+  const int64_t items = (int64_t)ntouch * K;
+  int64_t lo = 0, hi = items, first = blockIdx.x, nblk = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int64_t per = ((items + 8 * 256 - 1) / (8 * 256)) * 256;
+    const int xcd = blockIdx.x % 8;
+    lo = (int64_t)xcd * per;
+    hi = lo + per < items ? lo + per : items;
+    first = blockIdx.x / 8;
+    nblk = (gridDim.x + 7 - xcd) / 8;
+  }
+  for (int64_t id = lo + first * 256 + threadIdx.x; id < hi; id += nblk * 256) {
     const int u = (int)(id / K), c = (int)(id % K);
     double s = 0.0;
     for (int e = tptr[u]; e < tptr[u + 1]; ++e) s += tw[e] * sbuf[(int64_t)th[e] * K + c];
@@ -752,7 +833,7 @@ template <class T, int K>
 inline void enrich_coarse_fix(Enrich& E, T* bc, const int* skip, hipStream_t st) {
   hipLaunchKernelGGL((enrich_coarse_fix_kernel<T, K>), dim3(grid_for((int64_t)E.ntouch * K)), dim3(256), 0, st, E.ntouch,
                      (const int*)dptr<int>(E.tcell), (const int*)dptr<int>(E.tptr), (const int*)dptr<int>(E.th),
-                     (const double*)dptr<double>(E.tw), (const double*)dptr<double>(E.sbuf), bc, skip);
+                     (const double*)dptr<double>(E.tw), (const double*)dptr<double>(E.c), bc, skip);
 }
 
 }  // namespace csgpu
