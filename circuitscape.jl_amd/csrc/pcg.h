@@ -742,9 +742,12 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   }
   // pair solves on the lattice two-product path (see PcgParams::pair_src): the first restriction is a scatter of the pairs'
   // <= 18 entries per column -- any precision, any batch width -- and on the fused path r0 is never stored at all
+  // (an enriched level on the fused path takes the scatter too -- the pre-pass's share follows on the coarse side, exactly as
+  // after a fused update, so a column's first cycle sees the same b_c here and in the streaming loop -- but r0 itself is
+  // stored: the pre-pass reads it)
   const bool sparse_bc = pp.pair_src && pp.rhs_in_r && knobs().sparse_init && use_dia && two_product &&
-                         L0.lattice_two_product() && !grounded && !projected && !enrich;
-  const bool virtual_r0 = sparse_bc && fused_rr && pp.bb_host;
+                         L0.lattice_two_product() && !grounded && !projected && (!enrich || fused_rr);
+  const bool virtual_r0 = sparse_bc && fused_rr && pp.bb_host && !enrich;
   if (enrich && (EN.work_k != K || EN.work_bytes != (int)sizeof(TP))) {
     W.drop_graphs();  // (captured chunks hold the old work pointers)
     enrich_ensure_work<TP, K>(EN);

@@ -1685,7 +1685,7 @@ def check_single_level_handles_compute_in_matrix_precision(L):
         assert h.info["levels"] >= 2 and h.info["precond_bytes"] == 4
 
 
-def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nodata=False, sigma=1.0, oracle=None):
+def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nodata=False, sigma=1.0, oracle=None, extra=None):
     """Streaming pair solves (pcg_stream_pairs, csrc/pcg.h: a column takes the next pair of the call's list as soon as its
     own pair has converged) against the batch path on the same handle options: every per-column quantity is independent
     of the neighbouring columns, so resistances, gathered focal voltages and per-pair iteration counts must be IDENTICAL
@@ -1703,8 +1703,10 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
             # csgpu_opts.stream: 1 = from the first pair on, -1 = never; .stream_min = 1: whatever the problem size
             # (fixed_k = 1: the identity between the stream and the batches is one between columns of the SAME width -- the
             # batch path otherwise runs a short last batch at its own, narrower width, whose results differ in the last bits)
+            # (`extra`: further options; with an enrichment threshold in it the handle must have enriched aggregates AND have run
+            # the fused residual pass -- round 6: both loops then correct b_c on the coarse side, enrich_coarse_fix)
             with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1,
-                                                  stream=1 if mode == "stream" else -1)) as h:
+                                                  stream=1 if mode == "stream" else -1, **(extra or {}))) as h:
                 assert h.info["stream_mode"] == (1 if mode == "stream" else -1)
                 nm = h.raster_nodemap()
                 lab, _ = h.components()
@@ -1716,6 +1718,8 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
                 gather = [int(p) for p in pts[:5]]
                 R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
                 assert st["not_converged"] == 0 and st["max_relres"] < 1e-4, (mode, st)
+                if extra and "enrich_tau" in extra and pb == 0:
+                    assert h.info["enrich_vectors"] > 0 and h.info["fused_restrict_solves"] > 0, h.info
                 res[(pb, mode)] = (R.copy(), Gv.copy(), dict(st))
                 if mode == "stream":
                     assert st["stream_slots"] > 0, "the streaming path did not run"
@@ -1742,7 +1746,8 @@ def check_stream_pairs(L, monkeypatch, N=90, batch=8, npairs=29, pbs=(0, 4), nod
         assert ss["stream_slots"] <= (ss["total_iters"] + nsolved) // batch + ss["max_iters"] + 2
     # the adaptive rule (default): the first batch runs as a batch, the spread of its iteration counts decides for the rest
     for pb in pbs:
-        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1)) as h:
+        with L.raster_setup(g, L.default_opts(batch=batch, precond_bytes=pb, check_every=1, stream_min=1, fixed_k=1,
+                                              **(extra or {}))) as h:
             R, Gv, _, st = h.solve_pairs(src, dst, gather=gather)
             if pb == 0:
                 assert np.array_equal(R, res[(pb, "batch")][0]) and np.array_equal(Gv, res[(pb, "batch")][1])

@@ -1293,6 +1293,8 @@ def test_streaming_pair_solves_match_the_batch_path(emu_lib, oracle, monkeypatch
     from helpers import check_stream_pairs
     check_stream_pairs(emu_lib, monkeypatch, N=66, batch=8, npairs=21, pbs=(0,), oracle=oracle)
     check_stream_pairs(emu_lib, monkeypatch, N=60, batch=16, npairs=37, pbs=(4,), nodata=True, sigma=2.0)
+    # enriched level 0 on the fused residual pass (fp64, K = 16): the first cycle of a column sees the same b_c in both loops
+    check_stream_pairs(emu_lib, monkeypatch, N=57, batch=16, npairs=37, pbs=(0,), nodata=True, extra=dict(enrich_tau=0.15))
 
 
 def test_host_csr_component_with_offset_coordinates(emu_lib):

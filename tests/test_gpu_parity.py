@@ -543,7 +543,12 @@ def test_recurrence_residual_post_check_at_size(gpu_lib, sigma):
     src, dst = [int(v) for v in ids[:16]], [int(v) for v in ids[16:]]
     out = {}
     for explicit in (0, 1):
-        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, precond_bytes=4, explicit_check=explicit)) as h:
+        # (fused_restrict = -1: the sigma = 3 raster's fp32 hierarchy is replaced by an fp64 one -- hetero_fp64_frac -- and its
+        # refined tiles are enriched; since round 6 such a handle runs the fused residual pass when no x is carried, whose
+        # coarse-side correction sums b_c in another order than the two-pass form the explicit mode keeps. The comparison
+        # here is between the two CHECKS on one and the same iteration)
+        with gpu_lib.raster_setup(g, gpu_lib.default_opts(batch=16, precond_bytes=4, explicit_check=explicit,
+                                                          fused_restrict=-1)) as h:
             R, _, _, st = h.solve_pairs(src, dst)
             assert st["not_converged"] == 0 and st["max_relres"] < 1e-4
             out[explicit] = (R, st)
@@ -639,6 +644,7 @@ def test_streaming_pair_solves_match_the_batch_path_gpu(gpu_lib, oracle, monkeyp
     check_stream_pairs(gpu_lib, monkeypatch, N=300, batch=8, npairs=29, oracle=oracle)
     check_stream_pairs(gpu_lib, monkeypatch, N=700, batch=16, npairs=53, nodata=True, sigma=2.0)
     check_stream_pairs(gpu_lib, monkeypatch, N=500, batch=32, npairs=75, pbs=(4,), nodata=True)
+    check_stream_pairs(gpu_lib, monkeypatch, N=400, batch=32, npairs=75, pbs=(0,), nodata=True, extra=dict(enrich_tau=0.15))
 
 
 def test_polygon_rasters_on_the_lattice_path_gpu(gpu_lib, monkeypatch):
