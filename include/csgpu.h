@@ -229,7 +229,10 @@ typedef struct csgpu_opts {
                                  residual ping-pongs between two buffers: + n x batch values of device memory; results are
                                  those of the two-pass path bit for bit); -1 = two passes; 0 = fused in double precision
                                  (+7 % pair-solves/s at 10000^2), two passes in single precision (where the fused pass is
-                                 3 - 5 % slower) */
+                                 3 - 5 % slower). Levels with enriched aggregates (rasters with
+                                 NODATA cells, csrc/enrich.h) take the fused pass too: the enrichment's change of the residual
+                                 reaches b_c through a coarse-side correction (W = Q'AE), whose sums run in another order --
+                                 THERE the fused and the two-pass results agree to rounding, not bit for bit */
   int32_t sparse_init;        /* fused lattice path, pair solves: 0 / 1 = the right-hand side of a batch, r0 = e_dst - e_src, is
                                  never stored -- the first restriction scatters <= 18 entries per column, the first second
                                  product and the first residual update synthesise it (three passes over n x batch values and
