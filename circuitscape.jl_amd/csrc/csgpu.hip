@@ -151,6 +151,7 @@ inline Knobs knobs_from_opts(const csgpu_opts& o) {
   if (on("KERNEL_GAIN_REF")) k.kernel_gain_ref = true;
   if (on("TAIL_DEBUG")) k.tail_debug = true;
   if (on("GALERKIN_STAGED")) k.galerkin_staged = true;
+  if (on("NO_RASTER_TRANSPOSE")) k.raster_transpose = false;
   if (on("NO_ENRICH_FUSED")) k.enrich_fused = false;
   num("APQ_NT", [&](double v) { k.apq_nt = (int)v; });
   num("TIMED_LAUNCHES", [&](double v) { k.timed_launches = (int)v; });
@@ -921,7 +922,7 @@ struct Solver : ISolver {
   // Raster -> lattice form -> hierarchy, no CSR (lattice_setup.h). dcond / dground: device rasters (row-major); node: the
   // exclusive scan of the valid flags (column-major). Returns false when the pipeline declined (the caller falls back).
   bool setup_lattice_direct(DBuf& dcond, DBuf& dground, DBuf& node, int64_t R, int64_t C, int four, int avg_res, int reg,
-                            std::chrono::steady_clock::time_point t0) {
+                            std::chrono::steady_clock::time_point t0, int colmajor = 0) {
     const int64_t ncells = R * C;
     const int gc = grid_for(ncells);
     if (cellspace) {
@@ -931,7 +932,8 @@ struct Solver : ISolver {
     }
     hipLaunchKernelGGL((raster_maps_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
                        (const int*)dptr<int>(node), dptr<int>(nodemap), cellspace ? dptr<int>(cellmap) : (int*)nullptr,
-                       cellspace ? dptr<int>(node2cell) : (int*)nullptr, cellspace ? dptr<int>(cell2node) : (int*)nullptr);
+                       cellspace ? dptr<int>(node2cell) : (int*)nullptr, cellspace ? dptr<int>(cell2node) : (int*)nullptr,
+                       colmajor);
     dia.n = ncells;
     dia.R = (int)R;
     dia.rows.alloc((size_t)ncells * 5 * sizeof(T));
@@ -939,12 +941,13 @@ struct Solver : ISolver {
     DBuf part = dalloc<double>(gc), cnt = dalloc<unsigned long long>(gc), size0;
     hipLaunchKernelGGL((raster_dia_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, four, avg_res,
                        (const T*)dptr<T>(dcond), dground.p ? (const T*)dptr<T>(dground) : (const T*)nullptr, dptr<T>(dia.rows),
-                       dground.p ? dptr<T>(ground_node) : (T*)nullptr, dptr<double>(part), dptr<unsigned long long>(cnt));
+                       dground.p ? dptr<T>(ground_node) : (T*)nullptr, dptr<double>(part), dptr<unsigned long long>(cnt),
+                       colmajor);
     if (cellspace) size0.alloc((size_t)ncells * sizeof(long long));
     hipLaunchKernelGGL((raster_dia_finish_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
                        dptr<T>(dia.rows), (const double*)dptr<double>(part), gc,
                        reg ? (double)std::numeric_limits<T>::epsilon() : 0.0,
-                       cellspace ? dptr<long long>(size0) : (long long*)nullptr);
+                       cellspace ? dptr<long long>(size0) : (long long*)nullptr, colmajor);
     std::vector<unsigned long long> hc((size_t)gc);
     CS_HIP(hipMemcpyAsync(hc.data(), cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     check_launch("raster -> lattice form");
@@ -985,7 +988,22 @@ struct Solver : ISolver {
     DBuf node = dalloc<int>((size_t)ncells + 1);
     CS_HIP(hipMemsetAsync(node.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
     const int gc = grid_for(ncells);
-    hipLaunchKernelGGL((raster_valid_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C, dptr<T>(dcond), dptr<int>(node));
+    // (the raster kernels of the index-free pipeline read the column-major copies: coalesced along raster columns)
+    const bool transposed = kn.raster_transpose && R >= 32 && C >= 32;
+    DBuf dcondT, dgroundT;
+    if (transposed) {
+      const int gt = (int)std::min<int64_t>(((R + 31) / 32) * ((C + 31) / 32), 65536);
+      dcondT.alloc((size_t)ncells * sizeof(T));
+      hipLaunchKernelGGL((raster_transpose_kernel<T>), dim3(gt), dim3(256), 0, st, (int)R, (int)C, (const T*)dptr<T>(dcond),
+                         dptr<T>(dcondT));
+      if (ground) {
+        dgroundT.alloc((size_t)ncells * sizeof(T));
+        hipLaunchKernelGGL((raster_transpose_kernel<T>), dim3(gt), dim3(256), 0, st, (int)R, (int)C,
+                           (const T*)dptr<T>(dground), dptr<T>(dgroundT));
+      }
+    }
+    hipLaunchKernelGGL((raster_valid_kernel<T>), dim3(gc), dim3(256), 0, st, (int)R, (int)C,
+                       transposed ? dptr<T>(dcondT) : dptr<T>(dcond), dptr<int>(node), transposed ? 1 : 0);
     DBuf total = dalloc<int>(1);
     exclusive_scan_i32(dptr<int>(node), ncells + 1, st, dptr<int>(total));
     n_api = read_int(dptr<int>(total), st);
@@ -997,7 +1015,9 @@ struct Solver : ISolver {
     nodemap.alloc((size_t)ncells * sizeof(int));
     if (n == ncells && want_lattice_pipeline(R, C)) {
       // every cell a row: the whole level 0 is built from the lattice form, without a CSR matrix (lattice_setup.h)
-      if (setup_lattice_direct(dcond, dground, node, R, C, four, avg_res, reg, t0)) return;
+      if (setup_lattice_direct(transposed ? dcondT : dcond, transposed ? dgroundT : dground, node, R, C, four, avg_res, reg, t0,
+                               transposed ? 1 : 0))
+        return;
     }
     CS_REQUIRE(ncells * 9 < ((int64_t)1 << 31), CSGPU_BAD_ARGS,
                "raster too large for the CSR pipeline (int32 entry offsets); only all-valid / mostly-valid rasters without "

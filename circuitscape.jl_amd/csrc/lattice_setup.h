@@ -56,15 +56,18 @@ template <class T>
 __global__ __launch_bounds__(256) void raster_dia_kernel(int R, int C, int four, int avg_res, const T* __restrict__ cond,
                                                          const T* __restrict__ ground, T* __restrict__ rows,
                                                          T* __restrict__ ground_node, double* __restrict__ part,
-                                                         unsigned long long* __restrict__ cnt) {
+                                                         unsigned long long* __restrict__ cnt, int colmajor = 0) {
   __shared__ double sm[4];
   __shared__ unsigned long long smc[4];
   const int64_t n = (int64_t)R * C;
+  // (colmajor: cond / ground are the transposed copies -- cell (i, j) at j*R + i; same values, same order of operations)
+  const size_t si = colmajor ? (size_t)1 : (size_t)C, sj = colmajor ? (size_t)R : (size_t)1;
   double ss = 0.0;
   unsigned long long c = 0;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
-    const int i = (int)(id % R), j = (int)(id / R);
-    const double g0 = (double)cond[(size_t)i * C + j];
+    int i, j;
+    cell_rc(id, R, i, j);
+    const double g0 = (double)cond[(size_t)i * si + (size_t)j * sj];
     T out[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (g0 > 0.0) {
       double deg = 0.0;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void raster_dia_kernel(int R, int C, int four,
           if (ii < 0 || ii >= R || (di == 0 && dj == 0)) continue;
           const bool diag = (di != 0 && dj != 0);
           if (diag && four) continue;
-          const double g1 = (double)cond[(size_t)ii * C + jj];
+          const double g1 = (double)cond[(size_t)ii * si + (size_t)jj * sj];
           if (!(g1 > 0.0)) continue;
           const double w = raster_edge(g0, g1, diag, avg_res != 0);
           deg += w;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void raster_dia_kernel(int R, int C, int four,
           else if (dj == 1 && di == 1) out[4] = v;
         }
       }
-      const double gnd = ground ? (double)ground[(size_t)i * C + j] : 0.0;
+      const double gnd = ground ? (double)ground[(size_t)i * si + (size_t)j * sj] : 0.0;
       out[0] = (T)(deg + gnd);
       ss += (double)out[0] * (double)out[0];
       ++c;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void raster_dia_kernel(int R, int C, int four,
 template <class T>
 __global__ __launch_bounds__(256) void raster_dia_finish_kernel(int R, int C, const T* __restrict__ cond, T* __restrict__ rows,
                                                                 const double* __restrict__ part, int nparts, double eps,
-                                                                long long* __restrict__ size0) {
+                                                                long long* __restrict__ size0, int colmajor = 0) {
   __shared__ double sm[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -123,8 +126,14 @@ __global__ __launch_bounds__(256) void raster_dia_finish_kernel(int R, int C, co
   const T shift = (T)(eps * sqrt(s));
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
-    const int i = (int)(id % R), j = (int)(id / R);
-    const bool valid = cond[(size_t)i * C + j] > T(0);
+    bool valid;
+    if (colmajor) {
+      valid = cond[id] > T(0);
+    } else {
+      int i, j;
+      cell_rc(id, R, i, j);
+      valid = cond[(size_t)i * C + j] > T(0);
+    }
     if (size0) size0[id] = valid ? 1 : 0;
     if (!valid) {
       rows[id * 5] = T(1);
@@ -256,11 +265,13 @@ __global__ __launch_bounds__(256) void cell_identity_kernel(int64_t ncells, cons
 template <class T>
 __global__ __launch_bounds__(256) void raster_maps_kernel(int R, int C, const T* __restrict__ cond, const int* __restrict__ node,
                                                           int* __restrict__ nodemap, int* __restrict__ cellmap,
-                                                          int* __restrict__ node2cell, int* __restrict__ cell2node) {
+                                                          int* __restrict__ node2cell, int* __restrict__ cell2node,
+                                                          int colmajor = 0) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
-    const int i = (int)(id % R), j = (int)(id / R);
-    const bool valid = cond[(size_t)i * C + j] > T(0);
+    int i, j;
+    cell_rc(id, R, i, j);
+    const bool valid = (colmajor ? cond[id] : cond[(size_t)i * C + j]) > T(0);
     nodemap[(size_t)i * C + j] = valid ? node[id] + 1 : 0;
     if (cellmap) cellmap[(size_t)i * C + j] = valid ? (int)id + 1 : 0;
     if (node2cell && valid) node2cell[node[id]] = (int)id;
@@ -531,7 +542,9 @@ __global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc
                                                         const T* __restrict__ labs, double omega_p, T* __restrict__ pl,
                                                         int* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int I = lat_tile((int)(i % R), Rc), J = lat_tile((int)(i / R), Cc);
+    int ri, ci;
+    cell_rc(i, R, ri, ci);
+    const int I = lat_tile(ri, Rc), J = lat_tile(ci, Cc);
     T acc[9];
     bool has[9];
 #pragma unroll
@@ -601,7 +614,9 @@ __global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int 
     __syncthreads();
     const int64_t i = i0 + tid;
     const bool on = i < n;
-    const int I = on ? lat_tile((int)(i % R), Rc) : 0, J = on ? lat_tile((int)(i / R), Cc) : 0;
+    int ri = 0, ci = 0;
+    if (on) cell_rc(i, R, ri, ci);
+    const int I = lat_tile(ri, Rc), J = lat_tile(ci, Cc);
     T acc[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) acc[s] = T(0);
@@ -610,7 +625,17 @@ __global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int 
       int64_t j;
       const T a = (T)dia_row_entry(rows, n, R, i, k, j);
       if (a == T(0)) continue;
-      const int Ij = lat_tile((int)(j % R), Rc), Jj = lat_tile((int)(j / R), Cc);
+      // (row / column of j = i + (k / 3 - 1) R + (k % 3 - 1) from the cell's own: no division -- the kernel used to spend
+      // eighteen 64-bit divisions per cell here)
+      int rj = ri + (k % 3 - 1), cj = ci + (k / 3 - 1);
+      if (rj < 0) {
+        rj += R;
+        --cj;
+      } else if (rj >= R) {
+        rj -= R;
+        ++cj;
+      }
+      const int Ij = lat_tile(rj, Rc), Jj = lat_tile(cj, Cc);
       const int sI = Ij - I, sJ = Jj - J;  // tile of j relative to tile of i: -1, 0, 1
       const T* xr = &s_x[k / 3][(tid + k % 3) * 9];  // row j of pl
 #pragma unroll

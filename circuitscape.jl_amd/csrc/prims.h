@@ -126,6 +126,45 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ p, int64_t 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int)i;
 }
 
+// (row, column) of the column-major cell id of an R-row raster with ONE division, 32 bits wide when the id allows it (a 64-bit
+// division is a ~100-instruction routine on the device; the set-up kernels used to run up to twenty of them per cell)
+__device__ __forceinline__ void cell_rc(int64_t id, int R, int& r, int& c) {
+  if (id <= 0x7fffffffLL) {
+    const unsigned u = (unsigned)id, q = u / (unsigned)R;
+    c = (int)q;
+    r = (int)(u - q * (unsigned)R);
+  } else {
+    const int64_t q = id / R;
+    c = (int)q;
+    r = (int)(id - q * R);
+  }
+}
+
+// out[j * R + i] = in[i * C + j]: the caller's row-major raster in the column-major order of the node numbering, through a
+// 32 x 33 LDS tile (both sides coalesced). The raster kernels then read their cell and its neighbours along raster columns --
+// read straight from the row-major array, neighbouring threads are a raster ROW apart (one cache line per value).
+template <class T>
+__global__ __launch_bounds__(256) void raster_transpose_kernel(int R, int C, const T* __restrict__ in, T* __restrict__ out) {
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+  const int tiles_j = (C + 31) / 32, tiles_i = (R + 31) / 32;
+  for (int64_t t = blockIdx.x; t < (int64_t)tiles_i * tiles_j; t += gridDim.x) {
+    const int i0 = (int)(t / tiles_j) * 32, j0 = (int)(t % tiles_j) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      const int i = i0 + ty + k, j = j0 + tx;
+      if (i < R && j < C) tile[ty + k][tx] = in[(size_t)i * C + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      const int j = j0 + ty + k, i = i0 + tx;
+      if (i < R && j < C) out[(size_t)j * R + i] = tile[tx][ty + k];
+    }
+  }
+}
+
 inline int read_int(const int* dev, hipStream_t st) {
   int v = 0;
   CS_HIP(hipMemcpyAsync(&v, dev, sizeof(int), hipMemcpyDeviceToHost, st));

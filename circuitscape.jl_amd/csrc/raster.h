@@ -19,12 +19,18 @@ __device__ __forceinline__ double raster_edge(double x, double y, bool diag, boo
 
 // Cells with conductance <= 0 (or NaN) are NODATA and get no node (construct_node_map numbers the cells with
 // gmap > 0 in column-major order, pairwise.jl:273-275). flag: one int per cell in COLUMN-major order (id = j*R + i).
+// colmajor != 0: cond is the transposed copy (raster_transpose_kernel, prims.h), cell (i, j) at j*R + i = id.
 template <class T>
 __global__ __launch_bounds__(256) void raster_valid_kernel(int R, int C, const T* __restrict__ cond,
-                                                           int* __restrict__ flag) {
+                                                           int* __restrict__ flag, int colmajor = 0) {
   const int64_t n = (int64_t)R * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (int64_t)gridDim.x * 256) {
-    const int i = (int)(id % R), j = (int)(id / R);
+    if (colmajor) {
+      flag[id] = cond[id] > T(0) ? 1 : 0;
+      continue;
+    }
+    int i, j;
+    cell_rc(id, R, i, j);
     flag[id] = cond[(size_t)i * C + j] > T(0) ? 1 : 0;
   }
 }

@@ -35,7 +35,8 @@ def child(size, holes, emu, precond):
     pts = rng.choice(n, size=8, replace=False)
     R, _, _, st = h.solve_pairs([int(p) for p in pts[:4]], [int(p) for p in pts[4:]])
     out = {"size": size, "holes": holes, "precond": precond, "galerkin": "staged" if os.environ.get("CSGPU_GALERKIN_STAGED") else "plain",
-           "apq_nt": int(os.environ.get("CSGPU_APQ_NT", "256")), "setup_device_ms": best[0], "setup_wall_s": best[1],
+           "apq_nt": int(os.environ.get("CSGPU_APQ_NT", "256")), "raster_transpose": 0 if os.environ.get("CSGPU_NO_RASTER_TRANSPOSE") else 1,
+           "setup_ms": info["setup_ms"], "upload_ms": info["upload_ms"], "setup_device_ms": best[0], "setup_wall_s": best[1],
            "levels": info["levels"], "iters": st["total_iters"], "not_converged": st["not_converged"],
            "digest": hashlib.sha1(np.ascontiguousarray(R).tobytes()).hexdigest()[:16]}
     print(json.dumps(out))
@@ -46,11 +47,13 @@ if __name__ == "__main__":
         child(int(sys.argv[2]), float(sys.argv[3]), sys.argv[4] == "1", sys.argv[5])
         sys.exit(0)
     size = int(sys.argv[1])
-    holes = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 0.0
+    holes = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2][0].isdigit() else 0.0
     emu = "--emu" in sys.argv
     precond = "fp32" if "fp32" in sys.argv else "same"
     variants = [{}, {"CSGPU_GALERKIN_STAGED": "1"}, {"CSGPU_GALERKIN_STAGED": "1", "CSGPU_APQ_NT": "128"},
                 {"CSGPU_GALERKIN_STAGED": "1", "CSGPU_APQ_NT": "64"}]
+    if "--transpose" in sys.argv:   # (second A/B of the round: the raster kernels on a column-major copy of the raster)
+        variants = [{}, {"CSGPU_NO_RASTER_TRANSPOSE": "1"}, {}, {"CSGPU_NO_RASTER_TRANSPOSE": "1"}]
     for v in variants:
         env = dict(os.environ)
         env.update(v)
