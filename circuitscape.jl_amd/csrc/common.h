@@ -103,7 +103,8 @@ struct Knobs {
                                   // same bits, 36.7 against 19.4 ms at 10000^2 fp64 (profiles/r6_setup_staged_galerkin_ab.jsonl) -- off
   bool raster_transpose = true;   // csgpu_raster_setup: the raster kernels of the index-free pipeline read a column-major copy
   bool enrich_fused = true;       // enriched levels take the fused residual update + restriction (enrich_coarse_fix, enrich.h)
-  int apq_nt = 256;               // cells per workgroup of lattice_ap_q_kernel (256 / 128 / 64: 22.2 / 23.8 / 24 ms, same file)
+  int apq_nt = 256;               // cells per workgroup of lattice_ap_q_kernel (256 / 128 / 64: 22.2 / 23.8 / 24 ms, same file --
+                                  // measured BEFORE its loads were issued up front, which is what that kernel was waiting for)
   int timed_launches = 512;
 };
 

@@ -552,17 +552,28 @@ __global__ __launch_bounds__(256) void lattice_p_kernel(int64_t n, int R, int Rc
       acc[s] = T(0);
       has[s] = false;
     }
+    // (all loads of the row first -- entries, then aggregates and tentative values of the neighbours that exist -- so that
+    // their latencies overlap instead of following one another behind the branches below)
+    T av[9], tj[9];
+    int aj[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       int64_t j;
-      const T a = (T)dia_row_entry(rows, n, R, i, k, j);
+      av[k] = (T)dia_row_entry(rows, n, R, i, k, j);
+      const bool in = j >= 0 && j < n;
+      aj[k] = in ? agg[j] : 0;
+      tj[k] = in ? t[j] : T(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const T a = av[k];
       if (a == T(0) && k != 4) continue;  // (the diagonal is always a stored entry)
-      const int slot = lat_slot(agg[j], Rc, I, J);
+      const int slot = lat_slot(aj[k], Rc, I, J);
       if (slot < 0) {
         atomicOr(bad, 1);
         continue;
       }
-      const T v = a * t[j];
+      const T v = a * tj[k];
 #pragma unroll
       for (int s = 0; s < 9; ++s)
         if (s == slot) {
@@ -602,18 +613,39 @@ __global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int 
   __shared__ T s_x[3][RUN];
   const int tid = threadIdx.x;
   for (int64_t i0 = (int64_t)blockIdx.x * NT; i0 < n; i0 += (int64_t)gridDim.x * NT) {
-    __syncthreads();  // (the previous round's reads)
+    // Every global load of the round is issued before the first one is waited for (the staged runs into registers, the nine
+    // entries of the cell's row of A, its scaling): with two workgroups per CU the round used to be ~36 load latencies in a
+    // row -- a loop of ten load-then-store-to-LDS steps per run, then one load per visited entry of A behind a branch.
+    constexpr int NQ = (RUN + NT - 1) / NT;
+    T v[3][NQ];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int64_t c0 = i0 + (int64_t)(r - 1) * R - 1;  // first cell of the run
-      for (int e = tid; e < RUN; e += NT) {
+#pragma unroll
+      for (int qd = 0; qd < NQ; ++qd) {
+        const int e = tid + qd * NT;
         const int64_t cell = c0 + e / 9;
-        s_x[r][e] = (cell >= 0 && cell < n) ? pl[c0 * 9 + e] : T(0);
+        v[r][qd] = (e < RUN && cell >= 0 && cell < n) ? pl[c0 * 9 + e] : T(0);
       }
     }
-    __syncthreads();
     const int64_t i = i0 + tid;
     const bool on = i < n;
+    T av[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      int64_t j;
+      av[k] = on ? (T)dia_row_entry(rows, n, R, i, k, j) : T(0);
+    }
+    const T wq = on ? (dinv ? omega * dinv[i] : omega) : T(0);
+    __syncthreads();  // (the previous round's reads)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int qd = 0; qd < NQ; ++qd) {
+        const int e = tid + qd * NT;
+        if (e < RUN) s_x[r][e] = v[r][qd];
+      }
+    __syncthreads();
     int ri = 0, ci = 0;
     if (on) cell_rc(i, R, ri, ci);
     const int I = lat_tile(ri, Rc), J = lat_tile(ci, Cc);
@@ -622,8 +654,7 @@ __global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int 
     for (int s = 0; s < 9; ++s) acc[s] = T(0);
 #pragma unroll
     for (int k = 0; k < 9 && on; ++k) {
-      int64_t j;
-      const T a = (T)dia_row_entry(rows, n, R, i, k, j);
+      const T a = av[k];
       if (a == T(0)) continue;
       // (row / column of j = i + (k / 3 - 1) R + (k % 3 - 1) from the cell's own: no division -- the kernel used to spend
       // eighteen 64-bit divisions per cell here)
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(NT) void lattice_ap_q_kernel(int64_t n, int R, int 
     // through LDS so that the stores are contiguous too
     T qv[9];
     if (on) {
-      const T w = dinv ? omega * dinv[i] : omega;
+      const T w = wq;
 #pragma unroll
       for (int s = 0; s < 9; ++s) qv[s] = -w * acc[s] + (base ? base[i * 9 + s] : s_x[1][(tid + 1) * 9 + s]);
     }
@@ -696,6 +727,8 @@ inline void lattice_ap_q(int64_t n, int R, int Rc, int Cc, const U* rows, const 
 // (deterministic), adds P[i, a] * (A P)[i, b] into a 5 x 5 window of coarse columns b around a (two tiles reach: see the
 // header), and writes the non-zero entries (the diagonal always) in ascending column order into a padded row of 25
 // slots; lattice_galerkin_compact_kernel packs the rows into CSR.
+// (Round 6, measured and taken out again: the column's <= 10 values of P loaded up front into registers, the way the staging
+// loads of lattice_ap_q_kernel now are -- 18.9 -> 34.2 ms in fp64 (the twelve-fold unrolled body), 4 ms better in fp32.)
 template <class T>
 __global__ __launch_bounds__(128) void lattice_galerkin_kernel(int R, int C, int Rc, int Cc, const T* __restrict__ pl,
                                                                const T* __restrict__ ap, int* __restrict__ count,

@@ -15,7 +15,7 @@ def child(size, holes, emu, precond):
     import numpy as np
     import circuitscape_jl_amd  # noqa: F401
     from circuitscape_jl_amd import lib
-    lib.load(os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so") if emu else None)
+    lib.load(os.path.join(ROOT, "tests", "emu", "libcsgpu_emu.so") if emu else os.environ.get("CSGPU_LIB"))
     rng = np.random.default_rng(5)
     g = np.exp(0.3 * rng.standard_normal((size, size + 7 if emu else size)))
     if holes > 0:
