@@ -718,8 +718,9 @@ inline PcgBatchResult pcg_solve(const Csr<T>& A, Hierarchy<TP>& H, PcgWork<T, TP
   // Fused residual update + restriction (lattice.h, Knobs::fused_restrict): r_new = r - alpha A p and b_c = Q^T r_new in one
   // pass. The residual then ping-pongs between W.r and W.r2 -- `r` / `rp` below are re-pointed after every fused launch and
   // `rsel` (which buffer holds the current residual) is part of the graph key. One precision only (the V-cycle reads r
-  // itself), resistance-only pair solves without masks, projections or the enrichment (which all touch r between the update
-  // and the cycle; enrich_pre reads r before the cycle).
+  // itself), resistance-only pair solves without masks or projections (which touch r between the update and the cycle). An
+  // ENRICHED level takes it when the set-up built W = Q'AE (EN.ntouch > 0): enrich_pre changes r on its halo cells after
+  // the pass has restricted it, and enrich_coarse_fix applies the restriction's share of that change to b_c (enrich.h).
   bool fused_rr = false;
   T* rbuf[2] = {r, nullptr};
   int rsel = 0;
